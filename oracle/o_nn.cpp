@@ -1,0 +1,344 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.h).  CPU restatement of the network math of
+// ref network/py/{network_unit,alphazero_network,muzero_network}.py in eval mode.
+//
+// Pinned by tests/golden/nn_*.npz (outputs of the reference's own Python modules, f32 CPU) at
+// |diff| <= 1e-5.  The arithmetic ORDER below is a specification shared with the HIP kernels so the
+// GPU path can be compared bit-for-bit, not only within the north_star's 1e-3:
+//   * BatchNorm (eval, eps 1e-5) is folded on the host:  s = gamma / sqrtf(var + eps);
+//     w' = w * s;  b' = (b - mean) * s + beta                      (f32, no contraction)
+//   * conv3x3 (pad 1): acc = 0; for tap t = ky*3+kx (0..8), for c = 0..C_in-1:
+//         acc = fmaf(x[c][y+ky-1][x+kx-1] (0 outside), w'[oc][c][ky][kx], acc)
+//     y = acc + b'[oc]; (+ skip); relu.           (== an MFMA f32 k-ordered fma chain)
+//   * conv1x1 / linear: acc = 0; for i ascending: acc = fmaf(in[i], w[out][i], acc); + bias
+//   * softmax: m = max; e_i = mz_expf(l_i - m); s = sum in index order; p_i = e_i / s
+//   * tanh: mz_tanhf.   scale_hidden_state: min/max exact, (h - min) / scale
+#include "oracle.h"
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace mzo {
+
+float mz_expf(float x)
+{
+    if (x < -87.0f) { return 0.0f; }
+    if (x > 88.0f) { x = 88.0f; }
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = fmaf(p, r, 1.3981999507E-3f);
+    p = fmaf(p, r, 8.3334519073E-3f);
+    p = fmaf(p, r, 4.1665795894E-2f);
+    p = fmaf(p, r, 1.6666665459E-1f);
+    p = fmaf(p, r, 5.0000001201E-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    int ni = static_cast<int>(n);
+    uint32_t bits = static_cast<uint32_t>(ni + 127) << 23;
+    float scale;
+    memcpy(&scale, &bits, 4);
+    return y * scale;
+}
+
+float mz_tanhf(float x)
+{
+    float ax = fabsf(x);
+    if (ax > 10.0f) { return copysignf(1.0f, x); }
+    float e = mz_expf(-2.0f * ax);
+    float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+// ---- raw parameter manifest (state_dict order of the reference modules, num_batches_tracked skipped) ----
+enum Kind { W, B, BN_G, BN_B, BN_M, BN_V };
+struct TensorSpec { size_t n; int fan_in; Kind kind; };
+
+static void specConvBN(std::vector<TensorSpec>& m, int cin, int cout, int k)
+{
+    m.push_back({size_t(cout) * cin * k * k, cin * k * k, W});
+    m.push_back({size_t(cout), cin * k * k, B});
+    m.push_back({size_t(cout), 0, BN_G});
+    m.push_back({size_t(cout), 0, BN_B});
+    m.push_back({size_t(cout), 0, BN_M});
+    m.push_back({size_t(cout), 0, BN_V});
+}
+static void specLinear(std::vector<TensorSpec>& m, int in, int out)
+{
+    m.push_back({size_t(out) * in, in, W});
+    m.push_back({size_t(out), in, B});
+}
+static int policyChannels(const NetDesc& d) { int hw = d.hidden_channel_height * d.hidden_channel_width; return (d.action_size + hw - 1) / hw; }
+
+static std::vector<TensorSpec> manifest(const NetDesc& d)
+{
+    std::vector<TensorSpec> m;
+    const int C = d.num_hidden_channels, hw = d.hidden_channel_height * d.hidden_channel_width;
+    auto trunk = [&](int cin) { // ref alphazero_network.py:32-34 / muzero_network.py:10-12,27-29
+        specConvBN(m, cin, C, 3);
+        for (int b = 0; b < d.num_blocks; ++b) { specConvBN(m, C, C, 3); specConvBN(m, C, C, 3); } // ref network_unit.py:9-12
+    };
+    auto heads = [&]() { // ref network_unit.py:26-64 (PolicyNetwork, ValueNetwork)
+        int pc = policyChannels(d);
+        specConvBN(m, C, pc, 1);
+        specLinear(m, pc * hw, d.action_size);
+        specConvBN(m, C, 1, 1);
+        specLinear(m, hw, d.num_value_hidden_channels);
+        specLinear(m, d.num_value_hidden_channels, 1);
+    };
+    if (d.type == 0) {
+        trunk(d.num_input_channels);
+        heads();
+    } else { // muzero: representation, dynamics, prediction (ref muzero_network.py:79-81)
+        trunk(d.num_input_channels);
+        trunk(C + d.num_action_feature_channels);
+        heads();
+    }
+    return m;
+}
+
+size_t Net::rawParamCount(const NetDesc& d)
+{
+    size_t n = 0;
+    for (auto& t : manifest(d)) { n += t.n; }
+    return n;
+}
+
+static inline uint64_t mix64(uint64_t z) // splitmix64 finaliser, counter based
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+void Net::generateRaw(const NetDesc& d, uint64_t seed, float* out)
+{
+    size_t idx = 0;
+    for (auto& t : manifest(d)) {
+        float lo, hi;
+        switch (t.kind) {
+            case W:
+            case B: { float bound = 1.0f / sqrtf(static_cast<float>(t.fan_in)); lo = -bound; hi = bound; break; }
+            case BN_G: lo = 0.5f; hi = 1.5f; break;
+            case BN_V: lo = 0.5f; hi = 1.5f; break;
+            default: lo = -0.1f; hi = 0.1f; break;
+        }
+        for (size_t i = 0; i < t.n; ++i, ++idx) {
+            uint64_t z = mix64(seed + (idx + 1) * 0x9E3779B97F4A7C15ULL);
+            float u = static_cast<float>(z >> 40) * 5.9604644775390625e-08f; // 2^-24, exact in f32
+            out[idx] = lo + (hi - lo) * u;
+        }
+    }
+}
+
+// ---- folded layers ----
+struct Conv { int cin, cout, k; std::vector<float> w, b; }; // w[oc][c][ky][kx] folded, b folded
+struct Linear { int in, out; std::vector<float> w, b; };
+
+static Conv takeConvBN(const float*& p, int cin, int cout, int k)
+{
+    Conv c{cin, cout, k, {}, {}};
+    size_t nw = size_t(cout) * cin * k * k;
+    const float *w = p, *b = p + nw, *g = b + cout, *be = g + cout, *mu = be + cout, *var = mu + cout;
+    p = var + cout;
+    c.w.resize(nw);
+    c.b.resize(cout);
+    for (int oc = 0; oc < cout; ++oc) {
+        float s = g[oc] / sqrtf(var[oc] + 1e-5f);
+        for (int i = 0; i < cin * k * k; ++i) { c.w[size_t(oc) * cin * k * k + i] = w[size_t(oc) * cin * k * k + i] * s; }
+        float t = (b[oc] - mu[oc]) * s;
+        c.b[oc] = t + be[oc];
+    }
+    return c;
+}
+static Linear takeLinear(const float*& p, int in, int out)
+{
+    Linear l{in, out, {}, {}};
+    l.w.assign(p, p + size_t(in) * out);
+    p += size_t(in) * out;
+    l.b.assign(p, p + out);
+    p += out;
+    return l;
+}
+
+// conv3x3 pad1, optional skip, relu.  in[cin][H][W] -> out[cout][H][W]
+static void conv3x3(const Conv& cv, int H, int Wd, const float* in, const float* skip, float* out)
+{
+    const int P = H * Wd, cin = cv.cin, cout = cv.cout;
+    // weights re-laid as wk[t][c][oc] so the oc loop vectorises; per (pixel, oc) the chain order is (t, c).
+    thread_local std::vector<float> wk, acc;
+    wk.resize(size_t(9) * cin * cout);
+    for (int oc = 0; oc < cout; ++oc)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < 9; ++t) { wk[(size_t(t) * cin + c) * cout + oc] = cv.w[(size_t(oc) * cin + c) * 9 + t]; }
+    acc.resize(cout);
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < Wd; ++x) {
+            std::fill(acc.begin(), acc.end(), 0.0f);
+            for (int t = 0; t < 9; ++t) {
+                int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                bool inside = (yy >= 0 && yy < H && xx >= 0 && xx < Wd);
+                for (int c = 0; c < cin; ++c) {
+                    float xv = inside ? in[c * P + yy * Wd + xx] : 0.0f;
+                    const float* wr = &wk[(size_t(t) * cin + c) * cout];
+                    for (int oc = 0; oc < cout; ++oc) { acc[oc] = __builtin_fmaf(xv, wr[oc], acc[oc]); }
+                }
+            }
+            int p = y * Wd + x;
+            for (int oc = 0; oc < cout; ++oc) {
+                float v = acc[oc] + cv.b[oc];
+                if (skip) { v = v + skip[oc * P + p]; }
+                out[oc * P + p] = v > 0.0f ? v : 0.0f;
+            }
+        }
+    }
+}
+static void conv1x1relu(const Conv& cv, int P, const float* in, float* out)
+{
+    for (int oc = 0; oc < cv.cout; ++oc)
+        for (int p = 0; p < P; ++p) {
+            float acc = 0.0f;
+            for (int c = 0; c < cv.cin; ++c) { acc = __builtin_fmaf(in[c * P + p], cv.w[size_t(oc) * cv.cin + c], acc); }
+            float v = acc + cv.b[oc];
+            out[oc * P + p] = v > 0.0f ? v : 0.0f;
+        }
+}
+static void linear(const Linear& l, const float* in, float* out, bool relu)
+{
+    for (int o = 0; o < l.out; ++o) {
+        float acc = 0.0f;
+        for (int i = 0; i < l.in; ++i) { acc = __builtin_fmaf(in[i], l.w[size_t(o) * l.in + i], acc); }
+        float v = acc + l.b[o];
+        out[o] = (relu && !(v > 0.0f)) ? 0.0f : v;
+    }
+}
+
+struct Trunk {
+    Conv stem;
+    std::vector<Conv> blocks; // 2 per residual block
+};
+struct Heads {
+    Conv pconv, vconv;
+    Linear pfc, vfc1, vfc2;
+};
+
+class NetImpl : public Net {
+public:
+    Trunk repr, dyn;
+    Heads heads;
+    int H, Wd, P, C;
+
+    static Trunk takeTrunk(const float*& p, int cin, const NetDesc& d)
+    {
+        Trunk t;
+        t.stem = takeConvBN(p, cin, d.num_hidden_channels, 3);
+        for (int b = 0; b < 2 * d.num_blocks; ++b) { t.blocks.push_back(takeConvBN(p, d.num_hidden_channels, d.num_hidden_channels, 3)); }
+        return t;
+    }
+    void runTrunk(const Trunk& t, int h, int w, const float* in, float* x) const // ref alphazero_network.py:91-95, network_unit.py:14-23
+    {
+        std::vector<float> tmp(size_t(C) * h * w), y(size_t(C) * h * w);
+        conv3x3(t.stem, h, w, in, nullptr, x);
+        for (size_t b = 0; b < t.blocks.size(); b += 2) {
+            conv3x3(t.blocks[b], h, w, x, nullptr, tmp.data());
+            conv3x3(t.blocks[b + 1], h, w, tmp.data(), x, y.data());
+            memcpy(x, y.data(), y.size() * sizeof(float));
+        }
+    }
+    void runHeads(const float* x, float* policy, float* logit, float* value) const // ref network_unit.py:36-64, alphazero_network.py:97-104
+    {
+        const int A = desc.action_size, pc = heads.pconv.cout;
+        std::vector<float> pf(size_t(pc) * P), vf(P), h1(desc.num_value_hidden_channels);
+        conv1x1relu(heads.pconv, P, x, pf.data());
+        linear(heads.pfc, pf.data(), logit, false);
+        float m = logit[0];
+        for (int a = 1; a < A; ++a) { m = logit[a] > m ? logit[a] : m; }
+        float s = 0.0f;
+        for (int a = 0; a < A; ++a) { policy[a] = mz_expf(logit[a] - m); s += policy[a]; }
+        for (int a = 0; a < A; ++a) { policy[a] = policy[a] / s; }
+        conv1x1relu(heads.vconv, P, x, vf.data());
+        linear(heads.vfc1, vf.data(), h1.data(), true);
+        float v;
+        linear(heads.vfc2, h1.data(), &v, false);
+        *value = mz_tanhf(v);
+    }
+    void scaleHidden(float* h) const // ref muzero_network.py:154-164
+    {
+        const int n = C * P;
+        float mn = h[0], mx = h[0];
+        for (int i = 1; i < n; ++i) { mn = h[i] < mn ? h[i] : mn; mx = h[i] > mx ? h[i] : mx; }
+        float scale = mx - mn;
+        if (scale < 1e-5f) { scale += 1e-5f; }
+        for (int i = 0; i < n; ++i) { h[i] = (h[i] - mn) / scale; }
+    }
+    template <class F>
+    static void parallelFor(int n, F f)
+    {
+        int nt = std::min<int>(n, std::max(1u, std::thread::hardware_concurrency()));
+        if (nt <= 1) { for (int i = 0; i < n; ++i) { f(i); } return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) { th.emplace_back([=]() { for (int i = t; i < n; i += nt) { f(i); } }); }
+        for (auto& t : th) { t.join(); }
+    }
+
+    void forwardAZ(const float* features, int batch, float* policy, float* logit, float* value) const override
+    {
+        const int A = desc.action_size, fin = desc.num_input_channels * P;
+        parallelFor(batch, [&](int b) {
+            std::vector<float> x(size_t(C) * P);
+            runTrunk(repr, H, Wd, features + size_t(b) * fin, x.data());
+            runHeads(x.data(), policy + size_t(b) * A, logit + size_t(b) * A, value + b);
+        });
+    }
+    void initialMZ(const float* features, int batch, float* policy, float* logit, float* value, float* hidden) const override
+    { // ref muzero_network.py:137-143
+        const int A = desc.action_size, fin = desc.num_input_channels * P;
+        parallelFor(batch, [&](int b) {
+            float* h = hidden + size_t(b) * C * P;
+            runTrunk(repr, H, Wd, features + size_t(b) * fin, h);
+            scaleHidden(h);
+            runHeads(h, policy + size_t(b) * A, logit + size_t(b) * A, value + b);
+        });
+    }
+    void recurrentMZ(const float* hidden_in, const float* action_plane, int batch, float* policy, float* logit, float* value, float* reward,
+                     float* hidden_out) const override
+    { // ref muzero_network.py:146-152, :31-38 (cat(hidden, action_plane) on the channel axis)
+        const int A = desc.action_size, ac = desc.num_action_feature_channels;
+        parallelFor(batch, [&](int b) {
+            std::vector<float> in(size_t(C + ac) * P);
+            memcpy(in.data(), hidden_in + size_t(b) * C * P, size_t(C) * P * sizeof(float));
+            memcpy(in.data() + size_t(C) * P, action_plane + size_t(b) * ac * P, size_t(ac) * P * sizeof(float));
+            float* h = hidden_out + size_t(b) * C * P;
+            runTrunk(dyn, H, Wd, in.data(), h);
+            scaleHidden(h);
+            runHeads(h, policy + size_t(b) * A, logit + size_t(b) * A, value + b);
+            if (reward) { reward[b] = 0.0f; }
+        });
+    }
+};
+
+std::unique_ptr<Net> Net::create(const NetDesc& d, const float* raw, size_t n)
+{
+    if (n != rawParamCount(d) || d.type == 2) { return nullptr; }
+    auto net = std::make_unique<NetImpl>();
+    net->desc = d;
+    net->H = d.hidden_channel_height;
+    net->Wd = d.hidden_channel_width;
+    net->P = net->H * net->Wd;
+    net->C = d.num_hidden_channels;
+    const float* p = raw;
+    net->repr = NetImpl::takeTrunk(p, d.num_input_channels, d);
+    if (d.type == 1) { net->dyn = NetImpl::takeTrunk(p, d.num_hidden_channels + d.num_action_feature_channels, d); }
+    const int hw = net->P, pc = policyChannels(d);
+    net->heads.pconv = takeConvBN(p, d.num_hidden_channels, pc, 1);
+    net->heads.pfc = takeLinear(p, pc * hw, d.action_size);
+    net->heads.vconv = takeConvBN(p, d.num_hidden_channels, 1, 1);
+    net->heads.vfc1 = takeLinear(p, hw, d.num_value_hidden_channels);
+    net->heads.vfc2 = takeLinear(p, d.num_value_hidden_channels, 1);
+    assert(p == raw + n);
+    return net;
+}
+
+} // namespace mzo

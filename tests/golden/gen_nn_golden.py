@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Generate NN golden vectors from the REFERENCE's own Python modules (minizero/network/py).
+
+Runs ONLY in the build container (needs /root/reference); the reference code never travels.
+What is committed is data: for each config the generator seed, the input seed/shape and the f32-CPU
+outputs of the reference module (a few KB each, nn_<cfg>.npz).  Weights are NOT stored: they are
+regenerated from the repo's deterministic generator (same SplitMix64 stream in oracle/o_nn.cpp,
+minizero_amd/csrc/weights.cpp and below) and loaded into the reference module with load_state_dict.
+
+usage: python tests/golden/gen_nn_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.dirname(HERE))
+from minizero.network.py.create_network import create_network  # noqa: E402  (the reference)
+import oracle_lib as O  # noqa: E402
+
+M64 = (1 << 64) - 1
+
+
+def mix64(z):
+    z = np.asarray(z, np.uint64)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def counter_u01(seed, n):
+    """u in [0,1) with 24 bits, identical to the C generator: mix64(seed + (i+1)*GOLDEN) >> 40) * 2^-24."""
+    with np.errstate(over="ignore"):
+        idx = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed & M64)
+        z = mix64(idx)
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
+def gen_weights_numpy(module, seed):
+    """Python twin of Net::generateRaw (oracle/o_nn.cpp): state_dict order, num_batches_tracked skipped."""
+    specs = []
+    for name, t in module.state_dict().items():
+        if name.endswith("num_batches_tracked"):
+            continue
+        n = t.numel()
+        if name.endswith("running_var") or (name.endswith("weight") and t.dim() == 1):
+            lo, hi = np.float32(0.5), np.float32(1.5)
+        elif name.endswith("running_mean") or (name.endswith("bias") and ".bn" in "." + name.rsplit(".", 1)[0].split(".")[-1]):
+            lo, hi = np.float32(-0.1), np.float32(0.1)
+        else:  # conv / linear weight or bias: +-1/sqrt(fan_in)
+            w = module.state_dict()[name.rsplit(".", 1)[0] + ".weight"]
+            fan_in = int(np.prod(w.shape[1:]))
+            bound = np.float32(1.0) / np.sqrt(np.float32(fan_in))
+            lo, hi = -bound, bound
+        specs.append((name, tuple(t.shape), n, lo, hi))
+    total = sum(s[2] for s in specs)
+    u = counter_u01(seed, total)
+    blob = np.empty(total, np.float32)
+    off = 0
+    for _, _, n, lo, hi in specs:
+        blob[off:off + n] = lo + (hi - lo) * u[off:off + n]
+        off += n
+    return blob, specs
+
+
+def load_blob(module, blob, specs):
+    sd = module.state_dict()
+    off = 0
+    for name, shape, n, _, _ in specs:
+        sd[name] = torch.from_numpy(blob[off:off + n].reshape(shape).copy())
+        off += n
+    module.load_state_dict(sd)
+
+
+def binary_planes(seed, shape):
+    n = int(np.prod(shape))
+    return (counter_u01(seed, n) < 0.3).astype(np.float32).reshape(shape)
+
+
+CONFIGS = {
+    # name: (create_network args in the reference's order, type)
+    "c1_tictactoe_az": ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9, 256, 1, "alphazero"),
+    "c2_go_az": ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "alphazero"),
+    "c3_othello_az": ("othello_8x8", 4, 8, 8, 64, 8, 8, 1, 6, 65, 256, 1, "alphazero"),
+    "c4_go_mz": ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "muzero"),
+    "small_go_az": ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero"),
+}
+
+
+def main():
+    torch.set_num_threads(1)
+    for name, args in CONFIGS.items():
+        net = create_network(*args).eval()
+        wseed = 0
+        blob, specs = gen_weights_numpy(net, wseed)
+        # the numpy twin must equal the C generator bit for bit
+        d = O.make_desc(*args[:10], vh=args[10], dv=args[11], type_name=args[12])
+        cblob = O.gen_weights(d, wseed)
+        assert blob.shape == cblob.shape and np.array_equal(blob.view(np.uint32), cblob.view(np.uint32)), name
+        load_blob(net, blob, specs)
+        out = {"create_network_args": np.array([str(a) for a in args]), "weight_seed": wseed}
+        with torch.no_grad():
+            for B in (1, 3):
+                iseed = 1000 + B
+                x = binary_planes(iseed, (B, args[1], args[2], args[3]))
+                if args[12] == "alphazero":
+                    r = net(torch.from_numpy(x))
+                    out[f"b{B}_input_seed"] = iseed
+                    out[f"b{B}_policy"] = r["policy"].numpy()
+                    out[f"b{B}_policy_logit"] = r["policy_logit"].numpy()
+                    out[f"b{B}_value"] = r["value"].numpy().reshape(-1)
+                else:
+                    r = net.initial_inference(torch.from_numpy(x))
+                    out[f"b{B}_input_seed"] = iseed
+                    for k in ("policy", "policy_logit", "hidden_state"):
+                        out[f"b{B}_init_{k}"] = r[k].numpy().reshape(B, -1)
+                    out[f"b{B}_init_value"] = r["value"].numpy().reshape(-1)
+                    # recurrent step on the reference's own hidden state with a one-hot action plane
+                    act = np.zeros((B, args[7], args[5], args[6]), np.float32)
+                    for b in range(B):
+                        act[b, 0].reshape(-1)[(7 * b + 3) % (args[5] * args[6])] = 1.0
+                    r2 = net.recurrent_inference(r["hidden_state"], torch.from_numpy(act))
+                    for k in ("policy", "policy_logit", "hidden_state"):
+                        out[f"b{B}_rec_{k}"] = r2[k].numpy().reshape(B, -1)
+                    out[f"b{B}_rec_value"] = r2["value"].numpy().reshape(-1)
+        path = os.path.join(HERE, f"nn_{name}.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes; params", blob.size)
+
+
+if __name__ == "__main__":
+    main()
