@@ -1,0 +1,179 @@
+/* mzgpu.h - C ABI of the MI355X-native MiniZero self-play worker (libmzgpu.so).
+ *
+ * This is the drop-in boundary for the reference's self-play hot path: the reference's C++ classes
+ * minizero::network::{Network,AlphaZeroNetwork,MuZeroNetwork} and minizero::actor::{MCTS,ZeroActor,
+ * ActorGroup} become thin facades over these entry points (see INTEGRATION.md and
+ * the include/minizero/ facade headers).  Plain C types only: opaque handles owned by the library, caller-owned
+ * buffers, 0 / negative return codes with a thread-local error string (mz_last_error), no exceptions
+ * or STL across the ABI.  One host thread drives one handle; every handle owns one HIP stream.
+ *
+ * "ref" citations are file:line under /root/reference/minizero/.
+ */
+#ifndef MZGPU_H
+#define MZGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZ_OK 0
+#define MZ_ERR_ARG (-1)      /* bad argument / unsupported shape */
+#define MZ_ERR_DEVICE (-2)   /* HIP error or no GPU: the product has NO CPU fallback */
+#define MZ_ERR_STATE (-3)    /* call not valid in the current state */
+#define MZ_ERR_CAPACITY (-4) /* node pool / buffer capacity exceeded */
+
+/* where = where the caller's data buffers live */
+#define MZ_HOST 0
+#define MZ_DEVICE 1
+
+const char* mz_last_error(void);
+/* replaces torch::cuda::device_count() (ref actor/actor_group.cpp:152,170) */
+int mz_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Network.  Replaces Network::loadModel + getters (ref network/network.cpp:14-42,
+ * network/network.h:15-56) and the TorchScript forward of alphazero_network.h:63-104 /
+ * muzero_network.h:97-178.  The 12 hyper-parameters are the arguments of the reference's
+ * create_network (ref network/py/create_network.py:6-18), in that order.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mz_net_desc {
+    char game_name[64];
+    int num_input_channels, input_channel_height, input_channel_width;
+    int num_hidden_channels, hidden_channel_height, hidden_channel_width;
+    int num_action_feature_channels, num_blocks, action_size, num_value_hidden_channels, discrete_value_size;
+    int type; /* 0 alphazero, 1 muzero, 2 muzero_atari (ref get_type_name, alphazero_network.py:42-44) */
+} mz_net_desc;
+
+typedef struct mz_net mz_net;
+
+/* number of f32 values in the flat weight blob: every floating-point tensor of the module's
+ * state_dict() in order (conv/linear weight+bias, BN weight/bias/running_mean/running_var),
+ * num_batches_tracked skipped.  BN is folded by the library at load. */
+long mz_net_param_count(const mz_net_desc* desc);
+/* deterministic synthetic weights (SplitMix64 counter stream; the "synthetic fixed-weight network"
+ * of BASELINE.json).  out must hold mz_net_param_count() floats. */
+int mz_net_generate_weights(const mz_net_desc* desc, uint64_t seed, float* out);
+
+/* createNetwork(file, gpu_id) (ref network/create_network.h:11-30): here the caller hands the parsed
+ * blob; device must be a valid GPU ordinal (gpu_id == -1 / CPU is NOT supported: MZ_ERR_DEVICE). */
+mz_net* mz_net_create(int device, const mz_net_desc* desc, const float* weights, size_t count);
+/* load_model on a live network (ref actor/actor_group.cpp:227-232) */
+int mz_net_reload(mz_net* net, const float* weights, size_t count);
+void mz_net_destroy(mz_net* net);
+int mz_net_get_desc(const mz_net* net, mz_net_desc* out);
+
+/* AlphaZeroNetwork::forward() (ref network/alphazero_network.h:63-104): features [B][C_in][H][W] f32
+ * -> policy[B][A] (softmax), policy_logit[B][A], value[B].  Blocking. */
+int mz_net_forward_az(mz_net* net, const float* features, int batch, float* policy, float* policy_logit, float* value, int where);
+/* MuZeroNetwork::initialInference() (ref muzero_network.h:97-104, muzero_network.py:137-143):
+ * hidden_state[B][C][h][w] is also returned */
+int mz_net_initial(mz_net* net, const float* features, int batch, float* policy, float* policy_logit, float* value, float* hidden_state,
+                   int where);
+/* MuZeroNetwork::recurrentInference() (ref muzero_network.h:106-119, muzero_network.py:146-152):
+ * hidden_in[B][C][h][w], action_plane[B][a][h][w] -> outputs + reward[B] (0 for board games) */
+int mz_net_recurrent(mz_net* net, const float* hidden_in, const float* action_plane, int batch, float* policy, float* policy_logit,
+                     float* value, float* reward, float* hidden_out, int where);
+/* measurement hook for bench.py: runs `iters` forwards of batch B on resident synthetic inputs and
+ * returns HIP-event times on the network's own stream: total ms per forward, and ms spent in the
+ * 3x3-convolution kernels per forward (the dominant kernel; roofline numerator in DESIGN.md). */
+int mz_net_time_forward(mz_net* net, int batch, int iters, float* ms_total, float* ms_conv3x3, double* conv_flops_per_forward);
+
+/* ------------------------------------------------------------------------------------------
+ * Search pool: the structure-of-arrays node pool of `games` trees in HBM.  Replaces
+ * Tree/MCTSNode/MCTS (ref actor/tree.h:32-122, actor/mcts.h:17-119, actor/mcts.cpp:20-228).
+ * Node ids are 32-bit indices local to a game, root = 0, children of a node are one contiguous run.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mz_search_cfg {
+    int num_simulation;          /* actor_num_simulation (sizes the PUCT tables and path buffers) */
+    float puct_base, puct_init;  /* actor_mcts_puct_base / _init (ref configuration.cpp:14-15) */
+    float reward_discount;       /* actor_mcts_reward_discount */
+    int value_rescale;           /* actor_mcts_value_rescale (value-bound multiset, ref mcts.cpp:219-228) */
+    int flipping_player;         /* charToPlayer(actor_mcts_value_flipping_player): 1 = 'B', 2 = 'W' */
+    int atari_init_q;            /* the #if ATARI init-Q rule (ref mcts.cpp:211-216) as a run-time switch */
+} mz_search_cfg;
+
+typedef struct mz_pool mz_pool;
+
+/* ref actor_group.cpp:183 (tree_node_size = (n+1)*A) and tree.h:64-69: nodes_per_game = 1 + tree_node_size */
+mz_pool* mz_pool_create(int device, int games, int nodes_per_game, int action_size, const mz_search_cfg* cfg);
+void mz_pool_destroy(mz_pool* pool);
+/* MCTS::reset() + ZeroActor::resetSearch() (ref mcts.cpp:77-82, zero_actor.cpp:29-34) for the games
+ * with mask[g] != 0 (NULL = all); root_player[g] = player of the root's (id -1) action */
+int mz_pool_reset_search(mz_pool* pool, const uint8_t* mask, const int* root_player);
+/* MCTS::select()/selectFromNode() for every game (ref mcts.cpp:139-149,181-217; gumbel_zero.cpp:83-85):
+ * start_node NULL or start_node[g] <= 0: from the root; else path = root + PUCT path below that node.
+ * Outputs (host): path_len[g], paths[g*max_depth + d] (node ids), path_action[g*max_depth + d]
+ * (action ids; entry 0 is the root's -1).  max_depth = mz_pool_max_depth(). */
+int mz_pool_select(mz_pool* pool, const int* start_node, int* path_len, int* paths, int* path_action);
+int mz_pool_max_depth(const mz_pool* pool);
+/* MCTS::expand() + MCTS::backup() on the paths of the last select (ref mcts.cpp:151-179).
+ * cand_count[g] = k (0 = terminal leaf: backup only); candidates of game g at [g*A, g*A+k), already
+ * in child order (the caller ran the reference's std::sort, zero_actor.cpp:225-227,241-243);
+ * cand_player[g] = player of the new children's actions. */
+int mz_pool_expand_backup(mz_pool* pool, const int* cand_count, const int* cand_action, const float* cand_policy, const float* cand_logit,
+                          const int* cand_player, const float* value, const float* reward);
+/* ZeroActor::addNoiseToNodeChildren() result (ref zero_actor.cpp:194-213): overwrite policy / logit /
+ * noise of the root's children of the games with mask[g] != 0; arrays are [g*A + i], i = child order */
+int mz_pool_root_set_noise(mz_pool* pool, const uint8_t* mask, const float* policy, const float* logit, const float* noise);
+/* root statistics needed by the per-move host logic (move decision, resign test, P/V record strings,
+ * Gumbel halving; ref mcts.cpp:84-137, gumbel_zero.cpp:9-137): per game n = num_children[g], and at
+ * [g*A + i] action/count/mean/policy/logit/noise/value/reward of child i; root_* are [g] */
+int mz_pool_root_read(mz_pool* pool, int* num_children, int* action, float* count, float* mean, float* policy, float* logit, float* noise,
+                      float* value, float* reward, float* root_count, float* root_mean, float* root_value, float* bound_lo, float* bound_hi,
+                      int* bound_size);
+/* test / debug: copy the first n nodes of game g out of the SoA pool */
+int mz_pool_read_nodes(mz_pool* pool, int game, int n, int* action, int* player, int* num_children, int* first_child, float* mean,
+                       float* count, float* policy, float* logit, float* noise, float* value, float* reward);
+int mz_pool_num_nodes(mz_pool* pool, int game);
+
+/* ------------------------------------------------------------------------------------------
+ * Worker: the `-mode sp` loop.  Replaces ActorGroup::run() and its stdin/stdout protocol
+ * (ref actor/actor_group.cpp:136-252, console/mode_handler.cpp:145-149).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mz_worker mz_worker;
+
+/* conf: the reference's "k=v:k=v" configuration string (ref config/configure_loader.cpp:51-117) plus
+ * env_game=tictactoe|go|othello (the reference picks the game at compile time).  The worker owns a
+ * pool of zero_num_parallel_games trees and a network on `device`. */
+mz_worker* mz_worker_create(int device, const char* conf, const mz_net_desc* desc, const float* weights, size_t count);
+void mz_worker_destroy(mz_worker* w);
+/* one stdin line: start | stop | load_model <path> | update_config k=v:.. | reset_actors | quit | other (ignored)
+ * (ref actor_group.cpp:200-252).  load_model with a path needs mz_worker_set_weights first. */
+int mz_worker_command(mz_worker* w, const char* line);
+int mz_worker_set_weights(mz_worker* w, const float* weights, size_t count);
+/* run n lock-step cycles (one simulation of every game per cycle, ref actor_group.cpp:139-147);
+ * returns the number of cycles actually run (0 while stopped) or a negative error */
+int mz_worker_run_cycles(mz_worker* w, int n);
+/* next pending stdout line ("SelfPlay ... #", ref actor_group.cpp:24-50); returns its length, 0 if none */
+int mz_worker_pop_line(mz_worker* w, char* buf, int cap);
+typedef struct mz_worker_stats {
+    uint64_t cycles, leaf_evals, moves, games;
+    double ms_select, ms_env, ms_forward, ms_expand, ms_move, ms_total;
+} mz_worker_stats;
+int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out);
+mz_net* mz_worker_net(mz_worker* w);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side environment access (rules engines the worker uses for AlphaZero leaves; exposed so the
+ * parity tests can run the reference's env_test-style playout/replay check, ref
+ * console/mode_handler.cpp:167-192).  No device work.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mz_env mz_env;
+mz_env* mz_env_create(const char* conf);
+void mz_env_destroy(mz_env* e);
+void mz_env_reset(mz_env* e);
+int mz_env_act(mz_env* e, int action_id, int player);
+int mz_env_turn(const mz_env* e);
+int mz_env_is_terminal(const mz_env* e);
+float mz_env_eval_score(const mz_env* e, int is_resign);
+int mz_env_policy_size(const mz_env* e);
+int mz_env_feature_size(const mz_env* e);
+int mz_env_legal_mask(const mz_env* e, uint8_t* out);
+int mz_env_features(const mz_env* e, int rotation, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZGPU_H */

@@ -1,0 +1,76 @@
+// Shared declarations of libmzgpu (product).  HIP/gfx950 only; there is no CPU fallback anywhere.
+#pragma once
+#include "../../include/mzgpu.h"
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace mz {
+
+void setError(const char* fmt, ...);
+const char* lastError();
+
+#define MZ_HIP(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            mz::setError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);          \
+            return MZ_ERR_DEVICE;                                                                             \
+        }                                                                                                     \
+    } while (0)
+
+// device buffer with size bookkeeping (no exceptions across the ABI: alloc returns false on failure)
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    bool alloc(size_t count)
+    {
+        free();
+        if (count == 0) { return true; }
+        if (hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)) != hipSuccess) { p = nullptr; return false; }
+        n = count;
+        return true;
+    }
+    bool ensure(size_t count) { return count <= n ? true : alloc(count); }
+    void free()
+    {
+        if (p) { (void)hipFree(p); }
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { free(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// pinned host buffer
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    bool alloc(size_t count)
+    {
+        free();
+        if (count == 0) { return true; }
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        n = count;
+        return true;
+    }
+    bool ensure(size_t count) { return count <= n ? true : alloc(count); }
+    void free()
+    {
+        if (p) { (void)hipHostFree(p); }
+        p = nullptr;
+        n = 0;
+    }
+    ~PinBuf() { free(); }
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+};
+
+} // namespace mz

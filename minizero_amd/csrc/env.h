@@ -1,0 +1,58 @@
+// Host rules engines of libmzgpu (AlphaZero leaves need game rules: ref zero_actor.cpp:55,79 replays the
+// path on a copy of the root environment).  Own implementations, designed for cheap copy + replay:
+// flat PODs, bitboards, early-exit flood fills, precomputed rotation tables.  Behavioural contract:
+// ref environment/{tictactoe,othello,go}/*.cpp and SURVEY.md Appendix F; checked against the oracle's
+// restatement by the differential playout tests.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace mz {
+
+struct RotationTables {
+    int board_size = 0;
+    std::vector<int> fwd[8]; // fwd[r][a]  = getRotateAction(a, r)            (ref zero_actor.cpp:221, rotation.h:51-93)
+    std::vector<int> inv[8]; // inv[r][p]  = rotate(p, reversed_rotation[r])  (ref go.cpp:289, tictactoe.cpp:77, othello.cpp:242)
+    void build(int board_size, int num_actions);
+};
+
+class GameEnv {
+public:
+    virtual ~GameEnv() = default;
+    virtual std::unique_ptr<GameEnv> clone() const = 0;
+    virtual void copyFrom(const GameEnv& other) = 0; // same concrete type; cheap (no allocation in steady state)
+    virtual void reset() = 0;
+    virtual bool act(int action_id, int player) = 0;       // checks legality like the reference's act()
+    virtual void actUnchecked(int action_id, int player) = 0; // replay of moves the search already knows are legal
+    virtual bool isLegal(int action_id, int player) const = 0;
+    virtual void legalMask(uint8_t* out) const = 0;         // for the player to move, all actions
+    virtual bool isTerminal() const = 0;
+    virtual float evalScore(bool is_resign) const = 0;
+    virtual float reward() const { return 0.0f; }
+    virtual void features(int rotation, float* out) const = 0;
+    virtual int numInputChannels() const = 0;
+    virtual int boardSize() const = 0;
+    virtual int policySize() const = 0;
+    virtual int numPlayers() const { return 2; }
+    virtual std::string name() const = 0;
+    virtual std::vector<std::pair<std::string, std::string>> loaderTags() const = 0;
+    int turn() const { return turn_; }
+    int featureSize() const { return numInputChannels() * boardSize() * boardSize(); }
+    const std::vector<int16_t>& actionIds() const { return action_ids_; }
+    const std::vector<uint8_t>& actionPlayers() const { return action_players_; }
+    const RotationTables* rot() const { return rot_; }
+
+protected:
+    int turn_ = 1;
+    std::vector<int16_t> action_ids_;
+    std::vector<uint8_t> action_players_;
+    const RotationTables* rot_ = nullptr;
+};
+
+// game: "tictactoe" | "go" | "othello"; board_size 0 = the game's default (3 / 9 / 8)
+std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi);
+
+} // namespace mz

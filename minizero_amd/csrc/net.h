@@ -1,0 +1,71 @@
+// Network inference path of libmzgpu: BN-folded weights resident in HBM, im2col-free 3x3 convolutions on
+// the f32 MFMA pipe with an LDS-staged zero-padded input tile, fused bias(+skip)+ReLU, fused heads.
+// Math being reproduced: ref network/py/network_unit.py:6-87, alphazero_network.py:90-113,
+// muzero_network.py:137-164.  Arithmetic order is specified in DESIGN.md §"Network numerics".
+#pragma once
+#include "common.h"
+
+namespace mz {
+
+struct ConvLayer {
+    int cin, cin_pad, cout, cout_pad;
+    size_t w_off, b_off; // offsets (floats) into Net::params_
+};
+
+struct HeadOffsets {
+    int pc; // policy conv channels = ceil(A / (h*w)) (ref network_unit.py:31)
+    size_t pconv_w, pconv_b, pfc_wT, pfc_b, vconv_w, vconv_b, vfc1_wT, vfc1_b, vfc2_w, vfc2_b;
+};
+
+// host-side weight utilities (weights.cpp)
+long netParamCount(const mz_net_desc& d);
+bool netGenerate(const mz_net_desc& d, uint64_t seed, float* out);
+bool netValidateDesc(const mz_net_desc& d);
+bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<float>& packed, std::vector<ConvLayer>& repr, std::vector<ConvLayer>& dyn,
+                 HeadOffsets& h);
+
+class Net {
+public:
+    Net() = default;
+    ~Net();
+    int init(int device, const mz_net_desc& d, const float* raw, size_t n);
+    int reload(const float* raw, size_t n);
+
+    // device-pointer entry points (all on stream_)
+    int forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value);
+    int initial(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, float* d_hidden, const int* d_dst_idx);
+    // hidden source: d_hidden_src[(src_idx ? src_idx[b] : b)][C][P]; action: planes (d_action_planes) or ids (d_action_ids)
+    int recurrent(const float* d_hidden_src, const int* d_src_idx, const float* d_action_planes, const int* d_action_ids, int B, float* d_policy,
+                  float* d_logit, float* d_value, float* d_reward, float* d_hidden_dst, const int* d_dst_idx);
+    // host/device wrappers used by the C ABI
+    int forwardAZ_any(const float* feat, int B, float* policy, float* logit, float* value, int where);
+    int initial_any(const float* feat, int B, float* policy, float* logit, float* value, float* hidden, int where);
+    int recurrent_any(const float* hidden_in, const float* action, int B, float* policy, float* logit, float* value, float* reward, float* hidden_out,
+                      int where);
+    int timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops);
+
+    mz_net_desc desc_{};
+    int device_ = -1;
+    hipStream_t stream_ = nullptr;
+    bool own_stream_ = false;
+    int P() const { return desc_.hidden_channel_height * desc_.hidden_channel_width; }
+    int hiddenSize() const { return desc_.num_hidden_channels * P(); }
+    int featSize() const { return desc_.num_input_channels * desc_.input_channel_height * desc_.input_channel_width; }
+
+private:
+    int ensureBatch(int B);
+    int runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out);
+    int launchConv(const ConvLayer& L, const float* in, const float* skip, float* out, int B);
+    int launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden);
+
+    DevBuf<float> params_;
+    std::vector<ConvLayer> repr_, dyn_;
+    HeadOffsets heads_{};
+    int max_batch_ = 0;
+    DevBuf<float> act_[3];      // [B][C][P] ping-pong + residual temp
+    DevBuf<float> rec_in_;      // [B][C + a][P] dynamics input
+    DevBuf<float> io_in_, io_in2_, io_policy_, io_logit_, io_value_, io_reward_, io_hidden_; // staging for MZ_HOST callers
+    bool conv_only_ = false;    // timing mode: skip the heads
+};
+
+} // namespace mz

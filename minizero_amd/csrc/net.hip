@@ -1,0 +1,538 @@
+// gfx950 (MI355X / CDNA4) inference kernels of libmzgpu.  Built with -ffp-contract=off: every fused
+// multiply-add below is explicit, so the results are a pure function of the arithmetic order written in
+// DESIGN.md §"Network numerics" (the parity tests compare against a CPU restatement of that order).
+//
+// conv3x3_mfma  — im2col-free 3x3 convolution (pad 1) as an implicit GEMM on the f32 MFMA pipe:
+//                 D[oc][pixel] += W'[oc][k] * X[k][pixel], k = (tap, channel) tap-major.
+//                 One workgroup (4 wave64) per sample; the whole zero-padded input image of the sample
+//                 ([C_in][H+2][W+2] f32, <= 39 KB) is staged once in LDS, the 9 taps are 9 shifted LDS
+//                 reads of the same tile.  A-fragments (weights) are pre-packed on the host so one
+//                 coalesced 256-B global read per wave = one v_mfma_f32_16x16x4_f32 A operand, and they
+//                 are double-buffered one tap ahead in registers.  Epilogue fuses folded-BN bias,
+//                 residual skip and ReLU and writes 64-B contiguous pixel runs.
+// heads_kernel  — policy head (conv1x1+BN+ReLU+FC+softmax) and value head (conv1x1+BN+ReLU+FC+ReLU+FC+tanh)
+//                 fused in one workgroup per sample; for MuZero also the per-sample min/max rescale of
+//                 the hidden state (ref muzero_network.py:154-164) and its scatter into the HBM slab.
+#include "net.h"
+#include <cstring>
+
+namespace mz {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int planeStride(int H, int W)
+{
+    // padded plane (H+2)*(W+2) rounded up so that stride % 32 == 16: the two 16-lane channel groups
+    // that share a 32-lane ds_read_b32 service group then start on different bank halves
+    int ps = (H + 2) * (W + 2);
+    int r = ps % 32;
+    return ps + ((16 - r) + 32) % 32;
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic exp / tanh (same operation sequence as the CPU oracle)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mz_expf(float x)
+{
+    if (x < -87.0f) { return 0.0f; }
+    if (x > 88.0f) { x = 88.0f; }
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    int ni = static_cast<int>(n);
+    float scale = __builtin_bit_cast(float, static_cast<unsigned>(ni + 127) << 23);
+    return y * scale;
+}
+__device__ __forceinline__ float mz_tanhf(float x)
+{
+    float ax = __builtin_fabsf(x);
+    if (ax > 10.0f) { return __builtin_copysignf(1.0f, x); }
+    float e = mz_expf(-2.0f * ax);
+    float t = (1.0f - e) / (1.0f + e);
+    return __builtin_copysignf(t, x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3 on the f32 MFMA pipe
+// ---------------------------------------------------------------------------------------------
+template <int H, int W, int CIN_PAD>
+__global__ __launch_bounds__(256) void conv3x3_mfma(const float* __restrict__ in, int cin, const float* __restrict__ wp,
+                                                    const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ out,
+                                                    int cout, int OT)
+{
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), CG = CIN_PAD / 4, PT = (P + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) float xs[]; // [CIN_PAD][CS]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- stage the zero-padded input image of this sample in LDS ----
+    const float* src = in + size_t(b) * cin * P;
+    for (int idx = tid; idx < CIN_PAD * CS; idx += 256) {
+        int c = idx / CS, pos = idx - c * CS;
+        int yy = pos / PW, xx = pos - yy * PW;
+        float v = 0.0f;
+        if (c < cin && yy >= 1 && yy <= H && xx >= 1 && xx <= W) { v = src[c * P + (yy - 1) * W + (xx - 1)]; }
+        xs[idx] = v;
+    }
+    __syncthreads();
+
+    // B-fragment (activations) base offsets: lane l supplies X[k = l>>4][pixel = 16*pt + (l&15)]
+    int pixoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int q = 16 * pt + (lane & 15);
+        if (q >= P) { q = 0; } // padding column of the last pixel tile: any valid address, result discarded
+        pixoff[pt] = (lane >> 4) * CS + (q / W) * PW + (q % W);
+    }
+
+    for (int ot = wave; ot < OT; ot += 4) {
+        f32x4 acc[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) { acc[pt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+        const float* wl = wp + size_t(ot) * 64 + lane; // + ((t*CG + cg)*OT)*64
+        const size_t wstep = size_t(OT) * 64;
+        float a_cur[CG], a_nxt[CG];
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = wl[size_t(cg) * wstep]; }
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) { // runtime tap loop: keeps live ranges to one tap (96 MFMAs) + the next tap's weights
+            const int tn = t < 8 ? t + 1 : 8; // last iteration re-reads tap 8 (harmless, keeps the loop body uniform)
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) { a_nxt[cg] = wl[(size_t(tn) * CG + cg) * wstep]; }
+            const int tapoff = (t / 3) * PW + (t % 3);
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    float bv = xs[pixoff[pt] + cg * 4 * CS + tapoff];
+                    acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[cg], bv, acc[pt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = a_nxt[cg]; }
+        }
+        // ---- epilogue: D layout col = lane&15 (pixel), row = 4*(lane>>4) + r (oc within the tile) ----
+        float* dst = out + size_t(b) * cout * P;
+        const float* sk = skip ? skip + size_t(b) * cout * P : nullptr;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int q = 16 * pt + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oc = 16 * ot + 4 * (lane >> 4) + r;
+                if (q < P && oc < cout) {
+                    float v = acc[pt][r] + bias[oc];
+                    if (sk) { v = v + sk[oc * P + q]; }
+                    dst[oc * P + q] = v > 0.0f ? v : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dynamics input: cat(hidden[src], action plane) on the channel axis (ref muzero_network.py:32)
+// action_mode 1: board games, one-hot position plane (all zero for pass; ref go.cpp:310-315)
+// ---------------------------------------------------------------------------------------------
+__global__ void build_recurrent_input(const float* __restrict__ hidden, const int* __restrict__ src_idx, const float* __restrict__ planes,
+                                      const int* __restrict__ action_ids, int C, int AC, int P, float* __restrict__ out)
+{
+    const int b = blockIdx.x;
+    const int s = src_idx ? src_idx[b] : b;
+    const float* h = hidden + size_t(s) * C * P;
+    float* o = out + size_t(b) * (C + AC) * P;
+    for (int i = threadIdx.x; i < C * P; i += blockDim.x) { o[i] = h[i]; }
+    for (int i = threadIdx.x; i < AC * P; i += blockDim.x) {
+        float v;
+        if (planes) { v = planes[size_t(b) * AC * P + i]; }
+        else { v = (AC == 1) ? (i == action_ids[b] ? 1.0f : 0.0f) : ((i / P) == action_ids[b] ? 1.0f : 0.0f); }
+        o[C * P + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused heads (+ MuZero hidden-state rescale)
+// ---------------------------------------------------------------------------------------------
+struct HeadParams {
+    const float *pconv_w, *pconv_b, *pfc_wT, *pfc_b, *vconv_w, *vconv_b, *vfc1_wT, *vfc1_b, *vfc2_w, *vfc2_b;
+    int C, P, A, PC, VH;
+};
+
+__global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ x, HeadParams hp, float* __restrict__ policy,
+                                                    float* __restrict__ logit, float* __restrict__ value, float* __restrict__ hidden_dst,
+                                                    const int* __restrict__ dst_idx, int scale_hidden)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC, VH = hp.VH;
+    float* xs = sm;                // [C*P]
+    float* pf = xs + C * P;        // [PC*P]
+    float* vf = pf + PC * P;       // [P]
+    float* h1 = vf + P;            // [VH]
+    float* lg = h1 + VH;           // [A] logits, then exp values
+    float* red = lg + A;           // [16] reduction scratch
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = x + size_t(b) * C * P;
+    for (int i = tid; i < C * P; i += 256) { xs[i] = src[i]; }
+    __syncthreads();
+
+    if (scale_hidden) { // min/max are order-free; (h - min) / scale is one IEEE op each
+        float mn = 3.4e38f, mx = -3.4e38f;
+        for (int i = tid; i < C * P; i += 256) { float v = xs[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        for (int o = 32; o > 0; o >>= 1) {
+            float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
+            mn = m2 < mn ? m2 : mn;
+            mx = x2 > mx ? x2 : mx;
+        }
+        if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+        __syncthreads();
+        mn = red[0]; mx = red[4];
+        for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
+        float scale = mx - mn;
+        if (scale < 1e-5f) { scale += 1e-5f; }
+        float* hd = hidden_dst + size_t(dst_idx ? dst_idx[b] : b) * C * P;
+        for (int i = tid; i < C * P; i += 256) {
+            float v = (xs[i] - mn) / scale;
+            xs[i] = v;
+            hd[i] = v;
+        }
+        __syncthreads();
+    }
+
+    // conv1x1 + folded BN + ReLU: PC policy planes and 1 value plane, one output element per thread
+    for (int i = tid; i < (PC + 1) * P; i += 256) {
+        const int j = i / P, p = i - j * P;
+        const float* w = (j < PC) ? hp.pconv_w + j * C : hp.vconv_w;
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) { acc = __builtin_fmaf(xs[c * P + p], w[c], acc); }
+        float v = acc + ((j < PC) ? hp.pconv_b[j] : hp.vconv_b[0]);
+        v = v > 0.0f ? v : 0.0f;
+        if (j < PC) { pf[i] = v; } else { vf[p] = v; }
+    }
+    __syncthreads();
+
+    // policy FC (one logit per thread) and value FC1 (one hidden unit per thread)
+    for (int a = tid; a < A; a += 256) {
+        float acc = 0.0f;
+        const int n = PC * P;
+        for (int i = 0; i < n; ++i) { acc = __builtin_fmaf(pf[i], hp.pfc_wT[size_t(i) * A + a], acc); }
+        float v = acc + hp.pfc_b[a];
+        lg[a] = v;
+        logit[size_t(b) * A + a] = v;
+    }
+    for (int o = tid; o < VH; o += 256) {
+        float acc = 0.0f;
+        for (int p = 0; p < P; ++p) { acc = __builtin_fmaf(vf[p], hp.vfc1_wT[size_t(p) * VH + o], acc); }
+        float v = acc + hp.vfc1_b[o];
+        h1[o] = v > 0.0f ? v : 0.0f;
+    }
+    __syncthreads();
+
+    // value FC2 + tanh: one sequential chain (wave 1, lane 0) while wave 0 does the softmax
+    if (tid == 64) {
+        float acc = 0.0f;
+        for (int o = 0; o < VH; ++o) { acc = __builtin_fmaf(h1[o], hp.vfc2_w[o], acc); }
+        value[b] = mz_tanhf(acc + hp.vfc2_b[0]);
+    }
+    if (wave == 0) {
+        float m = -3.4e38f;
+        for (int a = lane; a < A; a += 64) { m = lg[a] > m ? lg[a] : m; }
+        for (int o = 32; o > 0; o >>= 1) { float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
+        for (int a = lane; a < A; a += 64) { lg[a] = mz_expf(lg[a] - m); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float s = 0.0f;
+        for (int a = 0; a < A; ++a) { s += lg[a]; } // index-order sum, every lane redundantly (LDS broadcast)
+        for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lg[a] / s; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+Net::~Net()
+{
+    if (own_stream_ && stream_) { (void)hipStreamDestroy(stream_); }
+}
+
+int Net::init(int device, const mz_net_desc& d, const float* raw, size_t n)
+{
+    if (!netValidateDesc(d)) { return MZ_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+        setError("no such GPU: device %d of %d (libmzgpu has no CPU path; createNetwork(file, -1) is not supported)", device, count);
+        return MZ_ERR_DEVICE;
+    }
+    desc_ = d;
+    device_ = device;
+    MZ_HIP(hipSetDevice(device));
+    if (!stream_) {
+        MZ_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        own_stream_ = true;
+    }
+    return reload(raw, n);
+}
+
+int Net::reload(const float* raw, size_t n)
+{
+    std::vector<float> packed;
+    if (!packWeights(desc_, raw, n, packed, repr_, dyn_, heads_)) { return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    if (!params_.ensure(packed.size())) { setError("hipMalloc of %zu parameter floats failed", packed.size()); return MZ_ERR_DEVICE; }
+    MZ_HIP(hipMemcpy(params_.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    return MZ_OK;
+}
+
+int Net::ensureBatch(int B)
+{
+    if (B <= max_batch_) { return MZ_OK; }
+    MZ_HIP(hipSetDevice(device_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    const size_t act = size_t(B) * hiddenSize();
+    for (auto& a : act_) { if (!a.alloc(act)) { setError("hipMalloc activations failed"); return MZ_ERR_DEVICE; } }
+    if (desc_.type == 1 && !rec_in_.alloc(size_t(B) * (desc_.num_hidden_channels + desc_.num_action_feature_channels) * P())) {
+        setError("hipMalloc dynamics input failed");
+        return MZ_ERR_DEVICE;
+    }
+    max_batch_ = B;
+    return MZ_OK;
+}
+
+template <int H, int W, int CIN_PAD>
+static int launchConvT(const ConvLayer& L, const float* params, const float* in, const float* skip, float* out, int B, hipStream_t s)
+{
+    constexpr size_t lds = size_t(CIN_PAD) * planeStride(H, W) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma<H, W, CIN_PAD>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_mfma<H, W, CIN_PAD>), dim3(B), dim3(256), lds, s, in, L.cin, params + L.w_off, params + L.b_off, skip, out, L.cout,
+                       L.cout_pad / 16);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int Net::launchConv(const ConvLayer& L, const float* in, const float* skip, float* out, int B)
+{
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width;
+#define MZ_CONV_CASE(h, w, c) \
+    if (H == h && W == w && L.cin_pad == c) { return launchConvT<h, w, c>(L, params_.p, in, skip, out, B, stream_); }
+    MZ_CONV_CASE(9, 9, 20)  // Go stem (18 planes)
+    MZ_CONV_CASE(9, 9, 64)  // Go tower
+    MZ_CONV_CASE(9, 9, 68)  // Go MuZero dynamics stem (64 + 1)
+    MZ_CONV_CASE(9, 9, 8)   // small test nets
+    MZ_CONV_CASE(9, 9, 12)
+    MZ_CONV_CASE(9, 9, 16)
+    MZ_CONV_CASE(8, 8, 4)   // Othello stem
+    MZ_CONV_CASE(8, 8, 64)
+    MZ_CONV_CASE(8, 8, 68)
+    MZ_CONV_CASE(8, 8, 8)
+    MZ_CONV_CASE(8, 8, 12)
+    MZ_CONV_CASE(3, 3, 4)   // TicTacToe stem
+    MZ_CONV_CASE(3, 3, 16)
+    MZ_CONV_CASE(3, 3, 20)
+#undef MZ_CONV_CASE
+    setError("no conv3x3 kernel instance for %dx%d board with %d (padded) input channels", H, W, L.cin_pad);
+    return MZ_ERR_ARG;
+}
+
+int Net::runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out)
+{
+    float *x = act_[0].p, *tmp = act_[1].p, *y = act_[2].p;
+    int rc = launchConv(t[0], d_in, nullptr, x, B);
+    if (rc) { return rc; }
+    for (size_t i = 1; i + 1 < t.size(); i += 2) { // ref network_unit.py:14-23
+        if ((rc = launchConv(t[i], x, nullptr, tmp, B))) { return rc; }
+        if ((rc = launchConv(t[i + 1], tmp, x, y, B))) { return rc; }
+        float* s = x; x = y; y = s;
+    }
+    *d_out = x;
+    return MZ_OK;
+}
+
+int Net::launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden)
+{
+    HeadParams hp;
+    const float* p = params_.p;
+    hp.pconv_w = p + heads_.pconv_w; hp.pconv_b = p + heads_.pconv_b; hp.pfc_wT = p + heads_.pfc_wT; hp.pfc_b = p + heads_.pfc_b;
+    hp.vconv_w = p + heads_.vconv_w; hp.vconv_b = p + heads_.vconv_b; hp.vfc1_wT = p + heads_.vfc1_wT; hp.vfc1_b = p + heads_.vfc1_b;
+    hp.vfc2_w = p + heads_.vfc2_w; hp.vfc2_b = p + heads_.vfc2_b;
+    hp.C = desc_.num_hidden_channels; hp.P = P(); hp.A = desc_.action_size; hp.PC = heads_.pc; hp.VH = desc_.num_value_hidden_channels;
+    size_t lds = (size_t(hp.C) * hp.P + size_t(hp.PC) * hp.P + hp.P + hp.VH + hp.A + 16) * sizeof(float);
+    if (lds > 48 * 1024) { MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); }
+    hipLaunchKernelGGL(heads_kernel, dim3(B), dim3(256), lds, stream_, x, hp, policy, logit, value, hidden_dst, dst_idx, scale_hidden ? 1 : 0);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int Net::forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value)
+{
+    if (desc_.type != 0) { setError("forward() called on a %s network", desc_.type == 1 ? "muzero" : "muzero_atari"); return MZ_ERR_STATE; }
+    int rc = ensureBatch(B);
+    if (rc) { return rc; }
+    float* x = nullptr;
+    if ((rc = runTrunk(repr_, d_feat, B, &x))) { return rc; }
+    if (conv_only_) { return MZ_OK; }
+    return launchHeads(x, B, d_policy, d_logit, d_value, nullptr, nullptr, false);
+}
+
+int Net::initial(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, float* d_hidden, const int* d_dst_idx)
+{
+    if (desc_.type != 1) { setError("initialInference() called on a non-muzero network"); return MZ_ERR_STATE; }
+    int rc = ensureBatch(B);
+    if (rc) { return rc; }
+    float* x = nullptr;
+    if ((rc = runTrunk(repr_, d_feat, B, &x))) { return rc; }
+    if (conv_only_) { return MZ_OK; }
+    return launchHeads(x, B, d_policy, d_logit, d_value, d_hidden, d_dst_idx, true);
+}
+
+int Net::recurrent(const float* d_hidden_src, const int* d_src_idx, const float* d_action_planes, const int* d_action_ids, int B, float* d_policy,
+                   float* d_logit, float* d_value, float* d_reward, float* d_hidden_dst, const int* d_dst_idx)
+{
+    if (desc_.type != 1) { setError("recurrentInference() called on a non-muzero network"); return MZ_ERR_STATE; }
+    int rc = ensureBatch(B);
+    if (rc) { return rc; }
+    hipLaunchKernelGGL(build_recurrent_input, dim3(B), dim3(256), 0, stream_, d_hidden_src, d_src_idx, d_action_planes, d_action_ids,
+                       desc_.num_hidden_channels, desc_.num_action_feature_channels, P(), rec_in_.p);
+    MZ_HIP(hipGetLastError());
+    float* x = nullptr;
+    if ((rc = runTrunk(dyn_, rec_in_.p, B, &x))) { return rc; }
+    if (conv_only_) { return MZ_OK; }
+    if (d_reward) { MZ_HIP(hipMemsetAsync(d_reward, 0, size_t(B) * sizeof(float), stream_)); } // board games: no reward head (ref muzero_network.h:129)
+    return launchHeads(x, B, d_policy, d_logit, d_value, d_hidden_dst, d_dst_idx, true);
+}
+
+// ---- MZ_HOST / MZ_DEVICE wrappers ----
+#define MZ_ENSURE(buf, n)                                                          \
+    if (!(buf).ensure(n)) { setError("hipMalloc of staging buffer failed"); return MZ_ERR_DEVICE; }
+
+int Net::forwardAZ_any(const float* feat, int B, float* policy, float* logit, float* value, int where)
+{
+    if (B <= 0 || !feat || !policy || !logit || !value) { setError("forward: bad arguments"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    if (where == MZ_DEVICE) {
+        int rc = forwardAZ(feat, B, policy, logit, value);
+        if (rc) { return rc; }
+        MZ_HIP(hipStreamSynchronize(stream_));
+        return MZ_OK;
+    }
+    const size_t A = desc_.action_size;
+    MZ_ENSURE(io_in_, size_t(B) * featSize()); MZ_ENSURE(io_policy_, B * A); MZ_ENSURE(io_logit_, B * A); MZ_ENSURE(io_value_, B);
+    MZ_HIP(hipMemcpyAsync(io_in_.p, feat, size_t(B) * featSize() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    int rc = forwardAZ(io_in_.p, B, io_policy_.p, io_logit_.p, io_value_.p);
+    if (rc) { return rc; }
+    MZ_HIP(hipMemcpyAsync(policy, io_policy_.p, B * A * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(logit, io_logit_.p, B * A * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(value, io_value_.p, size_t(B) * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    return MZ_OK;
+}
+
+int Net::initial_any(const float* feat, int B, float* policy, float* logit, float* value, float* hidden, int where)
+{
+    if (B <= 0 || !feat || !policy || !logit || !value || !hidden) { setError("initialInference: bad arguments"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    if (where == MZ_DEVICE) {
+        int rc = initial(feat, B, policy, logit, value, hidden, nullptr);
+        if (rc) { return rc; }
+        MZ_HIP(hipStreamSynchronize(stream_));
+        return MZ_OK;
+    }
+    const size_t A = desc_.action_size, HS = hiddenSize();
+    MZ_ENSURE(io_in_, size_t(B) * featSize()); MZ_ENSURE(io_policy_, B * A); MZ_ENSURE(io_logit_, B * A); MZ_ENSURE(io_value_, B);
+    MZ_ENSURE(io_hidden_, B * HS);
+    MZ_HIP(hipMemcpyAsync(io_in_.p, feat, size_t(B) * featSize() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    int rc = initial(io_in_.p, B, io_policy_.p, io_logit_.p, io_value_.p, io_hidden_.p, nullptr);
+    if (rc) { return rc; }
+    MZ_HIP(hipMemcpyAsync(policy, io_policy_.p, B * A * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(logit, io_logit_.p, B * A * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(value, io_value_.p, size_t(B) * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(hidden, io_hidden_.p, B * HS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    return MZ_OK;
+}
+
+int Net::recurrent_any(const float* hidden_in, const float* action, int B, float* policy, float* logit, float* value, float* reward, float* hidden_out,
+                       int where)
+{
+    if (B <= 0 || !hidden_in || !action || !policy || !logit || !value || !hidden_out) { setError("recurrentInference: bad arguments"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    if (where == MZ_DEVICE) {
+        int rc = recurrent(hidden_in, nullptr, action, nullptr, B, policy, logit, value, reward, hidden_out, nullptr);
+        if (rc) { return rc; }
+        MZ_HIP(hipStreamSynchronize(stream_));
+        return MZ_OK;
+    }
+    const size_t A = desc_.action_size, HS = hiddenSize(), AS = size_t(desc_.num_action_feature_channels) * P();
+    MZ_ENSURE(io_in_, B * HS); MZ_ENSURE(io_in2_, B * AS); MZ_ENSURE(io_policy_, B * A); MZ_ENSURE(io_logit_, B * A); MZ_ENSURE(io_value_, B);
+    MZ_ENSURE(io_reward_, B); MZ_ENSURE(io_hidden_, B * HS);
+    MZ_HIP(hipMemcpyAsync(io_in_.p, hidden_in, B * HS * sizeof(float), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(io_in2_.p, action, B * AS * sizeof(float), hipMemcpyHostToDevice, stream_));
+    int rc = recurrent(io_in_.p, nullptr, io_in2_.p, nullptr, B, io_policy_.p, io_logit_.p, io_value_.p, io_reward_.p, io_hidden_.p, nullptr);
+    if (rc) { return rc; }
+    MZ_HIP(hipMemcpyAsync(policy, io_policy_.p, B * A * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(logit, io_logit_.p, B * A * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(value, io_value_.p, size_t(B) * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (reward) { MZ_HIP(hipMemcpyAsync(reward, io_reward_.p, size_t(B) * sizeof(float), hipMemcpyDeviceToHost, stream_)); }
+    MZ_HIP(hipMemcpyAsync(hidden_out, io_hidden_.p, B * HS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    return MZ_OK;
+}
+
+// HIP-event timing on the network's own stream (bench.py roofline leg).  conv FLOPs = 2*MAC of the 3x3
+// convolutions of one forward (SURVEY.md §8d counts conv+linear; the 3x3 convs are > 99.8 % of it).
+int Net::timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops)
+{
+    if (B <= 0 || iters <= 0) { setError("timeForward: bad arguments"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    const size_t A = desc_.action_size;
+    const bool mz = desc_.type == 1;
+    MZ_ENSURE(io_in_, size_t(B) * (mz ? hiddenSize() : featSize())); MZ_ENSURE(io_policy_, B * A); MZ_ENSURE(io_logit_, B * A); MZ_ENSURE(io_value_, B);
+    MZ_ENSURE(io_hidden_, size_t(B) * hiddenSize()); MZ_ENSURE(io_in2_, size_t(B) * desc_.num_action_feature_channels * P()); MZ_ENSURE(io_reward_, B);
+    std::vector<float> h(io_in_.n);
+    uint64_t s = 0x1234567ULL;
+    for (auto& v : h) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; v = ((s >> 33) & 1) ? 1.0f : ((s >> 34) & 3) == 0 ? 0.5f : 0.0f; }
+    MZ_HIP(hipMemcpy(io_in_.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    MZ_HIP(hipMemset(io_in2_.p, 0, io_in2_.n * sizeof(float)));
+    auto run = [&]() -> int {
+        if (!mz) { return forwardAZ(io_in_.p, B, io_policy_.p, io_logit_.p, io_value_.p); }
+        return recurrent(io_in_.p, nullptr, io_in2_.p, nullptr, B, io_policy_.p, io_logit_.p, io_value_.p, io_reward_.p, io_hidden_.p, nullptr);
+    };
+    hipEvent_t e0, e1;
+    MZ_HIP(hipEventCreate(&e0));
+    MZ_HIP(hipEventCreate(&e1));
+    float out[2] = {0, 0};
+    for (int mode = 0; mode < 2; ++mode) {
+        conv_only_ = (mode == 1);
+        int rc = run(); // warm-up
+        if (rc) { conv_only_ = false; return rc; }
+        MZ_HIP(hipStreamSynchronize(stream_));
+        MZ_HIP(hipEventRecord(e0, stream_));
+        for (int i = 0; i < iters; ++i) { if ((rc = run())) { conv_only_ = false; return rc; } }
+        MZ_HIP(hipEventRecord(e1, stream_));
+        MZ_HIP(hipEventSynchronize(e1));
+        MZ_HIP(hipEventElapsedTime(&out[mode], e0, e1));
+        out[mode] /= iters;
+    }
+    conv_only_ = false;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const std::vector<ConvLayer>& t = mz ? dyn_ : repr_;
+    double fl = 0;
+    for (auto& L : t) { fl += 2.0 * 9.0 * L.cin * L.cout * P(); }
+    if (ms_total) { *ms_total = out[0]; }
+    if (ms_conv) { *ms_conv = out[1]; }
+    if (conv_flops) { *conv_flops = fl * B; }
+    return MZ_OK;
+}
+
+} // namespace mz

@@ -1,0 +1,526 @@
+// gfx950 kernels of the search pool.  One wave64 per game (grid = games, block = 64):
+//   select_kernel         wavefront-parallel PUCT arg-max walk root -> leaf (ref actor/mcts.cpp:139-149,181-217)
+//   expand_backup_kernel  bump-allocate + write children (coalesced SoA), then the leaf -> root running-mean
+//                         chain and the value-bound multiset (ref mcts.cpp:151-179,219-228)
+// Bit-exactness: built with -ffp-contract=off; the log()/sqrt() of the PUCT bias come from host-computed
+// tables indexed by N (ref mcts.cpp:57-58 uses the double libm functions); the init-Q sum is an ordered
+// f32 sum over the visited children in storage order; ties follow mcts.cpp:191.
+#include "pool.h"
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+namespace mz {
+
+__global__ void reset_kernel(PoolView v, const int* __restrict__ mask, const int* __restrict__ root_player)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= v.games || (mask && !mask[g])) { return; }
+    const size_t r = size_t(g) * v.cap;
+    v.count[r] = 0; v.mean[r] = 0; v.policy[r] = 0; v.logit[r] = 0; v.noise[r] = 0; v.value[r] = 0; v.reward[r] = 0;
+    v.first_child[r] = -1; v.num_children[r] = 0; v.action[r] = -1; v.hslot[r] = -1;
+    v.player[r] = static_cast<unsigned char>(root_player[g]);
+    v.num_nodes[g] = 1;
+    v.path_len[g] = 0;
+    v.bound_size[g] = 0;
+    v.bound_lo[g] = 0; v.bound_hi[g] = 0;
+}
+
+// normalized mean of a visited child (ref mcts.cpp:40-53 with virtual_loss == 0, which ActorGroup never uses)
+__device__ __forceinline__ float normalizedMean(const PoolView& v, float reward, float mean, float cnt, int player, int bsize, float lo, float hi)
+{
+    float value = reward + v.gamma * mean;
+    if (v.value_rescale) {
+        if (bsize < 2) { return 1.0f; }
+        value = (value - lo) / (hi - lo);
+        value = 2 * value - 1;
+        value = value < -1.0f ? -1.0f : value; // fmax(-1, .) then fmin(1, .), exact
+        value = value > 1.0f ? 1.0f : value;
+    }
+    value = (player == v.flipping_player) ? -value : value;
+    return (value * cnt - 0.0f) / (cnt + 0.0f);
+}
+
+__device__ __forceinline__ bool better(float s1, float p1, int i1, float s2, float p2, int i2)
+{
+    // (score, policy) lexicographic, first index wins full ties (ref mcts.cpp:189-195)
+    return (s1 > s2) || (s1 == s2 && (p1 > p2 || (p1 == p2 && i1 < i2)));
+}
+
+__global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __restrict__ start)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const size_t base = size_t(g) * v.cap;
+    int* path = v.path + size_t(g) * v.max_depth;
+    int* pact = v.path_action + size_t(g) * v.max_depth;
+    const int bsize = v.bound_size[g];
+    const float lo = v.bound_lo[g], hi = v.bound_hi[g];
+    int node = 0, depth = 1;
+    if (lane == 0) { path[0] = 0; pact[0] = v.action[base]; }
+    const int st = start ? start[g] : 0;
+    if (st > 0) { // Gumbel: path = root + PUCT path below the chosen candidate (ref gumbel_zero.cpp:83-85)
+        node = st;
+        if (lane == 0) { path[1] = st; pact[1] = v.action[base + st]; }
+        depth = 2;
+    }
+    while (true) {
+        const int nc = v.num_children[base + node];
+        if (nc == 0 || depth >= v.max_depth) { break; }
+        const size_t fc = base + v.first_child[base + node];
+        const int N = static_cast<int>(v.count[base + node] - 1);
+        // ---- init Q: ordered sum over visited children (ref mcts.cpp:200-217) ----
+        float sum_of_win = 0.0f, sum = 0.0f;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int i = c0 + lane;
+            float q = 0.0f;
+            bool visited = false;
+            if (i < nc) {
+                const float cnt = v.count[fc + i];
+                visited = (cnt != 0.0f);
+                if (visited) { q = normalizedMean(v, v.reward[fc + i], v.mean[fc + i], cnt, v.player[fc + i], bsize, lo, hi); }
+            }
+            unsigned long long m = __ballot(visited);
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                sum_of_win += __shfl(q, j);
+                sum += 1;
+            }
+        }
+        const float init_q = v.atari_init_q ? (sum > 0 ? sum_of_win / sum : 1.0f) : (sum_of_win - 1) / (sum + 1);
+        // ---- PUCT score + arg-max (ref mcts.cpp:55-61,181-198) ----
+        const float bias = v.bias_tab[N];
+        const double sqrtN = v.sqrt_tab[N];
+        float bs = -FLT_MAX, bp = -FLT_MAX;
+        int bi = INT_MAX;
+        for (int i = lane; i < nc; i += 64) {
+            const float cnt = v.count[fc + i], pol = v.policy[fc + i];
+            const float bpol = bias * pol;
+            const float value_u = static_cast<float>((static_cast<double>(bpol) * sqrtN) / static_cast<double>(1 + cnt));
+            const float value_q = (cnt == 0.0f) ? init_q : normalizedMean(v, v.reward[fc + i], v.mean[fc + i], cnt, v.player[fc + i], bsize, lo, hi);
+            const float score = value_u + value_q;
+            if (better(score, pol, i, bs, bp, bi)) { bs = score; bp = pol; bi = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float s2 = __shfl_xor(bs, o), p2 = __shfl_xor(bp, o);
+            const int i2 = __shfl_xor(bi, o);
+            if (better(s2, p2, i2, bs, bp, bi)) { bs = s2; bp = p2; bi = i2; }
+        }
+        node = v.first_child[base + node] + bi;
+        if (lane == 0) { path[depth] = node; pact[depth] = v.action[base + node]; }
+        ++depth;
+    }
+    if (lane == 0) { v.path_len[g] = depth; }
+}
+
+__global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int* __restrict__ cand_count, const int* __restrict__ cand_action,
+                                                           const float* __restrict__ cand_policy, const float* __restrict__ cand_logit,
+                                                           const int* __restrict__ cand_player, const float* __restrict__ value_in,
+                                                           const float* __restrict__ reward_in, int hslot, int* __restrict__ err)
+{
+    extern __shared__ float lds[]; // value-bound multiset: keys [bound_cap] then counts [bound_cap] (only with value_rescale)
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const size_t base = size_t(g) * v.cap;
+    const int len = v.path_len[g];
+    if (len <= 0) { return; }
+    const int* path = v.path + size_t(g) * v.max_depth;
+    const int leaf = path[len - 1];
+    const int k = cand_count[g];
+    // ---- expand (ref mcts.cpp:151-164, tree.h:71-77) ----
+    if (k > 0) {
+        const int fc = v.num_nodes[g];
+        if (fc + k > v.cap) {
+            if (lane == 0) { atomicExch(err, MZ_ERR_CAPACITY); }
+            return;
+        }
+        const unsigned char pl = static_cast<unsigned char>(cand_player[g]);
+        for (int i = lane; i < k; i += 64) {
+            const size_t n = base + fc + i, c = size_t(g) * v.A + i;
+            v.action[n] = cand_action[c];
+            v.player[n] = pl;
+            v.policy[n] = cand_policy[c];
+            v.logit[n] = cand_logit[c];
+            v.count[n] = 0; v.mean[n] = 0; v.noise[n] = 0; v.value[n] = 0; v.reward[n] = 0;
+            v.num_children[n] = 0; v.first_child[n] = -1; v.hslot[n] = -1;
+        }
+        if (lane == 0) {
+            v.first_child[base + leaf] = fc;
+            v.num_children[base + leaf] = k;
+            v.num_nodes[g] = fc + k;
+        }
+    }
+    if (lane == 0 && hslot >= 0) { v.hslot[base + leaf] = hslot; }
+    // ---- backup (ref mcts.cpp:166-179): a serial leaf -> root dependence chain, done by lane 0 ----
+    if (lane != 0) { return; }
+    int bsize = 0;
+    float* bkey = lds;                                     // value-bound multiset, LDS copy (lane 0 only)
+    int* bcnt = reinterpret_cast<int*>(lds + v.bound_cap);
+    if (v.value_rescale) {
+        bsize = v.bound_size[g];
+        for (int j = 0; j < bsize; ++j) { bkey[j] = v.bound_key[size_t(g) * v.bound_cap + j]; bcnt[j] = v.bound_cnt[size_t(g) * v.bound_cap + j]; }
+    }
+    const float val = value_in[g], rew = reward_in[g];
+    v.value[base + leaf] = val;
+    v.reward[base + leaf] = rew;
+    float updated = val;
+    for (int i = len - 1; i >= 0; --i) {
+        const size_t n = base + path[i];
+        const float r = (i == len - 1) ? rew : v.reward[n];
+        float mean = v.mean[n], cnt = v.count[n];
+        const float old_mean = r + v.gamma * mean;
+        // MCTSNode::add(value, 1.0f) (ref mcts.cpp:20-28); count + 1 <= 0 cannot happen for count >= 0
+        cnt += 1.0f;
+        mean += 1.0f * (updated - mean) / cnt;
+        v.mean[n] = mean;
+        v.count[n] = cnt;
+        if (v.value_rescale) { // updateTreeValueBound(old, new) (ref mcts.cpp:219-228): std::map<float,int> as an unordered array
+            const float new_mean = r + v.gamma * mean;
+            for (int j = 0; j < bsize; ++j) {
+                if (bkey[j] == old_mean) {
+                    if (--bcnt[j] == 0) { --bsize; bkey[j] = bkey[bsize]; bcnt[j] = bcnt[bsize]; }
+                    break;
+                }
+            }
+            int j = 0;
+            for (; j < bsize; ++j) { if (bkey[j] == new_mean) { ++bcnt[j]; break; } }
+            if (j == bsize && bsize < v.bound_cap) { bkey[bsize] = new_mean; bcnt[bsize] = 1; ++bsize; }
+        }
+        updated = r + v.gamma * updated;
+    }
+    if (v.value_rescale) {
+        float lo = 0.0f, hi = 0.0f;
+        for (int j = 0; j < bsize; ++j) {
+            v.bound_key[size_t(g) * v.bound_cap + j] = bkey[j];
+            v.bound_cnt[size_t(g) * v.bound_cap + j] = bcnt[j];
+            if (j == 0 || bkey[j] < lo) { lo = bkey[j]; }
+            if (j == 0 || bkey[j] > hi) { hi = bkey[j]; }
+        }
+        v.bound_size[g] = bsize;
+        v.bound_lo[g] = lo;
+        v.bound_hi[g] = hi;
+    }
+}
+
+} // namespace mz
+
+namespace mz {
+
+__global__ __launch_bounds__(64) void root_set_noise_kernel(PoolView v, const int* __restrict__ mask, const float* __restrict__ policy,
+                                                            const float* __restrict__ logit, const float* __restrict__ noise)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (mask && !mask[g]) { return; }
+    const size_t base = size_t(g) * v.cap;
+    const int nc = v.num_children[base];
+    const size_t fc = base + v.first_child[base];
+    for (int i = lane; i < nc; i += 64) {
+        const size_t c = size_t(g) * v.A + i;
+        v.policy[fc + i] = policy[c];
+        v.logit[fc + i] = logit[c];
+        v.noise[fc + i] = noise[c];
+    }
+}
+
+// gather the root's children into compact [games][A] arrays (f: action-major block of 8 float arrays, then 5 per-game arrays)
+__global__ __launch_bounds__(64) void root_read_kernel(PoolView v, float* __restrict__ f, int* __restrict__ iv)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const size_t base = size_t(g) * v.cap, GA = size_t(v.games) * v.A;
+    const int nc = v.num_children[base];
+    const size_t fc = base + (nc > 0 ? v.first_child[base] : 0);
+    for (int i = lane; i < nc; i += 64) {
+        const size_t c = size_t(g) * v.A + i;
+        f[0 * GA + c] = v.count[fc + i];
+        f[1 * GA + c] = v.mean[fc + i];
+        f[2 * GA + c] = v.policy[fc + i];
+        f[3 * GA + c] = v.logit[fc + i];
+        f[4 * GA + c] = v.noise[fc + i];
+        f[5 * GA + c] = v.value[fc + i];
+        f[6 * GA + c] = v.reward[fc + i];
+        iv[v.games + c] = v.action[fc + i];
+    }
+    if (lane == 0) {
+        float* pg = f + 7 * GA;
+        pg[0 * v.games + g] = v.count[base];
+        pg[1 * v.games + g] = v.mean[base];
+        pg[2 * v.games + g] = v.value[base];
+        pg[3 * v.games + g] = v.bound_lo[g];
+        pg[4 * v.games + g] = v.bound_hi[g];
+        iv[g] = nc;
+        iv[v.games + GA + g] = v.bound_size[g];
+    }
+}
+
+// MuZero: hidden-state slab slots for the leaves of the last select (parent slot -> source, dst_slot -> destination)
+__global__ void hidden_index_kernel(PoolView v, int slots_per_game, int dst_slot, int* __restrict__ src_idx, int* __restrict__ dst_idx,
+                                    int* __restrict__ action_ids)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= v.games) { return; }
+    const size_t base = size_t(g) * v.cap;
+    const int len = v.path_len[g];
+    const int* path = v.path + size_t(g) * v.max_depth;
+    const int leaf = path[len - 1];
+    const int parent = len >= 2 ? path[len - 2] : 0;
+    src_idx[g] = g * slots_per_game + (len >= 2 ? v.hslot[base + parent] : 0);
+    dst_idx[g] = g * slots_per_game + dst_slot;
+    action_ids[g] = v.action[base + leaf];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+Pool::~Pool()
+{
+    if (own_stream_ && stream_) { (void)hipStreamDestroy(stream_); }
+}
+
+#define MZ_ALLOC(buf, n) \
+    if (!(buf).alloc(n)) { setError("pool: allocation of %zu elements failed (%s)", size_t(n), #buf); return MZ_ERR_DEVICE; }
+
+int Pool::init(int device, int games, int nodes_per_game, int action_size, const mz_search_cfg& cfg, hipStream_t shared_stream)
+{
+    if (games <= 0 || nodes_per_game <= 0 || action_size <= 0 || cfg.num_simulation < 0) { setError("pool: bad arguments"); return MZ_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+        setError("no such GPU: device %d of %d (libmzgpu has no CPU path)", device, count);
+        return MZ_ERR_DEVICE;
+    }
+    device_ = device;
+    cfg_ = cfg;
+    MZ_HIP(hipSetDevice(device));
+    if (shared_stream) { stream_ = shared_stream; }
+    else { MZ_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }
+
+    const size_t G = games, NN = G * nodes_per_game, GA = G * action_size;
+    const int max_depth = cfg.num_simulation + 3; // root + one new level per simulation (+1 Gumbel prefix, +1 slack)
+    const int bound_cap = cfg.value_rescale ? cfg.num_simulation + 3 : 1;
+    MZ_ALLOC(f_nodes_, NN * 7); MZ_ALLOC(i_nodes_, NN * 4); MZ_ALLOC(player_, NN);
+    MZ_ALLOC(game_i_, G * 3 + 1); MZ_ALLOC(game_f_, G * 2);
+    MZ_ALLOC(path_, G * max_depth); MZ_ALLOC(path_action_, G * max_depth);
+    MZ_ALLOC(bound_key_, G * bound_cap); MZ_ALLOC(bound_cnt_, G * bound_cap);
+    MZ_ALLOC(bias_tab_, cfg.num_simulation + 3); MZ_ALLOC(sqrt_tab_, cfg.num_simulation + 3);
+    v_.games = games; v_.cap = nodes_per_game; v_.A = action_size; v_.max_depth = max_depth;
+    float* f = f_nodes_.p;
+    v_.count = f; v_.mean = f + NN; v_.policy = f + 2 * NN; v_.logit = f + 3 * NN; v_.noise = f + 4 * NN; v_.value = f + 5 * NN; v_.reward = f + 6 * NN;
+    int* ip = i_nodes_.p;
+    v_.first_child = ip; v_.num_children = ip + NN; v_.action = ip + 2 * NN; v_.hslot = ip + 3 * NN;
+    v_.player = player_.p;
+    v_.num_nodes = game_i_.p; v_.path_len = game_i_.p + G; v_.bound_size = game_i_.p + 2 * G;
+    v_.path = path_.p; v_.path_action = path_action_.p;
+    v_.bound_key = bound_key_.p; v_.bound_cnt = bound_cnt_.p; v_.bound_lo = game_f_.p; v_.bound_hi = game_f_.p + G; v_.bound_cap = bound_cap;
+    v_.gamma = cfg.reward_discount; v_.value_rescale = cfg.value_rescale; v_.flipping_player = cfg.flipping_player; v_.atari_init_q = cfg.atari_init_q;
+
+    // PUCT tables (ref mcts.cpp:57-58): float puct_bias = init + log((1 + N + base) / base)  [log = double libm];  sqrt(N) in double
+    std::vector<float> bias(cfg.num_simulation + 3);
+    std::vector<double> sq(cfg.num_simulation + 3);
+    for (int N = 0; N < cfg.num_simulation + 3; ++N) {
+        const float ratio = (1 + N + cfg.puct_base) / cfg.puct_base;
+        bias[N] = cfg.puct_init + ::log(static_cast<double>(ratio));
+        sq[N] = ::sqrt(static_cast<double>(N));
+    }
+    MZ_HIP(hipMemcpy(bias_tab_.p, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    MZ_HIP(hipMemcpy(sqrt_tab_.p, sq.data(), sq.size() * sizeof(double), hipMemcpyHostToDevice));
+    v_.bias_tab = bias_tab_.p;
+    v_.sqrt_tab = sqrt_tab_.p;
+    MZ_HIP(hipMemset(game_i_.p, 0, game_i_.n * sizeof(int)));
+
+    // staging
+    MZ_ALLOC(h_cand_count_, G); MZ_ALLOC(h_cand_action_, GA); MZ_ALLOC(h_cand_player_, G); MZ_ALLOC(h_cand_policy_, GA); MZ_ALLOC(h_cand_logit_, GA);
+    MZ_ALLOC(h_value_, G); MZ_ALLOC(h_reward_, G); MZ_ALLOC(h_path_len_, G); MZ_ALLOC(h_path_, G * max_depth); MZ_ALLOC(h_path_action_, G * max_depth);
+    MZ_ALLOC(h_start_, G);
+    MZ_ALLOC(d_cand_count_, G); MZ_ALLOC(d_cand_action_, GA); MZ_ALLOC(d_cand_player_, G); MZ_ALLOC(d_cand_policy_, GA); MZ_ALLOC(d_cand_logit_, GA);
+    MZ_ALLOC(d_value_, G); MZ_ALLOC(d_reward_, G); MZ_ALLOC(d_start_, G); MZ_ALLOC(d_mask_, G);
+    MZ_ALLOC(d_rr_f_, 7 * GA + 5 * G); MZ_ALLOC(d_rr_i_, G + GA + G); MZ_ALLOC(h_rr_f_, 7 * GA + 5 * G); MZ_ALLOC(h_rr_i_, G + GA + G);
+    std::vector<int> rp(games, 2);
+    return resetSearch(nullptr, rp.data());
+}
+
+int Pool::checkError()
+{
+    int e = 0;
+    MZ_HIP(hipMemcpyAsync(&e, game_i_.p + size_t(v_.games) * 3, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    if (e) {
+        setError("search pool capacity exceeded (nodes_per_game = %d)", v_.cap);
+        (void)hipMemsetAsync(game_i_.p + size_t(v_.games) * 3, 0, sizeof(int), stream_);
+        return e;
+    }
+    return MZ_OK;
+}
+
+int Pool::resetSearch(const uint8_t* mask, const int* root_player)
+{
+    if (!root_player) { setError("reset_search: root_player is NULL"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    const int G = v_.games;
+    // d_start_ doubles as the root-player staging; both uploads complete before the kernel runs (same stream)
+    for (int g = 0; g < G; ++g) { h_start_.p[g] = root_player[g]; h_cand_player_.p[g] = mask ? (mask[g] ? 1 : 0) : 1; }
+    MZ_HIP(hipMemcpyAsync(d_start_.p, h_start_.p, G * sizeof(int), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_mask_.p, h_cand_player_.p, G * sizeof(int), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(reset_kernel, dim3((G + 255) / 256), dim3(256), 0, stream_, v_, d_mask_.p, d_start_.p);
+    MZ_HIP(hipGetLastError());
+    MZ_HIP(hipStreamSynchronize(stream_)); // the pinned mirrors are reused by the caller right after
+    return MZ_OK;
+}
+
+int Pool::selectAsync(const int* d_start_node)
+{
+    hipLaunchKernelGGL(select_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, d_start_node);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int Pool::select(const int* start_node, int* path_len, int* paths, int* path_action)
+{
+    MZ_HIP(hipSetDevice(device_));
+    const size_t G = v_.games;
+    const int* d_start = nullptr;
+    if (start_node) {
+        memcpy(h_start_.p, start_node, G * sizeof(int));
+        MZ_HIP(hipMemcpyAsync(d_start_.p, h_start_.p, G * sizeof(int), hipMemcpyHostToDevice, stream_));
+        d_start = d_start_.p;
+    }
+    int rc = selectAsync(d_start);
+    if (rc) { return rc; }
+    MZ_HIP(hipMemcpyAsync(h_path_len_.p, v_.path_len, G * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(h_path_.p, v_.path, G * v_.max_depth * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(h_path_action_.p, v_.path_action, G * v_.max_depth * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    if (path_len) { memcpy(path_len, h_path_len_.p, G * sizeof(int)); }
+    if (paths) { memcpy(paths, h_path_.p, G * v_.max_depth * sizeof(int)); }
+    if (path_action) { memcpy(path_action, h_path_action_.p, G * v_.max_depth * sizeof(int)); }
+    return MZ_OK;
+}
+
+int Pool::expandBackupAsync(int hslot)
+{
+    const size_t lds = v_.value_rescale ? size_t(v_.bound_cap) * 8 : 0;
+    hipLaunchKernelGGL(expand_backup_kernel, dim3(v_.games), dim3(64), lds, stream_, v_, d_cand_count_.p, d_cand_action_.p, d_cand_policy_.p,
+                       d_cand_logit_.p, d_cand_player_.p, d_value_.p, d_reward_.p, hslot, game_i_.p + size_t(v_.games) * 3);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int Pool::expandBackupStaged(int hslot)
+{
+    const size_t G = v_.games, GA = G * v_.A;
+    MZ_HIP(hipMemcpyAsync(d_cand_count_.p, h_cand_count_.p, G * sizeof(int), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_cand_action_.p, h_cand_action_.p, GA * sizeof(int), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_cand_policy_.p, h_cand_policy_.p, GA * sizeof(float), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_cand_logit_.p, h_cand_logit_.p, GA * sizeof(float), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_cand_player_.p, h_cand_player_.p, G * sizeof(int), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_value_.p, h_value_.p, G * sizeof(float), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_reward_.p, h_reward_.p, G * sizeof(float), hipMemcpyHostToDevice, stream_));
+    return expandBackupAsync(hslot);
+}
+
+int Pool::expandBackup(const int* cand_count, const int* cand_action, const float* cand_policy, const float* cand_logit, const int* cand_player,
+                       const float* value, const float* reward)
+{
+    if (!cand_count || !cand_action || !cand_policy || !cand_logit || !cand_player || !value) { setError("expand_backup: NULL argument"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    const size_t G = v_.games, GA = G * v_.A;
+    for (size_t g = 0; g < G; ++g) {
+        if (cand_count[g] < 0 || cand_count[g] > v_.A) { setError("expand_backup: cand_count[%zu] = %d out of range", g, cand_count[g]); return MZ_ERR_ARG; }
+    }
+    memcpy(h_cand_count_.p, cand_count, G * sizeof(int));
+    memcpy(h_cand_action_.p, cand_action, GA * sizeof(int));
+    memcpy(h_cand_policy_.p, cand_policy, GA * sizeof(float));
+    memcpy(h_cand_logit_.p, cand_logit, GA * sizeof(float));
+    memcpy(h_cand_player_.p, cand_player, G * sizeof(int));
+    memcpy(h_value_.p, value, G * sizeof(float));
+    if (reward) { memcpy(h_reward_.p, reward, G * sizeof(float)); } else { memset(h_reward_.p, 0, G * sizeof(float)); }
+    int rc = expandBackupStaged(hslot_next_);
+    if (rc) { return rc; }
+    return checkError();
+}
+
+int Pool::rootSetNoise(const uint8_t* mask, const float* policy, const float* logit, const float* noise)
+{
+    if (!policy || !logit || !noise) { setError("root_set_noise: NULL argument"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    const size_t G = v_.games, GA = G * v_.A;
+    for (size_t g = 0; g < G; ++g) { h_cand_count_.p[g] = mask ? (mask[g] ? 1 : 0) : 1; }
+    memcpy(h_cand_policy_.p, policy, GA * sizeof(float));
+    memcpy(h_cand_logit_.p, logit, GA * sizeof(float));
+    // noise travels through the (otherwise idle) root-read float staging
+    memcpy(h_rr_f_.p, noise, GA * sizeof(float));
+    MZ_HIP(hipMemcpyAsync(d_mask_.p, h_cand_count_.p, G * sizeof(int), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_cand_policy_.p, h_cand_policy_.p, GA * sizeof(float), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_cand_logit_.p, h_cand_logit_.p, GA * sizeof(float), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_rr_f_.p, h_rr_f_.p, GA * sizeof(float), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(root_set_noise_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, d_mask_.p, d_cand_policy_.p, d_cand_logit_.p, d_rr_f_.p);
+    MZ_HIP(hipGetLastError());
+    MZ_HIP(hipStreamSynchronize(stream_));
+    return MZ_OK;
+}
+
+int Pool::rootRead(int* num_children, int* action, float* count, float* mean, float* policy, float* logit, float* noise, float* value, float* reward,
+                   float* root_count, float* root_mean, float* root_value, float* bound_lo, float* bound_hi, int* bound_size)
+{
+    MZ_HIP(hipSetDevice(device_));
+    const size_t G = v_.games, GA = G * v_.A;
+    hipLaunchKernelGGL(root_read_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, d_rr_f_.p, d_rr_i_.p);
+    MZ_HIP(hipGetLastError());
+    MZ_HIP(hipMemcpyAsync(h_rr_f_.p, d_rr_f_.p, (7 * GA + 5 * G) * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(h_rr_i_.p, d_rr_i_.p, (G + GA + G) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    const float* f = h_rr_f_.p;
+    const int* iv = h_rr_i_.p;
+    float* outs[7] = {count, mean, policy, logit, noise, value, reward};
+    for (int k = 0; k < 7; ++k) { if (outs[k]) { memcpy(outs[k], f + k * GA, GA * sizeof(float)); } }
+    float* pg[5] = {root_count, root_mean, root_value, bound_lo, bound_hi};
+    for (int k = 0; k < 5; ++k) { if (pg[k]) { memcpy(pg[k], f + 7 * GA + k * G, G * sizeof(float)); } }
+    if (num_children) { memcpy(num_children, iv, G * sizeof(int)); }
+    if (action) { memcpy(action, iv + G, GA * sizeof(int)); }
+    if (bound_size) { memcpy(bound_size, iv + G + GA, G * sizeof(int)); }
+    return MZ_OK;
+}
+
+int Pool::hiddenIndexAsync(int slots_per_game, int dst_slot, int* d_src_idx, int* d_dst_idx, int* d_action_ids)
+{
+    hipLaunchKernelGGL(hidden_index_kernel, dim3((v_.games + 255) / 256), dim3(256), 0, stream_, v_, slots_per_game, dst_slot, d_src_idx, d_dst_idx,
+                       d_action_ids);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int Pool::numNodes(int game)
+{
+    if (game < 0 || game >= v_.games) { setError("num_nodes: bad game index"); return MZ_ERR_ARG; }
+    int n = 0;
+    MZ_HIP(hipSetDevice(device_));
+    MZ_HIP(hipMemcpyAsync(&n, v_.num_nodes + game, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    return n;
+}
+
+int Pool::readNodes(int game, int n, int* action, int* player, int* num_children, int* first_child, float* mean, float* count, float* policy,
+                    float* logit, float* noise, float* value, float* reward)
+{
+    if (game < 0 || game >= v_.games || n < 0 || n > v_.cap) { setError("read_nodes: bad arguments"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    const size_t base = size_t(game) * v_.cap;
+    auto cp = [&](void* dst, const void* src, size_t bytes) { return dst ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) : hipSuccess; };
+    MZ_HIP(cp(action, v_.action + base, n * sizeof(int)));
+    MZ_HIP(cp(num_children, v_.num_children + base, n * sizeof(int)));
+    MZ_HIP(cp(first_child, v_.first_child + base, n * sizeof(int)));
+    MZ_HIP(cp(mean, v_.mean + base, n * sizeof(float)));
+    MZ_HIP(cp(count, v_.count + base, n * sizeof(float)));
+    MZ_HIP(cp(policy, v_.policy + base, n * sizeof(float)));
+    MZ_HIP(cp(logit, v_.logit + base, n * sizeof(float)));
+    MZ_HIP(cp(noise, v_.noise + base, n * sizeof(float)));
+    MZ_HIP(cp(value, v_.value + base, n * sizeof(float)));
+    MZ_HIP(cp(reward, v_.reward + base, n * sizeof(float)));
+    if (player) {
+        std::vector<unsigned char> p(n);
+        MZ_HIP(hipMemcpy(p.data(), v_.player + base, n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) { player[i] = p[i]; }
+    }
+    return MZ_OK;
+}
+
+} // namespace mz

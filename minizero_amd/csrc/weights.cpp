@@ -1,0 +1,213 @@
+// Host-side weight handling of libmzgpu: blob manifest (state_dict order of ref network/py/*.py modules),
+// deterministic synthetic generator, eval-mode BatchNorm folding (ref network_unit.py:9-12, eps 1e-5) and
+// packing into the layouts the gfx950 kernels read:
+//   conv3x3  : wp[((t*CG + cg)*OT + ot)*64 + lane] = w'[16*ot + (lane&15)][4*cg + (lane>>4)][t]
+//              (one coalesced 256-B read per wave = one 16x16x4 MFMA "A" fragment; zero padded)
+//   linear   : transposed to [in][out] so that consecutive lanes (= outputs) read consecutive floats
+#include "net.h"
+#include <cmath>
+#include <cstring>
+
+namespace mz {
+
+namespace {
+enum Kind { W, Bv, BN_G, BN_B, BN_M, BN_V };
+struct Spec { size_t n; int fan_in; Kind kind; };
+
+int policyChannels(const mz_net_desc& d)
+{
+    int hw = d.hidden_channel_height * d.hidden_channel_width;
+    return (d.action_size + hw - 1) / hw;
+}
+void convBN(std::vector<Spec>& m, int cin, int cout, int k)
+{
+    m.push_back({size_t(cout) * cin * k * k, cin * k * k, W});
+    m.push_back({size_t(cout), cin * k * k, Bv});
+    m.push_back({size_t(cout), 0, BN_G});
+    m.push_back({size_t(cout), 0, BN_B});
+    m.push_back({size_t(cout), 0, BN_M});
+    m.push_back({size_t(cout), 0, BN_V});
+}
+void lin(std::vector<Spec>& m, int in, int out)
+{
+    m.push_back({size_t(out) * in, in, W});
+    m.push_back({size_t(out), in, Bv});
+}
+std::vector<Spec> manifest(const mz_net_desc& d)
+{
+    std::vector<Spec> m;
+    const int C = d.num_hidden_channels, hw = d.hidden_channel_height * d.hidden_channel_width;
+    auto trunk = [&](int cin) {
+        convBN(m, cin, C, 3);
+        for (int b = 0; b < d.num_blocks; ++b) { convBN(m, C, C, 3); convBN(m, C, C, 3); }
+    };
+    trunk(d.num_input_channels);
+    if (d.type == 1) { trunk(C + d.num_action_feature_channels); }
+    int pc = policyChannels(d);
+    convBN(m, C, pc, 1);
+    lin(m, pc * hw, d.action_size);
+    convBN(m, C, 1, 1);
+    lin(m, hw, d.num_value_hidden_channels);
+    lin(m, d.num_value_hidden_channels, 1);
+    return m;
+}
+inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+} // namespace
+
+bool netValidateDesc(const mz_net_desc& d)
+{
+    if (d.type != 0 && d.type != 1) { setError("network type %d not supported yet (alphazero=0, muzero=1)", d.type); return false; }
+    if (d.discrete_value_size != 1) { setError("discrete_value_size %d not supported yet", d.discrete_value_size); return false; }
+    if (d.input_channel_height != d.hidden_channel_height || d.input_channel_width != d.hidden_channel_width) {
+        setError("input and hidden planes must have the same size (board games)");
+        return false;
+    }
+    if (d.num_hidden_channels <= 0 || d.num_blocks < 0 || d.action_size <= 0 || d.num_input_channels <= 0) { setError("bad network descriptor"); return false; }
+    return true;
+}
+
+long netParamCount(const mz_net_desc& d)
+{
+    size_t n = 0;
+    for (auto& s : manifest(d)) { n += s.n; }
+    return static_cast<long>(n);
+}
+
+bool netGenerate(const mz_net_desc& d, uint64_t seed, float* out)
+{
+    size_t idx = 0;
+    for (auto& s : manifest(d)) {
+        float lo, hi;
+        if (s.kind == W || s.kind == Bv) {
+            float bound = 1.0f / sqrtf(static_cast<float>(s.fan_in));
+            lo = -bound;
+            hi = bound;
+        } else if (s.kind == BN_G || s.kind == BN_V) {
+            lo = 0.5f;
+            hi = 1.5f;
+        } else {
+            lo = -0.1f;
+            hi = 0.1f;
+        }
+        for (size_t i = 0; i < s.n; ++i, ++idx) {
+            uint64_t z = mix64(seed + (idx + 1) * 0x9E3779B97F4A7C15ULL);
+            float u = static_cast<float>(z >> 40) * 5.9604644775390625e-08f;
+            out[idx] = lo + (hi - lo) * u;
+        }
+    }
+    return true;
+}
+
+// ---- folding + packing ----
+namespace {
+struct Folded { int cin, cout, k; std::vector<float> w, b; };
+
+Folded takeConvBN(const float*& p, int cin, int cout, int k)
+{
+    Folded f{cin, cout, k, {}, {}};
+    const size_t per = size_t(cin) * k * k, nw = per * cout;
+    const float *w = p, *b = p + nw, *g = b + cout, *be = g + cout, *mu = be + cout, *var = mu + cout;
+    p = var + cout;
+    f.w.resize(nw);
+    f.b.resize(cout);
+    for (int oc = 0; oc < cout; ++oc) {
+        const float s = g[oc] / sqrtf(var[oc] + 1e-5f);
+        for (size_t i = 0; i < per; ++i) { f.w[oc * per + i] = w[oc * per + i] * s; }
+        const float t = (b[oc] - mu[oc]) * s;
+        f.b[oc] = t + be[oc];
+    }
+    return f;
+}
+
+size_t append(std::vector<float>& dst, const std::vector<float>& src)
+{
+    // keep every tensor 64-float (256 B) aligned so wave-wide reads stay on cache-line boundaries
+    while (dst.size() % 64) { dst.push_back(0.0f); }
+    size_t off = dst.size();
+    dst.insert(dst.end(), src.begin(), src.end());
+    return off;
+}
+
+ConvLayer packConv3(std::vector<float>& dst, const Folded& f)
+{
+    ConvLayer L;
+    L.cin = f.cin;
+    L.cin_pad = (f.cin + 3) / 4 * 4;
+    L.cout = f.cout;
+    L.cout_pad = (f.cout + 15) / 16 * 16;
+    const int CG = L.cin_pad / 4, OT = L.cout_pad / 16;
+    std::vector<float> wp(size_t(9) * CG * OT * 64, 0.0f);
+    for (int t = 0; t < 9; ++t)
+        for (int cg = 0; cg < CG; ++cg)
+            for (int ot = 0; ot < OT; ++ot)
+                for (int l = 0; l < 64; ++l) {
+                    int oc = 16 * ot + (l & 15), c = 4 * cg + (l >> 4);
+                    if (oc < f.cout && c < f.cin) { wp[((size_t(t) * CG + cg) * OT + ot) * 64 + l] = f.w[(size_t(oc) * f.cin + c) * 9 + t]; }
+                }
+    L.w_off = append(dst, wp);
+    std::vector<float> b(L.cout_pad, 0.0f);
+    for (int oc = 0; oc < f.cout; ++oc) { b[oc] = f.b[oc]; }
+    L.b_off = append(dst, b);
+    return L;
+}
+
+std::vector<ConvLayer> packTrunk(std::vector<float>& dst, const float*& p, int cin, const mz_net_desc& d)
+{
+    std::vector<ConvLayer> t;
+    t.push_back(packConv3(dst, takeConvBN(p, cin, d.num_hidden_channels, 3)));
+    for (int b = 0; b < 2 * d.num_blocks; ++b) { t.push_back(packConv3(dst, takeConvBN(p, d.num_hidden_channels, d.num_hidden_channels, 3))); }
+    return t;
+}
+
+std::vector<float> transposeLinear(const float* w, int in, int out)
+{
+    std::vector<float> t(size_t(in) * out);
+    for (int o = 0; o < out; ++o)
+        for (int i = 0; i < in; ++i) { t[size_t(i) * out + o] = w[size_t(o) * in + i]; }
+    return t;
+}
+} // namespace
+
+bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<float>& packed, std::vector<ConvLayer>& repr, std::vector<ConvLayer>& dyn,
+                 HeadOffsets& h)
+{
+    if (static_cast<long>(n) != netParamCount(d)) {
+        setError("weight blob has %zu floats, descriptor needs %ld", n, netParamCount(d));
+        return false;
+    }
+    packed.clear();
+    const float* p = raw;
+    const int C = d.num_hidden_channels, hw = d.hidden_channel_height * d.hidden_channel_width;
+    repr = packTrunk(packed, p, d.num_input_channels, d);
+    dyn.clear();
+    if (d.type == 1) { dyn = packTrunk(packed, p, C + d.num_action_feature_channels, d); }
+    h.pc = policyChannels(d);
+    Folded pconv = takeConvBN(p, C, h.pc, 1);
+    h.pconv_w = append(packed, pconv.w); // [pc][C]
+    h.pconv_b = append(packed, pconv.b);
+    h.pfc_wT = append(packed, transposeLinear(p, h.pc * hw, d.action_size));
+    p += size_t(h.pc) * hw * d.action_size;
+    h.pfc_b = append(packed, std::vector<float>(p, p + d.action_size));
+    p += d.action_size;
+    Folded vconv = takeConvBN(p, C, 1, 1);
+    h.vconv_w = append(packed, vconv.w); // [C]
+    h.vconv_b = append(packed, vconv.b);
+    const int VH = d.num_value_hidden_channels;
+    h.vfc1_wT = append(packed, transposeLinear(p, hw, VH));
+    p += size_t(hw) * VH;
+    h.vfc1_b = append(packed, std::vector<float>(p, p + VH));
+    p += VH;
+    h.vfc2_w = append(packed, std::vector<float>(p, p + VH));
+    p += VH;
+    h.vfc2_b = append(packed, std::vector<float>(p, p + 1));
+    p += 1;
+    if (p != raw + n) { setError("internal: weight manifest mismatch"); return false; }
+    return true;
+}
+
+} // namespace mz

@@ -44,7 +44,7 @@ bool Config::loadFromString(const std::string& conf)
 #define PS(name) p[#name] = [this](const std::string& v) { name = v; return true; }
     P_(program_seed); PB(program_auto_seed); PB(program_quiet);
     P_(actor_num_simulation); P_(actor_mcts_puct_base); P_(actor_mcts_puct_init); P_(actor_mcts_reward_discount);
-    PB(actor_mcts_value_rescale); P_(actor_mcts_think_batch_size); P_(actor_mcts_think_time_limit);
+    PB(actor_mcts_value_rescale); P_(actor_mcts_value_flipping_player); P_(actor_mcts_think_batch_size); P_(actor_mcts_think_time_limit);
     PB(actor_select_action_by_count); PB(actor_select_action_by_softmax_count); P_(actor_select_action_softmax_temperature);
     PB(actor_select_action_softmax_temperature_decay); PB(actor_use_random_rotation_features); PB(actor_use_dirichlet_noise);
     P_(actor_dirichlet_noise_alpha); P_(actor_dirichlet_noise_epsilon); PB(actor_use_gumbel); PB(actor_use_gumbel_noise);
