@@ -1,0 +1,56 @@
+// Run-time configuration of the worker: the reference's `config::*` globals that the self-play path reads
+// (ref config/configuration.cpp:7-90; same key names, defaults and "k=v:k=v" syntax as
+// config/configure_loader.cpp:51-117), held in a struct so several workers can live in one process.
+#pragma once
+#include <string>
+
+namespace mz {
+
+struct WorkerConfig {
+    int program_seed = 0;
+    bool program_auto_seed = false;
+    bool program_quiet = false;
+    int actor_num_simulation = 50;
+    float actor_mcts_puct_base = 19652;
+    float actor_mcts_puct_init = 1.25;
+    float actor_mcts_reward_discount = 1.0f;
+    int actor_mcts_think_batch_size = 1;
+    float actor_mcts_think_time_limit = 0;
+    bool actor_mcts_value_rescale = false;
+    char actor_mcts_value_flipping_player = 'W';
+    bool actor_select_action_by_count = false;
+    bool actor_select_action_by_softmax_count = true;
+    float actor_select_action_softmax_temperature = 1.0f;
+    bool actor_select_action_softmax_temperature_decay = false;
+    bool actor_use_random_rotation_features = true;
+    bool actor_use_dirichlet_noise = true;
+    float actor_dirichlet_noise_alpha = 0.03f;
+    float actor_dirichlet_noise_epsilon = 0.25f;
+    bool actor_use_gumbel = false;
+    bool actor_use_gumbel_noise = false;
+    int actor_gumbel_sample_size = 16;
+    float actor_gumbel_sigma_visit_c = 50;
+    float actor_gumbel_sigma_scale_c = 1;
+    float actor_resign_threshold = -0.9f;
+    int zero_num_threads = 4;
+    int zero_num_parallel_games = 32;
+    float zero_disable_resign_ratio = 0.1;
+    int zero_actor_intermediate_sequence_length = 0;
+    std::string zero_actor_ignored_command = "reset_actors";
+    int learner_muzero_unrolling_step = 5;
+    int learner_n_step_return = 0;
+    std::string nn_file_name = "";
+    std::string nn_type_name = "alphazero";
+    int env_board_size = 0;
+    float env_go_komi = 7.5;
+    std::string env_go_ko_rule = "positional";
+    // run-time replacements of the reference's compile-time switches (-D<GAME>, #if ATARI in mcts.cpp:211)
+    std::string env_game = "tictactoe";
+    bool atari_init_q = false;
+
+    // returns false (and sets the library error string) on an unknown key or an unparsable value,
+    // like ConfigureLoader::loadFromString; keys are applied left to right, later ones win
+    bool loadFromString(const std::string& s);
+};
+
+} // namespace mz

@@ -1,0 +1,572 @@
+// Host rules engines of libmzgpu — see env.h.  Not a translation of the reference's data structures:
+//   Go      : flat byte board + on-demand early-exit flood fills for captures (no incremental blocks /
+//             liberty bitsets / areas / Benson), one whole-board group pass only when a legal mask is
+//             needed, positional-superko set as a small open-addressing table that is copied with the env,
+//             8-deep ring of stone bitboards for the history planes.
+//   Othello : two 64-bit bitboards, shift-and-mask move generation (8x8 and smaller).
+//   TicTacToe: two 9-bit masks.
+// All feature planes are written straight into caller memory (the worker's pinned staging buffer).
+#include "env.h"
+#include "common.h"
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <random>
+
+namespace mz {
+
+// ---------------------------------------------------------------------------------------------
+// rotation tables (ref utils/rotation.h:21-29,51-93: float centre arithmetic with truncation)
+// ---------------------------------------------------------------------------------------------
+static int rotatePos(int rotation, int pos, int n)
+{
+    if (pos == n * n) { return pos; }
+    const float center = (n - 1) / 2.0;
+    const float x = pos % n - center, y = pos / n - center;
+    float rx = x, ry = y;
+    switch (rotation) {
+        case 0: rx = x; ry = y; break;
+        case 1: rx = y; ry = -x; break;
+        case 2: rx = -x; ry = -y; break;
+        case 3: rx = -y; ry = x; break;
+        case 4: rx = x; ry = -y; break;
+        case 5: rx = -y; ry = -x; break;
+        case 6: rx = -x; ry = y; break;
+        case 7: rx = y; ry = x; break;
+    }
+    return static_cast<int>((ry + center) * n + (rx + center));
+}
+
+void RotationTables::build(int n, int num_actions)
+{
+    static const int reversed[8] = {0, 3, 2, 1, 4, 5, 6, 7};
+    board_size = n;
+    for (int r = 0; r < 8; ++r) {
+        fwd[r].resize(num_actions);
+        inv[r].resize(n * n);
+        for (int a = 0; a < num_actions; ++a) { fwd[r][a] = (a >= n * n) ? a : rotatePos(r, a, n); }
+        for (int p = 0; p < n * n; ++p) { inv[r][p] = rotatePos(reversed[r], p, n); }
+    }
+}
+
+static const RotationTables* rotationTables(int n, int num_actions)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::unique_ptr<RotationTables>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto& slot = cache[{n, num_actions}];
+    if (!slot) {
+        slot = std::make_unique<RotationTables>();
+        slot->build(n, num_actions);
+    }
+    return slot.get();
+}
+
+static inline float scoreOf(int winner) { return winner == 1 ? 1.0f : (winner == 2 ? -1.0f : 0.0f); }
+
+// ---------------------------------------------------------------------------------------------
+// TicTacToe (ref tictactoe.cpp:11-146)
+// ---------------------------------------------------------------------------------------------
+class TicTacToe final : public GameEnv {
+public:
+    TicTacToe() { rot_ = rotationTables(3, 9); reset(); }
+    std::unique_ptr<GameEnv> clone() const override { return std::make_unique<TicTacToe>(*this); }
+    void copyFrom(const GameEnv& o) override { *this = static_cast<const TicTacToe&>(o); }
+    void reset() override { turn_ = 1; action_ids_.clear(); action_players_.clear(); m_[0] = m_[1] = 0; }
+    bool isLegal(int a, int) const override { return a >= 0 && a < 9 && !((m_[0] | m_[1]) >> a & 1); }
+    bool act(int a, int player) override
+    {
+        if (!isLegal(a, player)) { return false; }
+        actUnchecked(a, player);
+        return true;
+    }
+    void actUnchecked(int a, int player) override
+    {
+        m_[player - 1] |= 1u << a;
+        action_ids_.push_back(static_cast<int16_t>(a));
+        action_players_.push_back(static_cast<uint8_t>(player));
+        turn_ = 3 - player;
+    }
+    void legalMask(uint8_t* out) const override { for (int a = 0; a < 9; ++a) { out[a] = isLegal(a, turn_); } }
+    int winner() const
+    {
+        static const unsigned lines[8] = {0007, 0070, 0700, 0111, 0222, 0444, 0421, 0124};
+        for (unsigned l : lines) {
+            if ((m_[0] & l) == l) { return 1; }
+            if ((m_[1] & l) == l) { return 2; }
+        }
+        return 0;
+    }
+    bool isTerminal() const override { return winner() != 0 || (m_[0] | m_[1]) == 0777; }
+    float evalScore(bool is_resign) const override { return scoreOf(is_resign ? 3 - turn_ : winner()); }
+    void features(int r, float* out) const override
+    {
+        const unsigned own = m_[turn_ - 1], opp = m_[2 - turn_];
+        const int* map = rot_->inv[r].data();
+        for (int p = 0; p < 9; ++p) {
+            out[p] = (own >> map[p]) & 1 ? 1.0f : 0.0f;
+            out[9 + p] = (opp >> map[p]) & 1 ? 1.0f : 0.0f;
+            out[18 + p] = turn_ == 1 ? 1.0f : 0.0f;
+            out[27 + p] = turn_ == 2 ? 1.0f : 0.0f;
+        }
+    }
+    int numInputChannels() const override { return 4; }
+    int boardSize() const override { return 3; }
+    int policySize() const override { return 9; }
+    std::string name() const override { return "tictactoe"; }
+    std::vector<std::pair<std::string, std::string>> loaderTags() const override { return {{"SZ", "3"}}; }
+
+private:
+    unsigned m_[2];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Othello, board <= 8x8 (ref othello.cpp:14-262)
+// ---------------------------------------------------------------------------------------------
+class Othello final : public GameEnv {
+public:
+    explicit Othello(int n) : n_(n)
+    {
+        rot_ = rotationTables(n, n * n + 1);
+        full_ = 0; not_left_ = 0; not_right_ = 0;
+        for (int y = 0; y < n; ++y)
+            for (int x = 0; x < n; ++x) {
+                uint64_t b = 1ull << (y * n + x);
+                full_ |= b;
+                if (x != 0) { not_left_ |= b; }
+                if (x != n - 1) { not_right_ |= b; }
+            }
+        reset();
+    }
+    std::unique_ptr<GameEnv> clone() const override { return std::make_unique<Othello>(*this); }
+    void copyFrom(const GameEnv& o) override { *this = static_cast<const Othello&>(o); }
+    void reset() override // ref othello.cpp:14-27 (black on init, init+n+1; white on init+1, init+n)
+    {
+        turn_ = 1;
+        action_ids_.clear();
+        action_players_.clear();
+        const int init = n_ * (n_ / 2 - (1 - n_ % 2)) + (n_ / 2 - 1);
+        s_[0] = (1ull << init) | (1ull << (init + n_ + 1));
+        s_[1] = (1ull << (init + 1)) | (1ull << (init + n_));
+    }
+    // one step in direction d for every stone; stones that would leave the board vanish
+    uint64_t shift(uint64_t b, int d) const
+    {
+        switch (d) {
+            case 0: return (b << n_) & full_;                 // up
+            case 1: return b >> n_;                           // down
+            case 2: return (b & not_left_) >> 1;              // left
+            case 3: return ((b & not_right_) << 1) & full_;   // right
+            case 4: return ((b & not_left_) << (n_ - 1)) & full_;
+            case 5: return ((b & not_right_) << (n_ + 1)) & full_;
+            case 6: return (b & not_right_) >> (n_ - 1);
+            default: return (b & not_left_) >> (n_ + 1);
+        }
+    }
+    uint64_t moves(int player) const
+    {
+        const uint64_t me = s_[player - 1], op = s_[2 - player], empty = full_ & ~(me | op);
+        uint64_t m = 0;
+        for (int d = 0; d < 8; ++d) {
+            uint64_t x = shift(me, d) & op;
+            for (int i = 0; i < n_ - 3; ++i) { x |= shift(x, d) & op; }
+            m |= shift(x, d) & empty;
+        }
+        return m;
+    }
+    bool isLegal(int a, int player) const override
+    {
+        const uint64_t m = moves(player);
+        if (a == n_ * n_) { return m == 0; } // pass only when the mover has no move (ref othello.cpp:195-201)
+        return a >= 0 && a < n_ * n_ && ((m >> a) & 1);
+    }
+    bool act(int a, int player) override
+    {
+        if (!isLegal(a, player)) { return false; }
+        actUnchecked(a, player);
+        return true;
+    }
+    void actUnchecked(int a, int player) override
+    {
+        action_ids_.push_back(static_cast<int16_t>(a));
+        action_players_.push_back(static_cast<uint8_t>(player));
+        turn_ = 3 - player;
+        if (a == n_ * n_) { return; }
+        uint64_t& me = s_[player - 1];
+        uint64_t& op = s_[2 - player];
+        const uint64_t placed = 1ull << a;
+        uint64_t flip = 0;
+        for (int d = 0; d < 8; ++d) {
+            uint64_t line = 0, x = shift(placed, d);
+            while (x & op) { line |= x; x = shift(x, d); }
+            if (x & me) { flip |= line; }
+        }
+        me |= placed | flip;
+        op &= ~flip;
+    }
+    void legalMask(uint8_t* out) const override
+    {
+        const uint64_t m = moves(turn_);
+        for (int a = 0; a < n_ * n_; ++a) { out[a] = (m >> a) & 1; }
+        out[n_ * n_] = (m == 0);
+    }
+    bool isTerminal() const override
+    {
+        const size_t k = action_ids_.size();
+        return k >= 2 && action_ids_[k - 1] == n_ * n_ && action_ids_[k - 2] == n_ * n_;
+    }
+    float evalScore(bool is_resign) const override // ref othello.cpp:211-236: winner only once neither side can move
+    {
+        if (is_resign) { return scoreOf(3 - turn_); }
+        if (moves(1) != 0 || moves(2) != 0) { return 0.0f; }
+        const int b = __builtin_popcountll(s_[0]), w = __builtin_popcountll(s_[1]);
+        return scoreOf(b > w ? 1 : (b < w ? 2 : 0));
+    }
+    void features(int r, float* out) const override
+    {
+        const int P = n_ * n_;
+        const uint64_t own = s_[turn_ - 1], opp = s_[2 - turn_];
+        const int* map = rot_->inv[r].data();
+        for (int p = 0; p < P; ++p) {
+            out[p] = (own >> map[p]) & 1 ? 1.0f : 0.0f;
+            out[P + p] = (opp >> map[p]) & 1 ? 1.0f : 0.0f;
+            out[2 * P + p] = turn_ == 1 ? 1.0f : 0.0f;
+            out[3 * P + p] = turn_ == 2 ? 1.0f : 0.0f;
+        }
+    }
+    int numInputChannels() const override { return 4; }
+    int boardSize() const override { return n_; }
+    int policySize() const override { return n_ * n_ + 1; }
+    std::string name() const override { return "othello_" + std::to_string(n_) + "x" + std::to_string(n_); }
+    std::vector<std::pair<std::string, std::string>> loaderTags() const override { return {{"SZ", std::to_string(n_)}}; }
+
+private:
+    int n_;
+    uint64_t full_, not_left_, not_right_, s_[2];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Go (ref go.cpp:102-315,690-723)
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxN = 19, kMaxP = kMaxN * kMaxN, kWords = (kMaxP + 63) / 64;
+struct Bits {
+    uint64_t w[kWords];
+    void clear() { memset(w, 0, sizeof(w)); }
+    void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
+    void reset(int i) { w[i >> 6] &= ~(1ull << (i & 63)); }
+    bool test(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
+};
+struct GoStatic {
+    int n = 0;
+    int16_t nbr[kMaxP][4];
+    uint8_t nnbr[kMaxP];
+    uint64_t key[2][kMaxP];
+};
+const GoStatic* goStatic(int n)
+{
+    static std::mutex mu;
+    static std::map<int, std::unique_ptr<GoStatic>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto& slot = cache[n];
+    if (!slot) {
+        slot = std::make_unique<GoStatic>();
+        slot->n = n;
+        // the superko test only needs "equal positions <=> equal keys": any good 64-bit Zobrist keys do
+        // (the reference draws its keys from mt19937_64(0), go.cpp:19-43; the values themselves are unobservable)
+        std::mt19937_64 gen(0x6d7a677075ULL);
+        for (int p = 0; p < n * n; ++p) {
+            slot->key[0][p] = gen();
+            slot->key[1][p] = gen();
+            int x = p % n, y = p / n, k = 0;
+            if (y + 1 < n) { slot->nbr[p][k++] = static_cast<int16_t>(p + n); }
+            if (x + 1 < n) { slot->nbr[p][k++] = static_cast<int16_t>(p + 1); }
+            if (y - 1 >= 0) { slot->nbr[p][k++] = static_cast<int16_t>(p - n); }
+            if (x - 1 >= 0) { slot->nbr[p][k++] = static_cast<int16_t>(p - 1); }
+            slot->nnbr[p] = static_cast<uint8_t>(k);
+        }
+    }
+    return slot.get();
+}
+} // namespace
+
+class Go final : public GameEnv {
+    static constexpr int kHashCap = 1024; // > 2 * (2*361 + 1) positions of the longest legal game at 19x19
+public:
+    Go(int n, float komi) : n_(n), P_(n * n), komi_(komi), st_(goStatic(n))
+    {
+        rot_ = rotationTables(n, n * n + 1);
+        reset();
+    }
+    std::unique_ptr<GameEnv> clone() const override { return std::make_unique<Go>(*this); }
+    void copyFrom(const GameEnv& o) override { *this = static_cast<const Go&>(o); }
+    void reset() override
+    {
+        turn_ = 1;
+        action_ids_.clear();
+        action_players_.clear();
+        memset(board_, 0, sizeof(board_));
+        hash_ = 0;
+        memset(seen_, 0, sizeof(seen_));
+        seen_used_ = 0;
+        hist_len_ = 0;
+        for (auto& h : hist_) { h[0].clear(); h[1].clear(); }
+        stones_[0].clear();
+        stones_[1].clear();
+    }
+
+    // ---- superko set: open addressing, 0 = empty slot (a zero hash is stored as 1) ----
+    static uint64_t norm(uint64_t h) { return h ? h : 1; }
+    bool seen(uint64_t h) const
+    {
+        h = norm(h);
+        for (uint32_t i = static_cast<uint32_t>(h) & (kHashCap - 1);; i = (i + 1) & (kHashCap - 1)) {
+            if (seen_[i] == 0) { return false; }
+            if (seen_[i] == h) { return true; }
+        }
+    }
+    void remember(uint64_t h)
+    {
+        h = norm(h);
+        for (uint32_t i = static_cast<uint32_t>(h) & (kHashCap - 1);; i = (i + 1) & (kHashCap - 1)) {
+            if (seen_[i] == h) { return; }
+            if (seen_[i] == 0) { seen_[i] = h; ++seen_used_; return; }
+        }
+    }
+
+    // flood fill the group at `start`; returns liberty count (stops at `cap` liberties), stones in grp[], XOR of keys in *gh
+    int group(int start, int cap, int16_t* grp, int* gsize, uint64_t* gh) const
+    {
+        uint8_t mark[kMaxP];
+        memset(mark, 0, P_);
+        const uint8_t color = board_[start];
+        int head = 0, tail = 0, libs = 0;
+        uint64_t h = 0;
+        grp[tail++] = static_cast<int16_t>(start);
+        mark[start] = 1;
+        while (head < tail) {
+            const int p = grp[head++];
+            h ^= st_->key[color - 1][p];
+            for (int k = 0; k < st_->nnbr[p]; ++k) {
+                const int q = st_->nbr[p][k];
+                if (mark[q]) { continue; }
+                if (board_[q] == 0) {
+                    mark[q] = 1;
+                    if (++libs >= cap) { *gsize = tail; if (gh) { *gh = 0; } return libs; } // early exit: enough liberties known
+                } else if (board_[q] == color) {
+                    mark[q] = 1;
+                    grp[tail++] = static_cast<int16_t>(q);
+                }
+            }
+        }
+        *gsize = tail;
+        if (gh) { *gh = h; }
+        return libs;
+    }
+
+    bool isLegal(int a, int player) const override // ref go.cpp:208-244
+    {
+        if (a == P_) { return true; }
+        if (a < 0 || a > P_ || board_[a] != 0) { return false; }
+        bool ok = false;
+        uint64_t nh = hash_ ^ st_->key[player - 1][a];
+        int16_t grp[kMaxP];
+        int16_t seen_rep[4];
+        int nrep = 0;
+        for (int k = 0; k < st_->nnbr[a]; ++k) {
+            const int q = st_->nbr[a][k];
+            if (board_[q] == 0) { ok = true; continue; }
+            int gs = 0;
+            uint64_t gh = 0;
+            if (board_[q] == player) {
+                if (!ok && group(q, 2, grp, &gs, nullptr) > 1) { ok = true; }
+            } else {
+                // an enemy block in atari is captured: each block once
+                bool dup = false;
+                const int libs = group(q, 2, grp, &gs, &gh);
+                if (libs == 1) {
+                    int rep = grp[0];
+                    for (int i = 1; i < gs; ++i) { rep = grp[i] < rep ? grp[i] : rep; }
+                    for (int i = 0; i < nrep; ++i) { dup |= (seen_rep[i] == rep); }
+                    if (!dup) { seen_rep[nrep++] = static_cast<int16_t>(rep); nh ^= gh; }
+                    ok = true;
+                }
+            }
+        }
+        return ok && !seen(nh);
+    }
+
+    void legalMask(uint8_t* out) const override
+    {
+        // one whole-board pass: group id, liberty count (saturated at 2) and key-XOR per group
+        int16_t gid[kMaxP];
+        uint8_t glibs[kMaxP];
+        uint64_t ghash[kMaxP];
+        for (int p = 0; p < P_; ++p) { gid[p] = -1; }
+        int16_t grp[kMaxP];
+        for (int p = 0; p < P_; ++p) {
+            if (board_[p] == 0 || gid[p] >= 0) { continue; }
+            int gs = 0;
+            uint64_t gh = 0;
+            // full fill (cap = infinity would also do; liberties beyond 2 are never needed, but the hash is)
+            const int libs = group(p, kMaxP, grp, &gs, &gh);
+            for (int i = 0; i < gs; ++i) { gid[grp[i]] = static_cast<int16_t>(p); }
+            glibs[p] = static_cast<uint8_t>(libs > 2 ? 2 : libs);
+            ghash[p] = gh;
+        }
+        const int player = turn_;
+        for (int a = 0; a < P_; ++a) {
+            if (board_[a] != 0) { out[a] = 0; continue; }
+            bool ok = false;
+            uint64_t nh = hash_ ^ st_->key[player - 1][a];
+            int16_t cap[4];
+            int ncap = 0;
+            for (int k = 0; k < st_->nnbr[a]; ++k) {
+                const int q = st_->nbr[a][k];
+                if (board_[q] == 0) { ok = true; continue; }
+                const int g = gid[q];
+                if (board_[q] == player) {
+                    if (glibs[g] > 1) { ok = true; }
+                } else if (glibs[g] == 1) {
+                    bool dup = false;
+                    for (int i = 0; i < ncap; ++i) { dup |= (cap[i] == g); }
+                    if (!dup) { cap[ncap++] = static_cast<int16_t>(g); nh ^= ghash[g]; }
+                    ok = true;
+                }
+            }
+            out[a] = ok && !seen(nh);
+        }
+        out[P_] = 1;
+    }
+
+    bool act(int a, int player) override
+    {
+        if (!isLegal(a, player)) { return false; }
+        actUnchecked(a, player);
+        return true;
+    }
+    void actUnchecked(int a, int player) override // ref go.cpp:132-190 (observable effects only)
+    {
+        action_ids_.push_back(static_cast<int16_t>(a));
+        action_players_.push_back(static_cast<uint8_t>(player));
+        turn_ = 3 - player;
+        if (a != P_) {
+            board_[a] = static_cast<uint8_t>(player);
+            stones_[player - 1].set(a);
+            hash_ ^= st_->key[player - 1][a];
+            int16_t grp[kMaxP];
+            for (int k = 0; k < st_->nnbr[a]; ++k) {
+                const int q = st_->nbr[a][k];
+                if (board_[q] != 3 - player) { continue; }
+                int gs = 0;
+                if (group(q, 1, grp, &gs, nullptr) == 0) { // captured
+                    for (int i = 0; i < gs; ++i) {
+                        const int s = grp[i];
+                        board_[s] = 0;
+                        stones_[2 - player].reset(s);
+                        hash_ ^= st_->key[2 - player][s];
+                    }
+                }
+            }
+        }
+        hist_[hist_len_ & 7][0] = stones_[0];
+        hist_[hist_len_ & 7][1] = stones_[1];
+        ++hist_len_;
+        remember(hash_);
+    }
+    bool isTerminal() const override // ref go.cpp:246-257
+    {
+        const size_t k = action_ids_.size();
+        if (k >= 2 && action_ids_[k - 1] == P_ && action_ids_[k - 2] == P_) { return true; }
+        return static_cast<int>(k) > 2 * P_;
+    }
+    float evalScore(bool is_resign) const override // Tromp-Taylor area + komi (ref go.cpp:259-278,703-723)
+    {
+        if (is_resign) { return scoreOf(3 - turn_); }
+        float t1 = 0, t2 = 0;
+        for (int p = 0; p < P_; ++p) { t1 += board_[p] == 1; t2 += board_[p] == 2; }
+        t2 += komi_;
+        uint8_t mark[kMaxP];
+        memset(mark, 0, P_);
+        int16_t q[kMaxP];
+        for (int s = 0; s < P_; ++s) {
+            if (board_[s] != 0 || mark[s]) { continue; }
+            int head = 0, tail = 0, border = 0; // border: bit0 = touches black, bit1 = touches white
+            q[tail++] = static_cast<int16_t>(s);
+            mark[s] = 1;
+            while (head < tail) {
+                const int p = q[head++];
+                for (int k = 0; k < st_->nnbr[p]; ++k) {
+                    const int r = st_->nbr[p][k];
+                    if (board_[r] == 0) { if (!mark[r]) { mark[r] = 1; q[tail++] = static_cast<int16_t>(r); } }
+                    else { border |= board_[r]; }
+                }
+            }
+            // a region bordered by black only — or by nothing at all (empty board) — counts for black (go.cpp:714),
+            // else one bordered by white only counts for white
+            if ((border & 2) == 0) { t1 += tail; }
+            else if ((border & 1) == 0) { t2 += tail; }
+        }
+        return scoreOf(t1 > t2 ? 1 : (t1 < t2 ? 2 : 0));
+    }
+    void features(int r, float* out) const override // ref go.cpp:280-308
+    {
+        const int* map = rot_->inv[r].data();
+        for (int k = 0; k < 8; ++k) {
+            float* own = out + (2 * k) * P_;
+            float* opp = own + P_;
+            if (hist_len_ - 1 - k < 0) {
+                memset(own, 0, 2 * P_ * sizeof(float));
+                continue;
+            }
+            const Bits* h = hist_[(hist_len_ - 1 - k) & 7];
+            const Bits& mine = h[turn_ - 1];
+            const Bits& theirs = h[2 - turn_];
+            for (int p = 0; p < P_; ++p) {
+                own[p] = mine.test(map[p]) ? 1.0f : 0.0f;
+                opp[p] = theirs.test(map[p]) ? 1.0f : 0.0f;
+            }
+        }
+        const float b = turn_ == 1 ? 1.0f : 0.0f, w = turn_ == 2 ? 1.0f : 0.0f;
+        for (int p = 0; p < P_; ++p) { out[16 * P_ + p] = b; out[17 * P_ + p] = w; }
+    }
+    int numInputChannels() const override { return 18; }
+    int boardSize() const override { return n_; }
+    int policySize() const override { return P_ + 1; }
+    std::string name() const override { return "go_" + std::to_string(n_) + "x" + std::to_string(n_); }
+    std::vector<std::pair<std::string, std::string>> loaderTags() const override
+    {
+        return {{"SZ", std::to_string(n_)}, {"KM", std::to_string(komi_)}};
+    }
+
+private:
+    int n_, P_;
+    float komi_;
+    const GoStatic* st_;
+    uint8_t board_[kMaxP];
+    uint64_t hash_;
+    uint64_t seen_[kHashCap];
+    int seen_used_;
+    Bits stones_[2];
+    Bits hist_[8][2];
+    int hist_len_;
+};
+
+std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi)
+{
+    if (game == "tictactoe") { return std::make_unique<TicTacToe>(); }
+    if (game == "othello") {
+        const int n = board_size > 0 ? board_size : 8;
+        if (n < 4 || n > 8 || n % 2) { setError("othello board size %d not supported (even, 4..8)", n); return nullptr; }
+        return std::make_unique<Othello>(n);
+    }
+    if (game == "go") {
+        const int n = board_size > 0 ? board_size : 9;
+        if (n < 2 || n > kMaxN) { setError("go board size %d not supported (2..19)", n); return nullptr; }
+        return std::make_unique<Go>(n, go_komi);
+    }
+    setError("unknown env_game '%s' (tictactoe | go | othello)", game.c_str());
+    return nullptr;
+}
+
+} // namespace mz

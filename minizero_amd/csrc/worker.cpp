@@ -1,0 +1,932 @@
+// The self-play worker of libmzgpu: the `-mode sp` loop of the reference (ref actor/actor_group.cpp:136-252)
+// re-designed around one device-resident search pool per GPU.
+//
+// Per lock-step cycle (one simulation of every game, ref actor_group.cpp:139-147 / SURVEY.md §3.1):
+//   device : expand+backup kernel  ->  PUCT select kernel  ->  network forward (f32 MFMA)
+//   host   : per-game candidate lists (legal filter, inverse rotation, the reference's std::sort), leaf
+//            environments (copy of the root position + path replay) and feature planes — embarrassingly
+//            parallel over games on a thread pool — plus the strictly serial, RNG-ordered per-move logic
+//            (root noise, move decision, resign coin, record strings) on one thread.
+// The order in which the single mt19937 stream is consumed is the reference's: for actor 0..B-1:
+// [root noise] [move decision] [reset: resign coin] [rotation draw].
+#include "config.h"
+#include "env.h"
+#include "net.h"
+#include "pool.h"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <limits>
+#include <mutex>
+#include <numeric>
+#include <random>
+#include <sstream>
+#include <thread>
+#include <unordered_map>
+
+namespace mz {
+
+namespace {
+
+// ---- RNG (ref utils/random.h:9-41): libstdc++'s distributions over one mt19937 ----
+struct Rng {
+    std::mt19937 gen;
+    std::uniform_int_distribution<int> int_dist;
+    std::uniform_real_distribution<double> real_dist;
+    void seed(int s) { gen.seed(s); }
+    int randInt() { return int_dist(gen); }
+    double randReal(double range = 1.0f) { return real_dist(gen) * range; }
+    void dirichlet(float alpha, int size, std::vector<float>& out)
+    {
+        out.clear();
+        std::gamma_distribution<float> gamma(alpha);
+        for (int i = 0; i < size; ++i) { out.emplace_back(gamma(gen)); }
+        float sum = std::accumulate(out.begin(), out.end(), 0.0f);
+        if (sum < std::numeric_limits<float>::min()) { return; }
+        for (int i = 0; i < size; ++i) { out[i] /= sum; }
+    }
+    void gumbel(int size, std::vector<float>& out)
+    {
+        out.clear();
+        std::extreme_value_distribution<float> ev(0.0, 1.0);
+        for (int i = 0; i < size; ++i) {
+            float v = ev(gen);
+            while (std::isinf(v)) { v = ev(gen); }
+            out.emplace_back(v);
+        }
+    }
+};
+
+// ---- persistent thread pool: parallelFor over games ----
+class ThreadPool {
+public:
+    explicit ThreadPool(int n) : n_(std::max(1, n))
+    {
+        for (int t = 1; t < n_; ++t) { threads_.emplace_back([this, t]() { loop(t); }); }
+    }
+    ~ThreadPool()
+    {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            quit_ = true;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) { t.join(); }
+    }
+    void parallelFor(int count, const std::function<void(int)>& fn)
+    {
+        if (n_ == 1 || count < 2) { for (int i = 0; i < count; ++i) { fn(i); } return; }
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            fn_ = &fn;
+            count_ = count;
+            next_.store(0);
+            pending_ = n_ - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(mu_);
+        done_cv_.wait(l, [this]() { return pending_ == 0; });
+    }
+
+private:
+    void work()
+    {
+        const int chunk = std::max(1, count_ / (n_ * 4));
+        while (true) {
+            int b = next_.fetch_add(chunk);
+            if (b >= count_) { break; }
+            int e = std::min(count_, b + chunk);
+            for (int i = b; i < e; ++i) { (*fn_)(i); }
+        }
+    }
+    void loop(int)
+    {
+        uint64_t seen = 0;
+        while (true) {
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [&]() { return epoch_ != seen; });
+                seen = epoch_;
+                if (quit_) { return; }
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> l(mu_);
+                if (--pending_ == 0) { done_cv_.notify_one(); }
+            }
+        }
+    }
+    int n_;
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int count_ = 0, pending_ = 0;
+    std::atomic<int> next_{0};
+    uint64_t epoch_ = 0;
+    bool quit_ = false;
+};
+
+struct Cand { int action; float policy, logit; };
+
+using ActionInfo = std::vector<std::pair<std::string, std::string>>;
+
+struct Game {
+    std::unique_ptr<GameEnv> env, leaf;
+    bool enable_resign = true;
+    int rot = 0;
+    // leaf cache (AlphaZero): filled when the features are built, consumed when the network output arrives
+    bool leaf_terminal = false;
+    float leaf_eval = 0, leaf_reward = 0;
+    int leaf_turn = 1, path_len = 1;
+    std::vector<uint8_t> legal;
+    // Gumbel root state (ref gumbel_zero.h:18-21); candidates are indices into the root's children
+    std::vector<int> candidates;
+    int sample_size = 0, simulation_budget = 0;
+    int selected = -1; // index of the chosen root child
+    std::vector<ActionInfo> action_info_history;
+};
+
+inline double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+std::string escapeSGF(const std::string& s) // ref base_env.h:303-313
+{
+    std::string out;
+    for (char c : s) {
+        if (c == '(' || c == ')' || c == '[' || c == ']' || c == '\\') { out += '\\'; }
+        out += c;
+    }
+    return out;
+}
+
+} // namespace
+
+class Worker {
+public:
+    int init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count);
+    int command(const std::string& line);
+    int setWeights(const float* w, size_t n)
+    {
+        pending_weights_.assign(w, w + n);
+        return MZ_OK;
+    }
+    int runCycles(int n);
+    int popLine(char* buf, int cap);
+    mz_worker_stats stats_{};
+    Net net_;
+
+private:
+    int cycle();
+    int createActors();
+    void resetGame(Game& g, Rng& rng);          // ZeroActor::reset (ref zero_actor.cpp:23-27)
+    int rootPlayerFor(const Game& g) const { return g.env->numPlayers() == 2 ? 3 - g.env->turn() : g.env->turn(); }
+    void buildCandidates(int g);
+    void buildLeaf(int g);
+    // per-move host logic on root statistics (rr_* mirrors)
+    float normalizedMean(float reward, float mean, float count, int player, int g) const;
+    int selectChildByMaxCount(int g) const;
+    int selectChildBySoftmaxCount(int g, float temperature, float value_threshold = 0.1f);
+    bool isResign(int g) const;
+    std::string searchDistributionString(int g) const;
+    std::string gumbelPolicyString(int g, int child_player) const;
+    void gumbelSortByScore(int g);
+    void gumbelSequentialHalving(int g);
+    int decideAction(int g);
+    void handleSearchDone(int g);
+    void outputGame(Game& gm);
+    std::pair<int, int> trainingDataRange(const Game& gm) const;
+    std::string record(const Game& gm, const ActionInfo& extra) const;
+    ActionInfo actionInfo(int g, int child_player) const;
+
+    WorkerConfig cfg_;
+    mz_net_desc desc_{};
+    int device_ = 0, G_ = 0, A_ = 0, n_ = 0;
+    hipStream_t stream_ = nullptr;
+    Pool pool_;
+    std::unique_ptr<ThreadPool> threads_;
+    std::vector<Game> games_;
+    Rng main_rng_, rng_;
+    bool running_ = false, pending_ = false;
+    int sims_done_ = 0; // root visit count of every game (lock-step: identical for all games)
+    std::deque<std::string> lines_;
+    std::vector<float> pending_weights_;
+    // staging
+    PinBuf<float> h_feat_, h_policy_, h_logit_, h_value_, h_reward_;
+    DevBuf<float> d_feat_, d_policy_, d_logit_, d_value_, d_reward_, d_hidden_;
+    DevBuf<int> d_src_idx_, d_dst_idx_, d_action_ids_;
+    // root statistics mirrors (valid after rootRead)
+    std::vector<int> rr_nc_, rr_action_, rr_bsize_;
+    std::vector<float> rr_count_, rr_mean_, rr_policy_, rr_logit_, rr_noise_, rr_value_, rr_reward_, rr_root_count_, rr_root_mean_, rr_root_value_,
+        rr_lo_, rr_hi_;
+    std::vector<uint8_t> noise_mask_;
+    std::vector<float> noise_policy_, noise_logit_, noise_noise_;
+    int flipping_player_ = 2;
+};
+
+// ------------------------------------------------------------------------------------------------
+int Worker::init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count)
+{
+    if (!conf || !cfg_.loadFromString(conf)) { return MZ_ERR_ARG; }
+    desc_ = desc;
+    device_ = device;
+    if (cfg_.nn_type_name == "muzero" && desc.type == 0) { setError("nn_type_name=muzero but the network descriptor is alphazero"); return MZ_ERR_ARG; }
+    if (cfg_.zero_num_parallel_games <= 0 || cfg_.actor_num_simulation <= 0) { setError("zero_num_parallel_games and actor_num_simulation must be > 0"); return MZ_ERR_ARG; }
+    if (cfg_.zero_num_parallel_games > 4096) { setError("zero_num_parallel_games > 4096 (ref alphazero_network.h:120 kReserved_batch_size)"); return MZ_ERR_ARG; }
+    int rc = net_.init(device, desc, weights, count);
+    if (rc) { return rc; }
+    stream_ = net_.stream_;
+    G_ = cfg_.zero_num_parallel_games;
+    A_ = desc.action_size;
+    n_ = cfg_.actor_num_simulation;
+    flipping_player_ = (cfg_.actor_mcts_value_flipping_player == 'B' || cfg_.actor_mcts_value_flipping_player == 'b') ? 1
+                       : (cfg_.actor_mcts_value_flipping_player == 'W' || cfg_.actor_mcts_value_flipping_player == 'w') ? 2 : 3;
+    mz_search_cfg sc{};
+    sc.num_simulation = n_;
+    sc.puct_base = cfg_.actor_mcts_puct_base;
+    sc.puct_init = cfg_.actor_mcts_puct_init;
+    sc.reward_discount = cfg_.actor_mcts_reward_discount;
+    sc.value_rescale = cfg_.actor_mcts_value_rescale;
+    sc.flipping_player = flipping_player_;
+    sc.atari_init_q = cfg_.atari_init_q;
+    // ref actor_group.cpp:183: tree_node_size = (n + 1) * action_size; tree.h:66: 1 + tree_node_size nodes
+    rc = pool_.init(device, G_, 1 + (n_ + 1) * A_, A_, sc, stream_);
+    if (rc) { return rc; }
+    threads_ = std::make_unique<ThreadPool>(std::max(1, cfg_.zero_num_threads));
+
+    const size_t GA = size_t(G_) * A_, feat = size_t(G_) * net_.featSize();
+#define WALLOC(b, n) \
+    if (!(b).alloc(n)) { setError("worker: allocation failed (%s)", #b); return MZ_ERR_DEVICE; }
+    WALLOC(h_feat_, feat); WALLOC(h_policy_, GA); WALLOC(h_logit_, GA); WALLOC(h_value_, G_); WALLOC(h_reward_, G_);
+    WALLOC(d_feat_, feat); WALLOC(d_policy_, GA); WALLOC(d_logit_, GA); WALLOC(d_value_, G_); WALLOC(d_reward_, G_);
+    if (desc.type == 1) {
+        WALLOC(d_hidden_, size_t(G_) * (n_ + 1) * net_.hiddenSize()); // hidden-state slab: one slot per expanded node
+        WALLOC(d_src_idx_, G_); WALLOC(d_dst_idx_, G_); WALLOC(d_action_ids_, G_);
+    }
+#undef WALLOC
+    rr_nc_.resize(G_); rr_action_.resize(GA); rr_bsize_.resize(G_);
+    for (auto* v : {&rr_count_, &rr_mean_, &rr_policy_, &rr_logit_, &rr_noise_, &rr_value_, &rr_reward_}) { v->resize(GA); }
+    for (auto* v : {&rr_root_count_, &rr_root_mean_, &rr_root_value_, &rr_lo_, &rr_hi_}) { v->resize(G_); }
+    noise_mask_.assign(G_, 1);
+    noise_policy_.resize(GA); noise_logit_.resize(GA); noise_noise_.resize(GA);
+    return createActors();
+}
+
+int Worker::createActors()
+{
+    // ref mode_handler.cpp:62 (main-thread seed) + actor_group.cpp:179-187 (createActors -> reset() draws the resign coin
+    // from the MAIN thread's generator) + actor_group.cpp:66-70 (slave thread 0 seeds its own generator: seed + 0)
+    const int seed = cfg_.program_auto_seed ? static_cast<int>(std::random_device()()) : cfg_.program_seed;
+    main_rng_.seed(seed);
+    games_.clear();
+    games_.resize(G_);
+    for (auto& g : games_) {
+        g.env = createGameEnv(cfg_.env_game, cfg_.env_board_size, cfg_.env_go_komi);
+        if (!g.env) { return MZ_ERR_ARG; }
+        if (g.env->policySize() != A_ || g.env->featureSize() != net_.featSize()) {
+            setError("network (A=%d, features=%d) does not fit env %s (A=%d, features=%d)", A_, net_.featSize(), g.env->name().c_str(),
+                     g.env->policySize(), g.env->featureSize());
+            return MZ_ERR_ARG;
+        }
+        g.leaf = g.env->clone();
+        g.legal.assign(A_, 0);
+        g.env->reset();
+        g.action_info_history.clear();
+        g.enable_resign = (main_rng_.randReal() < cfg_.zero_disable_resign_ratio ? false : true);
+    }
+    rng_.seed(cfg_.program_auto_seed ? static_cast<int>(std::random_device()()) : cfg_.program_seed + 0);
+    std::vector<int> rp(G_);
+    for (int g = 0; g < G_; ++g) { rp[g] = rootPlayerFor(games_[g]); }
+    sims_done_ = 0;
+    pending_ = false;
+    return pool_.resetSearch(nullptr, rp.data());
+}
+
+void Worker::resetGame(Game& g, Rng& rng)
+{
+    g.env->reset();
+    g.action_info_history.clear();
+    g.enable_resign = (rng.randReal() < cfg_.zero_disable_resign_ratio ? false : true);
+}
+
+// ------------------------------------------------------------------------------------------------
+// candidates: ref zero_actor.cpp:215-245
+void Worker::buildCandidates(int gi)
+{
+    Game& g = games_[gi];
+    const size_t off = size_t(gi) * A_;
+    int* ca = pool_.h_cand_action_.p + off;
+    float* cp = pool_.h_cand_policy_.p + off;
+    float* cl = pool_.h_cand_logit_.p + off;
+    const float* policy = h_policy_.p + off;
+    const float* logit = h_logit_.p + off;
+    Cand tmp[512];
+    std::vector<Cand> big;
+    Cand* c = tmp;
+    if (A_ > 512) { big.resize(A_); c = big.data(); }
+    int k = 0;
+    float value = h_value_.p[gi], reward = 0.0f;
+    int player;
+    if (desc_.type == 0) {
+        player = g.leaf_turn;
+        reward = g.leaf_reward;
+        if (g.leaf_terminal) {
+            value = g.leaf_eval; // ref zero_actor.cpp:85: backup(path, env_transition.getEvalScore(), reward)
+        } else {
+            const int* fwd = g.env->rot()->fwd[g.rot].data();
+            for (int a = 0; a < A_; ++a) {
+                if (!g.legal[a]) { continue; }
+                c[k++] = Cand{a, policy[fwd[a]], logit[fwd[a]]};
+            }
+        }
+    } else {
+        const int L = g.path_len - 1; // depth of the leaf; its children are moved by the player to move there
+        player = (g.env->numPlayers() == 2 && (L & 1)) ? 3 - g.env->turn() : g.env->turn();
+        reward = h_reward_.p[gi];
+        for (int a = 0; a < A_; ++a) {
+            if (L == 0 && !g.legal[a]) { continue; } // legality is only known (and checked) at the root (zero_actor.cpp:238)
+            c[k++] = Cand{a, policy[a], logit[a]};
+        }
+    }
+    std::sort(c, c + k, [](const Cand& l, const Cand& r) { return l.policy > r.policy; }); // the reference's (unstable) std::sort
+    for (int i = 0; i < k; ++i) { ca[i] = c[i].action; cp[i] = c[i].policy; cl[i] = c[i].logit; }
+    pool_.h_cand_count_.p[gi] = k;
+    pool_.h_cand_player_.p[gi] = player;
+    pool_.h_value_.p[gi] = value;
+    pool_.h_reward_.p[gi] = reward;
+}
+
+// leaf environment + features: ref zero_actor.cpp:51-72, 247-252
+void Worker::buildLeaf(int gi)
+{
+    Game& g = games_[gi];
+    const int len = pool_.h_path_len_.p[gi];
+    g.path_len = len;
+    float* feat = h_feat_.p + size_t(gi) * net_.featSize();
+    if (desc_.type == 0) {
+        const int* acts = pool_.h_path_action_.p + size_t(gi) * pool_.v_.max_depth;
+        g.leaf->copyFrom(*g.env);
+        int p = g.env->turn();
+        for (int d = 1; d < len; ++d) {
+            g.leaf->actUnchecked(acts[d], p);
+            if (g.env->numPlayers() == 2) { p = 3 - p; }
+        }
+        g.leaf_terminal = g.leaf->isTerminal();
+        g.leaf_turn = g.leaf->turn();
+        g.leaf_reward = g.leaf->reward();
+        if (g.leaf_terminal) { g.leaf_eval = g.leaf->evalScore(false); }
+        else { g.leaf->legalMask(g.legal.data()); }
+        g.leaf->features(g.rot, feat);
+    } else if (sims_done_ == 0) {
+        g.env->features(0, feat);
+        g.env->legalMask(g.legal.data());
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host logic on root statistics
+float Worker::normalizedMean(float reward, float mean, float count, int player, int g) const // ref mcts.cpp:40-53
+{
+    float value = reward + cfg_.actor_mcts_reward_discount * mean;
+    if (cfg_.actor_mcts_value_rescale) {
+        if (rr_bsize_[g] < 2) { return 1.0f; }
+        const float lo = rr_lo_[g], hi = rr_hi_[g];
+        value = (value - lo) / (hi - lo);
+        value = ::fmin(static_cast<double>(1), ::fmax(static_cast<double>(-1), static_cast<double>(2 * value - 1)));
+    }
+    value = (player == flipping_player_ ? -value : value);
+    value = (value * count - 0.0f) / (count + 0.0f);
+    return value;
+}
+
+int Worker::selectChildByMaxCount(int g) const // ref mcts.cpp:91-104
+{
+    const size_t off = size_t(g) * A_;
+    float max_count = 0.0f;
+    int selected = -1;
+    for (int i = 0; i < rr_nc_[g]; ++i) {
+        if (rr_count_[off + i] <= max_count) { continue; }
+        max_count = rr_count_[off + i];
+        selected = i;
+    }
+    return selected;
+}
+
+int Worker::selectChildBySoftmaxCount(int g, float temperature, float value_threshold) // ref mcts.cpp:106-124
+{
+    const size_t off = size_t(g) * A_;
+    const int child_player = games_[g].env->turn();
+    int selected = -1;
+    const int best = selectChildByMaxCount(g);
+    const float best_mean = normalizedMean(rr_reward_[off + best], rr_mean_[off + best], rr_count_[off + best], child_player, g);
+    float sum = 0.0f;
+    for (int i = 0; i < rr_nc_[g]; ++i) {
+        float count = std::pow(rr_count_[off + i], 1 / temperature);
+        float mean = normalizedMean(rr_reward_[off + i], rr_mean_[off + i], rr_count_[off + i], child_player, g);
+        if (count == 0 || (mean < best_mean - value_threshold)) { continue; }
+        sum += count;
+        float rand = rng_.randReal(sum);
+        if (selected == -1 || rand < count) { selected = i; }
+    }
+    return selected;
+}
+
+bool Worker::isResign(int g) const // ref mcts.cpp:84-89, zero_actor.h:40
+{
+    const Game& gm = games_[g];
+    if (!gm.enable_resign) { return false; }
+    const size_t off = size_t(g) * A_;
+    // the root's own reward field is only ever written by the first backup of the search with the root-evaluation
+    // reward, which is 0 for every environment this worker supports
+    const float root_win_rate = normalizedMean(0.0f, rr_root_mean_[g], rr_root_count_[g], rootPlayerFor(gm), g);
+    const int s = gm.selected;
+    const float action_win_rate = normalizedMean(rr_reward_[off + s], rr_mean_[off + s], rr_count_[off + s], gm.env->turn(), g);
+    return (-root_win_rate < cfg_.actor_resign_threshold && action_win_rate < cfg_.actor_resign_threshold);
+}
+
+std::string Worker::searchDistributionString(int g) const // ref mcts.cpp:126-137
+{
+    const size_t off = size_t(g) * A_;
+    std::ostringstream oss;
+    for (int i = 0; i < rr_nc_[g]; ++i) {
+        if (rr_count_[off + i] == 0) { continue; }
+        oss << (oss.str().empty() ? "" : ",") << rr_action_[off + i] << ":" << rr_count_[off + i];
+    }
+    return oss.str();
+}
+
+std::string Worker::gumbelPolicyString(int g, int child_player) const // ref gumbel_zero.cpp:9-58
+{
+    const size_t off = size_t(g) * A_;
+    const int nc = rr_nc_[g];
+    float pi_sum = 0.0f, q_sum = 0.0f;
+    for (int i = 0; i < nc; ++i) {
+        if (rr_count_[off + i] == 0) { continue; }
+        float value = normalizedMean(rr_reward_[off + i], rr_mean_[off + i], rr_count_[off + i], child_player, g);
+        pi_sum += rr_policy_[off + i];
+        q_sum += rr_policy_[off + i] * value;
+    }
+    float value_pi = rr_root_value_[g];
+    if (cfg_.actor_mcts_value_rescale) {
+        if (rr_bsize_[g] < 2) {
+            value_pi = 1.0f;
+        } else {
+            value_pi = (value_pi - rr_lo_[g]) / (rr_hi_[g] - rr_lo_[g]);
+            value_pi = ::fmin(static_cast<double>(1), ::fmax(static_cast<double>(-1), static_cast<double>(2 * value_pi - 1)));
+        }
+    }
+    value_pi = (child_player == flipping_player_ ? -value_pi : value_pi);
+    float non_visited_node_value = 1.0 / (1 + cfg_.actor_num_simulation) * (value_pi + (cfg_.actor_num_simulation / pi_sum) * q_sum);
+    std::unordered_map<int, float> new_logits; // its iteration order is part of the record format
+    float max_logit = -std::numeric_limits<float>::max();
+    float max_child_count = 0;
+    for (int i = 0; i < nc; ++i) { max_child_count = ::fmax(static_cast<double>(max_child_count), static_cast<double>(rr_count_[off + i])); }
+    for (int i = 0; i < nc; ++i) {
+        float value = (rr_count_[off + i] == 0 ? non_visited_node_value
+                                               : normalizedMean(rr_reward_[off + i], rr_mean_[off + i], rr_count_[off + i], child_player, g));
+        float logit_without_noise = rr_logit_[off + i] - rr_noise_[off + i];
+        float score = logit_without_noise + (cfg_.actor_gumbel_sigma_visit_c + max_child_count) * cfg_.actor_gumbel_sigma_scale_c * value;
+        new_logits.insert({rr_action_[off + i], score});
+        max_logit = ::fmax(static_cast<double>(max_logit), static_cast<double>(score));
+    }
+    std::ostringstream oss;
+    for (auto& logit : new_logits) {
+        logit.second = logit.second - max_logit;
+        if (logit.second < -38) { continue; }
+        oss << (oss.str().empty() ? "" : ",") << logit.first << ":" << ::exp(static_cast<double>(logit.second));
+    }
+    return oss.str();
+}
+
+void Worker::gumbelSortByScore(int g) // ref gumbel_zero.cpp:121-137
+{
+    const size_t off = size_t(g) * A_;
+    const int child_player = games_[g].env->turn();
+    float max_child_count = 0;
+    for (int i = 0; i < rr_nc_[g]; ++i) { max_child_count = ::fmax(static_cast<double>(max_child_count), static_cast<double>(rr_count_[off + i])); }
+    auto score = [&](int i) {
+        float min_value = -std::numeric_limits<float>::max();
+        float value = normalizedMean(rr_reward_[off + i], rr_mean_[off + i], rr_count_[off + i], child_player, g);
+        float s = rr_logit_[off + i] + (cfg_.actor_gumbel_sigma_visit_c + max_child_count) * cfg_.actor_gumbel_sigma_scale_c * value;
+        return (rr_count_[off + i] > 0 ? s : min_value);
+    };
+    std::sort(games_[g].candidates.begin(), games_[g].candidates.end(), [&](int l, int r) { return score(l) > score(r); });
+}
+
+void Worker::gumbelSequentialHalving(int g) // ref gumbel_zero.cpp:90-119
+{
+    Game& gm = games_[g];
+    const size_t off = size_t(g) * A_;
+    if (sims_done_ == 1) {
+        gm.candidates.clear();
+        for (int i = 0; i < rr_nc_[g]; ++i) { gm.candidates.push_back(i); }
+        std::sort(gm.candidates.begin(), gm.candidates.end(), [&](int l, int r) { return rr_logit_[off + l] > rr_logit_[off + r]; });
+        if (static_cast<int>(gm.candidates.size()) > cfg_.actor_gumbel_sample_size) { gm.candidates.resize(cfg_.actor_gumbel_sample_size); }
+        gm.sample_size = cfg_.actor_gumbel_sample_size;
+        gm.simulation_budget = std::max(1.0, std::floor(cfg_.actor_num_simulation / (std::log2(cfg_.actor_gumbel_sample_size) * gm.sample_size)));
+    } else {
+        bool all = true;
+        for (int i : gm.candidates) {
+            if (rr_count_[off + i] >= gm.simulation_budget) { continue; }
+            all = false;
+            break;
+        }
+        if (all) {
+            int next_budget = std::floor(cfg_.actor_num_simulation / (std::log2(cfg_.actor_gumbel_sample_size) * gm.sample_size / 2));
+            if (next_budget > 0 && gm.sample_size > 2) {
+                gm.sample_size /= 2;
+                gumbelSortByScore(g);
+                if (static_cast<int>(gm.candidates.size()) > gm.sample_size) { gm.candidates.resize(gm.sample_size); }
+                gm.simulation_budget = rr_count_[off + gm.candidates[0]] + next_budget;
+            }
+        }
+    }
+}
+
+int Worker::decideAction(int g) // ref zero_actor.cpp:178-192, gumbel_zero.cpp:60-72
+{
+    if (cfg_.actor_use_gumbel && cfg_.actor_select_action_by_count) {
+        gumbelSortByScore(g);
+        return games_[g].candidates[0];
+    }
+    if (!cfg_.actor_use_gumbel && cfg_.actor_select_action_by_count) { return selectChildByMaxCount(g); }
+    if (cfg_.actor_select_action_by_softmax_count) { return selectChildBySoftmaxCount(g, cfg_.actor_select_action_softmax_temperature); }
+    return selectChildByMaxCount(g);
+}
+
+ActionInfo Worker::actionInfo(int g, int child_player) const // ref base_actor.cpp:59-66, zero_actor.h:50-51, zero_actor.cpp:121-126
+{
+    ActionInfo info;
+    info.push_back({"P", cfg_.actor_use_gumbel ? gumbelPolicyString(g, child_player) : searchDistributionString(g)});
+    info.push_back({"V", std::to_string(rr_root_mean_[g])});
+    std::ostringstream oss;
+    oss << games_[g].env->reward();
+    info.push_back({"R", oss.str()});
+    return info;
+}
+
+std::string Worker::record(const Game& gm, const ActionInfo& extra) const // ref base_actor.cpp:39-57, base_env.h:207-233
+{
+    ActionInfo tags;
+    auto addTag = [&](const std::string& k, const std::string& v) {
+        for (auto& t : tags) { if (t.first == k) { t.second = v; return; } }
+        tags.push_back({k, v});
+    };
+    addTag("GM", gm.env->name());
+    addTag("RE", std::to_string(gm.env->evalScore(false)));
+    addTag("OBS", "");
+    for (auto& t : gm.env->loaderTags()) { addTag(t.first, t.second); }
+    addTag("EV", cfg_.nn_file_name.substr(cfg_.nn_file_name.find_last_of('/') + 1));
+    if (!gm.env->isTerminal()) { // unfinished game = resigned: the player to move loses (base_actor.cpp:49-54)
+        std::ostringstream oss;
+        oss << gm.env->evalScore(true);
+        addTag("RE", oss.str());
+    }
+    for (auto& t : extra) { addTag(t.first, t.second); }
+    std::ostringstream oss;
+    oss << "(;";
+    for (const auto& t : tags) { oss << t.first << "[" << escapeSGF(t.second) << "]"; }
+    const auto& ids = gm.env->actionIds();
+    const auto& pls = gm.env->actionPlayers();
+    for (size_t i = 0; i < ids.size(); ++i) {
+        oss << ";" << (pls[i] == 1 ? 'B' : 'W') << "[" << ids[i] << "]";
+        if (gm.action_info_history.size() > i) {
+            for (const auto& info : gm.action_info_history[i]) { oss << info.first << "[" << escapeSGF(info.second) << "]"; }
+        }
+    }
+    oss << ")";
+    return oss.str();
+}
+
+std::pair<int, int> Worker::trainingDataRange(const Game& gm) const // ref actor_group.cpp:52-64
+{
+    int game_length = static_cast<int>(gm.env->actionIds().size());
+    int data_start = 0, data_end = game_length - 1;
+    const int seq = cfg_.zero_actor_intermediate_sequence_length;
+    if (seq > 0) {
+        const int un = cfg_.learner_muzero_unrolling_step + cfg_.learner_n_step_return;
+        const bool term = gm.env->isTerminal();
+        data_end = std::max(0, (term ? data_end : data_end - un));
+        data_start = std::max(0, (term ? data_end - data_end % seq : data_end + 1 - seq));
+        if (term && (data_end % seq < un)) { data_start = std::max(0, data_start - seq); }
+    }
+    return {data_start, data_end};
+}
+
+void Worker::outputGame(Game& gm) // ref actor_group.cpp:24-50
+{
+    const int game_length = static_cast<int>(gm.env->actionIds().size());
+    const std::pair<int, int> range = trainingDataRange(gm);
+    const bool is_terminal = (cfg_.zero_actor_intermediate_sequence_length == 0 || gm.env->isTerminal());
+    std::ostringstream oss;
+    oss << "SelfPlay " << (is_terminal ? "true" : "false") << " " << (range.second - range.first + 1) << " " << game_length << " "
+        << gm.env->evalScore(!gm.env->isTerminal()) << " "
+        << record(gm, {{"DLEN", std::to_string(range.first) + "-" + std::to_string(range.second)}}) << " "
+        << "#";
+    if (!is_terminal) {
+        for (int i = range.first; i <= range.second; ++i) { gm.action_info_history[i].clear(); gm.action_info_history[i].shrink_to_fit(); }
+    }
+    lines_.push_back(oss.str());
+    if (is_terminal) { ++stats_.games; }
+}
+
+void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor.cpp:22-30
+{
+    Game& gm = games_[g];
+    const size_t off = size_t(g) * A_;
+    const bool resign = isResign(g);
+    if (!resign) {
+        const int action = rr_action_[off + gm.selected];
+        const int mover = gm.env->turn(); // == the player of every root child
+        if (gm.env->act(action, mover)) {
+            gm.action_info_history.resize(gm.env->actionIds().size());
+            gm.action_info_history.back() = actionInfo(g, mover);
+        }
+    }
+    ++stats_.moves;
+    const bool is_endgame = (resign || gm.env->isTerminal());
+    if (is_endgame) {
+        outputGame(gm);
+        resetGame(gm, rng_);
+    } else {
+        const int game_length = static_cast<int>(gm.env->actionIds().size());
+        const int seq = cfg_.zero_actor_intermediate_sequence_length;
+        if (seq > 0 && game_length >= seq && (game_length - cfg_.learner_n_step_return - cfg_.learner_muzero_unrolling_step) % seq == 0) { outputGame(gm); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+int Worker::cycle()
+{
+    const bool az = desc_.type == 0;
+    const size_t GA = size_t(G_) * A_;
+    const double t0 = nowMs();
+    double t1 = t0;
+    MZ_HIP(hipSetDevice(device_));
+    if (pending_) {
+        // ---- network results of the previous cycle ----
+        MZ_HIP(hipStreamSynchronize(stream_));
+        t1 = nowMs();
+        stats_.ms_forward += t1 - t0;
+        threads_->parallelFor(G_, [this](int g) { buildCandidates(g); });
+        int rc = pool_.expandBackupStaged(az ? -1 : sims_done_);
+        if (rc) { return rc; }
+        ++sims_done_;
+        const bool root_expansion = (sims_done_ == 1), done = (sims_done_ == n_ + 1);
+        const bool want_noise = root_expansion && (cfg_.actor_use_dirichlet_noise || cfg_.actor_use_gumbel_noise);
+        if (done || cfg_.actor_use_gumbel || want_noise) {
+            // root statistics for the per-move host logic (sync point; also surfaces pool capacity errors)
+            rc = pool_.rootRead(rr_nc_.data(), rr_action_.data(), rr_count_.data(), rr_mean_.data(), rr_policy_.data(), rr_logit_.data(),
+                                rr_noise_.data(), rr_value_.data(), rr_reward_.data(), rr_root_count_.data(), rr_root_mean_.data(),
+                                rr_root_value_.data(), rr_lo_.data(), rr_hi_.data(), rr_bsize_.data());
+            if (rc) { return rc; }
+            if ((rc = pool_.checkError())) { return rc; }
+        }
+        const double t2 = nowMs();
+        stats_.ms_expand += t2 - t1;
+        // ---- strictly serial, RNG-ordered section (actor index order) ----
+        std::vector<float> noise;
+        for (int g = 0; g < G_; ++g) {
+            Game& gm = games_[g];
+            const size_t off = size_t(g) * A_;
+            if (want_noise) { // ref zero_actor.cpp:194-213
+                const int k = rr_nc_[g];
+                if (cfg_.actor_use_dirichlet_noise) {
+                    const float epsilon = cfg_.actor_dirichlet_noise_epsilon;
+                    rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise);
+                    for (int i = 0; i < k; ++i) {
+                        rr_noise_[off + i] = noise[i];
+                        rr_policy_[off + i] = (1 - epsilon) * rr_policy_[off + i] + epsilon * noise[i];
+                    }
+                } else {
+                    rng_.gumbel(k, noise);
+                    for (int i = 0; i < k; ++i) {
+                        rr_noise_[off + i] = noise[i];
+                        rr_logit_[off + i] = rr_logit_[off + i] + noise[i];
+                    }
+                }
+                memcpy(noise_policy_.data() + off, rr_policy_.data() + off, k * sizeof(float));
+                memcpy(noise_logit_.data() + off, rr_logit_.data() + off, k * sizeof(float));
+                memcpy(noise_noise_.data() + off, rr_noise_.data() + off, k * sizeof(float));
+            }
+            if (done) { gm.selected = decideAction(g); }                  // zero_actor.cpp:96 handleSearchDone()
+            if (cfg_.actor_use_gumbel) { gumbelSequentialHalving(g); }     // zero_actor.cpp:97
+            if (done) { handleSearchDone(g); }                             // actor_group.cpp:92
+            if (az) { // beforeNNEvaluation: the rotation draw (zero_actor.cpp:56)
+                gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
+            }
+        }
+        if (want_noise) {
+            if ((rc = pool_.rootSetNoise(noise_mask_.data(), noise_policy_.data(), noise_logit_.data(), noise_noise_.data()))) { return rc; }
+        }
+        if (done) {
+            std::vector<int> rp(G_);
+            for (int g = 0; g < G_; ++g) { rp[g] = rootPlayerFor(games_[g]); }
+            if ((rc = pool_.resetSearch(nullptr, rp.data()))) { return rc; }
+            sims_done_ = 0;
+        }
+        t1 = nowMs();
+        stats_.ms_move += t1 - t2;
+    } else {
+        for (auto& gm : games_) {
+            if (az) { gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0; }
+        }
+        t1 = nowMs();
+    }
+
+    // ---- selection ----
+    const int* d_start = nullptr;
+    if (cfg_.actor_use_gumbel && sims_done_ >= 1) { // ref gumbel_zero.cpp:74-88
+        for (int g = 0; g < G_; ++g) {
+            Game& gm = games_[g];
+            const size_t off = size_t(g) * A_;
+            std::sort(gm.candidates.begin(), gm.candidates.end(), [&](int l, int r) {
+                return (rr_count_[off + l] < rr_count_[off + r] || (rr_count_[off + l] == rr_count_[off + r] && rr_logit_[off + l] > rr_logit_[off + r]));
+            });
+            pool_.h_start_.p[g] = 1 + gm.candidates[0]; // the root's children are nodes 1..k
+        }
+        MZ_HIP(hipMemcpyAsync(pool_.d_start_.p, pool_.h_start_.p, G_ * sizeof(int), hipMemcpyHostToDevice, stream_));
+        d_start = pool_.d_start_.p;
+    }
+    int rc = pool_.selectAsync(d_start);
+    if (rc) { return rc; }
+    MZ_HIP(hipMemcpyAsync(pool_.h_path_len_.p, pool_.v_.path_len, G_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (az) {
+        MZ_HIP(hipMemcpyAsync(pool_.h_path_action_.p, pool_.v_.path_action, size_t(G_) * pool_.v_.max_depth * sizeof(int), hipMemcpyDeviceToHost,
+                              stream_));
+    }
+    MZ_HIP(hipStreamSynchronize(stream_));
+    const double t3 = nowMs();
+    stats_.ms_select += t3 - t1;
+
+    // ---- leaf environments + feature planes (host, parallel over games) ----
+    threads_->parallelFor(G_, [this](int g) { buildLeaf(g); });
+    const double t4 = nowMs();
+    stats_.ms_env += t4 - t3;
+
+    // ---- network ----
+    if (az) {
+        MZ_HIP(hipMemcpyAsync(d_feat_.p, h_feat_.p, size_t(G_) * net_.featSize() * sizeof(float), hipMemcpyHostToDevice, stream_));
+        if ((rc = net_.forwardAZ(d_feat_.p, G_, d_policy_.p, d_logit_.p, d_value_.p))) { return rc; }
+    } else if (sims_done_ == 0) {
+        MZ_HIP(hipMemcpyAsync(d_feat_.p, h_feat_.p, size_t(G_) * net_.featSize() * sizeof(float), hipMemcpyHostToDevice, stream_));
+        if ((rc = pool_.hiddenIndexAsync(n_ + 1, 0, d_src_idx_.p, d_dst_idx_.p, d_action_ids_.p))) { return rc; }
+        if ((rc = net_.initial(d_feat_.p, G_, d_policy_.p, d_logit_.p, d_value_.p, d_hidden_.p, d_dst_idx_.p))) { return rc; }
+        MZ_HIP(hipMemsetAsync(d_reward_.p, 0, G_ * sizeof(float), stream_));
+    } else {
+        // device-resident MuZero step: parent hidden state gathered from the slab, action plane synthesised on device
+        if ((rc = pool_.hiddenIndexAsync(n_ + 1, sims_done_, d_src_idx_.p, d_dst_idx_.p, d_action_ids_.p))) { return rc; }
+        if ((rc = net_.recurrent(d_hidden_.p, d_src_idx_.p, nullptr, d_action_ids_.p, G_, d_policy_.p, d_logit_.p, d_value_.p, d_reward_.p,
+                                 d_hidden_.p, d_dst_idx_.p))) {
+            return rc;
+        }
+    }
+    MZ_HIP(hipMemcpyAsync(h_policy_.p, d_policy_.p, GA * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(h_logit_.p, d_logit_.p, GA * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(h_value_.p, d_value_.p, G_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (!az) { MZ_HIP(hipMemcpyAsync(h_reward_.p, d_reward_.p, G_ * sizeof(float), hipMemcpyDeviceToHost, stream_)); }
+    pending_ = true;
+    ++stats_.cycles;
+    stats_.leaf_evals += G_;
+    stats_.ms_total += nowMs() - t0;
+    return MZ_OK;
+}
+
+int Worker::runCycles(int n)
+{
+    if (!running_) { return 0; }
+    for (int i = 0; i < n; ++i) {
+        int rc = cycle();
+        if (rc) { return rc; }
+    }
+    return n;
+}
+
+int Worker::popLine(char* buf, int cap)
+{
+    if (lines_.empty()) { return 0; }
+    const std::string& s = lines_.front();
+    const int len = static_cast<int>(s.size());
+    if (cap <= len) { setError("pop_line: buffer of %d bytes too small for a %d-byte line", cap, len); return MZ_ERR_ARG; }
+    memcpy(buf, s.data(), len);
+    buf[len] = 0;
+    lines_.pop_front();
+    return len;
+}
+
+int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
+{
+    const std::string prefix = line.substr(0, line.find(' '));
+    std::istringstream ign(cfg_.zero_actor_ignored_command);
+    std::string tok;
+    while (ign >> tok) { if (tok == prefix) { return MZ_OK; } }
+    if (prefix == "start") { running_ = true; }
+    else if (prefix == "stop") { running_ = false; }
+    else if (prefix == "reset_actors") {
+        for (auto& gm : games_) { resetGame(gm, main_rng_); } // handleCommand runs on the main thread (actor_group.cpp:200-219)
+        std::vector<int> rp(G_);
+        for (int g = 0; g < G_; ++g) { rp[g] = rootPlayerFor(games_[g]); }
+        sims_done_ = 0;
+        pending_ = false;
+        MZ_HIP(hipStreamSynchronize(stream_));
+        return pool_.resetSearch(nullptr, rp.data());
+    } else if (prefix == "load_model") {
+        if (line.find(' ') == std::string::npos) { setError("load_model needs a path"); return MZ_ERR_ARG; }
+        cfg_.nn_file_name = line.substr(line.find(' ') + 1);
+        if (!pending_weights_.empty()) {
+            MZ_HIP(hipStreamSynchronize(stream_));
+            int rc = net_.reload(pending_weights_.data(), pending_weights_.size());
+            pending_weights_.clear();
+            return rc;
+        }
+    } else if (prefix == "update_config") {
+        if (line.find(' ') == std::string::npos || !cfg_.loadFromString(line.substr(line.find(' ') + 1))) { return MZ_ERR_ARG; }
+    } else if (prefix == "quit") {
+        running_ = false;
+        return 1;
+    }
+    return MZ_OK; // anything else (keep_alive, ...) is silently ignored
+}
+
+} // namespace mz
+
+// ------------------------------------------------------------------------------------------------
+struct mz_worker { mz::Worker w; };
+struct mz_net { mz::Net net; };
+struct mz_env { std::unique_ptr<mz::GameEnv> e; };
+
+extern "C" {
+
+mz_worker* mz_worker_create(int device, const char* conf, const mz_net_desc* desc, const float* weights, size_t count)
+{
+    if (!conf || !desc || !weights) { mz::setError("mz_worker_create: NULL argument"); return nullptr; }
+    std::unique_ptr<mz_worker> w(new mz_worker());
+    if (w->w.init(device, conf, *desc, weights, count) != MZ_OK) { return nullptr; }
+    return w.release();
+}
+void mz_worker_destroy(mz_worker* w) { delete w; }
+int mz_worker_command(mz_worker* w, const char* line)
+{
+    if (!w || !line) { mz::setError("mz_worker_command: NULL argument"); return MZ_ERR_ARG; }
+    return w->w.command(line);
+}
+int mz_worker_set_weights(mz_worker* w, const float* weights, size_t count)
+{
+    if (!w || !weights) { mz::setError("mz_worker_set_weights: NULL argument"); return MZ_ERR_ARG; }
+    return w->w.setWeights(weights, count);
+}
+int mz_worker_run_cycles(mz_worker* w, int n)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.runCycles(n);
+}
+int mz_worker_pop_line(mz_worker* w, char* buf, int cap)
+{
+    if (!w || !buf) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
+    return w->w.popLine(buf, cap);
+}
+int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out)
+{
+    if (!w || !out) { return MZ_ERR_ARG; }
+    *out = w->w.stats_;
+    return MZ_OK;
+}
+mz_net* mz_worker_net(mz_worker* w) { return w ? reinterpret_cast<mz_net*>(&w->w.net_) : nullptr; }
+
+mz_env* mz_env_create(const char* conf)
+{
+    mz::WorkerConfig c;
+    if (!conf || !c.loadFromString(conf)) { return nullptr; }
+    std::unique_ptr<mz_env> e(new mz_env());
+    e->e = mz::createGameEnv(c.env_game, c.env_board_size, c.env_go_komi);
+    if (!e->e) { return nullptr; }
+    return e.release();
+}
+void mz_env_destroy(mz_env* e) { delete e; }
+void mz_env_reset(mz_env* e) { e->e->reset(); }
+int mz_env_act(mz_env* e, int action_id, int player) { return e->e->act(action_id, player) ? 1 : 0; }
+int mz_env_turn(const mz_env* e) { return e->e->turn(); }
+int mz_env_is_terminal(const mz_env* e) { return e->e->isTerminal() ? 1 : 0; }
+float mz_env_eval_score(const mz_env* e, int is_resign) { return e->e->evalScore(is_resign != 0); }
+int mz_env_policy_size(const mz_env* e) { return e->e->policySize(); }
+int mz_env_feature_size(const mz_env* e) { return e->e->featureSize(); }
+int mz_env_legal_mask(const mz_env* e, uint8_t* out)
+{
+    e->e->legalMask(out);
+    return MZ_OK;
+}
+int mz_env_features(const mz_env* e, int rotation, float* out)
+{
+    if (rotation < 0 || rotation > 7) { mz::setError("rotation %d out of range", rotation); return MZ_ERR_ARG; }
+    e->e->features(rotation, out);
+    return MZ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,90 @@
+"""CPU tests: the product's host rules engines (libmzgpu, own design) against the oracle's restatement of the
+reference envs, in the style of the reference's `-mode env_test` (ref console/mode_handler.cpp:167-192):
+random legal playouts to the end, comparing at every ply the legal mask, turn, terminal flag, scores and the
+feature planes under all 8 rotations; plus replay-from-record determinism."""
+import numpy as np
+import pytest
+
+GAMES = [("env_game=tictactoe", 60), ("env_game=othello:env_board_size=8", 25), ("env_game=go:env_board_size=9", 12),
+         ("env_game=go:env_board_size=5", 25), ("env_game=othello:env_board_size=6", 20), ("env_game=go:env_board_size=13", 3)]
+
+
+@pytest.mark.parametrize("conf,playouts", GAMES)
+def test_random_playouts_match_oracle(mz, oracle, conf, playouts):
+    rng = np.random.default_rng(hash(conf) % (1 << 32))
+    a, b = mz.Env(conf), oracle.OracleEnv(conf)
+    total_moves = 0
+    for game in range(playouts):
+        a.reset()
+        b.reset()
+        history = []
+        while True:
+            ma, mb = a.legal_mask(), b.legal_mask()
+            assert np.array_equal(ma, mb), f"{conf}: legal mask differs after {history}"
+            assert a.turn() == b.turn() and a.is_terminal() == b.is_terminal()
+            assert a.eval_score() == b.eval_score() and a.eval_score(True) == b.eval_score(True)
+            if len(history) % 7 == 0 or a.is_terminal():
+                for rot in range(8):
+                    assert np.array_equal(a.features(rot), b.features(rot)), f"{conf}: features rot {rot} differ after {history}"
+            else:
+                rot = int(rng.integers(0, 8))
+                assert np.array_equal(a.features(rot), b.features(rot))
+            if a.is_terminal():
+                break
+            legal = np.nonzero(ma)[0]
+            # bias towards board moves so that Go games are not all immediate double passes
+            if len(legal) > 1 and rng.random() < 0.97:
+                legal = legal[legal != a.policy_size() - 1] if "tictactoe" not in conf else legal
+            act = int(rng.choice(legal))
+            # an illegal action must be refused by both and change nothing
+            illegal = np.nonzero(ma == 0)[0]
+            if len(illegal):
+                bad = int(rng.choice(illegal))
+                assert not a.act(bad) and not b.act(bad)
+            assert a.act(act) and b.act(act)
+            history.append(act)
+        total_moves += len(history)
+        # replay determinism (record round trip of env_test): same actions -> same final state
+        a.reset()
+        for act in history:
+            assert a.act(act)
+        assert a.is_terminal() and a.eval_score() == b.eval_score() and np.array_equal(a.features(0), b.features(0))
+    assert total_moves > playouts * 4
+
+
+def test_go_superko_and_capture_cases(mz, oracle):
+    """hand-made 5x5 positions: ko recapture is illegal (positional superko), suicide illegal, capture legal"""
+    conf = "env_game=go:env_board_size=5"
+    for env in (mz.Env(conf), oracle.OracleEnv(conf)):
+        # B: 1,5,11,7  W: 2,8,12  then W takes at 6?  build a ko around points 6/7
+        seq = [(1, 1), (2, 2), (5, 1), (8, 2), (11, 1), (12, 2), (7, 1), (6, 2)]  # W 6 captures B 7
+        for a, p in seq:
+            assert env.act(a, p), (a, p)
+        m = env.legal_mask()
+        assert m[7] == 0, "immediate ko recapture must be illegal (positional superko)"
+        assert env.act(24, 1) and env.act(23, 2)
+        assert env.legal_mask()[7] == 1, "after a ko threat elsewhere the position is new: recapture legal"
+    e = mz.Env(conf)
+    for a, p in [(1, 1), (24, 2), (5, 1), (23, 2)]:
+        assert e.act(a, p)
+    assert e.legal_mask()[0] == 1 and e.turn() == 1  # own eye: legal for black
+    e.act(22, 1)
+    assert e.legal_mask()[0] == 0  # suicide for white
+
+
+def test_tromp_taylor_empty_board_goes_to_black(mz, oracle):
+    """ref go.cpp:714: an empty region with an empty border counts for black"""
+    conf = "env_game=go:env_board_size=9"
+    for env in (mz.Env(conf), oracle.OracleEnv(conf)):
+        assert env.act(81) and env.act(81) and env.is_terminal()
+        assert env.eval_score() == 1.0
+
+
+def test_env_shapes(mz):
+    for conf, A, F in [("env_game=tictactoe", 9, 36), ("env_game=othello", 65, 256), ("env_game=go", 82, 18 * 81)]:
+        e = mz.Env(conf)
+        assert e.policy_size() == A and e.features(0).size == F
+    with pytest.raises(mz.MzError):
+        mz.Env("env_game=chess")
+    with pytest.raises(mz.MzError):
+        mz.Env("env_game=othello:env_board_size=10")

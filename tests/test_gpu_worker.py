@@ -1,0 +1,117 @@
+"""End-to-end parity of the self-play worker: the HIP worker (through the C ABI) must emit exactly the same
+`SelfPlay ... #` lines as the CPU oracle's ActorGroup loop under the same seed (1 host thread == the
+reference's deterministic contract).  Bit-identical records need bit-identical network
+outputs, which the order contract of DESIGN.md provides (f32 MFMA chain == fmaf chain)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(mz, oracle, conf, desc_args, cycles, threads=1, seed=1, wseed=0):
+    kw = dict(vh=desc_args[10], dv=desc_args[11], type_name=desc_args[12])
+    d, od = mz.make_desc(*desc_args[:10], **kw), oracle.make_desc(*desc_args[:10], **kw)
+    w = mz.generate_weights(d, wseed)
+    conf = f"{conf}:program_seed={seed}:nn_file_name=/tmp/weights/synthetic_{wseed}.pt"
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles(cycles)
+    wk = mz.Worker(conf + f":zero_num_threads={threads}", d, w)
+    wk.command("start")
+    assert wk.run_cycles(cycles) == cycles
+    st = wk.stats()
+    lines = wk.pop_lines()
+    assert st["leaf_evals"] == og.leaf_evals()
+    return lines, og.lines(), st
+
+
+def check(lines, olines, min_lines):
+    assert len(olines) >= min_lines, "test too short to finish games"
+    for i, (a, b) in enumerate(zip(lines, olines)):
+        assert a == b, f"line {i} differs:\n  hip   : {a}\n  oracle: {b}"
+    assert len(lines) == len(olines)
+    for l in lines:
+        assert l.startswith("SelfPlay ") and l.endswith(" #") and l.count("SelfPlay") == 1 and " " not in l.split(" ", 5)[5][:-2]
+
+
+C1 = ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9, 256, 1, "alphazero")
+
+
+def test_c1_tictactoe_alphazero(mz, oracle):
+    """BASELINE.json configs[0]: TicTacToe AZ n=16, 2b x 16ch, 8 games"""
+    lines, olines, st = run_both(mz, oracle, mz.CONFIGS["c1"], C1, 17 * 120)
+    check(lines, olines, 100)
+    assert st["games"] == len(lines)
+
+
+def test_c1_multithreaded_host_is_still_deterministic(mz, oracle):
+    lines, olines, _ = run_both(mz, oracle, mz.CONFIGS["c1"], C1, 17 * 40, threads=4, seed=7)
+    check(lines, olines, 30)
+
+
+def test_small_go_alphazero(mz, oracle):
+    conf = "env_game=go:env_board_size=9:actor_num_simulation=8:zero_num_parallel_games=6"
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    lines, olines, _ = run_both(mz, oracle, conf, args, 9 * 400, threads=3)
+    check(lines, olines, 6)
+
+
+def test_go_resign_and_count_selection(mz, oracle):
+    conf = ("env_game=go:env_board_size=9:actor_num_simulation=6:zero_num_parallel_games=4:actor_select_action_by_count=true:"
+            "actor_select_action_by_softmax_count=false:actor_resign_threshold=0.5:zero_disable_resign_ratio=0.5:"
+            "actor_use_random_rotation_features=false")
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    lines, olines, _ = run_both(mz, oracle, conf, args, 7 * 300, seed=3)
+    check(lines, olines, 4)
+
+
+def test_small_othello_gumbel_alphazero(mz, oracle):
+    conf = ("env_game=othello:env_board_size=8:actor_num_simulation=16:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+            "actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:actor_gumbel_sigma_visit_c=50:actor_gumbel_sigma_scale_c=1:"
+            "zero_num_parallel_games=12")
+    args = ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65, 16, 1, "alphazero")
+    lines, olines, _ = run_both(mz, oracle, conf, args, 17 * 150, threads=2)
+    check(lines, olines, 12)
+
+
+def test_gumbel_sequential_halving_n50(mz, oracle):
+    conf = ("env_game=othello:env_board_size=8:actor_num_simulation=50:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+            "actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:zero_num_parallel_games=4")
+    args = ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65, 16, 1, "alphazero")
+    lines, olines, _ = run_both(mz, oracle, conf, args, 51 * 140)
+    check(lines, olines, 4)
+
+
+def test_small_go_muzero(mz, oracle):
+    conf = "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=10:zero_num_parallel_games=4"
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "muzero")
+    lines, olines, _ = run_both(mz, oracle, conf, args, 11 * 340, threads=2)
+    check(lines, olines, 4)
+
+
+def test_tictactoe_muzero(mz, oracle):
+    conf = "env_game=tictactoe:nn_type_name=muzero:actor_num_simulation=12:zero_num_parallel_games=8"
+    args = ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 1, 9, 32, 1, "muzero")
+    lines, olines, _ = run_both(mz, oracle, conf, args, 13 * 100)
+    check(lines, olines, 50)
+
+
+def test_commands(mz):
+    d = mz.DESCS["c1"]()
+    w = mz.generate_weights(d, 0)
+    wk = mz.Worker(mz.CONFIGS["c1"] + ":program_seed=1", d, w)
+    assert wk.run_cycles(5) == 0  # not started
+    wk.command("keep_alive")
+    wk.command("reset_actors")  # ignored by default (ref configuration.cpp:47)
+    wk.command("start")
+    assert wk.run_cycles(17) == 17
+    wk.command("stop")
+    assert wk.run_cycles(17) == 0
+    wk.command("update_config actor_num_simulation=16")
+    with pytest.raises(mz.MzError):
+        wk.command("update_config no_such_key=1")
+    wk.set_weights(mz.generate_weights(d, 5))
+    wk.command("load_model /x/y/weight_iter_100.pt")
+    wk.command("start")
+    assert wk.run_cycles(17 * 12) == 17 * 12
+    assert any("EV[weight_iter_100.pt]" in l for l in wk.pop_lines())
+    assert wk.command("quit") == 1
