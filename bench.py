@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py — self-play hot path on N MI355X of one node.
+
+A "step" is one lock-step cycle of the worker: one MCTS simulation (select -> leaf environment + features ->
+network forward -> expand + backup) for every game of the batch, i.e. `games` leaf evaluations per GPU.
+Workload = BASELINE.json configs[1]: 9x9 Go AlphaZero, n=400, 6 blocks x 64 channels, 256 parallel games
+per GPU, synthetic fixed-weight network (deterministic generator, seed 0), games from the empty board.
+Games shard across GPUs with no data-path collective: weak scaling, rank r seeds program_seed + r.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak (== f32 vector peak)
+GO_GAME_LENGTH_CAP = 163       # 9x9 Go: terminal once #actions > 2*81 (ref go.cpp:253-254); synthetic nets neither pass twice nor resign
+
+
+def cpu_baseline(conf, seconds):
+    """CPU restatement of the reference's actor (oracle/, kind "port") on the same workload, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # cpu_baseline leg only
+    d = O.desc_c2()
+    w = O.gen_weights(d, 0)
+    g = O.OracleGroup(conf + ":zero_num_threads=1", d, w)
+    g.cycles(1)  # warm-up (thread start, page-in)
+    t0 = time.time()
+    cycles = 0
+    while time.time() - t0 < seconds or cycles < 3:
+        g.cycles(1)
+        cycles += 1
+    dt = time.time() - t0
+    evals = cycles * 256
+    cores = os.cpu_count() or 1
+    return {"value": evals / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
+            "sample": f"{cycles} lock-step cycles x 256 games of the same workload ({dt:.1f} s): tree+env on 1 thread "
+                      f"(the reference's deterministic contract), network forward on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=802)   # 2 full moves of every game (401 cycles per move)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--games", type=int, default=256)
+    ap.add_argument("--threads", type=int, default=0, help="host threads for env/feature/candidate work (0 = cores / ranks)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import minizero_amd as mz
+    if not torch.cuda.is_available() or mz.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU (libmzgpu has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cores = os.cpu_count() or 1
+    threads = args.threads or max(1, min(32, cores // max(1, world)))  # spin-wait pool: 32 workers cover 256 games
+    base_conf = mz.CONFIGS["c2"].replace("zero_num_parallel_games=256", f"zero_num_parallel_games={args.games}")
+    conf = f"{base_conf}:zero_num_threads={threads}:program_seed={1 + rank}:nn_file_name=synthetic_go_6bx64_seed0.pt"
+    desc = mz.DESCS["c2"]()
+    weights = mz.generate_weights(desc, 0)
+    if world > 1:  # the optional synchronous weight broadcast over xGMI (RCCL): rank 0's blob is the one everybody loads
+        wt = torch.from_numpy(weights).cuda()
+        dist.broadcast(wt, src=0)
+        weights = wt.cpu().numpy()
+    worker = mz.Worker(conf, desc, weights, device=local_rank)
+    worker.command("start")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    assert worker.run_cycles(args.warmup) == args.warmup
+    s0 = worker.stats()
+    barrier()
+    t0 = time.perf_counter()
+    assert worker.run_cycles(args.steps) == args.steps
+    barrier()
+    dt = time.perf_counter() - t0
+    s1 = worker.stats()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([s1["moves"] - s0["moves"], s1["games"] - s0["games"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        moves, games_done = float(cnt[0].item()), float(cnt[1].item())
+    else:
+        moves, games_done = s1["moves"] - s0["moves"], s1["games"] - s0["games"]
+
+    if rank == 0:
+        evals = args.games * args.steps * world
+        value = evals / dt
+        # dominant kernel: residual-tower conv3x3 64->64 on the f32 MFMA pipe, HIP events on the network's own stream
+        net = worker.net()
+        ms_launch, fl_launch, bytes_launch = net.time_tower_conv(args.games, 200)
+        ms_fwd, ms_convs, fl_convs = net.time_forward(args.games, 50)
+        achieved = fl_launch / (ms_launch * 1e-3) / 1e12
+        phase = {k: round((s1[k] - s0[k]) / args.steps, 4) for k in ("ms_select", "ms_env", "ms_forward", "ms_expand", "ms_move", "ms_total")}
+        out = {
+            "metric": "self-play leaf-evals/s (9x9 Go AlphaZero n=400)", "value": value, "unit": "leaf-evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 9x9 Go AlphaZero, n=400, 6 blocks x 64 ch, 256 parallel games per GPU, "
+                                   "synthetic fixed-weight net (seed 0), Dirichlet noise + random rotation + softmax-count moves (reference defaults)",
+                       "games_per_gpu": args.games, "actor_num_simulation": 400, "host_threads_per_gpu": threads, "host_cores": cores,
+                       "sharding": f"{world} x independent actor pools, no data-path collective"},
+            "moves_per_sec": moves / dt, "games_finished": games_done,
+            "games_per_sec": (games_done / dt) if games_done else None,
+            "games_per_sec_projected": moves / dt / GO_GAME_LENGTH_CAP,
+            "games_per_sec_note": f"projected = moves/s / {GO_GAME_LENGTH_CAP} (9x9 games of the synthetic net run to the move cap)",
+            "per_step_ms": phase,
+            "forward": {"ms_per_forward": ms_fwd, "ms_conv3x3_per_forward": ms_convs,
+                        "conv3x3_tflops_per_forward": fl_convs / (ms_convs * 1e-3) / 1e12},
+            "roofline": {"kernel": "conv3x3_mfma<9,9,64> (tower layer 64->64, fused bias+ReLU)", "bound": "mfma", "achieved": achieved,
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_launch": fl_launch, "us_per_launch": ms_launch * 1e3, "compulsory_bytes_per_launch": bytes_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del worker
+            out["cpu_baseline"] = cpu_baseline(base_conf + ":program_seed=1:nn_file_name=synthetic_go_6bx64_seed0.pt", args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,9 @@ int mz_net_recurrent(mz_net* net, const float* hidden_in, const float* action_pl
  * returns HIP-event times on the network's own stream: total ms per forward, and ms spent in the
  * 3x3-convolution kernels per forward (the dominant kernel; roofline numerator in DESIGN.md). */
 int mz_net_time_forward(mz_net* net, int batch, int iters, float* ms_total, float* ms_conv3x3, double* conv_flops_per_forward);
+/* average HIP-event duration of ONE launch of the dominant kernel (residual-tower conv3x3 C->C, fused
+ * bias+ReLU) at batch B, with its algorithmic FLOPs and compulsory HBM bytes per launch */
+int mz_net_time_tower_conv(mz_net* net, int batch, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch);
 
 /* ------------------------------------------------------------------------------------------
  * Search pool: the structure-of-arrays node pool of `games` trees in HBM.  Replaces

@@ -84,6 +84,12 @@ int mz_net_time_forward(mz_net* net, int batch, int iters, float* ms_total, floa
     return net->net.timeForward(batch, iters, ms_total, ms_conv3x3, conv_flops_per_forward);
 }
 
+int mz_net_time_tower_conv(mz_net* net, int batch, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch)
+{
+    if (!net) { mz::setError("NULL network"); return MZ_ERR_ARG; }
+    return net->net.timeTowerConv(batch, iters, ms_per_launch, flops_per_launch, bytes_per_launch);
+}
+
 mz_pool* mz_pool_create(int device, int games, int nodes_per_game, int action_size, const mz_search_cfg* cfg)
 {
     if (!cfg) { mz::setError("mz_pool_create: NULL cfg"); return nullptr; }

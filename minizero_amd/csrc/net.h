@@ -43,6 +43,7 @@ public:
     int recurrent_any(const float* hidden_in, const float* action, int B, float* policy, float* logit, float* value, float* reward, float* hidden_out,
                       int where);
     int timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops);
+    int timeTowerConv(int B, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch);
 
     mz_net_desc desc_{};
     int device_ = -1;

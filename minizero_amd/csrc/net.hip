@@ -535,4 +535,37 @@ int Net::timeForward(int B, int iters, float* ms_total, float* ms_conv, double* 
     return MZ_OK;
 }
 
+// Average duration of ONE launch of the dominant kernel (the residual-tower conv3x3, C -> C with fused bias+ReLU)
+// from HIP events on this network's stream, with its algorithmic FLOPs and compulsory HBM bytes per launch.
+int Net::timeTowerConv(int B, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch)
+{
+    if (B <= 0 || iters <= 0 || repr_.size() < 2) { setError("timeTowerConv: bad arguments or network without residual blocks"); return MZ_ERR_ARG; }
+    MZ_HIP(hipSetDevice(device_));
+    int rc = ensureBatch(B);
+    if (rc) { return rc; }
+    const ConvLayer& L = repr_[1];
+    std::vector<float> h(size_t(B) * hiddenSize());
+    uint64_t s = 0x9876543ULL;
+    for (auto& v : h) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; v = static_cast<float>((s >> 40) & 0xFFFF) / 65536.0f - 0.25f; }
+    MZ_HIP(hipMemcpy(act_[0].p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i < 3; ++i) { if ((rc = launchConv(L, act_[0].p, nullptr, act_[1].p, B))) { return rc; } }
+    hipEvent_t e0, e1;
+    MZ_HIP(hipEventCreate(&e0));
+    MZ_HIP(hipEventCreate(&e1));
+    MZ_HIP(hipStreamSynchronize(stream_));
+    MZ_HIP(hipEventRecord(e0, stream_));
+    for (int i = 0; i < iters; ++i) { if ((rc = launchConv(L, act_[0].p, nullptr, act_[1].p, B))) { return rc; } }
+    MZ_HIP(hipEventRecord(e1, stream_));
+    MZ_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    MZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ms_per_launch) { *ms_per_launch = ms / iters; }
+    if (flops_per_launch) { *flops_per_launch = 2.0 * 9.0 * L.cin * L.cout * P() * B; }
+    // compulsory traffic: read the input activations once, write the outputs once, read the layer's weights once
+    if (bytes_per_launch) { *bytes_per_launch = 4.0 * (double(B) * L.cin * P() + double(B) * L.cout * P() + 9.0 * L.cin * L.cout + L.cout); }
+    return MZ_OK;
+}
+
 } // namespace mz

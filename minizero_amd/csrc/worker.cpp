@@ -63,18 +63,21 @@ struct Rng {
 };
 
 // ---- persistent thread pool: parallelFor over games ----
+// Two short parallel sections per lock-step cycle (~1 ms apart), so wake-up latency matters more than
+// anything else: workers spin on an epoch counter (pause) and only fall back to a condition variable
+// after ~2 ms without work (worker stopped / between benchmarks).
 class ThreadPool {
 public:
     explicit ThreadPool(int n) : n_(std::max(1, n))
     {
-        for (int t = 1; t < n_; ++t) { threads_.emplace_back([this, t]() { loop(t); }); }
+        for (int t = 1; t < n_; ++t) { threads_.emplace_back([this]() { loop(); }); }
     }
     ~ThreadPool()
     {
         {
             std::lock_guard<std::mutex> l(mu_);
-            quit_ = true;
-            ++epoch_;
+            quit_.store(true);
+            epoch_.fetch_add(1);
         }
         cv_.notify_all();
         for (auto& t : threads_) { t.join(); }
@@ -82,57 +85,60 @@ public:
     void parallelFor(int count, const std::function<void(int)>& fn)
     {
         if (n_ == 1 || count < 2) { for (int i = 0; i < count; ++i) { fn(i); } return; }
+        fn_ = &fn;
+        count_ = count;
+        chunk_ = std::max(1, count / (n_ * 4));
+        next_.store(0, std::memory_order_relaxed);
+        done_.store(0, std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> l(mu_);
-            fn_ = &fn;
-            count_ = count;
-            next_.store(0);
-            pending_ = n_ - 1;
-            ++epoch_;
+            std::lock_guard<std::mutex> l(mu_); // pairs with the sleepers' predicate check
+            epoch_.fetch_add(1, std::memory_order_release);
         }
-        cv_.notify_all();
+        if (sleepers_.load(std::memory_order_acquire) > 0) { cv_.notify_all(); }
         work();
-        std::unique_lock<std::mutex> l(mu_);
-        done_cv_.wait(l, [this]() { return pending_ == 0; });
+        while (done_.load(std::memory_order_acquire) != n_ - 1) { __builtin_ia32_pause(); }
     }
 
 private:
     void work()
     {
-        const int chunk = std::max(1, count_ / (n_ * 4));
         while (true) {
-            int b = next_.fetch_add(chunk);
+            const int b = next_.fetch_add(chunk_, std::memory_order_relaxed);
             if (b >= count_) { break; }
-            int e = std::min(count_, b + chunk);
+            const int e = std::min(count_, b + chunk_);
             for (int i = b; i < e; ++i) { (*fn_)(i); }
         }
     }
-    void loop(int)
+    void loop()
     {
         uint64_t seen = 0;
         while (true) {
-            {
-                std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [&]() { return epoch_ != seen; });
-                seen = epoch_;
-                if (quit_) { return; }
+            int spins = 0;
+            while (epoch_.load(std::memory_order_acquire) == seen) {
+                __builtin_ia32_pause();
+                if (++spins > 60000) { // ~2 ms idle: sleep
+                    std::unique_lock<std::mutex> l(mu_);
+                    sleepers_.fetch_add(1);
+                    cv_.wait(l, [&]() { return epoch_.load(std::memory_order_acquire) != seen; });
+                    sleepers_.fetch_sub(1);
+                    break;
+                }
             }
+            seen = epoch_.load(std::memory_order_acquire);
+            if (quit_.load()) { return; }
             work();
-            {
-                std::lock_guard<std::mutex> l(mu_);
-                if (--pending_ == 0) { done_cv_.notify_one(); }
-            }
+            done_.fetch_add(1, std::memory_order_release);
         }
     }
     int n_;
     std::vector<std::thread> threads_;
     std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     const std::function<void(int)>* fn_ = nullptr;
-    int count_ = 0, pending_ = 0;
-    std::atomic<int> next_{0};
-    uint64_t epoch_ = 0;
-    bool quit_ = false;
+    int count_ = 0, chunk_ = 1;
+    std::atomic<int> next_{0}, done_{0}, sleepers_{0};
+    std::atomic<uint64_t> epoch_{0};
+    std::atomic<bool> quit_{false};
 };
 
 struct Cand { int action; float policy, logit; };

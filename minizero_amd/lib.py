@@ -92,6 +92,7 @@ def load():
     L.mz_net_initial.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int]
     L.mz_net_recurrent.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
     L.mz_net_time_forward.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.POINTER(C.c_double)]
+    L.mz_net_time_tower_conv.argtypes = [vp, C.c_int, C.c_int, fp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mz_pool_create.restype = vp
     L.mz_pool_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SearchCfg)]
     L.mz_pool_destroy.argtypes = [vp]
@@ -220,6 +221,12 @@ class Net:
         t, c, fl = C.c_float(), C.c_float(), C.c_double()
         _check(self.L, self.L.mz_net_time_forward(self.h, batch, iters, C.byref(t), C.byref(c), C.byref(fl)))
         return t.value, c.value, fl.value
+
+
+    def time_tower_conv(self, batch, iters):
+        t, fl, by = C.c_float(), C.c_double(), C.c_double()
+        _check(self.L, self.L.mz_net_time_tower_conv(self.h, batch, iters, C.byref(t), C.byref(fl), C.byref(by)))
+        return t.value, fl.value, by.value
 
 
 class Pool:
