@@ -64,50 +64,32 @@ def main():
 
     import torch
     import minizero_amd as mz
+    from minizero_amd.dist import Group, shard_seed
     if not torch.cuda.is_available() or mz.device_count() < 1:
         raise SystemExit("bench.py needs a GPU (libmzgpu has no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    grp = Group("nccl")  # RCCL over xGMI; only used for the weight broadcast, barriers and the final reductions
 
     cores = os.cpu_count() or 1
     threads = args.threads or max(1, min(32, cores // max(1, world)))  # spin-wait pool: 32 workers cover 256 games
     base_conf = mz.CONFIGS["c2"].replace("zero_num_parallel_games=256", f"zero_num_parallel_games={args.games}")
-    conf = f"{base_conf}:zero_num_threads={threads}:program_seed={1 + rank}:nn_file_name=synthetic_go_6bx64_seed0.pt"
+    conf = f"{base_conf}:zero_num_threads={threads}:program_seed={shard_seed(1, rank)}:nn_file_name=synthetic_go_6bx64_seed0.pt"
     desc = mz.DESCS["c2"]()
-    weights = mz.generate_weights(desc, 0)
-    if world > 1:  # the optional synchronous weight broadcast over xGMI (RCCL): rank 0's blob is the one everybody loads
-        wt = torch.from_numpy(weights).cuda()
-        dist.broadcast(wt, src=0)
-        weights = wt.cpu().numpy()
+    # the optional synchronous weight broadcast (load_model fan-out): rank 0's blob is the one every rank loads
+    weights = grp.broadcast_weights(mz.generate_weights(desc, 0))
     worker = mz.Worker(conf, desc, weights, device=local_rank)
     worker.command("start")
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     assert worker.run_cycles(args.warmup) == args.warmup
     s0 = worker.stats()
-    barrier()
+    grp.barrier()
     t0 = time.perf_counter()
     assert worker.run_cycles(args.steps) == args.steps
-    barrier()
+    grp.barrier()
     dt = time.perf_counter() - t0
     s1 = worker.stats()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        cnt = torch.tensor([s1["moves"] - s0["moves"], s1["games"] - s0["games"]], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        moves, games_done = float(cnt[0].item()), float(cnt[1].item())
-    else:
-        moves, games_done = s1["moves"] - s0["moves"], s1["games"] - s0["games"]
+    dt = float(grp.reduce([dt], "max")[0])
+    moves, games_done = grp.reduce([s1["moves"] - s0["moves"], s1["games"] - s0["games"]], "sum")
 
     if rank == 0:
         evals = args.games * args.steps * world
@@ -141,9 +123,7 @@ def main():
             del worker
             out["cpu_baseline"] = cpu_baseline(base_conf + ":program_seed=1:nn_file_name=synthetic_go_6bx64_seed0.pt", args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -353,6 +353,13 @@ void Group::traceAfter(int i)
     oss << "E " << cycles_ << " " << i << " cand=";
     for (size_t k = 0; k < a.last_cand_actions_.size(); ++k) { oss << (k ? "," : "") << a.last_cand_actions_[k]; }
     trace_lines_.push_back(oss.str());
+    if (a.isSearchDone()) { // root child visit counts at the end of a search
+        std::ostringstream r;
+        r << "R " << cycles_ << " " << i << " counts=";
+        const MCTSNode* root = a.mcts_.root();
+        for (int k = 0; k < root->num_children_; ++k) { r << (k ? "," : "") << a.mcts_.child(root, k)->count_; }
+        trace_lines_.push_back(r.str());
+    }
 }
 
 } // namespace mzo

@@ -1,0 +1,64 @@
+"""CPU tests of the drop-in boundary: libmzgpu.so loads without a GPU, exports every symbol include/mzgpu.h
+declares, and refuses (loudly, no CPU fallback) to compute without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mzgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mz_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(mz):
+    L = mz.load()
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, f"declared in include/mzgpu.h but not exported by libmzgpu.so: {missing}"
+
+
+def test_struct_layouts_match_header(mz):
+    assert C.sizeof(mz.NetDesc) == 64 + 12 * 4
+    assert C.sizeof(mz.SearchCfg) == 7 * 4
+    assert C.sizeof(mz.WorkerStats) == 4 * 8 + 6 * 8
+
+
+def test_host_side_entry_points_work_without_gpu(mz):
+    for key, n in (("c1", 13141), ("c2", 491718), ("c3", 474321), ("c4", 975686)):
+        assert mz.param_count(mz.DESCS[key]()) == n
+    d = mz.DESCS["c1"]()
+    d.type = 2
+    with pytest.raises(mz.MzError):
+        mz.param_count(d)  # muzero_atari not supported yet: says so
+    assert mz.device_count() >= 0
+
+
+def test_no_cpu_fallback(mz):
+    if mz.device_count() > 0:
+        pytest.skip("GPU present")
+    d = mz.DESCS["c1"]()
+    w = mz.generate_weights(d, 0)
+    with pytest.raises(mz.MzError, match="no such GPU"):
+        mz.Net(d, w)
+    with pytest.raises(mz.MzError, match="no such GPU"):
+        mz.Pool(2, 10, 4, 4)
+    with pytest.raises(mz.MzError):
+        mz.Worker(mz.CONFIGS["c1"], d, w)
+
+
+def test_product_does_not_reference_the_oracle():
+    """the product path must not include, link or call anything under oracle/"""
+    for base, _, files in os.walk(os.path.join(ROOT, "minizero_amd")):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".py")) or f == "Makefile":
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "liboracle" not in text and "oracle_lib" not in text and "../oracle" not in text and "mzo_" not in text, f
+    so = open(os.path.join(ROOT, "minizero_amd", "libmzgpu.so"), "rb").read()
+    assert b"mzo_" not in so and b"liboracle" not in so

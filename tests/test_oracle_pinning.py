@@ -1,0 +1,141 @@
+"""CPU tests pinning the ORACLE to the reference:
+  * network math            vs tests/golden/nn_*.npz   (outputs of the reference's own Python modules)
+  * RNG / rotation / config vs tests/golden/ref_rng_rotation_config.json (outputs of the reference's own C++
+                               sources compiled in place, oracle/_ref) and, when present, vs oracle/_ref live.
+The search/actor/env part of the oracle is PARITY UNPINNED (see oracle/oracle.h); its known-answer tests are in
+test_oracle_search.py."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import binary_planes, counter_u01, same_bits
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+NN_CFG = {
+    "c1_tictactoe_az": ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9, 256, 1, "alphazero"),
+    "c2_go_az": ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "alphazero"),
+    "c3_othello_az": ("othello_8x8", 4, 8, 8, 64, 8, 8, 1, 6, 65, 256, 1, "alphazero"),
+    "c4_go_mz": ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "muzero"),
+    "small_go_az": ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero"),
+}
+TOL = 1e-5  # f32 reference outputs; observed max |diff| ~1e-7 (logits) .. 7e-7 (hidden states)
+
+
+@pytest.mark.parametrize("name", sorted(NN_CFG))
+def test_oracle_network_matches_reference_python(oracle, name):
+    args = NN_CFG[name]
+    g = np.load(os.path.join(GOLD, f"nn_{name}.npz"))
+    assert [str(a) for a in args] == list(g["create_network_args"])
+    d = oracle.make_desc(*args[:10], vh=args[10], dv=args[11], type_name=args[12])
+    net = oracle.OracleNet(d, oracle.gen_weights(d, int(g["weight_seed"])))
+    for B in (1, 3):
+        x = binary_planes(int(g[f"b{B}_input_seed"]), (B, args[1] * args[2] * args[3]))
+        if args[12] == "alphazero":
+            p, l, v = net.forward_az(x)
+            assert np.abs(p - g[f"b{B}_policy"]).max() <= TOL
+            assert np.abs(l - g[f"b{B}_policy_logit"]).max() <= TOL
+            assert np.abs(v - g[f"b{B}_value"]).max() <= TOL
+        else:
+            p, l, v, h = net.initial(x)
+            assert np.abs(p - g[f"b{B}_init_policy"]).max() <= TOL and np.abs(l - g[f"b{B}_init_policy_logit"]).max() <= TOL
+            assert np.abs(v - g[f"b{B}_init_value"]).max() <= TOL and np.abs(h - g[f"b{B}_init_hidden_state"]).max() <= TOL
+            act = np.zeros((B, args[5] * args[6]), np.float32)
+            for b in range(B):
+                act[b, (7 * b + 3) % (args[5] * args[6])] = 1.0
+            p, l, v, r, h2 = net.recurrent(g[f"b{B}_init_hidden_state"], act)
+            assert np.abs(p - g[f"b{B}_rec_policy"]).max() <= TOL and np.abs(l - g[f"b{B}_rec_policy_logit"]).max() <= TOL
+            assert np.abs(v - g[f"b{B}_rec_value"]).max() <= TOL and np.abs(h2 - g[f"b{B}_rec_hidden_state"]).max() <= TOL
+            assert np.all(h2 >= 0) and np.all(h2 <= 1) and np.all(r == 0)
+
+
+def test_param_counts_match_survey(oracle):
+    # SURVEY.md §8a a20 parameter counts (+ BN running stats: 2 per BN channel)
+    for desc, params, bn_ch in ((oracle.desc_c1(), 12977, 16 * 5 + 1 + 1), (oracle.desc_c2(), 490048, 64 * 13 + 2 + 1),
+                                (oracle.desc_c3(), 472651, 64 * 13 + 2 + 1), (oracle.desc_c4(), 972352, 64 * 26 + 2 + 1)):
+        assert oracle.lib().mzo_net_param_count(C.byref(desc)) == params + 2 * bn_ch
+
+
+def test_weight_generator_twins(oracle, mz):
+    """the same SplitMix64 stream in oracle/o_nn.cpp, minizero_amd/csrc/weights.cpp and numpy"""
+    for d_o, d_m in ((oracle.desc_c1(), mz.DESCS["c1"]()), (oracle.desc_c4(), mz.DESCS["c4"]())):
+        for seed in (0, 12345):
+            a, b = oracle.gen_weights(d_o, seed), mz.generate_weights(d_m, seed)
+            assert same_bits(a, b)
+    d = oracle.desc_c1()
+    w = oracle.gen_weights(d, 0)
+    u = counter_u01(0, w.size)
+    bound = np.float32(1.0) / np.sqrt(np.float32(36))  # first tensor: stem conv weight, fan_in = 4*3*3
+    assert same_bits(w[:16 * 36], (-bound + (bound - (-bound)) * u[:16 * 36]).astype(np.float32))
+
+
+def test_deterministic_exp_tanh_accuracy(oracle):
+    x = np.concatenate([np.linspace(-87, 0, 20001), np.linspace(0, 5, 2001)]).astype(np.float32)
+    y = np.empty_like(x)
+    oracle.lib().mzo_expf(oracle.fptr(x), x.size, oracle.fptr(y))
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(y - ref) / ref) < 2.5e-7
+    x = np.linspace(-12, 12, 40001).astype(np.float32)
+    y = np.empty_like(x)
+    oracle.lib().mzo_tanhf(oracle.fptr(x), x.size, oracle.fptr(y))
+    assert np.max(np.abs(y - np.tanh(x.astype(np.float64)))) < 2e-7
+
+
+# ---------------------------------------------------------------------------------------------
+def _ref_fixture():
+    with open(os.path.join(GOLD, "ref_rng_rotation_config.json")) as f:
+        return json.load(f)
+
+
+def test_rng_matches_reference_random_h(oracle):
+    fx = _ref_fixture()
+    for case in fx["rng"]:
+        n = len(case["values"])
+        buf = (C.c_double * n)()
+        oracle.lib().mzo_rng_vector(case["seed"], case["kind"], n, case["k"], case["alpha"], buf)
+        got = [float.hex(v) for v in buf]
+        assert got == case["values"], f"RNG kind {case['kind']} k={case['k']} seed {case['seed']} differs from the reference"
+
+
+def test_rotation_matches_reference_rotation_h(oracle):
+    fx = _ref_fixture()
+    L = oracle.lib()
+    assert [L.mzo_reversed_rotation(r) for r in range(8)] == fx["reversed_rotation"]
+    for n, table in fx["rotation"].items():
+        n = int(n)
+        for r in range(8):
+            assert [L.mzo_rotate(r, p, n) for p in range(n * n + 1)] == table[r]
+
+
+def test_config_matches_reference_configuration_cpp(oracle):
+    fx = _ref_fixture()
+    L = oracle.lib()
+    for case in fx["config"]:
+        buf = C.create_string_buffer(1 << 16)
+        rc = L.mzo_config_dump(case["conf"].encode(), buf, len(buf))
+        assert (rc < 0) == case["rc_negative"], case["conf"]
+        if rc >= 0:
+            assert buf.value.decode() == case["dump"], case["conf"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libmzref.so")), reason="oracle/_ref not built")
+def test_live_reference_build_agrees(oracle):
+    """oracle/_ref (the reference's own sources) against the oracle on fresh seeds, beyond the committed fixture"""
+    R = C.CDLL(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libmzref.so"))
+    R.mzref_rng_vector.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double)]
+    L = oracle.lib()
+    for seed in (3, 99, 123456):
+        for kind, k, alpha in ((0, 0, 0.0), (1, 0, 0.0), (2, 30, 0.03), (3, 20, 0.0)):
+            n = 200
+            a, b = (C.c_double * n)(), (C.c_double * n)()
+            R.mzref_rng_vector(seed, kind, n, k, alpha, a)
+            L.mzo_rng_vector(seed, kind, n, k, alpha, b)
+            assert list(a) == list(b)
+    for n in (5, 7, 13):
+        for r in range(8):
+            for p in range(n * n + 1):
+                assert R.mzref_rotate(r, p, n) == L.mzo_rotate(r, p, n)
