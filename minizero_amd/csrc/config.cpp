@@ -27,6 +27,18 @@ const Key kKeys[] = {
 };
 #undef K
 
+// ref config/configuration.cpp:92-205: every other registered key
+const char* const kPassiveKeys[] = {
+    "program_use_color_message", "zero_server_port", "zero_training_directory", "zero_num_games_per_iteration", "zero_start_iteration",
+    "zero_end_iteration", "zero_replay_buffer", "zero_server_accept_different_model_games", "zero_display_latest_games", "learner_use_per",
+    "learner_per_alpha", "learner_per_init_beta", "learner_per_beta_anneal", "learner_training_step", "learner_training_display_step",
+    "learner_batch_size", "learner_optimizer", "learner_learning_rate", "learner_momentum", "learner_weight_decay", "learner_value_loss_scale",
+    "learner_num_thread", "nn_num_blocks", "nn_num_hidden_channels", "nn_num_value_hidden_channels", "env_atari_rom_dir", "env_atari_name",
+    "env_conhex_use_swap_rule", "env_gomoku_rule", "env_gomoku_exactly_five_stones", "env_havannah_use_swap_rule", "env_hex_use_swap_rule",
+    "env_killallgo_ko_rule", "env_killallgo_use_seki", "env_rubiks_scramble_rotate", "env_surakarta_no_capture_plies",
+    "env_tetris_block_puzzle_num_holding_block", "env_tetris_block_puzzle_num_preview_holding_block",
+};
+
 std::string trimmed(const std::string& s)
 {
     const size_t b = s.find_first_not_of(" \t");
@@ -60,7 +72,15 @@ bool WorkerConfig::loadFromString(const std::string& s)
         value = trimmed(value);
         const Key* k = nullptr;
         for (const Key& c : kKeys) { if (key == c.name) { k = &c; break; } }
-        if (!k) { setError("Invalid key \"%s\" and value \"%s\"", key.c_str(), value.c_str()); return false; }
+        if (!k) {
+            // keys of the reference's configuration that this path never reads (server, learner, other games) are
+            // accepted so that a real minizero .cfg file loads unchanged
+            bool passive = false;
+            for (const char* pk : kPassiveKeys) { if (key == pk) { passive = true; break; } }
+            if (passive) { continue; }
+            setError("Invalid key \"%s\" and value \"%s\"", key.c_str(), value.c_str());
+            return false;
+        }
         char* field = reinterpret_cast<char*>(this) + k->offset;
         bool ok = true;
         switch (k->type) {
