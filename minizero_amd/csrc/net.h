@@ -57,6 +57,7 @@ private:
     int ensureBatch(int B);
     int runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out);
     int launchConv(const ConvLayer& L, const float* in, const float* skip, float* out, int B);
+    int launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched);
     int launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden);
 
     DevBuf<float> params_;
@@ -67,6 +68,8 @@ private:
     DevBuf<float> rec_in_;      // [B][C + a][P] dynamics input
     DevBuf<float> io_in_, io_in2_, io_policy_, io_logit_, io_value_, io_reward_, io_hidden_; // staging for MZ_HOST callers
     bool conv_only_ = false;    // timing mode: skip the heads
+public:
+    bool use_fused_ = true;     // fused persistent tower kernel (same arithmetic as the per-layer kernels)
 };
 
 } // namespace mz

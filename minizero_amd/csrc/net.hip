@@ -138,6 +138,114 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const float* __restrict__ in
 }
 
 // ---------------------------------------------------------------------------------------------
+// tower_fused — the whole trunk (stem conv + 2*num_blocks residual convs) of one sample in ONE workgroup:
+// activations never leave LDS between layers.  Three zero-bordered LDS tiles [CMAX][CS] rotate as
+// (input, temp, output/skip); each layer is the same tap-major MFMA chain as conv3x3_mfma, its epilogue
+// (bias + skip + ReLU) writes straight into the interior of the next layer's padded tile.  8 wave64 per
+// workgroup (2 per SIMD): wave w owns output-channel tile (w & 3) and half of the pixel tiles, so MFMA issue of
+// one wave hides the LDS/global latency of its SIMD partner.  Weights stream from L2 (147 KB per layer), one
+// tap ahead in registers.  Removes 12 kernel boundaries, 12 LDS re-stagings and all inter-layer HBM traffic.
+// ---------------------------------------------------------------------------------------------
+struct TowerArgs {
+    int nlayers, cin0, C, OT; // C = hidden channels (== cout of every layer), OT = ceil(C/16)
+    unsigned w_off[48], b_off[48];
+};
+
+template <int H, int W, int CG, int PTW>
+__device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
+                                            float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
+                                            int lane, int wave)
+{
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16;
+    const int ot = wave & 3, half = wave >> 2;
+    if (ot >= OT) { return; }
+    int pixoff[PTW], pixdst[PTW];
+#pragma unroll
+    for (int j = 0; j < PTW; ++j) {
+        int q = 16 * (half * PTW + j) + (lane & 15);
+        if (q >= P) { q = 0; }
+        pixdst[j] = (q / W + 1) * PW + (q % W) + 1;          // interior position in a padded plane
+        pixoff[j] = (lane >> 4) * CS + (q / W) * PW + (q % W); // top-left tap of the 3x3 window, channel (lane>>4)
+    }
+    f32x4 acc[PTW];
+#pragma unroll
+    for (int j = 0; j < PTW; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const float* wl = wp + size_t(ot) * 64 + lane;
+    const size_t wstep = size_t(OT) * 64;
+    float a_cur[CG], a_nxt[CG];
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = wl[size_t(cg) * wstep]; }
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+        const int tn = t < 8 ? t + 1 : 8;
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) { a_nxt[cg] = wl[(size_t(tn) * CG + cg) * wstep]; }
+        const int tapoff = (t / 3) * PW + (t % 3);
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+#pragma unroll
+            for (int j = 0; j < PTW; ++j) {
+                float bv = tin[pixoff[j] + cg * 4 * CS + tapoff];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[cg], bv, acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = a_nxt[cg]; }
+    }
+#pragma unroll
+    for (int j = 0; j < PTW; ++j) {
+        const int pt = half * PTW + j;
+        const int q = 16 * pt + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = 16 * ot + 4 * (lane >> 4) + r;
+            if (pt < PT && q < P && oc < cout) {
+                float v = acc[j][r] + bias[oc];
+                if (tskip) { v = v + tskip[oc * CS + pixdst[j]]; }
+                v = v > 0.0f ? v : 0.0f;
+                if (gout) { gout[oc * P + q] = v; } else { tout[oc * CS + pixdst[j]] = v; }
+            }
+        }
+    }
+}
+
+template <int H, int W, int CIN0_PAD, int CPAD>
+__global__ __launch_bounds__(512) void tower_fused(const float* __restrict__ in, const float* __restrict__ params, TowerArgs ta,
+                                                   float* __restrict__ out)
+{
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16, PTW = (PT + 1) / 2;
+    constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
+    extern __shared__ __attribute__((aligned(16))) float tiles[]; // 3 x [CMAX][CS]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* T0 = tiles;
+    float* T1 = tiles + CMAX * CS;
+    float* T2 = tiles + 2 * CMAX * CS;
+    // zero all three tiles (borders and padding channels stay zero for the whole kernel), then the sample's planes into T0
+    for (int i = tid; i < 3 * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
+    __syncthreads();
+    const float* src = in + size_t(b) * ta.cin0 * P;
+    for (int i = tid; i < ta.cin0 * P; i += 512) {
+        const int c = i / P, p = i - c * P;
+        T0[c * CS + (p / W + 1) * PW + (p % W) + 1] = src[i];
+    }
+    __syncthreads();
+    float* gout = out + size_t(b) * ta.C * P;
+    // stem: T0 -> T1
+    tower_layer<H, W, CIN0_PAD / 4, PTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT, lane,
+                                          wave);
+    __syncthreads();
+    float *x = T1, *tmp = T0, *y = T2;
+    for (int l = 1; l + 1 < ta.nlayers; l += 2) { // residual block: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x)
+        tower_layer<H, W, CPAD / 4, PTW>(x, nullptr, tmp, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, wave);
+        __syncthreads();
+        const bool last = (l + 2 >= ta.nlayers);
+        tower_layer<H, W, CPAD / 4, PTW>(tmp, x, y, last ? gout : nullptr, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, ta.OT, lane, wave);
+        __syncthreads();
+        float* s = x; x = y; y = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // dynamics input: cat(hidden[src], action plane) on the channel axis (ref muzero_network.py:32)
 // action_mode 1: board games, one-hot position plane (all zero for pass; ref go.cpp:310-315)
 // ---------------------------------------------------------------------------------------------
@@ -344,8 +452,58 @@ int Net::launchConv(const ConvLayer& L, const float* in, const float* skip, floa
     return MZ_ERR_ARG;
 }
 
+template <int H, int W, int CIN0_PAD, int CPAD>
+static int launchTowerT(const TowerArgs& ta, const float* params, const float* in, float* out, int B, hipStream_t s)
+{
+    constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
+    constexpr size_t lds = size_t(3) * CMAX * planeStride(H, W) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fused<H, W, CIN0_PAD, CPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tower_fused<H, W, CIN0_PAD, CPAD>), dim3(B), dim3(512), lds, s, in, params, ta, out);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+// returns MZ_OK and sets *launched when a fused instance exists for this trunk
+int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched)
+{
+    *launched = false;
+    if (!use_fused_ || t.size() > 48 || (t.size() % 2) == 0) { return MZ_OK; }
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+    for (size_t i = 1; i < t.size(); ++i) { if (t[i].cin != C || t[i].cout != C) { return MZ_OK; } }
+    if (t[0].cout != C || C % 4 != 0) { return MZ_OK; }
+    TowerArgs ta;
+    ta.nlayers = static_cast<int>(t.size());
+    ta.cin0 = t[0].cin;
+    ta.C = C;
+    ta.OT = t[0].cout_pad / 16;
+    for (size_t i = 0; i < t.size(); ++i) { ta.w_off[i] = static_cast<unsigned>(t[i].w_off); ta.b_off[i] = static_cast<unsigned>(t[i].b_off); }
+    const int c0 = t[0].cin_pad;
+#define MZ_TOWER_CASE(h, w, cin0, cpad) \
+    if (H == h && W == w && c0 == cin0 && C == cpad) { *launched = true; return launchTowerT<h, w, cin0, cpad>(ta, params_.p, in, out, B, stream_); }
+    MZ_TOWER_CASE(9, 9, 20, 64)  // Go AlphaZero / MuZero representation
+    MZ_TOWER_CASE(9, 9, 68, 64)  // Go MuZero dynamics
+    MZ_TOWER_CASE(8, 8, 4, 64)   // Othello
+    MZ_TOWER_CASE(8, 8, 68, 64)
+    MZ_TOWER_CASE(9, 9, 20, 8)   // small test nets
+    MZ_TOWER_CASE(9, 9, 12, 8)
+    MZ_TOWER_CASE(8, 8, 4, 8)
+    MZ_TOWER_CASE(8, 8, 12, 8)
+    MZ_TOWER_CASE(3, 3, 4, 16)   // TicTacToe
+    MZ_TOWER_CASE(3, 3, 20, 16)
+#undef MZ_TOWER_CASE
+    return MZ_OK;
+}
+
 int Net::runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out)
 {
+    bool launched = false;
+    int frc = launchTower(t, d_in, act_[0].p, B, &launched);
+    if (frc) { return frc; }
+    if (launched) { *d_out = act_[0].p; return MZ_OK; }
     float *x = act_[0].p, *tmp = act_[1].p, *y = act_[2].p;
     int rc = launchConv(t[0], d_in, nullptr, x, B);
     if (rc) { return rc; }

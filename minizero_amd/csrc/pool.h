@@ -54,11 +54,19 @@ public:
     bool own_stream_ = false;
     mz_search_cfg cfg_{};
 
-    // pinned host mirrors + device staging of the per-cycle candidate lists
-    PinBuf<int> h_cand_count_, h_cand_action_, h_cand_player_, h_path_len_, h_path_, h_path_action_, h_start_;
-    PinBuf<float> h_cand_policy_, h_cand_logit_, h_value_, h_reward_;
-    DevBuf<int> d_cand_count_, d_cand_action_, d_cand_player_, d_start_, d_mask_;
-    DevBuf<float> d_cand_policy_, d_cand_logit_, d_value_, d_reward_;
+    // pinned host mirrors + device staging of the per-cycle candidate lists.  The seven candidate arrays are views
+    // into ONE pinned arena / ONE device arena (count, player, value, reward, action, policy, logit) so a cycle needs a
+    // single H2D copy; path_len + path_action (+ path) likewise share one device arena and one D2H copy.
+    template <class T>
+    struct View { T* p = nullptr; size_t n = 0; };
+    PinBuf<uint32_t> h_cand_arena_, h_path_arena_;
+    DevBuf<uint32_t> d_cand_arena_, d_path_arena_;
+    View<int> h_cand_count_, h_cand_action_, h_cand_player_, h_path_len_, h_path_, h_path_action_;
+    View<float> h_cand_policy_, h_cand_logit_, h_value_, h_reward_;
+    View<int> d_cand_count_, d_cand_action_, d_cand_player_;
+    View<float> d_cand_policy_, d_cand_logit_, d_value_, d_reward_;
+    PinBuf<int> h_start_;
+    DevBuf<int> d_start_, d_mask_;
     // root read staging
     DevBuf<float> d_rr_f_; // 8 arrays [games*A] + 5 arrays [games]
     DevBuf<int> d_rr_i_;   // num_children, action[games*A], bound_size
@@ -69,8 +77,8 @@ private:
     DevBuf<float> f_nodes_;  // 7 float arrays
     DevBuf<int> i_nodes_;    // 4 int arrays
     DevBuf<unsigned char> player_;
-    DevBuf<int> game_i_;     // num_nodes, path_len, bound_size, err
-    DevBuf<int> path_, path_action_, bound_cnt_;
+    DevBuf<int> game_i_;     // num_nodes, (unused), bound_size, err
+    DevBuf<int> bound_cnt_;
     DevBuf<float> bound_key_, game_f_;
     DevBuf<float> bias_tab_;
     DevBuf<double> sqrt_tab_;

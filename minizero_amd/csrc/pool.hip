@@ -298,7 +298,6 @@ int Pool::init(int device, int games, int nodes_per_game, int action_size, const
     const int bound_cap = cfg.value_rescale ? cfg.num_simulation + 3 : 1;
     MZ_ALLOC(f_nodes_, NN * 7); MZ_ALLOC(i_nodes_, NN * 4); MZ_ALLOC(player_, NN);
     MZ_ALLOC(game_i_, G * 3 + 1); MZ_ALLOC(game_f_, G * 2);
-    MZ_ALLOC(path_, G * max_depth); MZ_ALLOC(path_action_, G * max_depth);
     MZ_ALLOC(bound_key_, G * bound_cap); MZ_ALLOC(bound_cnt_, G * bound_cap);
     MZ_ALLOC(bias_tab_, cfg.num_simulation + 3); MZ_ALLOC(sqrt_tab_, cfg.num_simulation + 3);
     v_.games = games; v_.cap = nodes_per_game; v_.A = action_size; v_.max_depth = max_depth;
@@ -307,8 +306,15 @@ int Pool::init(int device, int games, int nodes_per_game, int action_size, const
     int* ip = i_nodes_.p;
     v_.first_child = ip; v_.num_children = ip + NN; v_.action = ip + 2 * NN; v_.hslot = ip + 3 * NN;
     v_.player = player_.p;
-    v_.num_nodes = game_i_.p; v_.path_len = game_i_.p + G; v_.bound_size = game_i_.p + 2 * G;
-    v_.path = path_.p; v_.path_action = path_action_.p;
+    // path arena: [path_len G][path_action G*max_depth][path G*max_depth]
+    MZ_ALLOC(d_path_arena_, G + 2 * G * max_depth); MZ_ALLOC(h_path_arena_, G + 2 * G * max_depth);
+    {
+        int* dp = reinterpret_cast<int*>(d_path_arena_.p);
+        int* hp = reinterpret_cast<int*>(h_path_arena_.p);
+        v_.num_nodes = game_i_.p; v_.bound_size = game_i_.p + 2 * G;
+        v_.path_len = dp; v_.path_action = dp + G; v_.path = dp + G + G * max_depth;
+        h_path_len_ = {hp, G}; h_path_action_ = {hp + G, G * max_depth}; h_path_ = {hp + G + G * max_depth, G * max_depth};
+    }
     v_.bound_key = bound_key_.p; v_.bound_cnt = bound_cnt_.p; v_.bound_lo = game_f_.p; v_.bound_hi = game_f_.p + G; v_.bound_cap = bound_cap;
     v_.gamma = cfg.reward_discount; v_.value_rescale = cfg.value_rescale; v_.flipping_player = cfg.flipping_player; v_.atari_init_q = cfg.atari_init_q;
 
@@ -327,11 +333,18 @@ int Pool::init(int device, int games, int nodes_per_game, int action_size, const
     MZ_HIP(hipMemset(game_i_.p, 0, game_i_.n * sizeof(int)));
 
     // staging
-    MZ_ALLOC(h_cand_count_, G); MZ_ALLOC(h_cand_action_, GA); MZ_ALLOC(h_cand_player_, G); MZ_ALLOC(h_cand_policy_, GA); MZ_ALLOC(h_cand_logit_, GA);
-    MZ_ALLOC(h_value_, G); MZ_ALLOC(h_reward_, G); MZ_ALLOC(h_path_len_, G); MZ_ALLOC(h_path_, G * max_depth); MZ_ALLOC(h_path_action_, G * max_depth);
-    MZ_ALLOC(h_start_, G);
-    MZ_ALLOC(d_cand_count_, G); MZ_ALLOC(d_cand_action_, GA); MZ_ALLOC(d_cand_player_, G); MZ_ALLOC(d_cand_policy_, GA); MZ_ALLOC(d_cand_logit_, GA);
-    MZ_ALLOC(d_value_, G); MZ_ALLOC(d_reward_, G); MZ_ALLOC(d_start_, G); MZ_ALLOC(d_mask_, G);
+    MZ_ALLOC(h_cand_arena_, 4 * G + 3 * GA); MZ_ALLOC(d_cand_arena_, 4 * G + 3 * GA);
+    {
+        uint32_t *h = h_cand_arena_.p, *d = d_cand_arena_.p;
+        h_cand_count_ = {reinterpret_cast<int*>(h), G}; d_cand_count_ = {reinterpret_cast<int*>(d), G};
+        h_cand_player_ = {reinterpret_cast<int*>(h + G), G}; d_cand_player_ = {reinterpret_cast<int*>(d + G), G};
+        h_value_ = {reinterpret_cast<float*>(h + 2 * G), G}; d_value_ = {reinterpret_cast<float*>(d + 2 * G), G};
+        h_reward_ = {reinterpret_cast<float*>(h + 3 * G), G}; d_reward_ = {reinterpret_cast<float*>(d + 3 * G), G};
+        h_cand_action_ = {reinterpret_cast<int*>(h + 4 * G), GA}; d_cand_action_ = {reinterpret_cast<int*>(d + 4 * G), GA};
+        h_cand_policy_ = {reinterpret_cast<float*>(h + 4 * G + GA), GA}; d_cand_policy_ = {reinterpret_cast<float*>(d + 4 * G + GA), GA};
+        h_cand_logit_ = {reinterpret_cast<float*>(h + 4 * G + 2 * GA), GA}; d_cand_logit_ = {reinterpret_cast<float*>(d + 4 * G + 2 * GA), GA};
+    }
+    MZ_ALLOC(h_start_, G); MZ_ALLOC(d_start_, G); MZ_ALLOC(d_mask_, G);
     MZ_ALLOC(d_rr_f_, 7 * GA + 5 * G); MZ_ALLOC(d_rr_i_, G + GA + G); MZ_ALLOC(h_rr_f_, 7 * GA + 5 * G); MZ_ALLOC(h_rr_i_, G + GA + G);
     std::vector<int> rp(games, 2);
     return resetSearch(nullptr, rp.data());
@@ -384,9 +397,7 @@ int Pool::select(const int* start_node, int* path_len, int* paths, int* path_act
     }
     int rc = selectAsync(d_start);
     if (rc) { return rc; }
-    MZ_HIP(hipMemcpyAsync(h_path_len_.p, v_.path_len, G * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    MZ_HIP(hipMemcpyAsync(h_path_.p, v_.path, G * v_.max_depth * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    MZ_HIP(hipMemcpyAsync(h_path_action_.p, v_.path_action, G * v_.max_depth * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(h_path_arena_.p, d_path_arena_.p, h_path_arena_.n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
     MZ_HIP(hipStreamSynchronize(stream_));
     if (path_len) { memcpy(path_len, h_path_len_.p, G * sizeof(int)); }
     if (paths) { memcpy(paths, h_path_.p, G * v_.max_depth * sizeof(int)); }
@@ -405,14 +416,7 @@ int Pool::expandBackupAsync(int hslot)
 
 int Pool::expandBackupStaged(int hslot)
 {
-    const size_t G = v_.games, GA = G * v_.A;
-    MZ_HIP(hipMemcpyAsync(d_cand_count_.p, h_cand_count_.p, G * sizeof(int), hipMemcpyHostToDevice, stream_));
-    MZ_HIP(hipMemcpyAsync(d_cand_action_.p, h_cand_action_.p, GA * sizeof(int), hipMemcpyHostToDevice, stream_));
-    MZ_HIP(hipMemcpyAsync(d_cand_policy_.p, h_cand_policy_.p, GA * sizeof(float), hipMemcpyHostToDevice, stream_));
-    MZ_HIP(hipMemcpyAsync(d_cand_logit_.p, h_cand_logit_.p, GA * sizeof(float), hipMemcpyHostToDevice, stream_));
-    MZ_HIP(hipMemcpyAsync(d_cand_player_.p, h_cand_player_.p, G * sizeof(int), hipMemcpyHostToDevice, stream_));
-    MZ_HIP(hipMemcpyAsync(d_value_.p, h_value_.p, G * sizeof(float), hipMemcpyHostToDevice, stream_));
-    MZ_HIP(hipMemcpyAsync(d_reward_.p, h_reward_.p, G * sizeof(float), hipMemcpyHostToDevice, stream_));
+    MZ_HIP(hipMemcpyAsync(d_cand_arena_.p, h_cand_arena_.p, h_cand_arena_.n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
     return expandBackupAsync(hslot);
 }
 

@@ -225,8 +225,10 @@ private:
     std::deque<std::string> lines_;
     std::vector<float> pending_weights_;
     // staging
-    PinBuf<float> h_feat_, h_policy_, h_logit_, h_value_, h_reward_;
-    DevBuf<float> d_feat_, d_policy_, d_logit_, d_value_, d_reward_, d_hidden_;
+    // network outputs: one device arena / one pinned arena [policy GA][logit GA][value G][reward G] -> a single D2H per cycle
+    PinBuf<float> h_feat_, h_out_;
+    DevBuf<float> d_feat_, d_out_, d_hidden_;
+    Pool::View<float> h_policy_, h_logit_, h_value_, h_reward_, d_policy_, d_logit_, d_value_, d_reward_;
     DevBuf<int> d_src_idx_, d_dst_idx_, d_action_ids_;
     // root statistics mirrors (valid after rootRead)
     std::vector<int> rr_nc_, rr_action_, rr_bsize_;
@@ -270,8 +272,10 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     const size_t GA = size_t(G_) * A_, feat = size_t(G_) * net_.featSize();
 #define WALLOC(b, n) \
     if (!(b).alloc(n)) { setError("worker: allocation failed (%s)", #b); return MZ_ERR_DEVICE; }
-    WALLOC(h_feat_, feat); WALLOC(h_policy_, GA); WALLOC(h_logit_, GA); WALLOC(h_value_, G_); WALLOC(h_reward_, G_);
-    WALLOC(d_feat_, feat); WALLOC(d_policy_, GA); WALLOC(d_logit_, GA); WALLOC(d_value_, G_); WALLOC(d_reward_, G_);
+    WALLOC(h_feat_, feat); WALLOC(d_feat_, feat); WALLOC(h_out_, 2 * GA + 2 * G_); WALLOC(d_out_, 2 * GA + 2 * G_);
+    h_policy_ = {h_out_.p, GA}; h_logit_ = {h_out_.p + GA, GA}; h_value_ = {h_out_.p + 2 * GA, size_t(G_)}; h_reward_ = {h_out_.p + 2 * GA + G_, size_t(G_)};
+    d_policy_ = {d_out_.p, GA}; d_logit_ = {d_out_.p + GA, GA}; d_value_ = {d_out_.p + 2 * GA, size_t(G_)}; d_reward_ = {d_out_.p + 2 * GA + G_, size_t(G_)};
+    MZ_HIP(hipMemset(d_out_.p, 0, d_out_.n * sizeof(float)));
     if (desc.type == 1) {
         WALLOC(d_hidden_, size_t(G_) * (n_ + 1) * net_.hiddenSize()); // hidden-state slab: one slot per expanded node
         WALLOC(d_src_idx_, G_); WALLOC(d_dst_idx_, G_); WALLOC(d_action_ids_, G_);
@@ -672,7 +676,6 @@ void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor
 int Worker::cycle()
 {
     const bool az = desc_.type == 0;
-    const size_t GA = size_t(G_) * A_;
     const double t0 = nowMs();
     double t1 = t0;
     MZ_HIP(hipSetDevice(device_));
@@ -763,11 +766,9 @@ int Worker::cycle()
     }
     int rc = pool_.selectAsync(d_start);
     if (rc) { return rc; }
-    MZ_HIP(hipMemcpyAsync(pool_.h_path_len_.p, pool_.v_.path_len, G_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    if (az) {
-        MZ_HIP(hipMemcpyAsync(pool_.h_path_action_.p, pool_.v_.path_action, size_t(G_) * pool_.v_.max_depth * sizeof(int), hipMemcpyDeviceToHost,
-                              stream_));
-    }
+    // one D2H: [path_len G] (+ [path_action G*max_depth] for AlphaZero, whose leaves need the moves for the replay)
+    MZ_HIP(hipMemcpyAsync(pool_.h_path_arena_.p, pool_.d_path_arena_.p, (size_t(G_) + (az ? size_t(G_) * pool_.v_.max_depth : 0)) * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, stream_));
     MZ_HIP(hipStreamSynchronize(stream_));
     const double t3 = nowMs();
     stats_.ms_select += t3 - t1;
@@ -794,10 +795,7 @@ int Worker::cycle()
             return rc;
         }
     }
-    MZ_HIP(hipMemcpyAsync(h_policy_.p, d_policy_.p, GA * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    MZ_HIP(hipMemcpyAsync(h_logit_.p, d_logit_.p, GA * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    MZ_HIP(hipMemcpyAsync(h_value_.p, d_value_.p, G_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (!az) { MZ_HIP(hipMemcpyAsync(h_reward_.p, d_reward_.p, G_ * sizeof(float), hipMemcpyDeviceToHost, stream_)); }
+    MZ_HIP(hipMemcpyAsync(h_out_.p, d_out_.p, h_out_.n * sizeof(float), hipMemcpyDeviceToHost, stream_));
     pending_ = true;
     ++stats_.cycles;
     stats_.leaf_evals += G_;
