@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--games", type=int, default=256)
     ap.add_argument("--threads", type=int, default=0, help="host threads for env/feature/candidate work (0 = cores / ranks)")
+    ap.add_argument("--lanes", type=int, default=1, help="software-pipelined lanes the 256 games are split into")
+    ap.add_argument("--zero-copy", type=int, default=3)
+    ap.add_argument("--pin", type=int, default=1, help="pin the host threads of rank r to CPUs [r*threads, (r+1)*threads)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -73,7 +76,8 @@ def main():
     cores = os.cpu_count() or 1
     threads = args.threads or max(1, min(32, cores // max(1, world)))  # spin-wait pool: 32 workers cover 256 games
     base_conf = mz.CONFIGS["c2"].replace("zero_num_parallel_games=256", f"zero_num_parallel_games={args.games}")
-    conf = f"{base_conf}:zero_num_threads={threads}:program_seed={shard_seed(1, rank)}:nn_file_name=synthetic_go_6bx64_seed0.pt"
+    conf = (f"{base_conf}:zero_num_threads={threads}:mz_pipeline_lanes={args.lanes}:mz_zero_copy={args.zero_copy}:mz_cpu_base={local_rank * threads if args.pin else -1}:program_seed={shard_seed(1, rank)}:"
+            "nn_file_name=synthetic_go_6bx64_seed0.pt")
     desc = mz.DESCS["c2"]()
     # the optional synchronous weight broadcast (load_model fan-out): rank 0's blob is the one every rank loads
     weights = grp.broadcast_weights(mz.generate_weights(desc, 0))
@@ -107,7 +111,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 9x9 Go AlphaZero, n=400, 6 blocks x 64 ch, 256 parallel games per GPU, "
                                    "synthetic fixed-weight net (seed 0), Dirichlet noise + random rotation + softmax-count moves (reference defaults)",
-                       "games_per_gpu": args.games, "actor_num_simulation": 400, "host_threads_per_gpu": threads, "host_cores": cores,
+                       "games_per_gpu": args.games, "actor_num_simulation": 400, "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_cores": cores,
                        "sharding": f"{world} x independent actor pools, no data-path collective"},
             "moves_per_sec": moves / dt, "games_finished": games_done,
             "games_per_sec": (games_done / dt) if games_done else None,

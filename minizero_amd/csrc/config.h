@@ -47,6 +47,12 @@ struct WorkerConfig {
     // run-time replacements of the reference's compile-time switches (-D<GAME>, #if ATARI in mcts.cpp:211)
     std::string env_game = "tictactoe";
     bool atari_init_q = false;
+    // not a reference key: number of software-pipelined lanes the games are split into (1 = no pipelining)
+    int mz_pipeline_lanes = 1;
+    // not a reference key: kernels read/write the pinned host staging directly (no per-cycle memcpy operations)
+    // not a reference key: >= 0 pins the worker's host threads to consecutive CPUs (NUMA node of the caller first) from this index
+    int mz_cpu_base = -1;
+    int mz_zero_copy = 3; // bit 0: kernels read their inputs from pinned host memory; bit 1: kernels write their outputs there
 
     // returns false (and sets the library error string) on an unknown key or an unparsable value,
     // like ConfigureLoader::loadFromString; keys are applied left to right, later ones win

@@ -62,6 +62,17 @@ static const RotationTables* rotationTables(int n, int num_actions)
     return slot.get();
 }
 
+void GameEnv::featureBits(int rotation, uint32_t* out) const
+{
+    const int P = boardSize() * boardSize(), W32 = (P + 31) / 32, C = numInputChannels();
+    std::vector<float> f(size_t(C) * P);
+    features(rotation, f.data());
+    for (int c = 0; c < C; ++c) {
+        for (int w = 0; w < W32; ++w) { out[c * W32 + w] = 0; }
+        for (int p = 0; p < P; ++p) { if (f[size_t(c) * P + p] != 0.0f) { out[c * W32 + (p >> 5)] |= 1u << (p & 31); } }
+    }
+}
+
 static inline float scoreOf(int winner) { return winner == 1 ? 1.0f : (winner == 2 ? -1.0f : 0.0f); }
 
 // ---------------------------------------------------------------------------------------------
@@ -529,6 +540,27 @@ public:
         }
         const float b = turn_ == 1 ? 1.0f : 0.0f, w = turn_ == 2 ? 1.0f : 0.0f;
         for (int p = 0; p < P_; ++p) { out[16 * P_ + p] = b; out[17 * P_ + p] = w; }
+    }
+    void featureBits(int r, uint32_t* out) const override
+    {
+        const int W32 = (P_ + 31) / 32;
+        const int* map = rot_->inv[r].data();
+        memset(out, 0, size_t(18) * W32 * sizeof(uint32_t));
+        for (int k = 0; k < 8; ++k) {
+            if (hist_len_ - 1 - k < 0) { break; }
+            const Bits* h = hist_[(hist_len_ - 1 - k) & 7];
+            const Bits& mine = h[turn_ - 1];
+            const Bits& theirs = h[2 - turn_];
+            uint32_t* own = out + (2 * k) * W32;
+            uint32_t* opp = own + W32;
+            for (int p = 0; p < P_; ++p) {
+                const int q = map[p];
+                own[p >> 5] |= static_cast<uint32_t>(mine.test(q)) << (p & 31);
+                opp[p >> 5] |= static_cast<uint32_t>(theirs.test(q)) << (p & 31);
+            }
+        }
+        uint32_t* t = out + (turn_ == 1 ? 16 : 17) * W32;
+        for (int p = 0; p < P_; ++p) { t[p >> 5] |= 1u << (p & 31); }
     }
     int numInputChannels() const override { return 18; }
     int boardSize() const override { return n_; }

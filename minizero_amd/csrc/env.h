@@ -33,6 +33,10 @@ public:
     virtual float evalScore(bool is_resign) const = 0;
     virtual float reward() const { return 0.0f; }
     virtual void features(int rotation, float* out) const = 0;
+    // the same planes, 1 bit per point (all board-game planes are 0/1): channel c occupies ceil(P/32) words, bit p%32 of word p/32.
+    // 32x less host->device traffic than the f32 planes; the tower kernel expands them while staging its LDS tile
+    virtual void featureBits(int rotation, uint32_t* out) const;
+    int featureWords() const { return numInputChannels() * ((boardSize() * boardSize() + 31) / 32); }
     virtual int numInputChannels() const = 0;
     virtual int boardSize() const = 0;
     virtual int policySize() const = 0;

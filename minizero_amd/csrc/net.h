@@ -32,7 +32,9 @@ public:
     int reload(const float* raw, size_t n);
 
     // device-pointer entry points (all on stream_)
-    int forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value);
+    // in_bits: d_feat holds bit-packed planes (GameEnv::featureBits layout) instead of f32 planes
+    int forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, bool in_bits = false);
+    bool hasFusedTower();
     int initial(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, float* d_hidden, const int* d_dst_idx);
     // hidden source: d_hidden_src[(src_idx ? src_idx[b] : b)][C][P]; action: planes (d_action_planes) or ids (d_action_ids)
     int recurrent(const float* d_hidden_src, const int* d_src_idx, const float* d_action_planes, const int* d_action_ids, int B, float* d_policy,
@@ -55,9 +57,9 @@ public:
 
 private:
     int ensureBatch(int B);
-    int runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out);
+    int runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out, bool in_bits = false);
     int launchConv(const ConvLayer& L, const float* in, const float* skip, float* out, int B);
-    int launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched);
+    int launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits);
     int launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden);
 
     DevBuf<float> params_;

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const float* __restrict__ in
 // ---------------------------------------------------------------------------------------------
 struct TowerArgs {
     int nlayers, cin0, C, OT; // C = hidden channels (== cout of every layer), OT = ceil(C/16)
+    int in_bits;              // input planes arrive bit-packed (1 bit per point, ceil(P/32) words per channel)
     unsigned w_off[48], b_off[48];
 };
 
@@ -223,10 +224,19 @@ __global__ __launch_bounds__(512) void tower_fused(const float* __restrict__ in,
     // zero all three tiles (borders and padding channels stay zero for the whole kernel), then the sample's planes into T0
     for (int i = tid; i < 3 * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
     __syncthreads();
-    const float* src = in + size_t(b) * ta.cin0 * P;
-    for (int i = tid; i < ta.cin0 * P; i += 512) {
-        const int c = i / P, p = i - c * P;
-        T0[c * CS + (p / W + 1) * PW + (p % W) + 1] = src[i];
+    if (ta.in_bits) {
+        constexpr int W32 = (P + 31) / 32;
+        const unsigned* bits = reinterpret_cast<const unsigned*>(in) + size_t(b) * ta.cin0 * W32;
+        for (int i = tid; i < ta.cin0 * P; i += 512) {
+            const int c = i / P, p = i - c * P;
+            T0[c * CS + (p / W + 1) * PW + (p % W) + 1] = ((bits[c * W32 + (p >> 5)] >> (p & 31)) & 1u) ? 1.0f : 0.0f;
+        }
+    } else {
+        const float* src = in + size_t(b) * ta.cin0 * P;
+        for (int i = tid; i < ta.cin0 * P; i += 512) {
+            const int c = i / P, p = i - c * P;
+            T0[c * CS + (p / W + 1) * PW + (p % W) + 1] = src[i];
+        }
     }
     __syncthreads();
     float* gout = out + size_t(b) * ta.C * P;
@@ -468,7 +478,7 @@ static int launchTowerT(const TowerArgs& ta, const float* params, const float* i
 }
 
 // returns MZ_OK and sets *launched when a fused instance exists for this trunk
-int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched)
+int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits)
 {
     *launched = false;
     if (!use_fused_ || t.size() > 48 || (t.size() % 2) == 0) { return MZ_OK; }
@@ -480,6 +490,7 @@ int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* ou
     ta.cin0 = t[0].cin;
     ta.C = C;
     ta.OT = t[0].cout_pad / 16;
+    ta.in_bits = in_bits ? 1 : 0;
     for (size_t i = 0; i < t.size(); ++i) { ta.w_off[i] = static_cast<unsigned>(t[i].w_off); ta.b_off[i] = static_cast<unsigned>(t[i].b_off); }
     const int c0 = t[0].cin_pad;
 #define MZ_TOWER_CASE(h, w, cin0, cpad) \
@@ -498,12 +509,13 @@ int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* ou
     return MZ_OK;
 }
 
-int Net::runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out)
+int Net::runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out, bool in_bits)
 {
     bool launched = false;
-    int frc = launchTower(t, d_in, act_[0].p, B, &launched);
+    int frc = launchTower(t, d_in, act_[0].p, B, &launched, in_bits);
     if (frc) { return frc; }
     if (launched) { *d_out = act_[0].p; return MZ_OK; }
+    if (in_bits) { setError("bit-packed input needs the fused tower kernel (no instance for this network shape)"); return MZ_ERR_ARG; }
     float *x = act_[0].p, *tmp = act_[1].p, *y = act_[2].p;
     int rc = launchConv(t[0], d_in, nullptr, x, B);
     if (rc) { return rc; }
@@ -531,13 +543,24 @@ int Net::launchHeads(const float* x, int B, float* policy, float* logit, float* 
     return MZ_OK;
 }
 
-int Net::forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value)
+bool Net::hasFusedTower()
+{
+    // probe with a zero-sized question: does launchTower have an instance for the representation trunk?
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels, c0 = repr_[0].cin_pad;
+    static const int inst[][4] = {{9, 9, 20, 64}, {9, 9, 68, 64}, {8, 8, 4, 64}, {8, 8, 68, 64}, {9, 9, 20, 8}, {9, 9, 12, 8}, {8, 8, 4, 8}, {8, 8, 12, 8},
+                                  {3, 3, 4, 16}, {3, 3, 20, 16}};
+    if (!use_fused_ || (repr_.size() % 2) == 0) { return false; }
+    for (auto& i : inst) { if (i[0] == H && i[1] == W && i[2] == c0 && i[3] == C) { return true; } }
+    return false;
+}
+
+int Net::forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, bool in_bits)
 {
     if (desc_.type != 0) { setError("forward() called on a %s network", desc_.type == 1 ? "muzero" : "muzero_atari"); return MZ_ERR_STATE; }
     int rc = ensureBatch(B);
     if (rc) { return rc; }
     float* x = nullptr;
-    if ((rc = runTrunk(repr_, d_feat, B, &x))) { return rc; }
+    if ((rc = runTrunk(repr_, d_feat, B, &x, in_bits))) { return rc; }
     if (conv_only_) { return MZ_OK; }
     return launchHeads(x, B, d_policy, d_logit, d_value, nullptr, nullptr, false);
 }

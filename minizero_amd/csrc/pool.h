@@ -14,6 +14,7 @@ struct PoolView { // device pointers, passed to kernels by value
     unsigned char* player;
     // per game
     int *num_nodes, *path_len, *path, *path_action; // path[g*max_depth + d]
+    int *host_path_len, *host_path_action;           // optional host-mapped (pinned) mirrors written by select_kernel (zero-copy D2H)
     float *bound_key;                                // [games][bound_cap] value-bound multiset keys (ref mcts.cpp:219-228)
     int *bound_cnt, *bound_size;                     // [games][bound_cap], [games]
     float *bound_lo, *bound_hi;                      // [games]
@@ -42,7 +43,8 @@ public:
 
     // async building blocks for the worker (device-resident arguments, no host sync)
     int selectAsync(const int* d_start_node);
-    int expandBackupAsync(int hslot);              // consumes d_cand_* staging below
+    int expandBackupAsync(int hslot, bool from_host = false); // consumes d_cand_* staging below (or the pinned h_cand_* views directly)
+    bool zero_copy_ = false;                        // kernels read/write the pinned host staging directly over PCIe: no memcpy ops per cycle
     int expandBackupStaged(int hslot);             // H2D of the pinned h_cand_* mirrors + expandBackupAsync
     int hiddenIndexAsync(int slots_per_game, int dst_slot, int* d_src_idx, int* d_dst_idx, int* d_action_ids); // MuZero: slots of the last select
     int checkError();                              // device-side error flag (capacity)

@@ -61,7 +61,11 @@ __global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __res
     const int st = start ? start[g] : 0;
     if (st > 0) { // Gumbel: path = root + PUCT path below the chosen candidate (ref gumbel_zero.cpp:83-85)
         node = st;
-        if (lane == 0) { path[1] = st; pact[1] = v.action[base + st]; }
+        if (lane == 0) {
+            path[1] = st;
+            pact[1] = v.action[base + st];
+            if (v.host_path_action) { v.host_path_action[size_t(g) * v.max_depth + 1] = pact[1]; }
+        }
         depth = 2;
     }
     while (true) {
@@ -108,10 +112,18 @@ __global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __res
             if (better(s2, p2, i2, bs, bp, bi)) { bs = s2; bp = p2; bi = i2; }
         }
         node = v.first_child[base + node] + bi;
-        if (lane == 0) { path[depth] = node; pact[depth] = v.action[base + node]; }
+        if (lane == 0) {
+            const int act = v.action[base + node];
+            path[depth] = node;
+            pact[depth] = act;
+            if (v.host_path_action) { v.host_path_action[size_t(g) * v.max_depth + depth] = act; }
+        }
         ++depth;
     }
-    if (lane == 0) { v.path_len[g] = depth; }
+    if (lane == 0) {
+        v.path_len[g] = depth;
+        if (v.host_path_len) { v.host_path_len[g] = depth; }
+    }
 }
 
 __global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int* __restrict__ cand_count, const int* __restrict__ cand_action,
@@ -405,9 +417,15 @@ int Pool::select(const int* start_node, int* path_len, int* paths, int* path_act
     return MZ_OK;
 }
 
-int Pool::expandBackupAsync(int hslot)
+int Pool::expandBackupAsync(int hslot, bool from_host)
 {
     const size_t lds = v_.value_rescale ? size_t(v_.bound_cap) * 8 : 0;
+    if (from_host) { // zero-copy: the kernel reads the pinned candidate arena over PCIe (<= 1 KB per game)
+        hipLaunchKernelGGL(expand_backup_kernel, dim3(v_.games), dim3(64), lds, stream_, v_, h_cand_count_.p, h_cand_action_.p, h_cand_policy_.p,
+                           h_cand_logit_.p, h_cand_player_.p, h_value_.p, h_reward_.p, hslot, game_i_.p + size_t(v_.games) * 3);
+        MZ_HIP(hipGetLastError());
+        return MZ_OK;
+    }
     hipLaunchKernelGGL(expand_backup_kernel, dim3(v_.games), dim3(64), lds, stream_, v_, d_cand_count_.p, d_cand_action_.p, d_cand_policy_.p,
                        d_cand_logit_.p, d_cand_player_.p, d_value_.p, d_reward_.p, hslot, game_i_.p + size_t(v_.games) * 3);
     MZ_HIP(hipGetLastError());
@@ -416,6 +434,7 @@ int Pool::expandBackupAsync(int hslot)
 
 int Pool::expandBackupStaged(int hslot)
 {
+    if (zero_copy_) { return expandBackupAsync(hslot, true); }
     MZ_HIP(hipMemcpyAsync(d_cand_arena_.p, h_cand_arena_.p, h_cand_arena_.n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
     return expandBackupAsync(hslot);
 }

@@ -13,6 +13,9 @@
 #include "env.h"
 #include "net.h"
 #include "pool.h"
+#include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -66,11 +69,51 @@ struct Rng {
 // Two short parallel sections per lock-step cycle (~1 ms apart), so wake-up latency matters more than
 // anything else: workers spin on an epoch counter (pause) and only fall back to a condition variable
 // after ~2 ms without work (worker stopped / between benchmarks).
+// CPUs this process may run on, grouped by NUMA node (node of the calling thread first), so that a worker's threads
+// share one memory domain with the pinned staging buffers they read and write.
+static std::vector<int> cpuOrder()
+{
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    std::vector<int> allowed;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        for (int c = 0; c < CPU_SETSIZE; ++c) { if (CPU_ISSET(c, &set)) { allowed.push_back(c); } }
+    }
+    auto nodeOf = [](int cpu) {
+        for (int node = 0; node < 64; ++node) {
+            char path[128];
+            snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpu%d", node, cpu);
+            if (access(path, F_OK) == 0) { return node; }
+        }
+        return 0;
+    };
+    const int here = nodeOf(sched_getcpu());
+    std::stable_sort(allowed.begin(), allowed.end(), [&](int a, int b) {
+        const int na = nodeOf(a), nb = nodeOf(b);
+        return (na != here) < (nb != here) || ((na != here) == (nb != here) && na < nb);
+    });
+    return allowed;
+}
+
 class ThreadPool {
 public:
-    explicit ThreadPool(int n) : n_(std::max(1, n))
+    // cpu_base >= 0: pin the calling thread and the workers to consecutive entries of cpuOrder() starting at cpu_base
+    explicit ThreadPool(int n, int cpu_base = -1) : n_(std::max(1, n))
     {
-        for (int t = 1; t < n_; ++t) { threads_.emplace_back([this]() { loop(); }); }
+        std::vector<int> cpus;
+        if (cpu_base >= 0) { cpus = cpuOrder(); }
+        auto pin = [&](pthread_t th, int idx) {
+            if (cpus.empty()) { return; }
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[(cpu_base + idx) % cpus.size()], &one);
+            (void)pthread_setaffinity_np(th, sizeof(one), &one);
+        };
+        pin(pthread_self(), 0);
+        for (int t = 1; t < n_; ++t) {
+            threads_.emplace_back([this]() { loop(); });
+            pin(threads_.back().native_handle(), t);
+        }
     }
     ~ThreadPool()
     {
@@ -161,6 +204,21 @@ struct Game {
     std::vector<ActionInfo> action_info_history;
 };
 
+// optional host-side phase trace (MZ_TRACE=1): prints per-sub-step averages to stderr when the worker is destroyed
+struct PhaseTrace {
+    bool on = getenv("MZ_TRACE") != nullptr;
+    double acc[16] = {0};
+    uint64_t cnt[16] = {0};
+    const char* names[16] = {"p1.sync", "p1.cand", "p1.expand_launch", "p1.rootread", "p1.serial", "p1.noise_reset", "p1.select_launch", "p2.sync", "p2.leaf",
+                             "p2.fwd_launch", "", "", "", "", "", ""};
+    void add(int i, double ms) { acc[i] += ms; ++cnt[i]; }
+    ~PhaseTrace()
+    {
+        if (!on) { return; }
+        for (int i = 0; i < 10; ++i) { if (cnt[i]) { fprintf(stderr, "[mz trace] %-18s calls %8llu  avg %8.4f ms  total %10.2f ms\n", names[i], (unsigned long long)cnt[i], acc[i] / cnt[i], acc[i]); } }
+    }
+};
+
 inline double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 std::string escapeSGF(const std::string& s) // ref base_env.h:303-313
@@ -187,11 +245,30 @@ public:
     int runCycles(int n);
     int popLine(char* buf, int cap);
     mz_worker_stats stats_{};
-    Net net_;
+    Net& net0() { return lanes_[0]->net; }
 
 private:
+    // A lane = a contiguous slice of the games with its own device pool, network instance, HIP stream and staging.
+    // Lanes are software-pipelined on the one host thread: while lane A's kernels (select / tower / heads) run, the
+    // host builds candidates / leaf positions for lane B, and the two streams let the GPU overlap one lane's tower
+    // (1 workgroup per sample: half the CUs at 128 games) with the other lane's tree kernels.  Results do not depend on
+    // the lane count: the RNG-ordered serial section still visits the games in index order.
+    struct Lane {
+        int g0 = 0, n = 0;
+        Net net;
+        Pool pool;
+        hipStream_t stream = nullptr;
+        PinBuf<float> h_feat, h_out;
+        DevBuf<float> d_feat, d_out, d_hidden;
+        Pool::View<float> h_policy, h_logit, h_value, h_reward, d_policy, d_logit, d_value, d_reward;
+        DevBuf<int> d_src_idx, d_dst_idx, d_action_ids;
+    };
+    Lane& laneOf(int g) { return *lanes_[g / lane_size_ < int(lanes_.size()) ? g / lane_size_ : int(lanes_.size()) - 1]; }
+    int phase1(Lane& L, bool root_expansion, bool done);
+    int phase2(Lane& L);
     int cycle();
     int createActors();
+    int resetAllSearches();
     void resetGame(Game& g, Rng& rng);          // ZeroActor::reset (ref zero_actor.cpp:23-27)
     int rootPlayerFor(const Game& g) const { return g.env->numPlayers() == 2 ? 3 - g.env->turn() : g.env->turn(); }
     void buildCandidates(int g);
@@ -215,28 +292,25 @@ private:
     WorkerConfig cfg_;
     mz_net_desc desc_{};
     int device_ = 0, G_ = 0, A_ = 0, n_ = 0;
-    hipStream_t stream_ = nullptr;
-    Pool pool_;
+    std::vector<std::unique_ptr<Lane>> lanes_;
+    int lane_size_ = 1;
     std::unique_ptr<ThreadPool> threads_;
     std::vector<Game> games_;
     Rng main_rng_, rng_;
     bool running_ = false, pending_ = false;
     int sims_done_ = 0; // root visit count of every game (lock-step: identical for all games)
+    int sim_pre_ = 0, sim_post_ = 0; // its value before / after the expand+backup of the current cycle
     std::deque<std::string> lines_;
     std::vector<float> pending_weights_;
-    // staging
-    // network outputs: one device arena / one pinned arena [policy GA][logit GA][value G][reward G] -> a single D2H per cycle
-    PinBuf<float> h_feat_, h_out_;
-    DevBuf<float> d_feat_, d_out_, d_hidden_;
-    Pool::View<float> h_policy_, h_logit_, h_value_, h_reward_, d_policy_, d_logit_, d_value_, d_reward_;
-    DevBuf<int> d_src_idx_, d_dst_idx_, d_action_ids_;
     // root statistics mirrors (valid after rootRead)
     std::vector<int> rr_nc_, rr_action_, rr_bsize_;
     std::vector<float> rr_count_, rr_mean_, rr_policy_, rr_logit_, rr_noise_, rr_value_, rr_reward_, rr_root_count_, rr_root_mean_, rr_root_value_,
         rr_lo_, rr_hi_;
     std::vector<uint8_t> noise_mask_;
     std::vector<float> noise_policy_, noise_logit_, noise_noise_;
+    PhaseTrace trace_;
     int flipping_player_ = 2;
+    bool feat_bits_ = false; // AlphaZero leaves travel host->device as bit-packed planes (all board-game planes are 0/1)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -248,9 +322,6 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     if (cfg_.nn_type_name == "muzero" && desc.type == 0) { setError("nn_type_name=muzero but the network descriptor is alphazero"); return MZ_ERR_ARG; }
     if (cfg_.zero_num_parallel_games <= 0 || cfg_.actor_num_simulation <= 0) { setError("zero_num_parallel_games and actor_num_simulation must be > 0"); return MZ_ERR_ARG; }
     if (cfg_.zero_num_parallel_games > 4096) { setError("zero_num_parallel_games > 4096 (ref alphazero_network.h:120 kReserved_batch_size)"); return MZ_ERR_ARG; }
-    int rc = net_.init(device, desc, weights, count);
-    if (rc) { return rc; }
-    stream_ = net_.stream_;
     G_ = cfg_.zero_num_parallel_games;
     A_ = desc.action_size;
     n_ = cfg_.actor_num_simulation;
@@ -264,29 +335,51 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     sc.value_rescale = cfg_.actor_mcts_value_rescale;
     sc.flipping_player = flipping_player_;
     sc.atari_init_q = cfg_.atari_init_q;
-    // ref actor_group.cpp:183: tree_node_size = (n + 1) * action_size; tree.h:66: 1 + tree_node_size nodes
-    rc = pool_.init(device, G_, 1 + (n_ + 1) * A_, A_, sc, stream_);
-    if (rc) { return rc; }
-    threads_ = std::make_unique<ThreadPool>(std::max(1, cfg_.zero_num_threads));
-
-    const size_t GA = size_t(G_) * A_, feat = size_t(G_) * net_.featSize();
+    int nl = std::max(1, cfg_.mz_pipeline_lanes);
+    if (G_ < 2 * nl) { nl = 1; }
+    lane_size_ = (G_ + nl - 1) / nl;
+    lanes_.clear();
+    for (int l = 0; l < nl; ++l) {
+        auto L = std::make_unique<Lane>();
+        L->g0 = l * lane_size_;
+        L->n = std::min(lane_size_, G_ - L->g0);
+        int rc = L->net.init(device, desc, weights, count);
+        if (rc) { return rc; }
+        L->stream = L->net.stream_;
+        // ref actor_group.cpp:183: tree_node_size = (n + 1) * action_size; tree.h:66: 1 + tree_node_size nodes
+        rc = L->pool.init(device, L->n, 1 + (n_ + 1) * A_, A_, sc, L->stream);
+        if (rc) { return rc; }
+        // kernels talk to the pinned staging directly: no memcpy operations on the per-cycle path
+        if (cfg_.mz_zero_copy & 1) { L->pool.zero_copy_ = true; }
+        if (cfg_.mz_zero_copy & 2) {
+            L->pool.v_.host_path_len = L->pool.h_path_len_.p;
+            L->pool.v_.host_path_action = L->pool.h_path_action_.p;
+        }
+        const size_t GA = size_t(L->n) * A_, feat = size_t(L->n) * L->net.featSize(), Gn = L->n;
 #define WALLOC(b, n) \
     if (!(b).alloc(n)) { setError("worker: allocation failed (%s)", #b); return MZ_ERR_DEVICE; }
-    WALLOC(h_feat_, feat); WALLOC(d_feat_, feat); WALLOC(h_out_, 2 * GA + 2 * G_); WALLOC(d_out_, 2 * GA + 2 * G_);
-    h_policy_ = {h_out_.p, GA}; h_logit_ = {h_out_.p + GA, GA}; h_value_ = {h_out_.p + 2 * GA, size_t(G_)}; h_reward_ = {h_out_.p + 2 * GA + G_, size_t(G_)};
-    d_policy_ = {d_out_.p, GA}; d_logit_ = {d_out_.p + GA, GA}; d_value_ = {d_out_.p + 2 * GA, size_t(G_)}; d_reward_ = {d_out_.p + 2 * GA + G_, size_t(G_)};
-    MZ_HIP(hipMemset(d_out_.p, 0, d_out_.n * sizeof(float)));
-    if (desc.type == 1) {
-        WALLOC(d_hidden_, size_t(G_) * (n_ + 1) * net_.hiddenSize()); // hidden-state slab: one slot per expanded node
-        WALLOC(d_src_idx_, G_); WALLOC(d_dst_idx_, G_); WALLOC(d_action_ids_, G_);
-    }
+        WALLOC(L->h_feat, feat); WALLOC(L->d_feat, feat); WALLOC(L->h_out, 2 * GA + 2 * Gn); WALLOC(L->d_out, 2 * GA + 2 * Gn);
+        L->h_policy = {L->h_out.p, GA}; L->h_logit = {L->h_out.p + GA, GA}; L->h_value = {L->h_out.p + 2 * GA, Gn}; L->h_reward = {L->h_out.p + 2 * GA + Gn, Gn};
+        L->d_policy = {L->d_out.p, GA}; L->d_logit = {L->d_out.p + GA, GA}; L->d_value = {L->d_out.p + 2 * GA, Gn}; L->d_reward = {L->d_out.p + 2 * GA + Gn, Gn};
+        MZ_HIP(hipMemset(L->d_out.p, 0, L->d_out.n * sizeof(float)));
+        if (desc.type == 1) {
+            WALLOC(L->d_hidden, Gn * (n_ + 1) * L->net.hiddenSize()); // hidden-state slab: one slot per expanded node
+            WALLOC(L->d_src_idx, Gn); WALLOC(L->d_dst_idx, Gn); WALLOC(L->d_action_ids, Gn);
+        }
 #undef WALLOC
+        lanes_.push_back(std::move(L));
+    }
+    threads_ = std::make_unique<ThreadPool>(std::max(1, cfg_.zero_num_threads), cfg_.mz_cpu_base);
+    const size_t GA = size_t(G_) * A_;
     rr_nc_.resize(G_); rr_action_.resize(GA); rr_bsize_.resize(G_);
     for (auto* v : {&rr_count_, &rr_mean_, &rr_policy_, &rr_logit_, &rr_noise_, &rr_value_, &rr_reward_}) { v->resize(GA); }
     for (auto* v : {&rr_root_count_, &rr_root_mean_, &rr_root_value_, &rr_lo_, &rr_hi_}) { v->resize(G_); }
     noise_mask_.assign(G_, 1);
     noise_policy_.resize(GA); noise_logit_.resize(GA); noise_noise_.resize(GA);
-    return createActors();
+    int rcc = createActors();
+    if (rcc) { return rcc; }
+    feat_bits_ = (desc.type == 0) && net0().hasFusedTower();
+    return MZ_OK;
 }
 
 int Worker::createActors()
@@ -300,8 +393,8 @@ int Worker::createActors()
     for (auto& g : games_) {
         g.env = createGameEnv(cfg_.env_game, cfg_.env_board_size, cfg_.env_go_komi);
         if (!g.env) { return MZ_ERR_ARG; }
-        if (g.env->policySize() != A_ || g.env->featureSize() != net_.featSize()) {
-            setError("network (A=%d, features=%d) does not fit env %s (A=%d, features=%d)", A_, net_.featSize(), g.env->name().c_str(),
+        if (g.env->policySize() != A_ || g.env->featureSize() != net0().featSize()) {
+            setError("network (A=%d, features=%d) does not fit env %s (A=%d, features=%d)", A_, net0().featSize(), g.env->name().c_str(),
                      g.env->policySize(), g.env->featureSize());
             return MZ_ERR_ARG;
         }
@@ -312,11 +405,20 @@ int Worker::createActors()
         g.enable_resign = (main_rng_.randReal() < cfg_.zero_disable_resign_ratio ? false : true);
     }
     rng_.seed(cfg_.program_auto_seed ? static_cast<int>(std::random_device()()) : cfg_.program_seed + 0);
-    std::vector<int> rp(G_);
-    for (int g = 0; g < G_; ++g) { rp[g] = rootPlayerFor(games_[g]); }
     sims_done_ = 0;
     pending_ = false;
-    return pool_.resetSearch(nullptr, rp.data());
+    return resetAllSearches();
+}
+
+int Worker::resetAllSearches()
+{
+    for (auto& L : lanes_) {
+        std::vector<int> rp(L->n);
+        for (int j = 0; j < L->n; ++j) { rp[j] = rootPlayerFor(games_[L->g0 + j]); }
+        int rc = L->pool.resetSearch(nullptr, rp.data());
+        if (rc) { return rc; }
+    }
+    return MZ_OK;
 }
 
 void Worker::resetGame(Game& g, Rng& rng)
@@ -331,18 +433,20 @@ void Worker::resetGame(Game& g, Rng& rng)
 void Worker::buildCandidates(int gi)
 {
     Game& g = games_[gi];
-    const size_t off = size_t(gi) * A_;
-    int* ca = pool_.h_cand_action_.p + off;
-    float* cp = pool_.h_cand_policy_.p + off;
-    float* cl = pool_.h_cand_logit_.p + off;
-    const float* policy = h_policy_.p + off;
-    const float* logit = h_logit_.p + off;
+    Lane& L = laneOf(gi);
+    const int j = gi - L.g0; // index inside the lane
+    const size_t off = size_t(j) * A_;
+    int* ca = L.pool.h_cand_action_.p + off;
+    float* cp = L.pool.h_cand_policy_.p + off;
+    float* cl = L.pool.h_cand_logit_.p + off;
+    const float* policy = L.h_policy.p + off;
+    const float* logit = L.h_logit.p + off;
     Cand tmp[512];
     std::vector<Cand> big;
     Cand* c = tmp;
     if (A_ > 512) { big.resize(A_); c = big.data(); }
     int k = 0;
-    float value = h_value_.p[gi], reward = 0.0f;
+    float value = L.h_value.p[j], reward = 0.0f;
     int player;
     if (desc_.type == 0) {
         player = g.leaf_turn;
@@ -357,31 +461,33 @@ void Worker::buildCandidates(int gi)
             }
         }
     } else {
-        const int L = g.path_len - 1; // depth of the leaf; its children are moved by the player to move there
-        player = (g.env->numPlayers() == 2 && (L & 1)) ? 3 - g.env->turn() : g.env->turn();
-        reward = h_reward_.p[gi];
+        const int depth = g.path_len - 1; // depth of the leaf; its children are moved by the player to move there
+        player = (g.env->numPlayers() == 2 && (depth & 1)) ? 3 - g.env->turn() : g.env->turn();
+        reward = L.h_reward.p[j];
         for (int a = 0; a < A_; ++a) {
-            if (L == 0 && !g.legal[a]) { continue; } // legality is only known (and checked) at the root (zero_actor.cpp:238)
+            if (depth == 0 && !g.legal[a]) { continue; } // legality is only known (and checked) at the root (zero_actor.cpp:238)
             c[k++] = Cand{a, policy[a], logit[a]};
         }
     }
     std::sort(c, c + k, [](const Cand& l, const Cand& r) { return l.policy > r.policy; }); // the reference's (unstable) std::sort
     for (int i = 0; i < k; ++i) { ca[i] = c[i].action; cp[i] = c[i].policy; cl[i] = c[i].logit; }
-    pool_.h_cand_count_.p[gi] = k;
-    pool_.h_cand_player_.p[gi] = player;
-    pool_.h_value_.p[gi] = value;
-    pool_.h_reward_.p[gi] = reward;
+    L.pool.h_cand_count_.p[j] = k;
+    L.pool.h_cand_player_.p[j] = player;
+    L.pool.h_value_.p[j] = value;
+    L.pool.h_reward_.p[j] = reward;
 }
 
 // leaf environment + features: ref zero_actor.cpp:51-72, 247-252
 void Worker::buildLeaf(int gi)
 {
     Game& g = games_[gi];
-    const int len = pool_.h_path_len_.p[gi];
+    Lane& L = laneOf(gi);
+    const int j = gi - L.g0;
+    const int len = L.pool.h_path_len_.p[j];
     g.path_len = len;
-    float* feat = h_feat_.p + size_t(gi) * net_.featSize();
+    float* feat = L.h_feat.p + size_t(j) * L.net.featSize();
     if (desc_.type == 0) {
-        const int* acts = pool_.h_path_action_.p + size_t(gi) * pool_.v_.max_depth;
+        const int* acts = L.pool.h_path_action_.p + size_t(j) * L.pool.v_.max_depth;
         g.leaf->copyFrom(*g.env);
         int p = g.env->turn();
         for (int d = 1; d < len; ++d) {
@@ -393,7 +499,8 @@ void Worker::buildLeaf(int gi)
         g.leaf_reward = g.leaf->reward();
         if (g.leaf_terminal) { g.leaf_eval = g.leaf->evalScore(false); }
         else { g.leaf->legalMask(g.legal.data()); }
-        g.leaf->features(g.rot, feat);
+        if (feat_bits_) { g.leaf->featureBits(g.rot, reinterpret_cast<uint32_t*>(L.h_feat.p) + size_t(j) * g.env->featureWords()); }
+        else { g.leaf->features(g.rot, feat); }
     } else if (sims_done_ == 0) {
         g.env->features(0, feat);
         g.env->legalMask(g.legal.data());
@@ -534,7 +641,7 @@ void Worker::gumbelSequentialHalving(int g) // ref gumbel_zero.cpp:90-119
 {
     Game& gm = games_[g];
     const size_t off = size_t(g) * A_;
-    if (sims_done_ == 1) {
+    if (sim_post_ == 1) {
         gm.candidates.clear();
         for (int i = 0; i < rr_nc_[g]; ++i) { gm.candidates.push_back(i); }
         std::sort(gm.candidates.begin(), gm.candidates.end(), [&](int l, int r) { return rr_logit_[off + l] > rr_logit_[off + r]; });
@@ -673,36 +780,41 @@ void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor
 }
 
 // ------------------------------------------------------------------------------------------------
-int Worker::cycle()
+// phase 1 of a lane: consume the network outputs of the previous cycle (expand + backup), run the RNG-ordered serial
+// section for the lane's games, then launch the selection of the next simulation (asynchronously).
+int Worker::phase1(Lane& L, bool root_expansion, bool done)
 {
     const bool az = desc_.type == 0;
-    const double t0 = nowMs();
-    double t1 = t0;
-    MZ_HIP(hipSetDevice(device_));
+    const int g0 = L.g0, g1 = L.g0 + L.n;
+    double t0 = nowMs();
     if (pending_) {
-        // ---- network results of the previous cycle ----
-        MZ_HIP(hipStreamSynchronize(stream_));
-        t1 = nowMs();
+        MZ_HIP(hipStreamSynchronize(L.stream)); // network outputs of this lane
+        double t1 = nowMs();
         stats_.ms_forward += t1 - t0;
-        threads_->parallelFor(G_, [this](int g) { buildCandidates(g); });
-        int rc = pool_.expandBackupStaged(az ? -1 : sims_done_);
+        trace_.add(0, t1 - t0);
+        threads_->parallelFor(L.n, [this, g0](int j) { buildCandidates(g0 + j); });
+        const double tc = nowMs();
+        trace_.add(1, tc - t1);
+        int rc = L.pool.expandBackupStaged(az ? -1 : sim_pre_);
         if (rc) { return rc; }
-        ++sims_done_;
-        const bool root_expansion = (sims_done_ == 1), done = (sims_done_ == n_ + 1);
+        const double te = nowMs();
+        trace_.add(2, te - tc);
         const bool want_noise = root_expansion && (cfg_.actor_use_dirichlet_noise || cfg_.actor_use_gumbel_noise);
         if (done || cfg_.actor_use_gumbel || want_noise) {
             // root statistics for the per-move host logic (sync point; also surfaces pool capacity errors)
-            rc = pool_.rootRead(rr_nc_.data(), rr_action_.data(), rr_count_.data(), rr_mean_.data(), rr_policy_.data(), rr_logit_.data(),
-                                rr_noise_.data(), rr_value_.data(), rr_reward_.data(), rr_root_count_.data(), rr_root_mean_.data(),
-                                rr_root_value_.data(), rr_lo_.data(), rr_hi_.data(), rr_bsize_.data());
+            const size_t o = size_t(g0) * A_;
+            rc = L.pool.rootRead(rr_nc_.data() + g0, rr_action_.data() + o, rr_count_.data() + o, rr_mean_.data() + o, rr_policy_.data() + o,
+                                 rr_logit_.data() + o, rr_noise_.data() + o, rr_value_.data() + o, rr_reward_.data() + o, rr_root_count_.data() + g0,
+                                 rr_root_mean_.data() + g0, rr_root_value_.data() + g0, rr_lo_.data() + g0, rr_hi_.data() + g0, rr_bsize_.data() + g0);
             if (rc) { return rc; }
-            if ((rc = pool_.checkError())) { return rc; }
+            if ((rc = L.pool.checkError())) { return rc; }
         }
         const double t2 = nowMs();
         stats_.ms_expand += t2 - t1;
+        trace_.add(3, t2 - te);
         // ---- strictly serial, RNG-ordered section (actor index order) ----
         std::vector<float> noise;
-        for (int g = 0; g < G_; ++g) {
+        for (int g = g0; g < g1; ++g) {
             Game& gm = games_[g];
             const size_t off = size_t(g) * A_;
             if (want_noise) { // ref zero_actor.cpp:194-213
@@ -732,70 +844,119 @@ int Worker::cycle()
                 gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
             }
         }
+        const double ts = nowMs();
+        trace_.add(4, ts - t2);
         if (want_noise) {
-            if ((rc = pool_.rootSetNoise(noise_mask_.data(), noise_policy_.data(), noise_logit_.data(), noise_noise_.data()))) { return rc; }
+            const size_t o = size_t(g0) * A_;
+            if ((rc = L.pool.rootSetNoise(noise_mask_.data() + g0, noise_policy_.data() + o, noise_logit_.data() + o, noise_noise_.data() + o))) { return rc; }
         }
         if (done) {
-            std::vector<int> rp(G_);
-            for (int g = 0; g < G_; ++g) { rp[g] = rootPlayerFor(games_[g]); }
-            if ((rc = pool_.resetSearch(nullptr, rp.data()))) { return rc; }
-            sims_done_ = 0;
+            std::vector<int> rp(L.n);
+            for (int j = 0; j < L.n; ++j) { rp[j] = rootPlayerFor(games_[g0 + j]); }
+            if ((rc = L.pool.resetSearch(nullptr, rp.data()))) { return rc; }
         }
-        t1 = nowMs();
-        stats_.ms_move += t1 - t2;
+        t0 = nowMs();
+        stats_.ms_move += t0 - t2;
+        trace_.add(5, t0 - ts);
     } else {
-        for (auto& gm : games_) {
-            if (az) { gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0; }
+        for (int g = g0; g < g1; ++g) {
+            if (az) { games_[g].rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0; }
         }
-        t1 = nowMs();
     }
-
-    // ---- selection ----
+    // ---- selection of the next simulation ----
+    const int next_sim = pending_ ? (done ? 0 : sim_post_) : 0;
     const int* d_start = nullptr;
-    if (cfg_.actor_use_gumbel && sims_done_ >= 1) { // ref gumbel_zero.cpp:74-88
-        for (int g = 0; g < G_; ++g) {
+    if (cfg_.actor_use_gumbel && next_sim >= 1) { // ref gumbel_zero.cpp:74-88
+        for (int g = g0; g < g1; ++g) {
             Game& gm = games_[g];
             const size_t off = size_t(g) * A_;
             std::sort(gm.candidates.begin(), gm.candidates.end(), [&](int l, int r) {
                 return (rr_count_[off + l] < rr_count_[off + r] || (rr_count_[off + l] == rr_count_[off + r] && rr_logit_[off + l] > rr_logit_[off + r]));
             });
-            pool_.h_start_.p[g] = 1 + gm.candidates[0]; // the root's children are nodes 1..k
+            L.pool.h_start_.p[g - g0] = 1 + gm.candidates[0]; // the root's children are nodes 1..k
         }
-        MZ_HIP(hipMemcpyAsync(pool_.d_start_.p, pool_.h_start_.p, G_ * sizeof(int), hipMemcpyHostToDevice, stream_));
-        d_start = pool_.d_start_.p;
+        MZ_HIP(hipMemcpyAsync(L.pool.d_start_.p, L.pool.h_start_.p, L.n * sizeof(int), hipMemcpyHostToDevice, L.stream));
+        d_start = L.pool.d_start_.p;
     }
-    int rc = pool_.selectAsync(d_start);
+    int rc = L.pool.selectAsync(d_start);
     if (rc) { return rc; }
-    // one D2H: [path_len G] (+ [path_action G*max_depth] for AlphaZero, whose leaves need the moves for the replay)
-    MZ_HIP(hipMemcpyAsync(pool_.h_path_arena_.p, pool_.d_path_arena_.p, (size_t(G_) + (az ? size_t(G_) * pool_.v_.max_depth : 0)) * sizeof(uint32_t),
-                          hipMemcpyDeviceToHost, stream_));
-    MZ_HIP(hipStreamSynchronize(stream_));
-    const double t3 = nowMs();
-    stats_.ms_select += t3 - t1;
+    if (!(cfg_.mz_zero_copy & 2)) {
+        // one D2H: [path_len n] (+ [path_action n*max_depth] for AlphaZero, whose leaves need the moves for the replay)
+        MZ_HIP(hipMemcpyAsync(L.pool.h_path_arena_.p, L.pool.d_path_arena_.p,
+                              (size_t(L.n) + (az ? size_t(L.n) * L.pool.v_.max_depth : 0)) * sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
+    } // else: select_kernel already wrote path_len / path_action into the pinned mirrors
+    const double tz = nowMs();
+    stats_.ms_select += tz - t0;
+    trace_.add(6, tz - t0);
+    return MZ_OK;
+}
 
-    // ---- leaf environments + feature planes (host, parallel over games) ----
-    threads_->parallelFor(G_, [this](int g) { buildLeaf(g); });
-    const double t4 = nowMs();
-    stats_.ms_env += t4 - t3;
-
-    // ---- network ----
+// phase 2 of a lane: leaf positions + feature planes on the host, then the network (asynchronously).
+int Worker::phase2(Lane& L)
+{
+    const bool az = desc_.type == 0;
+    const int g0 = L.g0;
+    const double t0 = nowMs();
+    MZ_HIP(hipStreamSynchronize(L.stream)); // paths of this lane
+    const double t1 = nowMs();
+    stats_.ms_select += t1 - t0;
+    trace_.add(7, t1 - t0);
+    threads_->parallelFor(L.n, [this, g0](int j) { buildLeaf(g0 + j); });
+    const double t2 = nowMs();
+    stats_.ms_env += t2 - t1;
+    trace_.add(8, t2 - t1);
+    int rc;
     if (az) {
-        MZ_HIP(hipMemcpyAsync(d_feat_.p, h_feat_.p, size_t(G_) * net_.featSize() * sizeof(float), hipMemcpyHostToDevice, stream_));
-        if ((rc = net_.forwardAZ(d_feat_.p, G_, d_policy_.p, d_logit_.p, d_value_.p))) { return rc; }
+        const size_t fbytes = feat_bits_ ? size_t(L.n) * games_[0].env->featureWords() * sizeof(uint32_t) : size_t(L.n) * L.net.featSize() * sizeof(float);
+        // zero-copy: the tower kernel stages its LDS tile straight from pinned host memory / the heads kernel writes the outputs there
+        const bool zin = cfg_.mz_zero_copy & 1, zout = cfg_.mz_zero_copy & 2;
+        if (!zin) { MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, fbytes, hipMemcpyHostToDevice, L.stream)); }
+        if ((rc = L.net.forwardAZ(zin ? L.h_feat.p : L.d_feat.p, L.n, zout ? L.h_policy.p : L.d_policy.p, zout ? L.h_logit.p : L.d_logit.p,
+                                  zout ? L.h_value.p : L.d_value.p, feat_bits_))) {
+            return rc;
+        }
+        if (zout) {
+            const double t3z = nowMs();
+            stats_.ms_forward += t3z - t2;
+            trace_.add(9, t3z - t2);
+            return MZ_OK;
+        }
     } else if (sims_done_ == 0) {
-        MZ_HIP(hipMemcpyAsync(d_feat_.p, h_feat_.p, size_t(G_) * net_.featSize() * sizeof(float), hipMemcpyHostToDevice, stream_));
-        if ((rc = pool_.hiddenIndexAsync(n_ + 1, 0, d_src_idx_.p, d_dst_idx_.p, d_action_ids_.p))) { return rc; }
-        if ((rc = net_.initial(d_feat_.p, G_, d_policy_.p, d_logit_.p, d_value_.p, d_hidden_.p, d_dst_idx_.p))) { return rc; }
-        MZ_HIP(hipMemsetAsync(d_reward_.p, 0, G_ * sizeof(float), stream_));
+        MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, size_t(L.n) * L.net.featSize() * sizeof(float), hipMemcpyHostToDevice, L.stream));
+        if ((rc = L.pool.hiddenIndexAsync(n_ + 1, 0, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
+        if ((rc = L.net.initial(L.d_feat.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_hidden.p, L.d_dst_idx.p))) { return rc; }
+        MZ_HIP(hipMemsetAsync(L.d_reward.p, 0, L.n * sizeof(float), L.stream));
     } else {
         // device-resident MuZero step: parent hidden state gathered from the slab, action plane synthesised on device
-        if ((rc = pool_.hiddenIndexAsync(n_ + 1, sims_done_, d_src_idx_.p, d_dst_idx_.p, d_action_ids_.p))) { return rc; }
-        if ((rc = net_.recurrent(d_hidden_.p, d_src_idx_.p, nullptr, d_action_ids_.p, G_, d_policy_.p, d_logit_.p, d_value_.p, d_reward_.p,
-                                 d_hidden_.p, d_dst_idx_.p))) {
+        if ((rc = L.pool.hiddenIndexAsync(n_ + 1, sims_done_, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
+        if ((rc = L.net.recurrent(L.d_hidden.p, L.d_src_idx.p, nullptr, L.d_action_ids.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_reward.p,
+                                  L.d_hidden.p, L.d_dst_idx.p))) {
             return rc;
         }
     }
-    MZ_HIP(hipMemcpyAsync(h_out_.p, d_out_.p, h_out_.n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    MZ_HIP(hipMemcpyAsync(L.h_out.p, L.d_out.p, L.h_out.n * sizeof(float), hipMemcpyDeviceToHost, L.stream));
+    const double t3 = nowMs();
+    stats_.ms_forward += t3 - t2;
+    trace_.add(9, t3 - t2);
+    return MZ_OK;
+}
+
+int Worker::cycle()
+{
+    const double t0 = nowMs();
+    MZ_HIP(hipSetDevice(device_));
+    sim_pre_ = sims_done_;
+    sim_post_ = sims_done_ + 1;
+    const bool root_expansion = pending_ && (sim_post_ == 1), done = pending_ && (sim_post_ == n_ + 1);
+    for (auto& L : lanes_) {
+        int rc = phase1(*L, root_expansion, done);
+        if (rc) { return rc; }
+    }
+    if (pending_) { sims_done_ = done ? 0 : sim_post_; }
+    for (auto& L : lanes_) {
+        int rc = phase2(*L);
+        if (rc) { return rc; }
+    }
     pending_ = true;
     ++stats_.cycles;
     stats_.leaf_evals += G_;
@@ -835,20 +996,20 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
     else if (prefix == "stop") { running_ = false; }
     else if (prefix == "reset_actors") {
         for (auto& gm : games_) { resetGame(gm, main_rng_); } // handleCommand runs on the main thread (actor_group.cpp:200-219)
-        std::vector<int> rp(G_);
-        for (int g = 0; g < G_; ++g) { rp[g] = rootPlayerFor(games_[g]); }
         sims_done_ = 0;
         pending_ = false;
-        MZ_HIP(hipStreamSynchronize(stream_));
-        return pool_.resetSearch(nullptr, rp.data());
+        for (auto& L : lanes_) { MZ_HIP(hipStreamSynchronize(L->stream)); }
+        return resetAllSearches();
     } else if (prefix == "load_model") {
         if (line.find(' ') == std::string::npos) { setError("load_model needs a path"); return MZ_ERR_ARG; }
         cfg_.nn_file_name = line.substr(line.find(' ') + 1);
         if (!pending_weights_.empty()) {
-            MZ_HIP(hipStreamSynchronize(stream_));
-            int rc = net_.reload(pending_weights_.data(), pending_weights_.size());
+            for (auto& L : lanes_) {
+                MZ_HIP(hipStreamSynchronize(L->stream));
+                int rc = L->net.reload(pending_weights_.data(), pending_weights_.size());
+                if (rc) { return rc; }
+            }
             pending_weights_.clear();
-            return rc;
         }
     } else if (prefix == "update_config") {
         if (line.find(' ') == std::string::npos || !cfg_.loadFromString(line.substr(line.find(' ') + 1))) { return MZ_ERR_ARG; }
@@ -902,7 +1063,7 @@ int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out)
     *out = w->w.stats_;
     return MZ_OK;
 }
-mz_net* mz_worker_net(mz_worker* w) { return w ? reinterpret_cast<mz_net*>(&w->w.net_) : nullptr; }
+mz_net* mz_worker_net(mz_worker* w) { return w ? reinterpret_cast<mz_net*>(&w->w.net0()) : nullptr; }
 
 mz_env* mz_env_create(const char* conf)
 {
