@@ -75,6 +75,10 @@ int mz_net_initial(mz_net* net, const float* features, int batch, float* policy,
  * hidden_in[B][C][h][w], action_plane[B][a][h][w] -> outputs + reward[B] (0 for board games) */
 int mz_net_recurrent(mz_net* net, const float* hidden_in, const float* action_plane, int batch, float* policy, float* policy_logit,
                      float* value, float* reward, float* hidden_out, int where);
+/* muzero_atari: value / reward are 601-bin categorical heads (ref muzero_network.h:157-174).  With MZ_HOST buffers the
+ * library returns the decoded scalars; with MZ_DEVICE buffers it leaves the softmax expectation in the transformed space
+ * h(x) = sign(x)(sqrt(|x|+1)-1) + 0.001x and the caller applies mz_invert_value (ref utils/utils.h:102-108). */
+float mz_invert_value(float v);
 /* measurement hook for bench.py: runs `iters` forwards of batch B on resident synthetic inputs and
  * returns HIP-event times on the network's own stream: total ms per forward, and ms spent in the
  * 3x3-convolution kernels per forward (the dominant kernel; roofline numerator in DESIGN.md). */

@@ -90,6 +90,8 @@ int mz_net_time_tower_conv(mz_net* net, int batch, int iters, float* ms_per_laun
     return net->net.timeTowerConv(batch, iters, ms_per_launch, flops_per_launch, bytes_per_launch);
 }
 
+float mz_invert_value(float v) { return mz::invertValueHost(v); }
+
 mz_pool* mz_pool_create(int device, int games, int nodes_per_game, int action_size, const mz_search_cfg* cfg)
 {
     if (!cfg) { mz::setError("mz_pool_create: NULL cfg"); return nullptr; }

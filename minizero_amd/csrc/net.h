@@ -17,12 +17,26 @@ struct HeadOffsets {
     size_t pconv_w, pconv_b, pfc_wT, pfc_b, vconv_w, vconv_b, vfc1_wT, vfc1_b, vfc2_w, vfc2_b;
 };
 
+// muzero_atari (ref network/py/muzero_atari_network.py:7-70): extra layer groups of the representation and the 601-bin heads
+struct DiscreteHeadOffsets { // DiscreteValueNetwork (ref network_unit.py:67-87)
+    int hc = 0, hidden = 0, size = 0;
+    size_t conv_w = 0, conv_b = 0, fc1_wT = 0, fc1_b = 0, fc2_wT = 0, fc2_b = 0;
+};
+struct AtariLayers {
+    ConvLayer conv1{}, conv2{};            // stride-2 stem convs (96 -> 48 -> 24)
+    std::vector<ConvLayer> rb1, rb2, rb3; // one residual block each (2 convs) at 48x48xC/2, 24x24xC, 12x12xC
+    std::vector<ConvLayer> tail;          // num_blocks residual blocks at h x w
+    DiscreteHeadOffsets reward, value;
+};
+
 // host-side weight utilities (weights.cpp)
 long netParamCount(const mz_net_desc& d);
 bool netGenerate(const mz_net_desc& d, uint64_t seed, float* out);
 bool netValidateDesc(const mz_net_desc& d);
 bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<float>& packed, std::vector<ConvLayer>& repr, std::vector<ConvLayer>& dyn,
-                 HeadOffsets& h);
+                 HeadOffsets& h, AtariLayers& at);
+
+float invertValueHost(float value); // 601-bin decode helper (ref utils/utils.h:102-108)
 
 class Net {
 public:
@@ -59,12 +73,18 @@ private:
     int ensureBatch(int B);
     int runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out, bool in_bits = false);
     int launchConv(const ConvLayer& L, const float* in, const float* skip, float* out, int B);
-    int launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits);
+    int launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits, bool has_stem = true);
     int launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden);
 
     DevBuf<float> params_;
     std::vector<ConvLayer> repr_, dyn_;
     HeadOffsets heads_{};
+    AtariLayers at_;
+    DevBuf<float> at_buf_[3];   // muzero_atari representation activations (largest stage: [B][C/2][H/2][W/2])
+    int at_batch_ = 0;
+    int initialAtari(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, float* d_hidden, const int* d_dst_idx);
+    int recurrentAtari(const float* d_hidden_src, const int* d_src_idx, const float* d_action_planes, const int* d_action_ids, int B, float* d_policy,
+                       float* d_logit, float* d_value, float* d_reward, float* d_hidden_dst, const int* d_dst_idx);
     int max_batch_ = 0;
     DevBuf<float> act_[3];      // [B][C][P] ping-pong + residual temp
     DevBuf<float> rec_in_;      // [B][C + a][P] dynamics input

@@ -14,51 +14,11 @@
 //                 fused in one workgroup per sample; for MuZero also the per-sample min/max rescale of
 //                 the hidden state (ref muzero_network.py:154-164) and its scatter into the HBM slab.
 #include "net.h"
+#include "net_dev.h"
+#include <cmath>
 #include <cstring>
 
 namespace mz {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__host__ __device__ constexpr int planeStride(int H, int W)
-{
-    // padded plane (H+2)*(W+2) rounded up so that stride % 32 == 16: the two 16-lane channel groups
-    // that share a 32-lane ds_read_b32 service group then start on different bank halves
-    int ps = (H + 2) * (W + 2);
-    int r = ps % 32;
-    return ps + ((16 - r) + 32) % 32;
-}
-
-// ---------------------------------------------------------------------------------------------
-// deterministic exp / tanh (same operation sequence as the CPU oracle)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float mz_expf(float x)
-{
-    if (x < -87.0f) { return 0.0f; }
-    if (x > 88.0f) { x = 88.0f; }
-    float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693359375f, x);
-    r = __builtin_fmaf(n, 2.12194440e-4f, r);
-    float p = 1.9875691500E-4f;
-    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
-    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
-    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
-    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
-    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
-    float r2 = r * r;
-    float y = __builtin_fmaf(p, r2, r) + 1.0f;
-    int ni = static_cast<int>(n);
-    float scale = __builtin_bit_cast(float, static_cast<unsigned>(ni + 127) << 23);
-    return y * scale;
-}
-__device__ __forceinline__ float mz_tanhf(float x)
-{
-    float ax = __builtin_fabsf(x);
-    if (ax > 10.0f) { return __builtin_copysignf(1.0f, x); }
-    float e = mz_expf(-2.0f * ax);
-    float t = (1.0f - e) / (1.0f + e);
-    return __builtin_copysignf(t, x);
-}
 
 // ---------------------------------------------------------------------------------------------
 // conv3x3 on the f32 MFMA pipe
@@ -149,6 +109,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const float* __restrict__ in
 struct TowerArgs {
     int nlayers, cin0, C, OT; // C = hidden channels (== cout of every layer), OT = ceil(C/16)
     int in_bits;              // input planes arrive bit-packed (1 bit per point, ceil(P/32) words per channel)
+    int has_stem;             // 1: layer 0 is a stem conv (cin0 -> C); 0: the input already has C channels and layer 0 starts a residual block
     unsigned w_off[48], b_off[48];
 };
 
@@ -224,28 +185,30 @@ __global__ __launch_bounds__(512) void tower_fused(const float* __restrict__ in,
     // zero all three tiles (borders and padding channels stay zero for the whole kernel), then the sample's planes into T0
     for (int i = tid; i < 3 * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
     __syncthreads();
+    float* Tin = ta.has_stem ? T0 : T1; // without a stem the input IS the first block's x
     if (ta.in_bits) {
         constexpr int W32 = (P + 31) / 32;
         const unsigned* bits = reinterpret_cast<const unsigned*>(in) + size_t(b) * ta.cin0 * W32;
         for (int i = tid; i < ta.cin0 * P; i += 512) {
             const int c = i / P, p = i - c * P;
-            T0[c * CS + (p / W + 1) * PW + (p % W) + 1] = ((bits[c * W32 + (p >> 5)] >> (p & 31)) & 1u) ? 1.0f : 0.0f;
+            Tin[c * CS + (p / W + 1) * PW + (p % W) + 1] = ((bits[c * W32 + (p >> 5)] >> (p & 31)) & 1u) ? 1.0f : 0.0f;
         }
     } else {
         const float* src = in + size_t(b) * ta.cin0 * P;
         for (int i = tid; i < ta.cin0 * P; i += 512) {
             const int c = i / P, p = i - c * P;
-            T0[c * CS + (p / W + 1) * PW + (p % W) + 1] = src[i];
+            Tin[c * CS + (p / W + 1) * PW + (p % W) + 1] = src[i];
         }
     }
     __syncthreads();
     float* gout = out + size_t(b) * ta.C * P;
-    // stem: T0 -> T1
-    tower_layer<H, W, CIN0_PAD / 4, PTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT, lane,
-                                          wave);
-    __syncthreads();
+    if (ta.has_stem) { // stem: T0 -> T1
+        tower_layer<H, W, CIN0_PAD / 4, PTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT,
+                                              lane, wave);
+        __syncthreads();
+    }
     float *x = T1, *tmp = T0, *y = T2;
-    for (int l = 1; l + 1 < ta.nlayers; l += 2) { // residual block: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x)
+    for (int l = ta.has_stem; l + 1 < ta.nlayers; l += 2) { // residual block: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x)
         tower_layer<H, W, CPAD / 4, PTW>(x, nullptr, tmp, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, wave);
         __syncthreads();
         const bool last = (l + 2 >= ta.nlayers);
@@ -400,7 +363,7 @@ int Net::init(int device, const mz_net_desc& d, const float* raw, size_t n)
 int Net::reload(const float* raw, size_t n)
 {
     std::vector<float> packed;
-    if (!packWeights(desc_, raw, n, packed, repr_, dyn_, heads_)) { return MZ_ERR_ARG; }
+    if (!packWeights(desc_, raw, n, packed, repr_, dyn_, heads_, at_)) { return MZ_ERR_ARG; }
     MZ_HIP(hipSetDevice(device_));
     MZ_HIP(hipStreamSynchronize(stream_));
     if (!params_.ensure(packed.size())) { setError("hipMalloc of %zu parameter floats failed", packed.size()); return MZ_ERR_DEVICE; }
@@ -415,7 +378,7 @@ int Net::ensureBatch(int B)
     MZ_HIP(hipStreamSynchronize(stream_));
     const size_t act = size_t(B) * hiddenSize();
     for (auto& a : act_) { if (!a.alloc(act)) { setError("hipMalloc activations failed"); return MZ_ERR_DEVICE; } }
-    if (desc_.type == 1 && !rec_in_.alloc(size_t(B) * (desc_.num_hidden_channels + desc_.num_action_feature_channels) * P())) {
+    if (desc_.type >= 1 && !rec_in_.alloc(size_t(B) * (desc_.num_hidden_channels + desc_.num_action_feature_channels) * P())) {
         setError("hipMalloc dynamics input failed");
         return MZ_ERR_DEVICE;
     }
@@ -478,12 +441,12 @@ static int launchTowerT(const TowerArgs& ta, const float* params, const float* i
 }
 
 // returns MZ_OK and sets *launched when a fused instance exists for this trunk
-int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits)
+int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits, bool has_stem)
 {
     *launched = false;
-    if (!use_fused_ || t.size() > 48 || (t.size() % 2) == 0) { return MZ_OK; }
+    if (!use_fused_ || t.size() > 48 || t.empty() || (t.size() % 2) == (has_stem ? 0u : 1u)) { return MZ_OK; }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
-    for (size_t i = 1; i < t.size(); ++i) { if (t[i].cin != C || t[i].cout != C) { return MZ_OK; } }
+    for (size_t i = has_stem ? 1 : 0; i < t.size(); ++i) { if (t[i].cin != C || t[i].cout != C) { return MZ_OK; } }
     if (t[0].cout != C || C % 4 != 0) { return MZ_OK; }
     TowerArgs ta;
     ta.nlayers = static_cast<int>(t.size());
@@ -491,8 +454,9 @@ int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* ou
     ta.C = C;
     ta.OT = t[0].cout_pad / 16;
     ta.in_bits = in_bits ? 1 : 0;
+    ta.has_stem = has_stem ? 1 : 0;
     for (size_t i = 0; i < t.size(); ++i) { ta.w_off[i] = static_cast<unsigned>(t[i].w_off); ta.b_off[i] = static_cast<unsigned>(t[i].b_off); }
-    const int c0 = t[0].cin_pad;
+    const int c0 = has_stem ? t[0].cin_pad : C; // without a stem the template's CIN0_PAD is unused: pick the C instance
 #define MZ_TOWER_CASE(h, w, cin0, cpad) \
     if (H == h && W == w && c0 == cin0 && C == cpad) { *launched = true; return launchTowerT<h, w, cin0, cpad>(ta, params_.p, in, out, B, stream_); }
     MZ_TOWER_CASE(9, 9, 20, 64)  // Go AlphaZero / MuZero representation
@@ -505,6 +469,10 @@ int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* ou
     MZ_TOWER_CASE(8, 8, 12, 8)
     MZ_TOWER_CASE(3, 3, 4, 16)   // TicTacToe
     MZ_TOWER_CASE(3, 3, 20, 16)
+    MZ_TOWER_CASE(6, 6, 84, 64)  // Atari dynamics (64 + 18 action planes)
+    MZ_TOWER_CASE(6, 6, 64, 64)  // Atari representation tail (no stem)
+    MZ_TOWER_CASE(6, 6, 52, 32)  // small Atari test nets (C = 32)
+    MZ_TOWER_CASE(6, 6, 32, 32)
 #undef MZ_TOWER_CASE
     return MZ_OK;
 }
@@ -543,8 +511,17 @@ int Net::launchHeads(const float* x, int B, float* policy, float* logit, float* 
     return MZ_OK;
 }
 
+// ref utils/utils.h:102-108: inverse of h(x) = sign(x)(sqrt(|x|+1)-1) + eps x; inner part in double, powf in float
+float invertValueHost(float value)
+{
+    const float epsilon = 0.001;
+    const float sign_value = (value > 0.0f ? 1.0f : (value == 0.0f ? 0.0f : -1.0f));
+    return sign_value * (powf((::sqrt(1 + 4 * epsilon * (::fabs(static_cast<double>(value)) + 1 + epsilon)) - 1) / (2 * epsilon), 2.0f) - 1);
+}
+
 bool Net::hasFusedTower()
 {
+    if (repr_.empty()) { return false; }
     // probe with a zero-sized question: does launchTower have an instance for the representation trunk?
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels, c0 = repr_[0].cin_pad;
     static const int inst[][4] = {{9, 9, 20, 64}, {9, 9, 68, 64}, {8, 8, 4, 64}, {8, 8, 68, 64}, {9, 9, 20, 8}, {9, 9, 12, 8}, {8, 8, 4, 8}, {8, 8, 12, 8},
@@ -567,6 +544,7 @@ int Net::forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, 
 
 int Net::initial(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, float* d_hidden, const int* d_dst_idx)
 {
+    if (desc_.type == 2) { return initialAtari(d_feat, B, d_policy, d_logit, d_value, d_hidden, d_dst_idx); }
     if (desc_.type != 1) { setError("initialInference() called on a non-muzero network"); return MZ_ERR_STATE; }
     int rc = ensureBatch(B);
     if (rc) { return rc; }
@@ -579,6 +557,9 @@ int Net::initial(const float* d_feat, int B, float* d_policy, float* d_logit, fl
 int Net::recurrent(const float* d_hidden_src, const int* d_src_idx, const float* d_action_planes, const int* d_action_ids, int B, float* d_policy,
                    float* d_logit, float* d_value, float* d_reward, float* d_hidden_dst, const int* d_dst_idx)
 {
+    if (desc_.type == 2) {
+        return recurrentAtari(d_hidden_src, d_src_idx, d_action_planes, d_action_ids, B, d_policy, d_logit, d_value, d_reward, d_hidden_dst, d_dst_idx);
+    }
     if (desc_.type != 1) { setError("recurrentInference() called on a non-muzero network"); return MZ_ERR_STATE; }
     int rc = ensureBatch(B);
     if (rc) { return rc; }
@@ -639,6 +620,7 @@ int Net::initial_any(const float* feat, int B, float* policy, float* logit, floa
     MZ_HIP(hipMemcpyAsync(value, io_value_.p, size_t(B) * sizeof(float), hipMemcpyDeviceToHost, stream_));
     MZ_HIP(hipMemcpyAsync(hidden, io_hidden_.p, B * HS * sizeof(float), hipMemcpyDeviceToHost, stream_));
     MZ_HIP(hipStreamSynchronize(stream_));
+    if (desc_.type == 2) { for (int i = 0; i < B; ++i) { value[i] = invertValueHost(value[i]); } } // 601-bin decode (ref muzero_network.h:157-163)
     return MZ_OK;
 }
 
@@ -666,6 +648,12 @@ int Net::recurrent_any(const float* hidden_in, const float* action, int B, float
     if (reward) { MZ_HIP(hipMemcpyAsync(reward, io_reward_.p, size_t(B) * sizeof(float), hipMemcpyDeviceToHost, stream_)); }
     MZ_HIP(hipMemcpyAsync(hidden_out, io_hidden_.p, B * HS * sizeof(float), hipMemcpyDeviceToHost, stream_));
     MZ_HIP(hipStreamSynchronize(stream_));
+    if (desc_.type == 2) {
+        for (int i = 0; i < B; ++i) {
+            value[i] = invertValueHost(value[i]);
+            if (reward) { reward[i] = invertValueHost(reward[i]); }
+        }
+    }
     return MZ_OK;
 }
 

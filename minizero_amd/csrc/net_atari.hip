@@ -1,0 +1,362 @@
+// muzero_atari inference path (ref network/py/muzero_atari_network.py:7-198, network_unit.py:67-87): the
+// 96x96 representation stem (two stride-2 convs, three residual blocks at 48/24/12, two 3x3 average pools),
+// then the 6x6 towers (fused, net.hip) and the 601-bin value / reward heads.
+//
+// conv3x3_tiled   — tiled variant of the MFMA conv for planes that do not fit LDS whole: one workgroup computes an
+//                   8 x 16 output tile for every output channel; the (8-1)*S+3 x (16-1)*S+3 input patch of all input
+//                   channels is staged in LDS (46-72 KB), a pixel tile of the MFMA is one output row of 16 columns, so
+//                   the B-fragment is a stride-S LDS read.  Same tap-major / channel-ascending fmaf chain as everywhere.
+// avgpool3s2      — AvgPool2d(3, stride 2, padding 1), count_include_pad: (ky,kx)-ordered sum / 9.
+// heads_atari     — reward head (on the UN-scaled hidden state), min/max rescale + slab scatter, policy head, value head;
+//                   the 601-way softmax expectation is computed in index order; invertValue stays on the host (double libm).
+#include "net.h"
+#include "net_dev.h"
+
+namespace mz {
+
+template <int STRIDE, int CIN_PAD, int OT>
+__global__ __launch_bounds__(256) void conv3x3_tiled(const float* __restrict__ in, int cin, int H, int W, const float* __restrict__ wp,
+                                                     const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ out, int cout)
+{
+    constexpr int TH = 8, TW = 16, PR = (TH - 1) * STRIDE + 3, PC = (TW - 1) * STRIDE + 3, PLANE = PR * PC, CG = CIN_PAD / 4;
+    constexpr int NGROUPS = 4 / OT, ROWS = TH / NGROUPS;
+    extern __shared__ __attribute__((aligned(16))) float xs[]; // [CIN_PAD][PR][PC]
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1, tiles_x = (Wo + TW - 1) / TW;
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+    const float* src = in + size_t(b) * cin * H * W;
+    for (int idx = tid; idx < CIN_PAD * PLANE; idx += 256) {
+        const int c = idx / PLANE, rem = idx - c * PLANE, r = rem / PC, q = rem - r * PC;
+        const int iy = oy0 * STRIDE + r - 1, ix = ox0 * STRIDE + q - 1;
+        float v = 0.0f;
+        if (c < cin && iy >= 0 && iy < H && ix >= 0 && ix < W) { v = src[(size_t(c) * H + iy) * W + ix]; }
+        xs[idx] = v;
+    }
+    __syncthreads();
+    const int ot = wave % OT, row0 = (wave / OT) * ROWS;
+    f32x4 acc[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const int lane_off = (lane >> 4) * PLANE + (lane & 15) * STRIDE;
+    const float* wl = wp + size_t(ot) * 64 + lane;
+    constexpr size_t wstep = size_t(OT) * 64;
+    float a_cur[CG], a_nxt[CG];
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = wl[size_t(cg) * wstep]; }
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+        const int tn = t < 8 ? t + 1 : 8;
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) { a_nxt[cg] = wl[(size_t(tn) * CG + cg) * wstep]; }
+        const int tapoff = (t / 3) * PC + (t % 3);
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                float bv = xs[lane_off + cg * 4 * PLANE + (row0 + j) * STRIDE * PC + tapoff];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[cg], bv, acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = a_nxt[cg]; }
+    }
+    float* dst = out + size_t(b) * cout * Ho * Wo;
+    const float* sk = skip ? skip + size_t(b) * cout * Ho * Wo : nullptr;
+    const int ox = ox0 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int oy = oy0 + row0 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = 16 * ot + 4 * (lane >> 4) + r;
+            if (oy < Ho && ox < Wo && oc < cout) {
+                const size_t o = (size_t(oc) * Ho + oy) * Wo + ox;
+                float v = acc[j][r] + bias[oc];
+                if (sk) { v = v + sk[o]; }
+                dst[o] = v > 0.0f ? v : 0.0f;
+            }
+        }
+    }
+}
+
+__global__ void avgpool3s2_kernel(const float* __restrict__ in, int C, int H, int W, float* __restrict__ out, int total)
+{
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int x = i % Wo, y = (i / Wo) % Ho;
+        const int bc = i / (Wo * Ho); // sample * C + channel
+        const float* p = in + size_t(bc) * H * W;
+        float acc = 0.0f;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = 2 * y + ky - 1, xx = 2 * x + kx - 1;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) { acc = acc + p[yy * W + xx]; }
+            }
+        out[i] = acc / 9.0f;
+    }
+}
+
+struct DiscreteParams { const float *conv_w, *conv_b, *fc1_wT, *fc1_b, *fc2_wT, *fc2_b; int hc, hidden, size; };
+struct AtariHeadParams {
+    DiscreteParams reward, value;
+    const float *pconv_w, *pconv_b, *pfc_wT, *pfc_b;
+    int C, P, A, PC;
+};
+
+// DiscreteValueNetwork + softmax expectation on the LDS-resident activations xs[C][P]; result (transformed space) -> *out
+__device__ void discreteHead(const DiscreteParams& d, const float* xs, int C, int P, float* f, float* h1, float* lg, float* red, float* out, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < d.hc * P; i += 256) {
+        const int j = i / P, p = i - j * P;
+        const float* w = d.conv_w + j * C;
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) { acc = __builtin_fmaf(xs[c * P + p], w[c], acc); }
+        const float v = acc + d.conv_b[j];
+        f[i] = v > 0.0f ? v : 0.0f;
+    }
+    __syncthreads();
+    const int n1 = d.hc * P;
+    for (int o = tid; o < d.hidden; o += 256) {
+        float acc = 0.0f;
+        for (int i = 0; i < n1; ++i) { acc = __builtin_fmaf(f[i], d.fc1_wT[size_t(i) * d.hidden + o], acc); }
+        const float v = acc + d.fc1_b[o];
+        h1[o] = v > 0.0f ? v : 0.0f;
+    }
+    __syncthreads();
+    float m = -3.4e38f;
+    for (int o = tid; o < d.size; o += 256) {
+        float acc = 0.0f;
+        for (int i = 0; i < d.hidden; ++i) { acc = __builtin_fmaf(h1[i], d.fc2_wT[size_t(i) * d.size + o], acc); }
+        const float v = acc + d.fc2_b[o];
+        lg[o] = v;
+        m = v > m ? v : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
+    if (lane == 0) { red[wave] = m; }
+    __syncthreads();
+    m = red[0];
+    for (int w = 1; w < 4; ++w) { m = red[w] > m ? red[w] : m; }
+    for (int o = tid; o < d.size; o += 256) { lg[o] = mz_expf(lg[o] - m); }
+    __syncthreads();
+    if (tid == 0) { // index-ordered sums (ref muzero_network.h:157-162: accumulate(sum + value * start_value++))
+        float s = 0.0f;
+        for (int i = 0; i < d.size; ++i) { s += lg[i]; }
+        float e = 0.0f;
+        int start_value = -d.size / 2;
+        for (int i = 0; i < d.size; ++i) { e = e + (lg[i] / s) * start_value++; }
+        *out = e;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void heads_atari_kernel(const float* __restrict__ x, AtariHeadParams hp, float* __restrict__ policy,
+                                                          float* __restrict__ logit, float* __restrict__ value, float* __restrict__ reward,
+                                                          float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int do_reward)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC;
+    const int hcmax = hp.value.hc > hp.reward.hc ? hp.value.hc : hp.reward.hc;
+    const int hidmax = hp.value.hidden > hp.reward.hidden ? hp.value.hidden : hp.reward.hidden;
+    float* xs = sm;                     // [C*P]
+    float* f = xs + C * P;              // [hcmax*P]
+    float* h1 = f + hcmax * P;          // [hidmax]
+    float* lg = h1 + hidmax;            // [max(size, A)]
+    float* pf = lg + (hp.value.size > A ? hp.value.size : A); // [PC*P]
+    float* red = pf + PC * P;           // [16]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = x + size_t(b) * C * P;
+    for (int i = tid; i < C * P; i += 256) { xs[i] = src[i]; }
+    __syncthreads();
+    if (do_reward) { discreteHead(hp.reward, xs, C, P, f, h1, lg, red, reward + b, tid); }
+    // scale_hidden_state (ref muzero_atari_network.py:189-198)
+    {
+        float mn = 3.4e38f, mx = -3.4e38f;
+        for (int i = tid; i < C * P; i += 256) { const float v = xs[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
+            mn = m2 < mn ? m2 : mn;
+            mx = x2 > mx ? x2 : mx;
+        }
+        if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+        __syncthreads();
+        mn = red[0]; mx = red[4];
+        for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
+        float scale = mx - mn;
+        if (scale < 1e-5f) { scale += 1e-5f; }
+        float* hd = hidden_dst + size_t(dst_idx ? dst_idx[b] : b) * C * P;
+        __syncthreads();
+        for (int i = tid; i < C * P; i += 256) {
+            const float v = (xs[i] - mn) / scale;
+            xs[i] = v;
+            hd[i] = v;
+        }
+        __syncthreads();
+    }
+    // policy head
+    for (int i = tid; i < PC * P; i += 256) {
+        const int j = i / P, p = i - j * P;
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) { acc = __builtin_fmaf(xs[c * P + p], hp.pconv_w[j * C + c], acc); }
+        const float v = acc + hp.pconv_b[j];
+        pf[i] = v > 0.0f ? v : 0.0f;
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += 256) {
+        float acc = 0.0f;
+        for (int i = 0; i < PC * P; ++i) { acc = __builtin_fmaf(pf[i], hp.pfc_wT[size_t(i) * A + a], acc); }
+        const float v = acc + hp.pfc_b[a];
+        lg[a] = v;
+        logit[size_t(b) * A + a] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float m = -3.4e38f;
+        for (int a = lane; a < A; a += 64) { m = lg[a] > m ? lg[a] : m; }
+        for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
+        for (int a = lane; a < A; a += 64) { lg[a] = mz_expf(lg[a] - m); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float s = 0.0f;
+        for (int a = 0; a < A; ++a) { s += lg[a]; }
+        for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lg[a] / s; }
+    }
+    __syncthreads();
+    discreteHead(hp.value, xs, C, P, f, h1, lg, red, value + b, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+template <int STRIDE, int CIN_PAD, int OT>
+static int launchTiledT(const ConvLayer& L, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s)
+{
+    constexpr int PR = 7 * STRIDE + 3, PC = 15 * STRIDE + 3;
+    constexpr size_t lds = size_t(CIN_PAD) * PR * PC * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tiled<STRIDE, CIN_PAD, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const dim3 grid(((Wo + 15) / 16) * ((Ho + 7) / 8), B);
+    hipLaunchKernelGGL((conv3x3_tiled<STRIDE, CIN_PAD, OT>), grid, dim3(256), lds, s, in, L.cin, H, W, params + L.w_off, params + L.b_off, skip, out, L.cout);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+static int launchTiled(const ConvLayer& L, int stride, const float* params, const float* in, const float* skip, float* out, int B, int H, int W,
+                       hipStream_t s)
+{
+    const int ot = L.cout_pad / 16;
+#define MZ_TILED_CASE(st, c, o) \
+    if (stride == st && L.cin_pad == c && ot == o) { return launchTiledT<st, c, o>(L, params, in, skip, out, B, H, W, s); }
+    MZ_TILED_CASE(2, 32, 2) // conv1 32 -> 32 (C = 64)
+    MZ_TILED_CASE(1, 32, 2) // residual block at C/2 = 32
+    MZ_TILED_CASE(2, 32, 4) // conv2 32 -> 64
+    MZ_TILED_CASE(1, 64, 4) // residual blocks at C = 64 (24x24, 12x12)
+    MZ_TILED_CASE(2, 32, 1) // C = 32 test nets: conv1 32 -> 16
+    MZ_TILED_CASE(1, 16, 1)
+    MZ_TILED_CASE(2, 16, 2) // conv2 16 -> 32
+#undef MZ_TILED_CASE
+    setError("no tiled conv3x3 instance for stride %d, %d (padded) input channels, %d output-channel tiles", stride, L.cin_pad, ot);
+    return MZ_ERR_ARG;
+}
+
+static DiscreteParams discreteParams(const float* p, const DiscreteHeadOffsets& o)
+{
+    return DiscreteParams{p + o.conv_w, p + o.conv_b, p + o.fc1_wT, p + o.fc1_b, p + o.fc2_wT, p + o.fc2_b, o.hc, o.hidden, o.size};
+}
+
+static int launchAtariHeads(const Net& net, const float* params, const HeadOffsets& h, const AtariLayers& at, const float* x, int B, float* policy,
+                            float* logit, float* value, float* reward, float* hidden_dst, const int* dst_idx, bool do_reward, hipStream_t s)
+{
+    AtariHeadParams hp;
+    hp.reward = discreteParams(params, at.reward);
+    hp.value = discreteParams(params, at.value);
+    hp.pconv_w = params + h.pconv_w; hp.pconv_b = params + h.pconv_b; hp.pfc_wT = params + h.pfc_wT; hp.pfc_b = params + h.pfc_b;
+    hp.C = net.desc_.num_hidden_channels; hp.P = net.P(); hp.A = net.desc_.action_size; hp.PC = h.pc;
+    const int hcmax = std::max(at.value.hc, at.reward.hc), hidmax = std::max(at.value.hidden, at.reward.hidden);
+    const size_t lds = (size_t(hp.C) * hp.P + size_t(hcmax) * hp.P + hidmax + std::max(at.value.size, hp.A) + size_t(hp.PC) * hp.P + 16) * sizeof(float);
+    hipLaunchKernelGGL(heads_atari_kernel, dim3(B), dim3(256), lds, s, x, hp, policy, logit, value, reward, hidden_dst, dst_idx, do_reward ? 1 : 0);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int Net::initialAtari(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, float* d_hidden, const int* d_dst_idx)
+{
+    MZ_HIP(hipSetDevice(device_));
+    int rc = ensureBatch(B);
+    if (rc) { return rc; }
+    int H = desc_.input_channel_height, W = desc_.input_channel_width;
+    const int C = desc_.num_hidden_channels;
+    if (B > at_batch_) {
+        MZ_HIP(hipStreamSynchronize(stream_));
+        const size_t n = size_t(B) * (C / 2) * (H / 2) * (W / 2);
+        for (auto& b : at_buf_) { if (!b.alloc(n)) { setError("hipMalloc of the representation buffers failed"); return MZ_ERR_DEVICE; } }
+        at_batch_ = B;
+    }
+    float *b0 = at_buf_[0].p, *b1 = at_buf_[1].p, *b2 = at_buf_[2].p;
+    const float* P = params_.p;
+    // ref muzero_atari_network.py:21-39
+    if ((rc = launchTiled(at_.conv1, 2, P, d_feat, nullptr, b0, B, H, W, stream_))) { return rc; }
+    H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
+    if ((rc = launchTiled(at_.rb1[0], 1, P, b0, nullptr, b1, B, H, W, stream_))) { return rc; }
+    if ((rc = launchTiled(at_.rb1[1], 1, P, b1, b0, b2, B, H, W, stream_))) { return rc; }
+    if ((rc = launchTiled(at_.conv2, 2, P, b2, nullptr, b0, B, H, W, stream_))) { return rc; }
+    H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
+    if ((rc = launchTiled(at_.rb2[0], 1, P, b0, nullptr, b1, B, H, W, stream_))) { return rc; }
+    if ((rc = launchTiled(at_.rb2[1], 1, P, b1, b0, b2, B, H, W, stream_))) { return rc; }
+    auto pool = [&](const float* in, float* out) -> int {
+        const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, total = B * C * Ho * Wo;
+        hipLaunchKernelGGL(avgpool3s2_kernel, dim3((total + 255) / 256), dim3(256), 0, stream_, in, C, H, W, out, total);
+        MZ_HIP(hipGetLastError());
+        H = Ho; W = Wo;
+        return MZ_OK;
+    };
+    if ((rc = pool(b2, b0))) { return rc; }
+    if ((rc = launchTiled(at_.rb3[0], 1, P, b0, nullptr, b1, B, H, W, stream_))) { return rc; }
+    if ((rc = launchTiled(at_.rb3[1], 1, P, b1, b0, b2, B, H, W, stream_))) { return rc; }
+    if ((rc = pool(b2, b0))) { return rc; }
+    if (H != desc_.hidden_channel_height || W != desc_.hidden_channel_width) { setError("internal: representation output %dx%d", H, W); return MZ_ERR_ARG; }
+    const float* x = b0;
+    if (!at_.tail.empty()) {
+        bool launched = false;
+        if ((rc = launchTower(at_.tail, b0, act_[0].p, B, &launched, false, false))) { return rc; }
+        if (!launched) { setError("no fused tower instance for the %dx%d x %d-channel representation tail", H, W, C); return MZ_ERR_ARG; }
+        x = act_[0].p;
+    }
+    return launchAtariHeads(*this, P, heads_, at_, x, B, d_policy, d_logit, d_value, nullptr, d_hidden, d_dst_idx, false, stream_);
+}
+
+// dynamics input for Atari: cat(hidden[src], 18 action planes with plane `action` all ones) (ref atari.cpp:124-130)
+__global__ void build_recurrent_input_atari(const float* __restrict__ hidden, const int* __restrict__ src_idx, const float* __restrict__ planes,
+                                            const int* __restrict__ action_ids, int C, int AC, int P, float* __restrict__ out)
+{
+    const int b = blockIdx.x;
+    const int s = src_idx ? src_idx[b] : b;
+    const float* h = hidden + size_t(s) * C * P;
+    float* o = out + size_t(b) * (C + AC) * P;
+    for (int i = threadIdx.x; i < C * P; i += blockDim.x) { o[i] = h[i]; }
+    for (int i = threadIdx.x; i < AC * P; i += blockDim.x) {
+        o[C * P + i] = planes ? planes[size_t(b) * AC * P + i] : ((i / P) == action_ids[b] ? 1.0f : 0.0f);
+    }
+}
+
+int Net::recurrentAtari(const float* d_hidden_src, const int* d_src_idx, const float* d_action_planes, const int* d_action_ids, int B, float* d_policy,
+                        float* d_logit, float* d_value, float* d_reward, float* d_hidden_dst, const int* d_dst_idx)
+{
+    MZ_HIP(hipSetDevice(device_));
+    int rc = ensureBatch(B);
+    if (rc) { return rc; }
+    hipLaunchKernelGGL(build_recurrent_input_atari, dim3(B), dim3(256), 0, stream_, d_hidden_src, d_src_idx, d_action_planes, d_action_ids,
+                       desc_.num_hidden_channels, desc_.num_action_feature_channels, P(), rec_in_.p);
+    MZ_HIP(hipGetLastError());
+    bool launched = false;
+    if ((rc = launchTower(dyn_, rec_in_.p, act_[0].p, B, &launched, false, true))) { return rc; }
+    if (!launched) { setError("no fused tower instance for the muzero_atari dynamics network"); return MZ_ERR_ARG; }
+    if (conv_only_) { return MZ_OK; }
+    return launchAtariHeads(*this, params_.p, heads_, at_, act_[0].p, B, d_policy, d_logit, d_value, d_reward, d_hidden_dst, d_dst_idx, true, stream_);
+}
+
+} // namespace mz

@@ -41,9 +41,31 @@ std::vector<Spec> manifest(const mz_net_desc& d)
         convBN(m, cin, C, 3);
         for (int b = 0; b < d.num_blocks; ++b) { convBN(m, C, C, 3); convBN(m, C, C, 3); }
     };
+    int pc = policyChannels(d);
+    if (d.type == 2) { // ref muzero_atari_network.py:7-70: representation, dynamics (+ reward head), prediction (policy, 601-bin value)
+        auto rb = [&](int ch) { convBN(m, ch, ch, 3); convBN(m, ch, ch, 3); };
+        auto discrete = [&](int hidden, int size) {
+            int hc = (size + hw - 1) / hw;
+            convBN(m, C, hc, 1);
+            lin(m, hw * hc, hidden);
+            lin(m, hidden, size);
+        };
+        convBN(m, d.num_input_channels, C / 2, 3);
+        rb(C / 2);
+        convBN(m, C / 2, C, 3);
+        rb(C);
+        rb(C);
+        for (int b = 0; b < d.num_blocks; ++b) { rb(C); }
+        convBN(m, C + d.num_action_feature_channels, C, 3);
+        for (int b = 0; b < d.num_blocks; ++b) { rb(C); }
+        discrete(C, d.discrete_value_size);
+        convBN(m, C, pc, 1);
+        lin(m, pc * hw, d.action_size);
+        discrete(d.num_value_hidden_channels, d.discrete_value_size);
+        return m;
+    }
     trunk(d.num_input_channels);
     if (d.type == 1) { trunk(C + d.num_action_feature_channels); }
-    int pc = policyChannels(d);
     convBN(m, C, pc, 1);
     lin(m, pc * hw, d.action_size);
     convBN(m, C, 1, 1);
@@ -61,11 +83,19 @@ inline uint64_t mix64(uint64_t z)
 
 bool netValidateDesc(const mz_net_desc& d)
 {
-    if (d.type != 0 && d.type != 1) { setError("network type %d not supported yet (alphazero=0, muzero=1)", d.type); return false; }
-    if (d.discrete_value_size != 1) { setError("discrete_value_size %d not supported yet", d.discrete_value_size); return false; }
-    if (d.input_channel_height != d.hidden_channel_height || d.input_channel_width != d.hidden_channel_width) {
-        setError("input and hidden planes must have the same size (board games)");
-        return false;
+    if (d.type < 0 || d.type > 2) { setError("unknown network type %d (alphazero=0, muzero=1, muzero_atari=2)", d.type); return false; }
+    if (d.type == 2) {
+        if (d.discrete_value_size < 3 || d.input_channel_height != 16 * d.hidden_channel_height || d.input_channel_width != 16 * d.hidden_channel_width ||
+            d.num_hidden_channels % 32 != 0) {
+            setError("muzero_atari needs discrete_value_size >= 3, input = 16 x hidden resolution and hidden channels %% 32 == 0");
+            return false;
+        }
+    } else {
+        if (d.discrete_value_size != 1) { setError("discrete_value_size %d is only supported by the muzero_atari network", d.discrete_value_size); return false; }
+        if (d.input_channel_height != d.hidden_channel_height || d.input_channel_width != d.hidden_channel_width) {
+            setError("input and hidden planes must have the same size (board games)");
+            return false;
+        }
     }
     if (d.num_hidden_channels <= 0 || d.num_blocks < 0 || d.action_size <= 0 || d.num_input_channels <= 0) { setError("bad network descriptor"); return false; }
     return true;
@@ -173,9 +203,68 @@ std::vector<float> transposeLinear(const float* w, int in, int out)
 }
 } // namespace
 
-bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<float>& packed, std::vector<ConvLayer>& repr, std::vector<ConvLayer>& dyn,
-                 HeadOffsets& h)
+namespace {
+DiscreteHeadOffsets packDiscrete(std::vector<float>& packed, const float*& p, int C, int hw, int hidden, int size)
 {
+    DiscreteHeadOffsets o;
+    o.hc = (size + hw - 1) / hw;
+    o.hidden = hidden;
+    o.size = size;
+    Folded conv = takeConvBN(p, C, o.hc, 1);
+    o.conv_w = append(packed, conv.w); // [hc][C]
+    o.conv_b = append(packed, conv.b);
+    o.fc1_wT = append(packed, transposeLinear(p, hw * o.hc, hidden));
+    p += size_t(hw) * o.hc * hidden;
+    o.fc1_b = append(packed, std::vector<float>(p, p + hidden));
+    p += hidden;
+    o.fc2_wT = append(packed, transposeLinear(p, hidden, size));
+    p += size_t(hidden) * size;
+    o.fc2_b = append(packed, std::vector<float>(p, p + size));
+    p += size;
+    return o;
+}
+void packRB(std::vector<float>& packed, const float*& p, int ch, std::vector<ConvLayer>& v)
+{
+    v.push_back(packConv3(packed, takeConvBN(p, ch, ch, 3)));
+    v.push_back(packConv3(packed, takeConvBN(p, ch, ch, 3)));
+}
+} // namespace
+
+bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<float>& packed, std::vector<ConvLayer>& repr, std::vector<ConvLayer>& dyn,
+                 HeadOffsets& h, AtariLayers& at)
+{
+    if (d.type == 2) {
+        if (static_cast<long>(n) != netParamCount(d)) {
+            setError("weight blob has %zu floats, descriptor needs %ld", n, netParamCount(d));
+            return false;
+        }
+        packed.clear();
+        repr.clear();
+        dyn.clear();
+        at = AtariLayers();
+        const float* p = raw;
+        const int C = d.num_hidden_channels, hw = d.hidden_channel_height * d.hidden_channel_width;
+        at.conv1 = packConv3(packed, takeConvBN(p, d.num_input_channels, C / 2, 3));
+        packRB(packed, p, C / 2, at.rb1);
+        at.conv2 = packConv3(packed, takeConvBN(p, C / 2, C, 3));
+        packRB(packed, p, C, at.rb2);
+        packRB(packed, p, C, at.rb3);
+        for (int b = 0; b < d.num_blocks; ++b) { packRB(packed, p, C, at.tail); }
+        dyn.push_back(packConv3(packed, takeConvBN(p, C + d.num_action_feature_channels, C, 3)));
+        for (int b = 0; b < d.num_blocks; ++b) { packRB(packed, p, C, dyn); }
+        at.reward = packDiscrete(packed, p, C, hw, C, d.discrete_value_size);
+        h.pc = policyChannels(d);
+        Folded pconv = takeConvBN(p, C, h.pc, 1);
+        h.pconv_w = append(packed, pconv.w);
+        h.pconv_b = append(packed, pconv.b);
+        h.pfc_wT = append(packed, transposeLinear(p, h.pc * hw, d.action_size));
+        p += size_t(h.pc) * hw * d.action_size;
+        h.pfc_b = append(packed, std::vector<float>(p, p + d.action_size));
+        p += d.action_size;
+        at.value = packDiscrete(packed, p, C, hw, d.num_value_hidden_channels, d.discrete_value_size);
+        if (p != raw + n) { setError("internal: atari weight manifest mismatch"); return false; }
+        return true;
+    }
     if (static_cast<long>(n) != netParamCount(d)) {
         setError("weight blob has %zu floats, descriptor needs %ld", n, netParamCount(d));
         return false;

@@ -57,6 +57,7 @@ DESCS = {
     "c2": lambda: make_desc("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82),
     "c3": lambda: make_desc("othello_8x8", 4, 8, 8, 64, 8, 8, 1, 6, 65),
     "c4": lambda: make_desc("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, type_name="muzero"),
+    "c5": lambda: make_desc("atari_ms_pacman", 32, 96, 96, 64, 6, 6, 18, 6, 18, 256, 601, type_name="muzero_atari"),
 }
 CONFIGS = {
     "c1": "env_game=tictactoe:actor_num_simulation=16:zero_num_parallel_games=8:zero_num_threads=1",
@@ -65,6 +66,11 @@ CONFIGS = {
            "actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:actor_gumbel_sigma_visit_c=50:actor_gumbel_sigma_scale_c=1:"
            "zero_num_parallel_games=1024"),
     "c4": "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=50:zero_num_parallel_games=256",
+    # per GPU (512 games over 8 GPUs); synthetic Atari-shaped environment (ALE / ROMs are not available)
+    "c5": ("env_game=atari:nn_type_name=muzero:actor_num_simulation=50:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+           "actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:"
+           "actor_mcts_reward_discount=0.997:atari_init_q=true:zero_actor_intermediate_sequence_length=200:learner_n_step_return=10:"
+           "zero_num_parallel_games=64"),
 }
 
 

@@ -12,7 +12,7 @@ namespace mzo {
 // ZeroActor — ref actor/zero_actor.cpp, actor/base_actor.cpp
 // ---------------------------------------------------------------------------------------------
 ZeroActor::ZeroActor(const Config* cfg, Random* rng, const NetDesc* nd, NetQueue* q, uint64_t tree_node_size)
-    : cfg_(cfg), rng_(rng), nd_(nd), q_(q), env_(createEnv(*cfg)), mcts_(cfg, rng, tree_node_size)
+    : cfg_(cfg), rng_(rng), nd_(nd), q_(q), env_(createEnv(*cfg, rng)), mcts_(cfg, rng, tree_node_size)
 {
 }
 
@@ -271,7 +271,7 @@ Group::Group(const Config& cfg, const NetDesc& nd, const float* raw, size_t nraw
     }
     // ref actor_group.cpp:66-70: slave thread 0 seeds ITS generator with program_seed + 0
     slave_rng_.seed(cfg_.program_seed + 0);
-    for (auto& a : actors_) { a->rng_ = &slave_rng_; a->mcts_.rng_ = &slave_rng_; }
+    for (auto& a : actors_) { a->rng_ = &slave_rng_; a->mcts_.rng_ = &slave_rng_; a->env_->rng_ = &slave_rng_; }
 }
 
 std::pair<int, int> Group::calculateTrainingDataRange(const ZeroActor& actor) const // ref actor_group.cpp:52-64

@@ -101,7 +101,8 @@ void* mzo_env_create(const char* conf)
     Config c;
     if (!c.loadFromString(conf)) { return nullptr; }
     if (c.env_board_size == 0) { c.setUpEnv(); }
-    return createEnv(c).release();
+    static Random env_rng; // only the Atari-shaped env draws from it
+    return createEnv(c, &env_rng).release();
 }
 void mzo_env_destroy(void* e) { delete static_cast<Env*>(e); }
 void mzo_env_reset(void* e) { static_cast<Env*>(e)->reset(); }
@@ -112,6 +113,8 @@ float mzo_env_eval_score(void* e, int is_resign) { return static_cast<Env*>(e)->
 int mzo_env_policy_size(void* e) { return static_cast<Env*>(e)->getPolicySize(); }
 int mzo_env_num_input_channels(void* e) { return static_cast<Env*>(e)->getNumInputChannels(); }
 int mzo_env_board_size(void* e) { return static_cast<Env*>(e)->getBoardSize(); }
+float mzo_env_reward(void* e) { return static_cast<Env*>(e)->getReward(); }
+float mzo_invert_value(float v) { return invertValue(v); }
 void mzo_env_legal_mask(void* e, unsigned char* out)
 {
     Env* env = static_cast<Env*>(e);

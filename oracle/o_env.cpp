@@ -548,8 +548,101 @@ private:
     std::unordered_set<GoHashKey> hash_table_;
 };
 
-std::unique_ptr<Env> createEnv(const Config& cfg)
+// =====================================================================================
+// Atari-shaped synthetic environment (ALE / OpenCV / ROMs are absent: SURVEY.md §8d C5).  Keeps the reference's
+// feature contract (ref atari.h:17-27, atari.cpp:48-131): 1 player, 18 actions all legal, features = for the last 8
+// steps [1 plane action_id/18, 3 planes RGB/255 of a 96x96 screen], oldest first; getActionFeatures = 18x6x6 with
+// plane action_id all ones; eval score = cumulative reward.  Screen bytes and rewards are a counter hash of
+// (seed, step); episodes last env_atari_episode_length steps.
+// =====================================================================================
+static inline uint64_t amix(uint64_t z)
 {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+class AtariSynthEnv : public Env {
+public:
+    static constexpr int kRes = 96, kHist = 8, kActions = 18;
+    AtariSynthEnv(const Config& cfg, Random* rng) : name_(cfg.env_atari_name), episode_length_(cfg.env_atari_episode_length)
+    {
+        rng_ = rng;
+        reset(); // ref atari.h:47-50: the constructor resets (and draws a seed)
+    }
+    std::unique_ptr<Env> clone() const override { return std::make_unique<AtariSynthEnv>(*this); }
+    void reset() override { resetSeed(rng_ ? rng_->randInt() : 0); } // ref atari.h:54
+    void resetSeed(int seed) // ref atari.cpp:48-72
+    {
+        turn_ = kPlayer1;
+        seed_ = seed;
+        reward_ = 0;
+        total_reward_ = 0;
+        actions_.clear();
+        feature_history_.assign(kHist, std::vector<float>(3 * kRes * kRes, 0.0f));
+        feature_history_.push_back(observation(0));
+        feature_history_.erase(feature_history_.begin());
+        action_feature_history_.assign(kHist, 0.0f);
+    }
+    bool act(const Action& action) override // ref atari.cpp:74-99
+    {
+        const int step = static_cast<int>(actions_.size()) + 1;
+        reward_ = ((amix(static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0x9E3779B97F4A7C15ULL + 0x5157ULL * step) >> 40) < uint64_t(0.05 * (1 << 24))) ? 1.0f : 0.0f;
+        total_reward_ += reward_;
+        actions_.push_back(action);
+        action_feature_history_.push_back(action.getActionID() * 1.0f / kActions);
+        action_feature_history_.erase(action_feature_history_.begin());
+        feature_history_.push_back(observation(step));
+        feature_history_.erase(feature_history_.begin());
+        return true;
+    }
+    bool isLegalAction(const Action& a) const override { return a.getActionID() >= 0 && a.getActionID() < kActions; }
+    bool isTerminal() const override { return static_cast<int>(actions_.size()) >= episode_length_; }
+    float getReward() const override { return reward_; }
+    float getEvalScore(bool = false) const override { return total_reward_; }
+    std::vector<float> getFeatures(Rotation) const override // ref atari.cpp:112-122
+    {
+        std::vector<float> f;
+        f.reserve(size_t(kHist) * 4 * kRes * kRes);
+        for (int i = 0; i < kHist; ++i) {
+            f.insert(f.end(), size_t(kRes) * kRes, action_feature_history_[i]);
+            f.insert(f.end(), feature_history_[i].begin(), feature_history_[i].end());
+        }
+        return f;
+    }
+    std::vector<float> getActionFeatures(const Action& action, Rotation) const override // ref atari.cpp:124-130
+    {
+        std::vector<float> f(size_t(kActions) * 36, 0.0f);
+        std::fill(f.begin() + action.getActionID() * 36, f.begin() + (action.getActionID() + 1) * 36, 1.0f);
+        return f;
+    }
+    int getNumInputChannels() const override { return kHist * 4; }
+    int getBoardSize() const override { return kRes; }
+    int getPolicySize() const override { return kActions; }
+    int getNumPlayer() const override { return 1; }
+    std::string name() const override { return "atari_" + name_; }
+    std::vector<std::pair<std::string, std::string>> loaderTags() const override { return {{"SD", std::to_string(seed_)}}; } // ref atari.cpp:190
+
+private:
+    std::vector<float> observation(int step) const // bytes / 255 (ref atari.cpp:142-158 getObservation(scale_01))
+    {
+        std::vector<float> o(size_t(3) * kRes * kRes);
+        const uint64_t base = static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0xD1B54A32D192ED03ULL + static_cast<uint64_t>(step) * 0x100000001B3ULL;
+        for (size_t i = 0; i < o.size(); i += 8) { // 8 bytes per hash
+            uint64_t z = amix(base + (i >> 3) * 0x9E3779B97F4A7C15ULL);
+            for (int k = 0; k < 8; ++k) { o[i + k] = static_cast<float>((z >> (8 * k)) & 0xFF) / 255.0f; }
+        }
+        return o;
+    }
+    std::string name_;
+    int episode_length_, seed_ = 0;
+    float reward_ = 0, total_reward_ = 0;
+    std::vector<std::vector<float>> feature_history_;
+    std::vector<float> action_feature_history_; // one scalar per step (the plane is constant)
+};
+
+std::unique_ptr<Env> createEnv(const Config& cfg, Random* rng)
+{
+    if (cfg.env_game == "atari") { return std::make_unique<AtariSynthEnv>(cfg, rng); }
     if (cfg.env_game == "tictactoe") { return std::make_unique<TicTacToeEnv>(); }
     if (cfg.env_game == "othello") { return std::make_unique<OthelloEnv>(cfg.env_board_size); }
     if (cfg.env_game == "go") { return std::make_unique<GoEnv>(cfg.env_board_size, cfg.env_go_komi); }

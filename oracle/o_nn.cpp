@@ -91,10 +91,34 @@ static std::vector<TensorSpec> manifest(const NetDesc& d)
     if (d.type == 0) {
         trunk(d.num_input_channels);
         heads();
-    } else { // muzero: representation, dynamics, prediction (ref muzero_network.py:79-81)
+    } else if (d.type == 1) { // muzero: representation, dynamics, prediction (ref muzero_network.py:79-81)
         trunk(d.num_input_channels);
         trunk(C + d.num_action_feature_channels);
         heads();
+    } else { // muzero_atari (ref muzero_atari_network.py:7-70,116-118)
+        auto rb = [&](int ch) { specConvBN(m, ch, ch, 3); specConvBN(m, ch, ch, 3); };
+        auto discrete = [&](int hidden, int size) { // DiscreteValueNetwork (ref network_unit.py:67-87)
+            int hc = (size + hw - 1) / hw;
+            specConvBN(m, C, hc, 1);
+            specLinear(m, hw * hc, hidden);
+            specLinear(m, hidden, size);
+        };
+        // representation: conv1 s2, bn1, RB(C/2), conv2 s2, bn2, RB(C), [pool], RB(C), [pool], num_blocks x RB(C)
+        specConvBN(m, d.num_input_channels, C / 2, 3);
+        rb(C / 2);
+        specConvBN(m, C / 2, C, 3);
+        rb(C);
+        rb(C);
+        for (int b = 0; b < d.num_blocks; ++b) { rb(C); }
+        // dynamics: conv, bn, blocks, reward_network
+        specConvBN(m, C + d.num_action_feature_channels, C, 3);
+        for (int b = 0; b < d.num_blocks; ++b) { rb(C); }
+        discrete(C, d.discrete_value_size);
+        // prediction: policy, value
+        int pc = policyChannels(d);
+        specConvBN(m, C, pc, 1);
+        specLinear(m, pc * hw, d.action_size);
+        discrete(d.num_value_hidden_channels, d.discrete_value_size);
     }
     return m;
 }
@@ -319,9 +343,217 @@ public:
     }
 };
 
+// =====================================================================================
+// muzero_atari — ref network/py/muzero_atari_network.py:7-198, network_unit.py:67-87,
+// muzero_network.h:157-174 (601-bin decode), utils/utils.h:102-108 (invertValue)
+// =====================================================================================
+// conv3x3 pad 1 with stride; same (tap, channel) fmaf chain as conv3x3()
+static void conv3x3s(const Conv& cv, int H, int Wd, int stride, const float* in, const float* skip, float* out)
+{
+    const int cin = cv.cin, cout = cv.cout, Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1, Pi = H * Wd, Po = Ho * Wo;
+    std::vector<float> wk(size_t(9) * cin * cout), acc(cout);
+    for (int oc = 0; oc < cout; ++oc)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < 9; ++t) { wk[(size_t(t) * cin + c) * cout + oc] = cv.w[(size_t(oc) * cin + c) * 9 + t]; }
+    for (int y = 0; y < Ho; ++y) {
+        for (int x = 0; x < Wo; ++x) {
+            std::fill(acc.begin(), acc.end(), 0.0f);
+            for (int t = 0; t < 9; ++t) {
+                int yy = y * stride + t / 3 - 1, xx = x * stride + t % 3 - 1;
+                bool inside = (yy >= 0 && yy < H && xx >= 0 && xx < Wd);
+                for (int c = 0; c < cin; ++c) {
+                    float xv = inside ? in[c * Pi + yy * Wd + xx] : 0.0f;
+                    const float* wr = &wk[(size_t(t) * cin + c) * cout];
+                    for (int oc = 0; oc < cout; ++oc) { acc[oc] = __builtin_fmaf(xv, wr[oc], acc[oc]); }
+                }
+            }
+            int p = y * Wo + x;
+            for (int oc = 0; oc < cout; ++oc) {
+                float v = acc[oc] + cv.b[oc];
+                if (skip) { v = v + skip[oc * Po + p]; }
+                out[oc * Po + p] = v > 0.0f ? v : 0.0f;
+            }
+        }
+    }
+}
+// AvgPool2d(kernel 3, stride 2, padding 1), count_include_pad: sum in (ky, kx) order, / 9
+static void avgpool3s2(int C, int H, int Wd, const float* in, float* out)
+{
+    const int Ho = (H - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x) {
+                float acc = 0.0f;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        int yy = 2 * y + ky - 1, xx = 2 * x + kx - 1;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < Wd) { acc = acc + in[(c * H + yy) * Wd + xx]; }
+                    }
+                out[(c * Ho + y) * Wo + x] = acc / 9.0f;
+            }
+}
+float invertValue(float value) // ref utils/utils.h:102-108 (inner part in double, powf in float)
+{
+    const float epsilon = 0.001;
+    const float sign_value = (value > 0.0f ? 1.0f : (value == 0.0f ? 0.0f : -1.0f));
+    return sign_value * (powf((::sqrt(1 + 4 * epsilon * (::fabs(static_cast<double>(value)) + 1 + epsilon)) - 1) / (2 * epsilon), 2.0f) - 1);
+}
+struct DiscreteHead { Conv conv; Linear fc1, fc2; };
+
+class AtariNetImpl : public Net {
+public:
+    Conv conv1, conv2, dconv;
+    std::vector<Conv> rb1, rb2, rb3, rblocks, dblocks; // two convs per residual block
+    DiscreteHead reward, value;
+    Conv pconv;
+    Linear pfc;
+    int C, H0, W0, h, w, P;
+
+    static void takeRB(const float*& p, int ch, std::vector<Conv>& v) { v.push_back(takeConvBN(p, ch, ch, 3)); v.push_back(takeConvBN(p, ch, ch, 3)); }
+    static DiscreteHead takeDiscrete(const float*& p, int C, int hw, int hidden, int size)
+    {
+        DiscreteHead d;
+        int hc = (size + hw - 1) / hw;
+        d.conv = takeConvBN(p, C, hc, 1);
+        d.fc1 = takeLinear(p, hw * hc, hidden);
+        d.fc2 = takeLinear(p, hidden, size);
+        return d;
+    }
+    static void runRB(const std::vector<Conv>& v, size_t i, int H, int W, std::vector<float>& x)
+    {
+        std::vector<float> tmp(x.size()), y(x.size());
+        conv3x3s(v[i], H, W, 1, x.data(), nullptr, tmp.data());
+        conv3x3s(v[i + 1], H, W, 1, tmp.data(), x.data(), y.data());
+        x.swap(y);
+    }
+    // expectation of the 601-bin softmax in the transformed space (ref muzero_network.h:157-162)
+    float discreteExpectation(const DiscreteHead& dh, const float* x) const
+    {
+        const int hc = dh.conv.cout, size = dh.fc2.out;
+        std::vector<float> f(size_t(hc) * P), h1(dh.fc1.out), lg(size);
+        conv1x1relu(dh.conv, P, x, f.data());
+        linear(dh.fc1, f.data(), h1.data(), true);
+        linear(dh.fc2, h1.data(), lg.data(), false);
+        float m = lg[0];
+        for (int i = 1; i < size; ++i) { m = lg[i] > m ? lg[i] : m; }
+        float s = 0.0f;
+        for (int i = 0; i < size; ++i) { lg[i] = mz_expf(lg[i] - m); s += lg[i]; }
+        float e = 0.0f;
+        int start_value = -size / 2;
+        for (int i = 0; i < size; ++i) { e = e + (lg[i] / s) * start_value++; }
+        return e;
+    }
+    void policyHead(const float* x, float* policy, float* logit) const
+    {
+        const int A = desc.action_size;
+        std::vector<float> pf(size_t(pconv.cout) * P);
+        conv1x1relu(pconv, P, x, pf.data());
+        linear(pfc, pf.data(), logit, false);
+        float m = logit[0];
+        for (int a = 1; a < A; ++a) { m = logit[a] > m ? logit[a] : m; }
+        float s = 0.0f;
+        for (int a = 0; a < A; ++a) { policy[a] = mz_expf(logit[a] - m); s += policy[a]; }
+        for (int a = 0; a < A; ++a) { policy[a] = policy[a] / s; }
+    }
+    void scaleHidden(float* hd) const
+    {
+        const int n = C * P;
+        float mn = hd[0], mx = hd[0];
+        for (int i = 1; i < n; ++i) { mn = hd[i] < mn ? hd[i] : mn; mx = hd[i] > mx ? hd[i] : mx; }
+        float scale = mx - mn;
+        if (scale < 1e-5f) { scale += 1e-5f; }
+        for (int i = 0; i < n; ++i) { hd[i] = (hd[i] - mn) / scale; }
+    }
+    template <class F>
+    static void parallelFor(int n, F f)
+    {
+        int nt = std::min<int>(n, std::max(1u, std::thread::hardware_concurrency()));
+        if (nt <= 1) { for (int i = 0; i < n; ++i) { f(i); } return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) { th.emplace_back([=]() { for (int i = t; i < n; i += nt) { f(i); } }); }
+        for (auto& t : th) { t.join(); }
+    }
+    void forwardAZ(const float*, int, float*, float*, float*) const override {}
+    void initialMZ(const float* features, int batch, float* policy, float* logit, float* value, float* hidden) const override
+    { // ref muzero_atari_network.py:21-39,155-168
+        const int A = desc.action_size, fin = desc.num_input_channels * H0 * W0;
+        parallelFor(batch, [&](int b) {
+            int H = H0, W = W0;
+            std::vector<float> x(size_t(C / 2) * (H / 2) * (W / 2));
+            conv3x3s(conv1, H, W, 2, features + size_t(b) * fin, nullptr, x.data());
+            H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
+            runRB(rb1, 0, H, W, x);
+            std::vector<float> y(size_t(C) * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1));
+            conv3x3s(conv2, H, W, 2, x.data(), nullptr, y.data());
+            H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
+            runRB(rb2, 0, H, W, y);
+            std::vector<float> z(size_t(C) * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1));
+            avgpool3s2(C, H, W, y.data(), z.data());
+            H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
+            runRB(rb3, 0, H, W, z);
+            std::vector<float> u(size_t(C) * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1));
+            avgpool3s2(C, H, W, z.data(), u.data());
+            H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
+            assert(H == h && W == w);
+            for (size_t i = 0; i < rblocks.size(); i += 2) { runRB(rblocks, i, H, W, u); }
+            float* hd = hidden + size_t(b) * C * P;
+            memcpy(hd, u.data(), u.size() * sizeof(float));
+            scaleHidden(hd);
+            policyHead(hd, policy + size_t(b) * A, logit + size_t(b) * A);
+            value[b] = invertValue(discreteExpectation(this->value, hd));
+        });
+    }
+    void recurrentMZ(const float* hidden_in, const float* action_plane, int batch, float* policy, float* logit, float* value, float* reward_out,
+                     float* hidden_out) const override
+    { // ref muzero_atari_network.py:49-58,170-187: the reward head reads the UN-scaled next hidden state
+        const int A = desc.action_size, ac = desc.num_action_feature_channels;
+        parallelFor(batch, [&](int b) {
+            std::vector<float> in(size_t(C + ac) * P), x(size_t(C) * P);
+            memcpy(in.data(), hidden_in + size_t(b) * C * P, size_t(C) * P * sizeof(float));
+            memcpy(in.data() + size_t(C) * P, action_plane + size_t(b) * ac * P, size_t(ac) * P * sizeof(float));
+            conv3x3s(dconv, h, w, 1, in.data(), nullptr, x.data());
+            for (size_t i = 0; i < dblocks.size(); i += 2) { runRB(dblocks, i, h, w, x); }
+            if (reward_out) { reward_out[b] = invertValue(discreteExpectation(reward, x.data())); }
+            float* hd = hidden_out + size_t(b) * C * P;
+            memcpy(hd, x.data(), x.size() * sizeof(float));
+            scaleHidden(hd);
+            policyHead(hd, policy + size_t(b) * A, logit + size_t(b) * A);
+            value[b] = invertValue(discreteExpectation(this->value, hd));
+        });
+    }
+};
+
+static std::unique_ptr<Net> createAtari(const NetDesc& d, const float* raw, size_t n)
+{
+    auto net = std::make_unique<AtariNetImpl>();
+    net->desc = d;
+    net->C = d.num_hidden_channels;
+    net->H0 = d.input_channel_height; net->W0 = d.input_channel_width;
+    net->h = d.hidden_channel_height; net->w = d.hidden_channel_width;
+    net->P = net->h * net->w;
+    const int C = net->C, hw = net->P;
+    const float* p = raw;
+    net->conv1 = takeConvBN(p, d.num_input_channels, C / 2, 3);
+    AtariNetImpl::takeRB(p, C / 2, net->rb1);
+    net->conv2 = takeConvBN(p, C / 2, C, 3);
+    AtariNetImpl::takeRB(p, C, net->rb2);
+    AtariNetImpl::takeRB(p, C, net->rb3);
+    for (int b = 0; b < d.num_blocks; ++b) { AtariNetImpl::takeRB(p, C, net->rblocks); }
+    net->dconv = takeConvBN(p, C + d.num_action_feature_channels, C, 3);
+    for (int b = 0; b < d.num_blocks; ++b) { AtariNetImpl::takeRB(p, C, net->dblocks); }
+    net->reward = AtariNetImpl::takeDiscrete(p, C, hw, C, d.discrete_value_size);
+    int pc = policyChannels(d);
+    net->pconv = takeConvBN(p, C, pc, 1);
+    net->pfc = takeLinear(p, pc * hw, d.action_size);
+    net->value = AtariNetImpl::takeDiscrete(p, C, hw, d.num_value_hidden_channels, d.discrete_value_size);
+    if (p != raw + n) { return nullptr; }
+    return net;
+}
+
 std::unique_ptr<Net> Net::create(const NetDesc& d, const float* raw, size_t n)
 {
-    if (n != rawParamCount(d) || d.type == 2) { return nullptr; }
+    if (n != rawParamCount(d)) { return nullptr; }
+    if (d.type == 2) { return createAtari(d, raw, n); }
     auto net = std::make_unique<NetImpl>();
     net->desc = d;
     net->H = d.hidden_channel_height;

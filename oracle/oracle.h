@@ -79,6 +79,8 @@ struct Config {
     // environment/environment.h:5-110) and the ATARI init-Q rule with it (actor/mcts.cpp:211-216).
     std::string env_game = "tictactoe";
     bool atari_init_q = false;
+    std::string env_atari_name = "ms_pacman";
+    int env_atari_episode_length = 1000; // synthetic Atari-shaped env: steps per episode
 
     // "k=v:k=v" string, later keys win (ref: configure_loader.cpp:51-117). Returns false on bad key/value.
     bool loadFromString(const std::string& s);
@@ -151,8 +153,11 @@ public:
 protected:
     Player turn_ = kPlayer1;
     std::vector<Action> actions_;
+
+public:
+    Random* rng_ = nullptr; // only the Atari-shaped env draws from it (ref atari.h:54: reset(Random::randInt()))
 };
-std::unique_ptr<Env> createEnv(const Config& cfg);
+std::unique_ptr<Env> createEnv(const Config& cfg, Random* rng = nullptr);
 
 // ----------------------------------------------------------------------------
 // network (the math of network/py/*.py with BN folded; see o_nn.cpp)
@@ -184,6 +189,7 @@ public:
 };
 float mz_expf(float x);  // deterministic expf shared (by specification) with the HIP kernels
 float mz_tanhf(float x);
+float invertValue(float value); // ref utils/utils.h:102-108
 
 // ----------------------------------------------------------------------------
 // search (ref: actor/tree.h, actor/mcts.{h,cpp}, actor/gumbel_zero.{h,cpp})

@@ -87,7 +87,14 @@ CONFIGS = {
     "c3_othello_az": ("othello_8x8", 4, 8, 8, 64, 8, 8, 1, 6, 65, 256, 1, "alphazero"),
     "c4_go_mz": ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "muzero"),
     "small_go_az": ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero"),
+    # BASELINE configs[4] network (the reference picks MuZeroAtariNetwork because "atari" is in the game name)
+    "c5_atari_mz": ("atari_ms_pacman", 32, 96, 96, 64, 6, 6, 18, 6, 18, 256, 601, "muzero"),
+    "small_atari_mz": ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero"),
 }
+
+
+def float_planes(seed, shape):
+    return counter_u01(seed, int(np.prod(shape))).reshape(shape).astype(np.float32)
 
 
 def main():
@@ -97,15 +104,16 @@ def main():
         wseed = 0
         blob, specs = gen_weights_numpy(net, wseed)
         # the numpy twin must equal the C generator bit for bit
-        d = O.make_desc(*args[:10], vh=args[10], dv=args[11], type_name=args[12])
+        atari = "atari" in args[0]
+        d = O.make_desc(*args[:10], vh=args[10], dv=args[11], type_name="muzero_atari" if atari else args[12])
         cblob = O.gen_weights(d, wseed)
         assert blob.shape == cblob.shape and np.array_equal(blob.view(np.uint32), cblob.view(np.uint32)), name
         load_blob(net, blob, specs)
         out = {"create_network_args": np.array([str(a) for a in args]), "weight_seed": wseed}
         with torch.no_grad():
-            for B in (1, 3):
+            for B in ((1, 2) if atari else (1, 3)):
                 iseed = 1000 + B
-                x = binary_planes(iseed, (B, args[1], args[2], args[3]))
+                x = (float_planes if atari else binary_planes)(iseed, (B, args[1], args[2], args[3]))
                 if args[12] == "alphazero":
                     r = net(torch.from_numpy(x))
                     out[f"b{B}_input_seed"] = iseed
@@ -121,11 +129,20 @@ def main():
                     # recurrent step on the reference's own hidden state with a one-hot action plane
                     act = np.zeros((B, args[7], args[5], args[6]), np.float32)
                     for b in range(B):
-                        act[b, 0].reshape(-1)[(7 * b + 3) % (args[5] * args[6])] = 1.0
+                        if atari:
+                            act[b, (7 * b + 3) % args[7]] = 1.0  # plane `action` all ones (ref atari.cpp:124-130)
+                        else:
+                            act[b, 0].reshape(-1)[(7 * b + 3) % (args[5] * args[6])] = 1.0
                     r2 = net.recurrent_inference(r["hidden_state"], torch.from_numpy(act))
                     for k in ("policy", "policy_logit", "hidden_state"):
                         out[f"b{B}_rec_{k}"] = r2[k].numpy().reshape(B, -1)
-                    out[f"b{B}_rec_value"] = r2["value"].numpy().reshape(-1)
+                    if atari:  # 601-bin distributions: store the expectation in the transformed space (f64 sum of the reference's f32 probabilities)
+                        bins = np.arange(-(args[11] // 2), args[11] // 2 + 1, dtype=np.float64)
+                        out[f"b{B}_init_value"] = (r["value"].numpy().astype(np.float64) * bins).sum(1).astype(np.float32)
+                        out[f"b{B}_rec_value"] = (r2["value"].numpy().astype(np.float64) * bins).sum(1).astype(np.float32)
+                        out[f"b{B}_rec_reward"] = (r2["reward"].numpy().astype(np.float64) * bins).sum(1).astype(np.float32)
+                    else:
+                        out[f"b{B}_rec_value"] = r2["value"].numpy().reshape(-1)
         path = os.path.join(HERE, f"nn_{name}.npz")
         np.savez_compressed(path, **out)
         print("wrote", path, os.path.getsize(path), "bytes; params", blob.size)

@@ -41,6 +41,7 @@ def desc_c1(): return make_desc("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9)
 def desc_c2(): return make_desc("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82)
 def desc_c3(): return make_desc("othello_8x8", 4, 8, 8, 64, 8, 8, 1, 6, 65)
 def desc_c4(): return make_desc("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, type_name="muzero")
+def desc_c5(): return make_desc("atari_ms_pacman", 32, 96, 96, 64, 6, 6, 18, 6, 18, 256, 601, type_name="muzero_atari")
 
 
 def build():
@@ -68,6 +69,8 @@ def lib():
     L.mzo_net_forward_az.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, fp]
     L.mzo_net_initial.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, fp, fp]
     L.mzo_net_recurrent.argtypes = [C.c_void_p, fp, fp, C.c_int, fp, fp, fp, fp, fp]
+    L.mzo_invert_value.restype = C.c_float
+    L.mzo_invert_value.argtypes = [C.c_float]
     L.mzo_expf.argtypes = [fp, C.c_int, fp]
     L.mzo_tanhf.argtypes = [fp, C.c_int, fp]
     L.mzo_rng_vector.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double)]
@@ -152,6 +155,9 @@ class OracleNet:
     def _hs(self):
         d = self.desc
         return d.num_hidden_channels * d.hidden_channel_height * d.hidden_channel_width
+
+    def invert(self, a):
+        return np.array([self.L.mzo_invert_value(float(v)) for v in np.asarray(a).reshape(-1)], np.float32)
 
     def initial(self, feat):
         feat = np.ascontiguousarray(feat, np.float32)

@@ -124,3 +124,37 @@ def test_errors_are_loud(mz):
         mz.Net(d, w, device=99)
     with pytest.raises(mz.MzError):
         mz.Net(d, w).initial_inference(np.zeros((1, 36), np.float32))  # MuZero call on an AlphaZero net
+
+
+ATARI = {
+    "c5_atari_mz": ("atari_ms_pacman", 32, 96, 96, 64, 6, 6, 18, 6, 18, 256, 601, "muzero_atari"),
+    "small_atari_mz": ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ATARI))
+def test_muzero_atari_network(mz, oracle, name):
+    """BASELINE configs[4] network: tiled strided convs, average pools, fused 6x6 towers, 601-bin value / reward heads"""
+    import os
+    args = ATARI[name]
+    d, od = _descs(mz, oracle, args)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"nn_{name}.npz"))
+    w = mz.generate_weights(d, 0)
+    net, onet = mz.Net(d, w), oracle.OracleNet(od, w)
+    for B in (1, 2):
+        x = counter_u01(int(g[f"b{B}_input_seed"]), B * 32 * 96 * 96).reshape(B, -1).astype(np.float32)
+        p, l, v, h = net.initial_inference(x)
+        op, ol, ov, oh = onet.initial(x)
+        assert same_bits(h, oh), f"hidden not bit-exact: {frac_bit_equal(h, oh):.4f}"
+        assert same_bits(l, ol) and same_bits(p, op) and same_bits(v, ov)
+        assert np.abs(h - g[f"b{B}_init_hidden_state"]).max() <= 1e-4 and np.abs(p - g[f"b{B}_init_policy"]).max() <= 1e-4
+        assert np.abs(v - onet.invert(g[f"b{B}_init_value"])).max() <= 1e-3
+        act = np.zeros((B, 18, 36), np.float32)
+        for b in range(B):
+            act[b, (7 * b + 3) % 18] = 1.0
+        hin = g[f"b{B}_init_hidden_state"]
+        p2, l2, v2, r2, h2 = net.recurrent_inference(hin, act.reshape(B, -1))
+        op2, ol2, ov2, or2, oh2 = onet.recurrent(hin, act.reshape(B, -1))
+        assert same_bits(h2, oh2) and same_bits(l2, ol2) and same_bits(p2, op2) and same_bits(v2, ov2) and same_bits(r2, or2)
+        assert np.abs(h2 - g[f"b{B}_rec_hidden_state"]).max() <= 1e-4 and np.abs(p2 - g[f"b{B}_rec_policy"]).max() <= 1e-4
+        assert np.abs(v2 - onet.invert(g[f"b{B}_rec_value"])).max() <= 1e-3 and np.abs(r2 - onet.invert(g[f"b{B}_rec_reward"])).max() <= 1e-3

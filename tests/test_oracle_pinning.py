@@ -23,6 +23,10 @@ NN_CFG = {
     "c4_go_mz": ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "muzero"),
     "small_go_az": ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero"),
 }
+ATARI_CFG = {
+    "c5_atari_mz": ("atari_ms_pacman", 32, 96, 96, 64, 6, 6, 18, 6, 18, 256, 601, "muzero_atari"),
+    "small_atari_mz": ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari"),
+}
 TOL = 1e-5  # f32 reference outputs; observed max |diff| ~1e-7 (logits) .. 7e-7 (hidden states)
 
 
@@ -53,10 +57,33 @@ def test_oracle_network_matches_reference_python(oracle, name):
             assert np.all(h2 >= 0) and np.all(h2 <= 1) and np.all(r == 0)
 
 
+@pytest.mark.parametrize("name", sorted(ATARI_CFG))
+def test_oracle_atari_network_matches_reference_python(oracle, name):
+    """muzero_atari (ref network/py/muzero_atari_network.py): strided stem, pooled residual stages, 601-bin heads"""
+    args = ATARI_CFG[name]
+    g = np.load(os.path.join(GOLD, f"nn_{name}.npz"))
+    d = oracle.make_desc(*args[:10], vh=args[10], dv=args[11], type_name=args[12])
+    net = oracle.OracleNet(d, oracle.gen_weights(d, int(g["weight_seed"])))
+    for B in (1, 2):
+        x = counter_u01(int(g[f"b{B}_input_seed"]), B * 32 * 96 * 96).reshape(B, -1).astype(np.float32)
+        p, l, v, h = net.initial(x)
+        assert np.abs(p - g[f"b{B}_init_policy"]).max() <= TOL and np.abs(l - g[f"b{B}_init_policy_logit"]).max() <= TOL
+        assert np.abs(h - g[f"b{B}_init_hidden_state"]).max() <= TOL
+        # value = invertValue(expectation of the 601-bin softmax) (ref muzero_network.h:157-163, utils.h:102-108)
+        assert np.abs(v - net.invert(g[f"b{B}_init_value"])).max() <= 5e-4  # f32 index-ordered sum of 601 terms x |i-300| (as the reference does) vs an f64 sum
+        act = np.zeros((B, 18, 36), np.float32)
+        for b in range(B):
+            act[b, (7 * b + 3) % 18] = 1.0
+        p, l, v, r, h2 = net.recurrent(g[f"b{B}_init_hidden_state"], act.reshape(B, -1))
+        assert np.abs(p - g[f"b{B}_rec_policy"]).max() <= TOL and np.abs(h2 - g[f"b{B}_rec_hidden_state"]).max() <= TOL
+        assert np.abs(v - net.invert(g[f"b{B}_rec_value"])).max() <= 5e-4 and np.abs(r - net.invert(g[f"b{B}_rec_reward"])).max() <= 5e-4
+
+
 def test_param_counts_match_survey(oracle):
     # SURVEY.md §8a a20 parameter counts (+ BN running stats: 2 per BN channel)
     for desc, params, bn_ch in ((oracle.desc_c1(), 12977, 16 * 5 + 1 + 1), (oracle.desc_c2(), 490048, 64 * 13 + 2 + 1),
-                                (oracle.desc_c3(), 472651, 64 * 13 + 2 + 1), (oracle.desc_c4(), 972352, 64 * 26 + 2 + 1)):
+                                (oracle.desc_c3(), 472651, 64 * 13 + 2 + 1), (oracle.desc_c4(), 972352, 64 * 26 + 2 + 1),
+                                (oracle.desc_c5(), 1524245, 32 * 3 + 64 * 29 + 17 + 1 + 17)):
         assert oracle.lib().mzo_net_param_count(C.byref(desc)) == params + 2 * bn_ch
 
 
