@@ -83,7 +83,7 @@ def test_param_counts_match_survey(oracle):
     # SURVEY.md §8a a20 parameter counts (+ BN running stats: 2 per BN channel)
     for desc, params, bn_ch in ((oracle.desc_c1(), 12977, 16 * 5 + 1 + 1), (oracle.desc_c2(), 490048, 64 * 13 + 2 + 1),
                                 (oracle.desc_c3(), 472651, 64 * 13 + 2 + 1), (oracle.desc_c4(), 972352, 64 * 26 + 2 + 1),
-                                (oracle.desc_c5(), 1524245, 32 * 3 + 64 * 29 + 17 + 1 + 17)):
+                                (oracle.desc_c5(), 1524245, 32 * 3 + 64 * 30 + 17 + 1 + 17)):
         assert oracle.lib().mzo_net_param_count(C.byref(desc)) == params + 2 * bn_ch
 
 
