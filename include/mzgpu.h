@@ -171,6 +171,8 @@ typedef struct mz_env mz_env;
 mz_env* mz_env_create(const char* conf);
 void mz_env_destroy(mz_env* e);
 void mz_env_reset(mz_env* e);
+void mz_env_reset_seed(mz_env* e, int seed); /* envs that draw a seed on reset (ref atari.h:54) */
+float mz_env_reward(const mz_env* e);
 int mz_env_act(mz_env* e, int action_id, int player);
 int mz_env_turn(const mz_env* e);
 int mz_env_is_terminal(const mz_env* e);

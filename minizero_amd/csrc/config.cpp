@@ -23,7 +23,7 @@ const Key kKeys[] = {
     K(actor_resign_threshold, T_FLOAT), K(zero_num_threads, T_INT), K(zero_num_parallel_games, T_INT),
     K(zero_disable_resign_ratio, T_FLOAT), K(zero_actor_intermediate_sequence_length, T_INT), K(zero_actor_ignored_command, T_STRING),
     K(learner_muzero_unrolling_step, T_INT), K(learner_n_step_return, T_INT), K(nn_file_name, T_STRING), K(nn_type_name, T_STRING),
-    K(env_board_size, T_INT), K(env_go_komi, T_FLOAT), K(env_go_ko_rule, T_STRING), K(env_game, T_STRING), K(atari_init_q, T_BOOL), K(mz_pipeline_lanes, T_INT), K(mz_zero_copy, T_INT), K(mz_cpu_base, T_INT),
+    K(env_board_size, T_INT), K(env_go_komi, T_FLOAT), K(env_go_ko_rule, T_STRING), K(env_game, T_STRING), K(atari_init_q, T_BOOL), K(mz_pipeline_lanes, T_INT), K(mz_zero_copy, T_INT), K(mz_cpu_base, T_INT), K(env_atari_name, T_STRING), K(env_atari_episode_length, T_INT),
 };
 #undef K
 
@@ -33,7 +33,7 @@ const char* const kPassiveKeys[] = {
     "zero_end_iteration", "zero_replay_buffer", "zero_server_accept_different_model_games", "zero_display_latest_games", "learner_use_per",
     "learner_per_alpha", "learner_per_init_beta", "learner_per_beta_anneal", "learner_training_step", "learner_training_display_step",
     "learner_batch_size", "learner_optimizer", "learner_learning_rate", "learner_momentum", "learner_weight_decay", "learner_value_loss_scale",
-    "learner_num_thread", "nn_num_blocks", "nn_num_hidden_channels", "nn_num_value_hidden_channels", "env_atari_rom_dir", "env_atari_name",
+    "learner_num_thread", "nn_num_blocks", "nn_num_hidden_channels", "nn_num_value_hidden_channels", "env_atari_rom_dir",
     "env_conhex_use_swap_rule", "env_gomoku_rule", "env_gomoku_exactly_five_stones", "env_havannah_use_swap_rule", "env_hex_use_swap_rule",
     "env_killallgo_ko_rule", "env_killallgo_use_seki", "env_rubiks_scramble_rotate", "env_surakarta_no_capture_plies",
     "env_tetris_block_puzzle_num_holding_block", "env_tetris_block_puzzle_num_preview_holding_block",

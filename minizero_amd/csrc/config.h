@@ -47,6 +47,8 @@ struct WorkerConfig {
     // run-time replacements of the reference's compile-time switches (-D<GAME>, #if ATARI in mcts.cpp:211)
     std::string env_game = "tictactoe";
     bool atari_init_q = false;
+    std::string env_atari_name = "ms_pacman";
+    int env_atari_episode_length = 1000; // synthetic Atari-shaped environment: steps per episode
     // not a reference key: number of software-pipelined lanes the games are split into (1 = no pipelining)
     int mz_pipeline_lanes = 1;
     // not a reference key: kernels read/write the pinned host staging directly (no per-cycle memcpy operations)

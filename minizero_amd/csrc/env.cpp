@@ -584,8 +584,109 @@ private:
     int hist_len_;
 };
 
-std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi)
+// ---------------------------------------------------------------------------------------------
+// Atari-shaped synthetic environment (BASELINE configs[4]; ALE, OpenCV and the ROMs are not available).
+// Feature contract of the reference's AtariEnv (ref atari.h:17-27, atari.cpp:48-131): 1 player, 18 actions all legal,
+// features = for the last 8 steps [1 plane action_id / 18, 3 planes RGB / 255 of a 96x96 screen], oldest first.
+// Screens are kept as bytes in an 8-deep ring (27 KB each) and expanded to f32 only when the planes are written.
+// ---------------------------------------------------------------------------------------------
+class AtariSynth final : public GameEnv {
+    static constexpr int kRes = 96, kHist = 8, kActions = 18, kFrame = 3 * kRes * kRes;
+    static uint64_t mix(uint64_t z)
+    {
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+public:
+    AtariSynth(const std::string& name, int episode_length) : name_(name), episode_length_(episode_length), frames_(size_t(kHist) * kFrame, 0) { resetSeed(0); }
+    std::unique_ptr<GameEnv> clone() const override { return std::make_unique<AtariSynth>(*this); }
+    void copyFrom(const GameEnv& o) override { *this = static_cast<const AtariSynth&>(o); }
+    bool needsSeed() const override { return true; }
+    void reset() override { resetSeed(0); }
+    void resetSeed(int seed) override
+    {
+        turn_ = 1;
+        seed_ = seed;
+        reward_ = total_reward_ = 0;
+        action_ids_.clear();
+        action_players_.clear();
+        std::fill(frames_.begin(), frames_.end(), 0);
+        for (auto& v : valid_) { v = false; }
+        for (auto& a : action_plane_) { a = 0.0f; }
+        head_ = 0;
+        pushFrame(0, 0.0f, false);
+    }
+    bool isLegal(int a, int) const override { return a >= 0 && a < kActions; }
+    bool act(int a, int player) override
+    {
+        if (!isLegal(a, player)) { return false; }
+        actUnchecked(a, player);
+        return true;
+    }
+    void actUnchecked(int a, int player) override
+    {
+        const int step = static_cast<int>(action_ids_.size()) + 1;
+        const uint64_t h = mix(static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0x9E3779B97F4A7C15ULL + 0x5157ULL * step);
+        reward_ = ((h >> 40) < uint64_t(0.05 * (1 << 24))) ? 1.0f : 0.0f;
+        total_reward_ += reward_;
+        action_ids_.push_back(static_cast<int16_t>(a));
+        action_players_.push_back(static_cast<uint8_t>(player));
+        pushFrame(step, a * 1.0f / kActions, true);
+    }
+    void legalMask(uint8_t* out) const override { for (int a = 0; a < kActions; ++a) { out[a] = 1; } }
+    bool isTerminal() const override { return static_cast<int>(action_ids_.size()) >= episode_length_; }
+    float evalScore(bool) const override { return total_reward_; }
+    float reward() const override { return reward_; }
+    void features(int, float* out) const override
+    {
+        for (int i = 0; i < kHist; ++i) { // oldest first; slot = (head_ + i) % kHist
+            const int slot = (head_ + i) % kHist;
+            float* dst = out + size_t(i) * 4 * kRes * kRes;
+            const float av = action_plane_[slot];
+            for (int p = 0; p < kRes * kRes; ++p) { dst[p] = av; }
+            float* rgb = dst + kRes * kRes;
+            if (!valid_[slot]) {
+                memset(rgb, 0, size_t(kFrame) * sizeof(float));
+            } else {
+                const uint8_t* f = frames_.data() + size_t(slot) * kFrame;
+                for (int p = 0; p < kFrame; ++p) { rgb[p] = static_cast<float>(f[p]) / 255.0f; }
+            }
+        }
+    }
+    int numInputChannels() const override { return kHist * 4; }
+    int boardSize() const override { return kRes; }
+    int policySize() const override { return kActions; }
+    int numPlayers() const override { return 1; }
+    std::string name() const override { return "atari_" + name_; }
+    std::vector<std::pair<std::string, std::string>> loaderTags() const override { return {{"SD", std::to_string(seed_)}}; }
+
+private:
+    void pushFrame(int step, float action_value, bool with_action)
+    {
+        // ring of the last 8 (action, screen) pairs: overwrite the oldest slot, which then becomes the newest
+        const int slot = head_;
+        uint8_t* f = frames_.data() + size_t(slot) * kFrame;
+        const uint64_t base = static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0xD1B54A32D192ED03ULL + static_cast<uint64_t>(step) * 0x100000001B3ULL;
+        for (int i = 0; i < kFrame; i += 8) {
+            const uint64_t z = mix(base + static_cast<uint64_t>(i >> 3) * 0x9E3779B97F4A7C15ULL);
+            memcpy(f + i, &z, 8); // little-endian: byte k = (z >> 8k) & 0xFF
+        }
+        valid_[slot] = true;
+        action_plane_[slot] = with_action ? action_value : 0.0f;
+        head_ = (head_ + 1) % kHist;
+    }
+    std::string name_;
+    int episode_length_, seed_ = 0, head_ = 0;
+    float reward_ = 0, total_reward_ = 0;
+    std::vector<uint8_t> frames_;
+    bool valid_[kHist] = {};
+    float action_plane_[kHist] = {};
+};
+
+std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi, const std::string& atari_name, int atari_episode_length)
 {
+    if (game == "atari") { return std::make_unique<AtariSynth>(atari_name, atari_episode_length); }
     if (game == "tictactoe") { return std::make_unique<TicTacToe>(); }
     if (game == "othello") {
         const int n = board_size > 0 ? board_size : 8;
@@ -597,7 +698,7 @@ std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, 
         if (n < 2 || n > kMaxN) { setError("go board size %d not supported (2..19)", n); return nullptr; }
         return std::make_unique<Go>(n, go_komi);
     }
-    setError("unknown env_game '%s' (tictactoe | go | othello)", game.c_str());
+    setError("unknown env_game '%s' (tictactoe | go | othello | atari)", game.c_str());
     return nullptr;
 }
 

@@ -25,6 +25,9 @@ public:
     virtual std::unique_ptr<GameEnv> clone() const = 0;
     virtual void copyFrom(const GameEnv& other) = 0; // same concrete type; cheap (no allocation in steady state)
     virtual void reset() = 0;
+    // environments whose reset draws a seed from the actor's RNG stream (ref atari.h:54 reset(Random::randInt()))
+    virtual bool needsSeed() const { return false; }
+    virtual void resetSeed(int) { reset(); }
     virtual bool act(int action_id, int player) = 0;       // checks legality like the reference's act()
     virtual void actUnchecked(int action_id, int player) = 0; // replay of moves the search already knows are legal
     virtual bool isLegal(int action_id, int player) const = 0;
@@ -57,6 +60,8 @@ protected:
 };
 
 // game: "tictactoe" | "go" | "othello"; board_size 0 = the game's default (3 / 9 / 8)
-std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi);
+// game "atari": the synthetic Atari-shaped environment (18 actions, 32 x 96 x 96 features, 1 player)
+std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi, const std::string& atari_name = "ms_pacman",
+                                       int atari_episode_length = 1000);
 
 } // namespace mz

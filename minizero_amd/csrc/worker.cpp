@@ -362,7 +362,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         L->h_policy = {L->h_out.p, GA}; L->h_logit = {L->h_out.p + GA, GA}; L->h_value = {L->h_out.p + 2 * GA, Gn}; L->h_reward = {L->h_out.p + 2 * GA + Gn, Gn};
         L->d_policy = {L->d_out.p, GA}; L->d_logit = {L->d_out.p + GA, GA}; L->d_value = {L->d_out.p + 2 * GA, Gn}; L->d_reward = {L->d_out.p + 2 * GA + Gn, Gn};
         MZ_HIP(hipMemset(L->d_out.p, 0, L->d_out.n * sizeof(float)));
-        if (desc.type == 1) {
+        if (desc.type >= 1) {
             WALLOC(L->d_hidden, Gn * (n_ + 1) * L->net.hiddenSize()); // hidden-state slab: one slot per expanded node
             WALLOC(L->d_src_idx, Gn); WALLOC(L->d_dst_idx, Gn); WALLOC(L->d_action_ids, Gn);
         }
@@ -391,7 +391,7 @@ int Worker::createActors()
     games_.clear();
     games_.resize(G_);
     for (auto& g : games_) {
-        g.env = createGameEnv(cfg_.env_game, cfg_.env_board_size, cfg_.env_go_komi);
+        g.env = createGameEnv(cfg_.env_game, cfg_.env_board_size, cfg_.env_go_komi, cfg_.env_atari_name, cfg_.env_atari_episode_length);
         if (!g.env) { return MZ_ERR_ARG; }
         if (g.env->policySize() != A_ || g.env->featureSize() != net0().featSize()) {
             setError("network (A=%d, features=%d) does not fit env %s (A=%d, features=%d)", A_, net0().featSize(), g.env->name().c_str(),
@@ -400,7 +400,12 @@ int Worker::createActors()
         }
         g.leaf = g.env->clone();
         g.legal.assign(A_, 0);
-        g.env->reset();
+        if (g.env->needsSeed()) {
+            (void)main_rng_.randInt();                 // the reference env's constructor already resets once (atari.h:47-50)
+            g.env->resetSeed(main_rng_.randInt());     // BaseActor::reset -> env_.reset() (atari.h:54)
+        } else {
+            g.env->reset();
+        }
         g.action_info_history.clear();
         g.enable_resign = (main_rng_.randReal() < cfg_.zero_disable_resign_ratio ? false : true);
     }
@@ -423,7 +428,7 @@ int Worker::resetAllSearches()
 
 void Worker::resetGame(Game& g, Rng& rng)
 {
-    g.env->reset();
+    if (g.env->needsSeed()) { g.env->resetSeed(rng.randInt()); } else { g.env->reset(); }
     g.action_info_history.clear();
     g.enable_resign = (rng.randReal() < cfg_.zero_disable_resign_ratio ? false : true);
 }
@@ -464,6 +469,10 @@ void Worker::buildCandidates(int gi)
         const int depth = g.path_len - 1; // depth of the leaf; its children are moved by the player to move there
         player = (g.env->numPlayers() == 2 && (depth & 1)) ? 3 - g.env->turn() : g.env->turn();
         reward = L.h_reward.p[j];
+        if (desc_.type == 2) { // 601-bin heads: the kernels return the softmax expectation, the double-libm inverse stays here
+            value = invertValueHost(value);
+            reward = invertValueHost(reward);
+        }
         for (int a = 0; a < A_; ++a) {
             if (depth == 0 && !g.legal[a]) { continue; } // legality is only known (and checked) at the root (zero_actor.cpp:238)
             c[k++] = Cand{a, policy[a], logit[a]};
@@ -1070,12 +1079,14 @@ mz_env* mz_env_create(const char* conf)
     mz::WorkerConfig c;
     if (!conf || !c.loadFromString(conf)) { return nullptr; }
     std::unique_ptr<mz_env> e(new mz_env());
-    e->e = mz::createGameEnv(c.env_game, c.env_board_size, c.env_go_komi);
+    e->e = mz::createGameEnv(c.env_game, c.env_board_size, c.env_go_komi, c.env_atari_name, c.env_atari_episode_length);
     if (!e->e) { return nullptr; }
     return e.release();
 }
 void mz_env_destroy(mz_env* e) { delete e; }
 void mz_env_reset(mz_env* e) { e->e->reset(); }
+void mz_env_reset_seed(mz_env* e, int seed) { e->e->resetSeed(seed); }
+float mz_env_reward(const mz_env* e) { return e->e->reward(); }
 int mz_env_act(mz_env* e, int action_id, int player) { return e->e->act(action_id, player) ? 1 : 0; }
 int mz_env_turn(const mz_env* e) { return e->e->turn(); }
 int mz_env_is_terminal(const mz_env* e) { return e->e->isTerminal() ? 1 : 0; }

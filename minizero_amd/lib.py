@@ -125,6 +125,9 @@ def load():
         L.mz_env_create.argtypes = [C.c_char_p]
         L.mz_env_destroy.argtypes = [vp]
         L.mz_env_reset.argtypes = [vp]
+        L.mz_env_reset_seed.argtypes = [vp, C.c_int]
+        L.mz_env_reward.restype = C.c_float
+        L.mz_env_reward.argtypes = [vp]
         L.mz_env_act.argtypes = [vp, C.c_int, C.c_int]
         for n in ("mz_env_turn", "mz_env_is_terminal", "mz_env_policy_size", "mz_env_feature_size"):
             getattr(L, n).argtypes = [vp]
@@ -374,6 +377,8 @@ class Env:
     __del__ = close
 
     def reset(self): self.L.mz_env_reset(self.h)
+    def reset_seed(self, seed): self.L.mz_env_reset_seed(self.h, seed)
+    def reward(self): return self.L.mz_env_reward(self.h)
     def act(self, a, player=None): return bool(self.L.mz_env_act(self.h, a, self.turn() if player is None else player))
     def turn(self): return self.L.mz_env_turn(self.h)
     def is_terminal(self): return bool(self.L.mz_env_is_terminal(self.h))

@@ -115,6 +115,11 @@ int mzo_env_num_input_channels(void* e) { return static_cast<Env*>(e)->getNumInp
 int mzo_env_board_size(void* e) { return static_cast<Env*>(e)->getBoardSize(); }
 float mzo_env_reward(void* e) { return static_cast<Env*>(e)->getReward(); }
 float mzo_invert_value(float v) { return invertValue(v); }
+int mzo_env_seed(void* e)
+{
+    for (auto& t : static_cast<Env*>(e)->loaderTags()) { if (t.first == "SD") { return std::stoi(t.second); } }
+    return 0;
+}
 void mzo_env_legal_mask(void* e, unsigned char* out)
 {
     Env* env = static_cast<Env*>(e);

@@ -84,6 +84,9 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p]
     L.mzo_env_eval_score.restype = C.c_float
     L.mzo_env_eval_score.argtypes = [C.c_void_p, C.c_int]
+    L.mzo_env_reward.restype = C.c_float
+    L.mzo_env_reward.argtypes = [C.c_void_p]
+    L.mzo_env_seed.argtypes = [C.c_void_p]
     L.mzo_env_legal_mask.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte)]
     L.mzo_env_features.argtypes = [C.c_void_p, C.c_int, fp]
     L.mzo_env_action_features.argtypes = [C.c_void_p, C.c_int, C.c_int, fp]
@@ -237,6 +240,8 @@ class OracleEnv:
     def is_terminal(self): return bool(self.L.mzo_env_is_terminal(self.h))
     def eval_score(self, resign=False): return self.L.mzo_env_eval_score(self.h, int(resign))
     def policy_size(self): return self.L.mzo_env_policy_size(self.h)
+    def reward(self): return self.L.mzo_env_reward(self.h)
+    def seed(self): return self.L.mzo_env_seed(self.h)
 
     def legal_mask(self):
         m = np.zeros(self.policy_size(), np.uint8)

@@ -88,3 +88,27 @@ def test_env_shapes(mz):
         mz.Env("env_game=chess")
     with pytest.raises(mz.MzError):
         mz.Env("env_game=othello:env_board_size=10")
+
+
+def test_atari_shaped_env_matches_oracle(mz, oracle):
+    conf = "env_game=atari:env_atari_episode_length=12"
+    a, b = mz.Env(conf), oracle.OracleEnv(conf)
+    # both sides take the seed from their caller's RNG stream; pin it to the oracle's for the comparison
+    rng = np.random.default_rng(3)
+    for episode in range(2):
+        b.reset()
+        seed = b.seed()
+        a.reset_seed(seed)
+        steps = 0
+        while True:
+            assert a.is_terminal() == b.is_terminal() and a.eval_score() == b.eval_score()
+            assert np.array_equal(a.legal_mask(), b.legal_mask()) and a.legal_mask().sum() == 18
+            fa, fb = a.features(0), b.features(0)
+            assert fa.size == 32 * 96 * 96 and np.array_equal(fa, fb), f"features differ at step {steps}"
+            if a.is_terminal():
+                break
+            act = int(rng.integers(0, 18))
+            assert a.act(act) and b.act(act)
+            assert a.reward() == b.reward()
+            steps += 1
+        assert steps == 12

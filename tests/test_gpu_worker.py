@@ -115,3 +115,18 @@ def test_commands(mz):
     assert wk.run_cycles(17 * 12) == 17 * 12
     assert any("EV[weight_iter_100.pt]" in l for l in wk.pop_lines())
     assert wk.command("quit") == 1
+
+
+def test_small_atari_gumbel_muzero(mz, oracle):
+    """BASELINE configs[4] shape at test size: synthetic Atari-shaped env, Gumbel MuZero with value rescale, discount,
+    ATARI init-Q, 601-bin value / reward heads, intermediate-sequence emission (SelfPlay false ... DLEN[a-b])."""
+    conf = ("env_game=atari:nn_type_name=muzero:actor_num_simulation=8:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+            "actor_use_gumbel_noise=true:actor_gumbel_sample_size=4:actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:"
+            "actor_mcts_reward_discount=0.997:atari_init_q=true:zero_actor_intermediate_sequence_length=6:learner_n_step_return=2:"
+            "learner_muzero_unrolling_step=1:env_atari_episode_length=20:zero_num_parallel_games=4")
+    args = ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari")
+    lines, olines, st = run_both(mz, oracle, conf, args, 9 * 45, threads=2)
+    assert len(olines) >= 12 and any(l.startswith("SelfPlay false") for l in olines) and any(l.startswith("SelfPlay true") for l in olines)
+    for i, (a, b) in enumerate(zip(lines, olines)):
+        assert a == b, f"line {i} differs:\n  hip   : {a[:300]}\n  oracle: {b[:300]}"
+    assert len(lines) == len(olines)
