@@ -104,6 +104,14 @@ def main():
         ms_fwd, ms_tower, fl_tower = net.time_forward(args.games, 100)
         ms_layer, fl_layer, bytes_layer = net.time_tower_conv(args.games, 200)  # the stand-alone per-layer kernel, for reference
         achieved = fl_tower / (ms_tower * 1e-3) / 1e12
+        # HBM traffic of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, KB ->
+        # bytes; the x2 on gfx950 was re-calibrated on a known-size copy kernel with the same 4-B/lane access, see profiles/README.md)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["mz::tower_fused<9, 9, 20, 64>"]
+            traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+        except Exception:
+            pass
         phase = {k: round((s1[k] - s0[k]) / args.steps, 4) for k in ("ms_select", "ms_env", "ms_forward", "ms_expand", "ms_move", "ms_total")}
         out = {
             "metric": "self-play leaf-evals/s (9x9 Go AlphaZero n=400)", "value": value, "unit": "leaf-evals/s",
@@ -122,7 +130,8 @@ def main():
                         "per_layer_kernel": {"us_per_launch": ms_layer * 1e3, "tflops": fl_layer / (ms_layer * 1e-3) / 1e12}},
             "roofline": {"kernel": "tower_fused<9,9,20,64> (stem + 12 x conv3x3 64->64, bias+skip+ReLU fused, activations in LDS)",
                          "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_summary.json (separate rocprofv3 --pmc passes, B=256)",
                          "flops_per_launch": fl_tower, "us_per_launch": ms_tower * 1e3,
                          "compulsory_bytes_per_launch": 4.0 * args.games * (18 * 81 + 64 * 81) + 4.0 * 490048},
         }

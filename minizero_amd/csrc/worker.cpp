@@ -109,7 +109,9 @@ public:
             CPU_SET(cpus[(cpu_base + idx) % cpus.size()], &one);
             (void)pthread_setaffinity_np(th, sizeof(one), &one);
         };
-        pin(pthread_self(), 0);
+        // The calling thread is NOT pinned to one CPU: the HIP runtime's helper threads (signal / completion handlers,
+        // created lazily) inherit the caller's mask, and a single-CPU mask would put them on the very core the caller
+        // busy-waits on.  Only the pool's own spin-wait workers get exclusive CPUs.
         for (int t = 1; t < n_; ++t) {
             threads_.emplace_back([this]() { loop(); });
             pin(threads_.back().native_handle(), t);
