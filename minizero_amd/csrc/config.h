@@ -54,6 +54,8 @@ struct WorkerConfig {
     // not a reference key: kernels read/write the pinned host staging directly (no per-cycle memcpy operations)
     // not a reference key: >= 0 pins the worker's host threads to consecutive CPUs (NUMA node of the caller first) from this index
     int mz_cpu_base = -1;
+    // not a reference key: wait for the GPU on a pinned completion word (spin) instead of hipStreamSynchronize
+    bool mz_signal_wait = true;
     int mz_zero_copy = 3; // bit 0: kernels read their inputs from pinned host memory; bit 1: kernels write their outputs there
 
     // returns false (and sets the library error string) on an unknown key or an unparsable value,

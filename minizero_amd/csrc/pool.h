@@ -6,12 +6,20 @@
 
 namespace mz {
 
+// count/mean/policy/reward: the f32 statistics of ref mcts.h:54-63; action = action_id (root: -1);
+// players = own action player | (player of this node's children << 8)
+struct __attribute__((aligned(16))) NodeRec {
+    float count, mean, policy, reward;
+    int first_child, num_children, action, players;
+};
+
 struct PoolView { // device pointers, passed to kernels by value
     int games, cap, A, max_depth;
-    // per node [games*cap]
-    float *count, *mean, *policy, *logit, *noise, *value, *reward;
-    int *first_child, *num_children, *action, *hslot; // action = action_id (root: -1); hslot = MuZero hidden-state slot
-    unsigned char* player;
+    // per node [games*cap]: a 32-byte "hot" record with everything the PUCT walk needs — the children scan of a level also
+    // brings in each child's own (first_child, num_children), so a level costs ONE dependent load — plus cold arrays
+    NodeRec* rec;
+    float *logit, *noise, *value;
+    int* hslot; // MuZero hidden-state slot
     // per game
     int *num_nodes, *path_len, *path, *path_action; // path[g*max_depth + d]
     int *host_path_len, *host_path_action;           // optional host-mapped (pinned) mirrors written by select_kernel (zero-copy D2H)
@@ -48,6 +56,11 @@ public:
     int expandBackupStaged(int hslot);             // H2D of the pinned h_cand_* mirrors + expandBackupAsync
     int hiddenIndexAsync(int slots_per_game, int dst_slot, int* d_src_idx, int* d_dst_idx, int* d_action_ids); // MuZero: slots of the last select
     int checkError();                              // device-side error flag (capacity)
+    // low-latency completion: a 1-thread kernel stores `value` into a pinned host word behind everything already queued on
+    // the stream; the host spins on that word instead of going through hipStreamSynchronize (falls back to it after 20 ms)
+    int signalAsync(int value);
+    int waitSignal(int value);
+    PinBuf<int> h_flag_;
     int hslot_next_ = -1;
 
     PoolView v_{};
@@ -76,9 +89,9 @@ public:
     PinBuf<int> h_rr_i_;
 
 private:
-    DevBuf<float> f_nodes_;  // 7 float arrays
-    DevBuf<int> i_nodes_;    // 4 int arrays
-    DevBuf<unsigned char> player_;
+    DevBuf<NodeRec> rec_;
+    DevBuf<float> f_nodes_;  // 3 cold float arrays
+    DevBuf<int> i_nodes_;    // hslot
     DevBuf<int> game_i_;     // num_nodes, (unused), bound_size, err
     DevBuf<int> bound_cnt_;
     DevBuf<float> bound_key_, game_f_;

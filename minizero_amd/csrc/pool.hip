@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <atomic>
 #include <cstring>
 
 namespace mz {
@@ -18,9 +19,12 @@ __global__ void reset_kernel(PoolView v, const int* __restrict__ mask, const int
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= v.games || (mask && !mask[g])) { return; }
     const size_t r = size_t(g) * v.cap;
-    v.count[r] = 0; v.mean[r] = 0; v.policy[r] = 0; v.logit[r] = 0; v.noise[r] = 0; v.value[r] = 0; v.reward[r] = 0;
-    v.first_child[r] = -1; v.num_children[r] = 0; v.action[r] = -1; v.hslot[r] = -1;
-    v.player[r] = static_cast<unsigned char>(root_player[g]);
+    NodeRec n;
+    n.count = 0; n.mean = 0; n.policy = 0; n.reward = 0;
+    n.first_child = -1; n.num_children = 0; n.action = -1;
+    n.players = root_player[g];
+    v.rec[r] = n;
+    v.logit[r] = 0; v.noise[r] = 0; v.value[r] = 0; v.hslot[r] = -1;
     v.num_nodes[g] = 1;
     v.path_len[g] = 0;
     v.bound_size[g] = 0;
@@ -48,75 +52,114 @@ __device__ __forceinline__ bool better(float s1, float p1, int i1, float s2, flo
     return (s1 > s2) || (s1 == s2 && (p1 > p2 || (p1 == p2 && i1 < i2)));
 }
 
+__device__ __forceinline__ NodeRec loadRec(const NodeRec* p)
+{
+    const float4 a = reinterpret_cast<const float4*>(p)[0];
+    const int4 b = reinterpret_cast<const int4*>(p)[1];
+    NodeRec n;
+    n.count = a.x; n.mean = a.y; n.policy = a.z; n.reward = a.w;
+    n.first_child = b.x; n.num_children = b.y; n.action = b.z; n.players = b.w;
+    return n;
+}
+
+// One wave64 per game.  Per level: every lane loads the 32-B records of its children (<= 2 per lane for A <= 128, a loop
+// beyond), all arithmetic runs from registers, and the winning lane's record supplies the next level's (first_child,
+// num_children, count) through shuffles — a single dependent memory round trip per level.
 __global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __restrict__ start)
 {
     const int g = blockIdx.x, lane = threadIdx.x;
-    const size_t base = size_t(g) * v.cap;
+    const NodeRec* recs = v.rec + size_t(g) * v.cap;
     int* path = v.path + size_t(g) * v.max_depth;
     int* pact = v.path_action + size_t(g) * v.max_depth;
+    int* hact = v.host_path_action ? v.host_path_action + size_t(g) * v.max_depth : nullptr;
     const int bsize = v.bound_size[g];
     const float lo = v.bound_lo[g], hi = v.bound_hi[g];
+    NodeRec cur = loadRec(recs); // root (uniform)
     int node = 0, depth = 1;
-    if (lane == 0) { path[0] = 0; pact[0] = v.action[base]; }
+    if (lane == 0) { path[0] = 0; pact[0] = cur.action; if (hact) { hact[0] = cur.action; } }
     const int st = start ? start[g] : 0;
     if (st > 0) { // Gumbel: path = root + PUCT path below the chosen candidate (ref gumbel_zero.cpp:83-85)
         node = st;
-        if (lane == 0) {
-            path[1] = st;
-            pact[1] = v.action[base + st];
-            if (v.host_path_action) { v.host_path_action[size_t(g) * v.max_depth + 1] = pact[1]; }
-        }
+        cur = loadRec(recs + st);
+        if (lane == 0) { path[1] = st; pact[1] = cur.action; if (hact) { hact[1] = cur.action; } }
         depth = 2;
     }
-    while (true) {
-        const int nc = v.num_children[base + node];
-        if (nc == 0 || depth >= v.max_depth) { break; }
-        const size_t fc = base + v.first_child[base + node];
-        const int N = static_cast<int>(v.count[base + node] - 1);
-        // ---- init Q: ordered sum over visited children (ref mcts.cpp:200-217) ----
-        float sum_of_win = 0.0f, sum = 0.0f;
-        for (int c0 = 0; c0 < nc; c0 += 64) {
-            const int i = c0 + lane;
-            float q = 0.0f;
-            bool visited = false;
-            if (i < nc) {
-                const float cnt = v.count[fc + i];
-                visited = (cnt != 0.0f);
-                if (visited) { q = normalizedMean(v, v.reward[fc + i], v.mean[fc + i], cnt, v.player[fc + i], bsize, lo, hi); }
-            }
-            unsigned long long m = __ballot(visited);
-            while (m) {
-                const int j = __builtin_ctzll(m);
-                m &= m - 1;
-                sum_of_win += __shfl(q, j);
-                sum += 1;
-            }
-        }
-        const float init_q = v.atari_init_q ? (sum > 0 ? sum_of_win / sum : 1.0f) : (sum_of_win - 1) / (sum + 1);
-        // ---- PUCT score + arg-max (ref mcts.cpp:55-61,181-198) ----
+    while (cur.num_children != 0 && depth < v.max_depth) {
+        const int nc = cur.num_children, fc = cur.first_child, cplayer = (cur.players >> 8) & 0xFF;
+        const int N = static_cast<int>(cur.count - 1);
         const float bias = v.bias_tab[N];
         const double sqrtN = v.sqrt_tab[N];
+        // ---- pass 1: init Q = ordered f32 sum over visited children (ref mcts.cpp:200-217); records stay in registers for A <= 128 ----
+        NodeRec c0, c1;
+        c0.count = 0; c1.count = 0;
+        const bool has0 = lane < nc, has1 = lane + 64 < nc;
+        if (has0) { c0 = loadRec(recs + fc + lane); }
+        if (has1) { c1 = loadRec(recs + fc + lane + 64); }
+        float sum_of_win = 0.0f, sum = 0.0f;
+        float q0 = 0.0f, q1 = 0.0f;
+        {
+            const bool vis0 = has0 && c0.count != 0.0f;
+            if (vis0) { q0 = normalizedMean(v, c0.reward, c0.mean, c0.count, cplayer, bsize, lo, hi); }
+            unsigned long long m = __ballot(vis0);
+            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += __shfl(q0, j); sum += 1; }
+            const bool vis1 = has1 && c1.count != 0.0f;
+            if (vis1) { q1 = normalizedMean(v, c1.reward, c1.mean, c1.count, cplayer, bsize, lo, hi); }
+            m = __ballot(vis1);
+            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += __shfl(q1, j); sum += 1; }
+        }
+        for (int cb = 128; cb < nc; cb += 64) { // wide nodes (A > 128): remaining chunks straight from memory
+            const int i = cb + lane;
+            float q = 0.0f;
+            bool vis = false;
+            if (i < nc) {
+                const NodeRec c = loadRec(recs + fc + i);
+                vis = c.count != 0.0f;
+                if (vis) { q = normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi); }
+            }
+            unsigned long long m = __ballot(vis);
+            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += __shfl(q, j); sum += 1; }
+        }
+        const float init_q = v.atari_init_q ? (sum > 0 ? sum_of_win / sum : 1.0f) : (sum_of_win - 1) / (sum + 1);
+        // ---- pass 2: PUCT score + arg-max (ref mcts.cpp:55-61,181-198) ----
         float bs = -FLT_MAX, bp = -FLT_MAX;
         int bi = INT_MAX;
-        for (int i = lane; i < nc; i += 64) {
-            const float cnt = v.count[fc + i], pol = v.policy[fc + i];
-            const float bpol = bias * pol;
-            const float value_u = static_cast<float>((static_cast<double>(bpol) * sqrtN) / static_cast<double>(1 + cnt));
-            const float value_q = (cnt == 0.0f) ? init_q : normalizedMean(v, v.reward[fc + i], v.mean[fc + i], cnt, v.player[fc + i], bsize, lo, hi);
+        NodeRec best = c0;
+        auto consider = [&](const NodeRec& c, float q, int i) {
+            const float bpol = bias * c.policy;
+            const float value_u = static_cast<float>((static_cast<double>(bpol) * sqrtN) / static_cast<double>(1 + c.count));
+            const float value_q = (c.count == 0.0f) ? init_q : q;
             const float score = value_u + value_q;
-            if (better(score, pol, i, bs, bp, bi)) { bs = score; bp = pol; bi = i; }
+            if (better(score, c.policy, i, bs, bp, bi)) { bs = score; bp = c.policy; bi = i; best = c; }
+        };
+        if (has0) { consider(c0, q0, lane); }
+        if (has1) { consider(c1, q1, lane + 64); }
+        for (int cb = 128; cb < nc; cb += 64) {
+            const int i = cb + lane;
+            if (i < nc) {
+                const NodeRec c = loadRec(recs + fc + i);
+                const float q = (c.count != 0.0f) ? normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi) : 0.0f;
+                consider(c, q, i);
+            }
         }
+        float rs = bs, rp = bp;
+        int ri = bi;
         for (int o = 32; o > 0; o >>= 1) {
-            const float s2 = __shfl_xor(bs, o), p2 = __shfl_xor(bp, o);
-            const int i2 = __shfl_xor(bi, o);
-            if (better(s2, p2, i2, bs, bp, bi)) { bs = s2; bp = p2; bi = i2; }
+            const float s2 = __shfl_xor(rs, o), p2 = __shfl_xor(rp, o);
+            const int i2 = __shfl_xor(ri, o);
+            if (better(s2, p2, i2, rs, rp, ri)) { rs = s2; rp = p2; ri = i2; }
         }
-        node = v.first_child[base + node] + bi;
+        // the lane that holds the winner broadcasts its record: that is the next level's header
+        const int owner = __builtin_ctzll(__ballot(bi == ri));
+        cur.count = __shfl(best.count, owner);
+        cur.first_child = __shfl(best.first_child, owner);
+        cur.num_children = __shfl(best.num_children, owner);
+        cur.action = __shfl(best.action, owner);
+        cur.players = __shfl(best.players, owner);
+        node = fc + ri;
         if (lane == 0) {
-            const int act = v.action[base + node];
             path[depth] = node;
-            pact[depth] = act;
-            if (v.host_path_action) { v.host_path_action[size_t(g) * v.max_depth + depth] = act; }
+            pact[depth] = cur.action;
+            if (hact) { hact[depth] = cur.action; }
         }
         ++depth;
     }
@@ -146,19 +189,22 @@ __global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int
             if (lane == 0) { atomicExch(err, MZ_ERR_CAPACITY); }
             return;
         }
-        const unsigned char pl = static_cast<unsigned char>(cand_player[g]);
+        const int pl = cand_player[g];
         for (int i = lane; i < k; i += 64) {
             const size_t n = base + fc + i, c = size_t(g) * v.A + i;
-            v.action[n] = cand_action[c];
-            v.player[n] = pl;
-            v.policy[n] = cand_policy[c];
+            NodeRec r;
+            r.count = 0; r.mean = 0; r.policy = cand_policy[c]; r.reward = 0;
+            r.first_child = -1; r.num_children = 0; r.action = cand_action[c]; r.players = pl;
+            reinterpret_cast<float4*>(v.rec + n)[0] = make_float4(r.count, r.mean, r.policy, r.reward);
+            reinterpret_cast<int4*>(v.rec + n)[1] = make_int4(r.first_child, r.num_children, r.action, r.players);
             v.logit[n] = cand_logit[c];
-            v.count[n] = 0; v.mean[n] = 0; v.noise[n] = 0; v.value[n] = 0; v.reward[n] = 0;
-            v.num_children[n] = 0; v.first_child[n] = -1; v.hslot[n] = -1;
+            v.noise[n] = 0; v.value[n] = 0; v.hslot[n] = -1;
         }
         if (lane == 0) {
-            v.first_child[base + leaf] = fc;
-            v.num_children[base + leaf] = k;
+            NodeRec* l = v.rec + base + leaf;
+            l->first_child = fc;
+            l->num_children = k;
+            l->players = (l->players & 0xFF) | (pl << 8);
             v.num_nodes[g] = fc + k;
         }
     }
@@ -174,18 +220,18 @@ __global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int
     }
     const float val = value_in[g], rew = reward_in[g];
     v.value[base + leaf] = val;
-    v.reward[base + leaf] = rew;
+    v.rec[base + leaf].reward = rew;
     float updated = val;
     for (int i = len - 1; i >= 0; --i) {
-        const size_t n = base + path[i];
-        const float r = (i == len - 1) ? rew : v.reward[n];
-        float mean = v.mean[n], cnt = v.count[n];
+        NodeRec* n = v.rec + base + path[i];
+        const float r = (i == len - 1) ? rew : n->reward;
+        float mean = n->mean, cnt = n->count;
         const float old_mean = r + v.gamma * mean;
         // MCTSNode::add(value, 1.0f) (ref mcts.cpp:20-28); count + 1 <= 0 cannot happen for count >= 0
         cnt += 1.0f;
         mean += 1.0f * (updated - mean) / cnt;
-        v.mean[n] = mean;
-        v.count[n] = cnt;
+        n->mean = mean;
+        n->count = cnt;
         if (v.value_rescale) { // updateTreeValueBound(old, new) (ref mcts.cpp:219-228): std::map<float,int> as an unordered array
             const float new_mean = r + v.gamma * mean;
             for (int j = 0; j < bsize; ++j) {
@@ -214,54 +260,57 @@ __global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int
     }
 }
 
-} // namespace mz
-
-namespace mz {
-
 __global__ __launch_bounds__(64) void root_set_noise_kernel(PoolView v, const int* __restrict__ mask, const float* __restrict__ policy,
                                                             const float* __restrict__ logit, const float* __restrict__ noise)
 {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (mask && !mask[g]) { return; }
     const size_t base = size_t(g) * v.cap;
-    const int nc = v.num_children[base];
-    const size_t fc = base + v.first_child[base];
+    const int nc = v.rec[base].num_children;
+    const size_t fc = base + v.rec[base].first_child;
     for (int i = lane; i < nc; i += 64) {
         const size_t c = size_t(g) * v.A + i;
-        v.policy[fc + i] = policy[c];
+        v.rec[fc + i].policy = policy[c];
         v.logit[fc + i] = logit[c];
         v.noise[fc + i] = noise[c];
     }
 }
 
-// gather the root's children into compact [games][A] arrays (f: action-major block of 8 float arrays, then 5 per-game arrays)
+// gather the root's children into compact [games][A] arrays (f: action-major block of 7 float arrays, then 5 per-game arrays)
 __global__ __launch_bounds__(64) void root_read_kernel(PoolView v, float* __restrict__ f, int* __restrict__ iv)
 {
     const int g = blockIdx.x, lane = threadIdx.x;
     const size_t base = size_t(g) * v.cap, GA = size_t(v.games) * v.A;
-    const int nc = v.num_children[base];
-    const size_t fc = base + (nc > 0 ? v.first_child[base] : 0);
+    const NodeRec root = v.rec[base];
+    const int nc = root.num_children;
+    const size_t fc = base + (nc > 0 ? root.first_child : 0);
     for (int i = lane; i < nc; i += 64) {
         const size_t c = size_t(g) * v.A + i;
-        f[0 * GA + c] = v.count[fc + i];
-        f[1 * GA + c] = v.mean[fc + i];
-        f[2 * GA + c] = v.policy[fc + i];
+        const NodeRec r = v.rec[fc + i];
+        f[0 * GA + c] = r.count;
+        f[1 * GA + c] = r.mean;
+        f[2 * GA + c] = r.policy;
         f[3 * GA + c] = v.logit[fc + i];
         f[4 * GA + c] = v.noise[fc + i];
         f[5 * GA + c] = v.value[fc + i];
-        f[6 * GA + c] = v.reward[fc + i];
-        iv[v.games + c] = v.action[fc + i];
+        f[6 * GA + c] = r.reward;
+        iv[v.games + c] = r.action;
     }
     if (lane == 0) {
         float* pg = f + 7 * GA;
-        pg[0 * v.games + g] = v.count[base];
-        pg[1 * v.games + g] = v.mean[base];
+        pg[0 * v.games + g] = root.count;
+        pg[1 * v.games + g] = root.mean;
         pg[2 * v.games + g] = v.value[base];
         pg[3 * v.games + g] = v.bound_lo[g];
         pg[4 * v.games + g] = v.bound_hi[g];
         iv[g] = nc;
         iv[v.games + GA + g] = v.bound_size[g];
     }
+}
+
+__global__ void signal_kernel(int* flag, int value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // MuZero: hidden-state slab slots for the leaves of the last select (parent slot -> source, dst_slot -> destination)
@@ -277,7 +326,7 @@ __global__ void hidden_index_kernel(PoolView v, int slots_per_game, int dst_slot
     const int parent = len >= 2 ? path[len - 2] : 0;
     src_idx[g] = g * slots_per_game + (len >= 2 ? v.hslot[base + parent] : 0);
     dst_idx[g] = g * slots_per_game + dst_slot;
-    action_ids[g] = v.action[base + leaf];
+    action_ids[g] = v.rec[base + leaf].action;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -308,16 +357,15 @@ int Pool::init(int device, int games, int nodes_per_game, int action_size, const
     const size_t G = games, NN = G * nodes_per_game, GA = G * action_size;
     const int max_depth = cfg.num_simulation + 3; // root + one new level per simulation (+1 Gumbel prefix, +1 slack)
     const int bound_cap = cfg.value_rescale ? cfg.num_simulation + 3 : 1;
-    MZ_ALLOC(f_nodes_, NN * 7); MZ_ALLOC(i_nodes_, NN * 4); MZ_ALLOC(player_, NN);
+    MZ_ALLOC(rec_, NN); MZ_ALLOC(f_nodes_, NN * 3); MZ_ALLOC(i_nodes_, NN);
     MZ_ALLOC(game_i_, G * 3 + 1); MZ_ALLOC(game_f_, G * 2);
     MZ_ALLOC(bound_key_, G * bound_cap); MZ_ALLOC(bound_cnt_, G * bound_cap);
     MZ_ALLOC(bias_tab_, cfg.num_simulation + 3); MZ_ALLOC(sqrt_tab_, cfg.num_simulation + 3);
     v_.games = games; v_.cap = nodes_per_game; v_.A = action_size; v_.max_depth = max_depth;
     float* f = f_nodes_.p;
-    v_.count = f; v_.mean = f + NN; v_.policy = f + 2 * NN; v_.logit = f + 3 * NN; v_.noise = f + 4 * NN; v_.value = f + 5 * NN; v_.reward = f + 6 * NN;
-    int* ip = i_nodes_.p;
-    v_.first_child = ip; v_.num_children = ip + NN; v_.action = ip + 2 * NN; v_.hslot = ip + 3 * NN;
-    v_.player = player_.p;
+    v_.rec = rec_.p;
+    v_.logit = f; v_.noise = f + NN; v_.value = f + 2 * NN;
+    v_.hslot = i_nodes_.p;
     // path arena: [path_len G][path_action G*max_depth][path G*max_depth]
     MZ_ALLOC(d_path_arena_, G + 2 * G * max_depth); MZ_ALLOC(h_path_arena_, G + 2 * G * max_depth);
     {
@@ -357,9 +405,32 @@ int Pool::init(int device, int games, int nodes_per_game, int action_size, const
         h_cand_logit_ = {reinterpret_cast<float*>(h + 4 * G + 2 * GA), GA}; d_cand_logit_ = {reinterpret_cast<float*>(d + 4 * G + 2 * GA), GA};
     }
     MZ_ALLOC(h_start_, G); MZ_ALLOC(d_start_, G); MZ_ALLOC(d_mask_, G);
+    MZ_ALLOC(h_flag_, 16);
+    h_flag_.p[0] = 0;
     MZ_ALLOC(d_rr_f_, 7 * GA + 5 * G); MZ_ALLOC(d_rr_i_, G + GA + G); MZ_ALLOC(h_rr_f_, 7 * GA + 5 * G); MZ_ALLOC(h_rr_i_, G + GA + G);
     std::vector<int> rp(games, 2);
     return resetSearch(nullptr, rp.data());
+}
+
+int Pool::signalAsync(int value)
+{
+    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, stream_, h_flag_.p, value);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int Pool::waitSignal(int value)
+{
+    volatile int* f = h_flag_.p;
+    for (int spin = 0; *f != value; ++spin) {
+        __builtin_ia32_pause();
+        if (spin > 600000) { // ~20 ms without the signal: let the runtime report what happened
+            MZ_HIP(hipStreamSynchronize(stream_));
+            if (*f != value) { setError("completion signal %d never arrived (flag = %d)", value, *f); return MZ_ERR_DEVICE; }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return MZ_OK;
 }
 
 int Pool::checkError()
@@ -527,22 +598,23 @@ int Pool::readNodes(int game, int n, int* action, int* player, int* num_children
     MZ_HIP(hipSetDevice(device_));
     MZ_HIP(hipStreamSynchronize(stream_));
     const size_t base = size_t(game) * v_.cap;
+    std::vector<NodeRec> recs(n);
+    MZ_HIP(hipMemcpy(recs.data(), v_.rec + base, size_t(n) * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        const NodeRec& r = recs[i];
+        if (action) { action[i] = r.action; }
+        if (player) { player[i] = r.players & 0xFF; }
+        if (num_children) { num_children[i] = r.num_children; }
+        if (first_child) { first_child[i] = r.first_child; }
+        if (mean) { mean[i] = r.mean; }
+        if (count) { count[i] = r.count; }
+        if (policy) { policy[i] = r.policy; }
+        if (reward) { reward[i] = r.reward; }
+    }
     auto cp = [&](void* dst, const void* src, size_t bytes) { return dst ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) : hipSuccess; };
-    MZ_HIP(cp(action, v_.action + base, n * sizeof(int)));
-    MZ_HIP(cp(num_children, v_.num_children + base, n * sizeof(int)));
-    MZ_HIP(cp(first_child, v_.first_child + base, n * sizeof(int)));
-    MZ_HIP(cp(mean, v_.mean + base, n * sizeof(float)));
-    MZ_HIP(cp(count, v_.count + base, n * sizeof(float)));
-    MZ_HIP(cp(policy, v_.policy + base, n * sizeof(float)));
     MZ_HIP(cp(logit, v_.logit + base, n * sizeof(float)));
     MZ_HIP(cp(noise, v_.noise + base, n * sizeof(float)));
     MZ_HIP(cp(value, v_.value + base, n * sizeof(float)));
-    MZ_HIP(cp(reward, v_.reward + base, n * sizeof(float)));
-    if (player) {
-        std::vector<unsigned char> p(n);
-        MZ_HIP(hipMemcpy(p.data(), v_.player + base, n, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i) { player[i] = p[i]; }
-    }
     return MZ_OK;
 }
 

@@ -97,7 +97,7 @@ static std::vector<int> cpuOrder()
 
 class ThreadPool {
 public:
-    // cpu_base >= 0: pin the calling thread and the workers to consecutive entries of cpuOrder() starting at cpu_base
+    // cpu_base >= 0: pin the workers to consecutive entries of cpuOrder() starting at cpu_base + 1
     explicit ThreadPool(int n, int cpu_base = -1) : n_(std::max(1, n))
     {
         std::vector<int> cpus;
@@ -122,36 +122,42 @@ public:
         {
             std::lock_guard<std::mutex> l(mu_);
             quit_.store(true);
-            epoch_.fetch_add(1);
+            state_.fetch_add(1ull << 32);
         }
         cv_.notify_all();
         for (auto& t : threads_) { t.join(); }
     }
+    // Completion is counted in ITEMS, not in threads: a worker that the OS has descheduled (noisy neighbours on a shared
+    // host) delays nothing but the one chunk it holds; workers that wake up late find the epoch gone and go back to waiting.
     void parallelFor(int count, const std::function<void(int)>& fn)
     {
         if (n_ == 1 || count < 2) { for (int i = 0; i < count; ++i) { fn(i); } return; }
         fn_ = &fn;
         count_ = count;
         chunk_ = std::max(1, count / (n_ * 4));
-        next_.store(0, std::memory_order_relaxed);
-        done_.store(0, std::memory_order_relaxed);
+        processed_.store(0, std::memory_order_relaxed);
+        const uint64_t epoch = (state_.load(std::memory_order_relaxed) >> 32) + 1;
         {
             std::lock_guard<std::mutex> l(mu_); // pairs with the sleepers' predicate check
-            epoch_.fetch_add(1, std::memory_order_release);
+            state_.store(epoch << 32, std::memory_order_release);
         }
         if (sleepers_.load(std::memory_order_acquire) > 0) { cv_.notify_all(); }
-        work();
-        while (done_.load(std::memory_order_acquire) != n_ - 1) { __builtin_ia32_pause(); }
+        work(epoch);
+        while (processed_.load(std::memory_order_acquire) != count) { __builtin_ia32_pause(); }
     }
 
 private:
-    void work()
+    void work(uint64_t epoch)
     {
         while (true) {
-            const int b = next_.fetch_add(chunk_, std::memory_order_relaxed);
-            if (b >= count_) { break; }
+            uint64_t s = state_.load(std::memory_order_acquire);
+            if ((s >> 32) != epoch) { return; }
+            const int b = static_cast<int>(s & 0xffffffffu);
+            if (b >= count_) { return; }
+            if (!state_.compare_exchange_weak(s, s + static_cast<uint64_t>(chunk_), std::memory_order_acq_rel)) { continue; }
             const int e = std::min(count_, b + chunk_);
             for (int i = b; i < e; ++i) { (*fn_)(i); }
+            processed_.fetch_add(e - b, std::memory_order_release);
         }
     }
     void loop()
@@ -159,20 +165,19 @@ private:
         uint64_t seen = 0;
         while (true) {
             int spins = 0;
-            while (epoch_.load(std::memory_order_acquire) == seen) {
+            while ((state_.load(std::memory_order_acquire) >> 32) == seen) {
                 __builtin_ia32_pause();
                 if (++spins > 60000) { // ~2 ms idle: sleep
                     std::unique_lock<std::mutex> l(mu_);
                     sleepers_.fetch_add(1);
-                    cv_.wait(l, [&]() { return epoch_.load(std::memory_order_acquire) != seen; });
+                    cv_.wait(l, [&]() { return (state_.load(std::memory_order_acquire) >> 32) != seen; });
                     sleepers_.fetch_sub(1);
                     break;
                 }
             }
-            seen = epoch_.load(std::memory_order_acquire);
+            seen = state_.load(std::memory_order_acquire) >> 32;
             if (quit_.load()) { return; }
-            work();
-            done_.fetch_add(1, std::memory_order_release);
+            work(seen);
         }
     }
     int n_;
@@ -181,8 +186,8 @@ private:
     std::condition_variable cv_;
     const std::function<void(int)>* fn_ = nullptr;
     int count_ = 0, chunk_ = 1;
-    std::atomic<int> next_{0}, done_{0}, sleepers_{0};
-    std::atomic<uint64_t> epoch_{0};
+    std::atomic<uint64_t> state_{0}; // epoch << 32 | next item
+    std::atomic<int> processed_{0}, sleepers_{0};
     std::atomic<bool> quit_{false};
 };
 
@@ -264,6 +269,7 @@ private:
         DevBuf<float> d_feat, d_out, d_hidden;
         Pool::View<float> h_policy, h_logit, h_value, h_reward, d_policy, d_logit, d_value, d_reward;
         DevBuf<int> d_src_idx, d_dst_idx, d_action_ids;
+        int signal_seq = 0; // last completion signal queued on this lane's stream
     };
     Lane& laneOf(int g) { return *lanes_[g / lane_size_ < int(lanes_.size()) ? g / lane_size_ : int(lanes_.size()) - 1]; }
     int phase1(Lane& L, bool root_expansion, bool done);
@@ -312,6 +318,7 @@ private:
     std::vector<float> noise_policy_, noise_logit_, noise_noise_;
     PhaseTrace trace_;
     int flipping_player_ = 2;
+    bool use_signal_ = true;  // wait on a pinned completion word written by a 1-thread kernel instead of hipStreamSynchronize
     bool feat_bits_ = false; // AlphaZero leaves travel host->device as bit-packed planes (all board-game planes are 0/1)
 };
 
@@ -381,6 +388,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     int rcc = createActors();
     if (rcc) { return rcc; }
     feat_bits_ = (desc.type == 0) && net0().hasFusedTower();
+    use_signal_ = cfg_.mz_signal_wait;
     return MZ_OK;
 }
 
@@ -799,7 +807,8 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done)
     const int g0 = L.g0, g1 = L.g0 + L.n;
     double t0 = nowMs();
     if (pending_) {
-        MZ_HIP(hipStreamSynchronize(L.stream)); // network outputs of this lane
+        if (use_signal_) { int rcw = L.pool.waitSignal(L.signal_seq); if (rcw) { return rcw; } }
+        else { MZ_HIP(hipStreamSynchronize(L.stream)); } // network outputs of this lane
         double t1 = nowMs();
         stats_.ms_forward += t1 - t0;
         trace_.add(0, t1 - t0);
@@ -896,6 +905,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done)
         MZ_HIP(hipMemcpyAsync(L.pool.h_path_arena_.p, L.pool.d_path_arena_.p,
                               (size_t(L.n) + (az ? size_t(L.n) * L.pool.v_.max_depth : 0)) * sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
     } // else: select_kernel already wrote path_len / path_action into the pinned mirrors
+    if (use_signal_) { int rcs = L.pool.signalAsync(++L.signal_seq); if (rcs) { return rcs; } }
     const double tz = nowMs();
     stats_.ms_select += tz - t0;
     trace_.add(6, tz - t0);
@@ -908,7 +918,8 @@ int Worker::phase2(Lane& L)
     const bool az = desc_.type == 0;
     const int g0 = L.g0;
     const double t0 = nowMs();
-    MZ_HIP(hipStreamSynchronize(L.stream)); // paths of this lane
+    if (use_signal_) { int rcw = L.pool.waitSignal(L.signal_seq); if (rcw) { return rcw; } }
+    else { MZ_HIP(hipStreamSynchronize(L.stream)); } // paths of this lane
     const double t1 = nowMs();
     stats_.ms_select += t1 - t0;
     trace_.add(7, t1 - t0);
@@ -927,6 +938,7 @@ int Worker::phase2(Lane& L)
             return rc;
         }
         if (zout) {
+            if (use_signal_) { if ((rc = L.pool.signalAsync(++L.signal_seq))) { return rc; } }
             const double t3z = nowMs();
             stats_.ms_forward += t3z - t2;
             trace_.add(9, t3z - t2);
@@ -946,6 +958,7 @@ int Worker::phase2(Lane& L)
         }
     }
     MZ_HIP(hipMemcpyAsync(L.h_out.p, L.d_out.p, L.h_out.n * sizeof(float), hipMemcpyDeviceToHost, L.stream));
+    if (use_signal_) { if ((rc = L.pool.signalAsync(++L.signal_seq))) { return rc; } }
     const double t3 = nowMs();
     stats_.ms_forward += t3 - t2;
     trace_.add(9, t3 - t2);
