@@ -30,7 +30,9 @@ def cpu_baseline(conf, seconds):
     import oracle_lib as O  # cpu_baseline leg only
     d = O.desc_c2()
     w = O.gen_weights(d, 0)
-    g = O.OracleGroup(conf + ":zero_num_threads=1", d, w)
+    cores = os.cpu_count() or 1
+    host_threads = max(1, min(64, cores))
+    g = O.OracleGroup(conf + f":zero_num_threads=1:oracle_throughput_threads={host_threads}", d, w)
     g.cycles(1)  # warm-up (thread start, page-in)
     t0 = time.time()
     cycles = 0
@@ -39,10 +41,9 @@ def cpu_baseline(conf, seconds):
         cycles += 1
     dt = time.time() - t0
     evals = cycles * 256
-    cores = os.cpu_count() or 1
     return {"value": evals / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
-            "sample": f"{cycles} lock-step cycles x 256 games of the same workload ({dt:.1f} s): tree+env on 1 thread "
-                      f"(the reference's deterministic contract), network forward on {cores} threads"}
+            "sample": f"{cycles} lock-step cycles x 256 games of the same workload ({dt:.1f} s): tree+env phase on "
+                      f"{host_threads} threads, network forward (f32, same arithmetic as the GPU path) on {cores} threads"}
 
 
 def main():

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cassert>
 #include <sstream>
+#include <thread>
 
 namespace mzo {
 
@@ -122,15 +123,15 @@ void ZeroActor::beforeNNEvaluation() // ref zero_actor.cpp:51-72
     if (nd_->type == 0) {
         std::unique_ptr<Env> env_transition = getEnvironmentTransition(node_path_);
         feature_rotation_ = cfg_->actor_use_random_rotation_features ? static_cast<Rotation>(rng_->randInt() % static_cast<int>(kRotateSize)) : kRotationNone;
-        nn_evaluation_batch_id_ = q_->pushBack(env_transition->getFeatures(feature_rotation_));
+        nn_evaluation_batch_id_ = q_->pushBack(env_transition->getFeatures(feature_rotation_), slot_override_);
     } else {
         if (mcts_.getNumSimulation() == 0) {
-            nn_evaluation_batch_id_ = q_->pushBackInitial(env_->getFeatures());
+            nn_evaluation_batch_id_ = q_->pushBackInitial(env_->getFeatures(), slot_override_);
         } else {
             MCTSNode* leaf = node_path_.back();
             MCTSNode* parent = node_path_[node_path_.size() - 2];
             const std::vector<float>& hidden = mcts_.hidden(parent->hidden_state_data_index_);
-            nn_evaluation_batch_id_ = q_->pushBackRecurrent(hidden, env_->getActionFeatures(leaf->action_));
+            nn_evaluation_batch_id_ = q_->pushBackRecurrent(hidden, env_->getActionFeatures(leaf->action_), slot_override_);
         }
     }
 }
@@ -272,6 +273,18 @@ Group::Group(const Config& cfg, const NetDesc& nd, const float* raw, size_t nraw
     // ref actor_group.cpp:66-70: slave thread 0 seeds ITS generator with program_seed + 0
     slave_rng_.seed(cfg_.program_seed + 0);
     for (auto& a : actors_) { a->rng_ = &slave_rng_; a->mcts_.rng_ = &slave_rng_; a->env_->rng_ = &slave_rng_; }
+    // throughput mode (NOT the deterministic contract): T slave threads, thread t seeds program_seed + t (actor_group.cpp:66-70).
+    // The reference hands actors to threads first-come-first-served (:18-22); here actor i belongs to thread i % T.
+    if (cfg_.oracle_throughput_threads > 1) {
+        for (int t = 0; t < cfg_.oracle_throughput_threads; ++t) {
+            thread_rngs_.emplace_back(std::make_unique<Random>());
+            thread_rngs_.back()->seed(cfg_.program_seed + t);
+        }
+        for (size_t i = 0; i < actors_.size(); ++i) {
+            Random* r = thread_rngs_[i % thread_rngs_.size()].get();
+            actors_[i]->rng_ = r; actors_[i]->mcts_.rng_ = r; actors_[i]->env_->rng_ = r;
+        }
+    }
 }
 
 std::pair<int, int> Group::calculateTrainingDataRange(const ZeroActor& actor) const // ref actor_group.cpp:52-64
@@ -301,6 +314,7 @@ void Group::outputGame(ZeroActor& actor) // ref actor_group.cpp:24-50
     if (!is_terminal) {
         for (int i = data_range.first; i <= data_range.second; ++i) { actor.action_info_history_[i].clear(); }
     }
+    std::lock_guard<std::mutex> lock(out_mutex_);
     lines_.push_back(oss.str());
     if (is_terminal) { ++games_; }
 }
@@ -323,6 +337,29 @@ void Group::handleSearchDone(int actor_id) // ref actor_group.cpp:116-134
 
 void Group::cycle() // ref actor_group.cpp:81-114 (one CPU phase + one GPU phase)
 {
+    if (!thread_rngs_.empty()) { // throughput mode: the CPU phase on T threads; batch slots are assigned up front in actor order
+        const int T = static_cast<int>(thread_rngs_.size()), B = static_cast<int>(actors_.size());
+        std::vector<std::thread> th;
+        q_.reserveSlots(B, nd_);
+        for (int t = 0; t < T; ++t) {
+            th.emplace_back([this, t, T, B]() {
+                for (int i = t; i < B; i += T) {
+                    ZeroActor& actor = *actors_[i];
+                    const int out_id = actor.nn_evaluation_batch_id_;
+                    if (out_id >= 0) {
+                        actor.afterNNEvaluation(outputs_[out_id]);
+                        if (actor.isSearchDone()) { handleSearchDone(i); }
+                    }
+                    actor.slot_override_ = i;
+                    actor.beforeNNEvaluation();
+                }
+            });
+        }
+        for (auto& t : th) { t.join(); }
+        outputs_ = q_.run();
+        ++cycles_;
+        return;
+    }
     for (size_t i = 0; i < actors_.size(); ++i) { // doCPUJob in actor-index order
         ZeroActor& actor = *actors_[i];
         int out_id = actor.nn_evaluation_batch_id_;

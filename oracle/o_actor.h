@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.h).
 #pragma once
 #include "oracle.h"
+#include <mutex>
 
 namespace mzo {
 
@@ -10,15 +11,34 @@ struct NetQueue {
     size_t feat_size = 0;
     std::vector<float> az, init, rec_h, rec_a;
     uint64_t leaf_evals = 0;
-    int pushBack(const std::vector<float>& f) { az.insert(az.end(), f.begin(), f.end()); return int(az.size() / feat_size) - 1; }
-    int pushBackInitial(const std::vector<float>& f) { init.insert(init.end(), f.begin(), f.end()); return int(init.size() / feat_size) - 1; }
-    int pushBackRecurrent(const std::vector<float>& h, const std::vector<float>& a)
+    // slot < 0: append (single-threaded, deterministic mode); slot >= 0: write into a pre-reserved slot (throughput mode)
+    int pushBack(const std::vector<float>& f, int slot = -1) { return put(az, f, slot); }
+    int pushBackInitial(const std::vector<float>& f, int slot = -1) { return put(init, f, slot); }
+    int pushBackRecurrent(const std::vector<float>& h, const std::vector<float>& a, int slot = -1)
     {
-        rec_h.insert(rec_h.end(), h.begin(), h.end());
-        rec_a.insert(rec_a.end(), a.begin(), a.end());
-        return int(rec_h.size() / h.size()) - 1;
+        put(rec_a, a, slot);
+        return put(rec_h, h, slot);
     }
+    void reserveSlots(int B, const NetDesc& d)
+    {
+        reserve_b = B;
+        (void)d;
+    }
+    int reserve_b = 0;
     std::vector<NetOutput> run();
+
+private:
+    int put(std::vector<float>& dst, const std::vector<float>& src, int slot)
+    {
+        if (slot < 0) { dst.insert(dst.end(), src.begin(), src.end()); return int(dst.size() / src.size()) - 1; }
+        {
+            std::lock_guard<std::mutex> l(mu);
+            if (dst.size() < size_t(reserve_b) * src.size()) { dst.resize(size_t(reserve_b) * src.size()); }
+        }
+        std::copy(src.begin(), src.end(), dst.begin() + size_t(slot) * src.size());
+        return slot;
+    }
+    std::mutex mu;
 };
 
 class Group {
@@ -30,11 +50,13 @@ public:
     std::unique_ptr<Net> net_;
     NetQueue q_;
     Random main_rng_, slave_rng_;
+    std::vector<std::unique_ptr<Random>> thread_rngs_; // oracle_throughput_threads > 1: one generator per slave thread (seed + id), throughput mode
     std::vector<std::unique_ptr<ZeroActor>> actors_;
     std::vector<NetOutput> outputs_;
     std::vector<std::string> lines_, trace_lines_;
     uint64_t cycles_ = 0, games_ = 0;
     bool trace_ = false;
+    std::mutex out_mutex_;
 
 private:
     std::pair<int, int> calculateTrainingDataRange(const ZeroActor& actor) const;

@@ -16,10 +16,52 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace mzo {
+
+// persistent worker pool for the per-sample loops of the forward pass (cpu_baseline: no thread creation per call)
+namespace {
+class NNPool {
+public:
+    static NNPool& get() { static NNPool* p = new NNPool(); return *p; } // leaked on purpose: detached workers must never see it destroyed
+    void run(int n, const std::function<void(int)>& f)
+    {
+        if (n <= 1 || nt_ <= 1) { for (int i = 0; i < n; ++i) { f(i); } return; }
+        std::unique_lock<std::mutex> l(mu_);
+        fn_ = &f; n_ = n; next_ = 0; done_ = 0; ++epoch_;
+        cv_.notify_all();
+        l.unlock();
+        work();
+        l.lock();
+        dcv_.wait(l, [&] { return done_ == n_; });
+    }
+private:
+    NNPool()
+    {
+        nt_ = std::max(1u, std::thread::hardware_concurrency());
+        for (int t = 1; t < nt_; ++t) { std::thread([this] { uint64_t seen = 0; for (;;) { { std::unique_lock<std::mutex> l(mu_); cv_.wait(l, [&] { return epoch_ != seen; }); seen = epoch_; } work(); } }).detach(); }
+    }
+    void work()
+    {
+        for (;;) {
+            int i;
+            { std::lock_guard<std::mutex> l(mu_); if (next_ >= n_) { return; } i = next_++; }
+            (*fn_)(i);
+            { std::lock_guard<std::mutex> l(mu_); if (++done_ == n_) { dcv_.notify_all(); } }
+        }
+    }
+    int nt_ = 1, n_ = 0, next_ = 0, done_ = 0;
+    uint64_t epoch_ = 0;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::mutex mu_;
+    std::condition_variable cv_, dcv_;
+};
+} // namespace
 
 float mz_expf(float x)
 {
@@ -300,11 +342,8 @@ public:
     template <class F>
     static void parallelFor(int n, F f)
     {
-        int nt = std::min<int>(n, std::max(1u, std::thread::hardware_concurrency()));
-        if (nt <= 1) { for (int i = 0; i < n; ++i) { f(i); } return; }
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) { th.emplace_back([=]() { for (int i = t; i < n; i += nt) { f(i); } }); }
-        for (auto& t : th) { t.join(); }
+        std::function<void(int)> fn = f;
+        NNPool::get().run(n, fn);
     }
 
     void forwardAZ(const float* features, int batch, float* policy, float* logit, float* value) const override
@@ -467,11 +506,8 @@ public:
     template <class F>
     static void parallelFor(int n, F f)
     {
-        int nt = std::min<int>(n, std::max(1u, std::thread::hardware_concurrency()));
-        if (nt <= 1) { for (int i = 0; i < n; ++i) { f(i); } return; }
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) { th.emplace_back([=]() { for (int i = t; i < n; i += nt) { f(i); } }); }
-        for (auto& t : th) { t.join(); }
+        std::function<void(int)> fn = f;
+        NNPool::get().run(n, fn);
     }
     void forwardAZ(const float*, int, float*, float*, float*) const override {}
     void initialMZ(const float* features, int batch, float* policy, float* logit, float* value, float* hidden) const override

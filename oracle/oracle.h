@@ -79,6 +79,7 @@ struct Config {
     // environment/environment.h:5-110) and the ATARI init-Q rule with it (actor/mcts.cpp:211-216).
     std::string env_game = "tictactoe";
     bool atari_init_q = false;
+    int oracle_throughput_threads = 0; // oracle-only: >1 runs the CPU phase on T threads (bench cpu_baseline; NOT the deterministic contract)
     std::string env_atari_name = "ms_pacman";
     int env_atari_episode_length = 1000; // synthetic Atari-shaped env: steps per episode
 
@@ -283,6 +284,7 @@ public:
     GumbelZero gumbel_zero_;
     bool enable_resign_ = true;
     int nn_evaluation_batch_id_ = -1;
+    int slot_override_ = -1; // throughput mode: pre-assigned batch slot (threads push concurrently)
     Rotation feature_rotation_ = kRotationNone;
     MCTSNode* selected_node_ = nullptr;
     std::vector<MCTSNode*> node_path_;
