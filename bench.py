@@ -30,7 +30,8 @@ def cpu_baseline(conf, seconds):
     import oracle_lib as O  # cpu_baseline leg only
     d = O.desc_c2()
     w = O.gen_weights(d, 0)
-    cores = os.cpu_count() or 1
+    import minizero_amd as mz
+    cores = mz.usable_cpus()
     host_threads = max(1, min(64, cores))
     g = O.OracleGroup(conf + f":zero_num_threads=1:oracle_throughput_threads={host_threads}", d, w)
     g.cycles(1)  # warm-up (thread start, page-in)
@@ -75,7 +76,8 @@ def main():
     grp = Group("nccl")  # RCCL over xGMI; only used for the weight broadcast, barriers and the final reductions
 
     cores = os.cpu_count() or 1
-    threads = args.threads or max(1, min(32, cores // max(1, world)))  # spin-wait pool: 32 workers cover 256 games
+    usable = mz.usable_cpus()  # affinity mask capped by the cgroup CPU quota: spinning past the quota gets the container throttled
+    threads = args.threads or max(1, min(32, usable // max(1, world) - 1))  # spin-wait pool incl. the calling thread
     base_conf = mz.CONFIGS["c2"].replace("zero_num_parallel_games=256", f"zero_num_parallel_games={args.games}")
     conf = (f"{base_conf}:zero_num_threads={threads}:mz_pipeline_lanes={args.lanes}:mz_zero_copy={args.zero_copy}:mz_cpu_base={local_rank * threads if args.pin else -1}:program_seed={shard_seed(1, rank)}:"
             "nn_file_name=synthetic_go_6bx64_seed0.pt")
@@ -120,7 +122,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 9x9 Go AlphaZero, n=400, 6 blocks x 64 ch, 256 parallel games per GPU, "
                                    "synthetic fixed-weight net (seed 0), Dirichlet noise + random rotation + softmax-count moves (reference defaults)",
-                       "games_per_gpu": args.games, "actor_num_simulation": 400, "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_cores": cores,
+                       "games_per_gpu": args.games, "actor_num_simulation": 400, "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_cores": cores, "host_cpus_usable": usable,
                        "sharding": f"{world} x independent actor pools, no data-path collective"},
             "moves_per_sec": moves / dt, "games_finished": games_done,
             "games_per_sec": (games_done / dt) if games_done else None,

@@ -31,6 +31,9 @@ extern "C" {
 const char* mz_last_error(void);
 /* replaces torch::cuda::device_count() (ref actor/actor_group.cpp:152,170) */
 int mz_device_count(void);
+/* CPUs the worker's spin-wait host pool may use: affinity mask capped by the cgroup CPU quota (no reference equivalent; the
+ * reference's zero_num_threads is taken at face value, ref actor/actor_group.cpp:172-177). zero_num_threads is clamped to this - 1. */
+int mz_usable_cpus(void);
 
 /* ------------------------------------------------------------------------------------------
  * Network.  Replaces Network::loadModel + getters (ref network/network.cpp:14-42,

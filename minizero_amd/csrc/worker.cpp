@@ -95,6 +95,32 @@ static std::vector<int> cpuOrder()
     return allowed;
 }
 
+// CPUs this process can actually burn: the affinity mask, capped by the cgroup CPU bandwidth quota (cgroup v2 cpu.max, v1
+// cpu.cfs_quota_us).  A spin-wait pool larger than the quota gets the whole container throttled for the rest of each 100-ms
+// period (measured on the 1-GPU box: quota 16 CPUs, 32 spinners -> 40-50 ms stalls every ~100 cycles, 270k instead of 470k evals/s).
+static int usableCpus()
+{
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = (sched_getaffinity(0, sizeof(set), &set) == 0) ? CPU_COUNT(&set) : static_cast<int>(std::thread::hardware_concurrency());
+    if (n < 1) { n = 1; }
+    double quota = -1, period = 100000;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) { quota = atof(q); }
+        fclose(f);
+    } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(f1, "%lf", &quota) != 1) { quota = -1; }
+        fclose(f1);
+        if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(f2, "%lf", &period) != 1) { period = 100000; }
+            fclose(f2);
+        }
+    }
+    if (quota > 0 && period > 0) { n = std::min(n, std::max(1, static_cast<int>(quota / period))); }
+    return n;
+}
+
 class ThreadPool {
 public:
     // cpu_base >= 0: pin the workers to consecutive entries of cpuOrder() starting at cpu_base + 1
@@ -378,7 +404,8 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
 #undef WALLOC
         lanes_.push_back(std::move(L));
     }
-    threads_ = std::make_unique<ThreadPool>(std::max(1, cfg_.zero_num_threads), cfg_.mz_cpu_base);
+    // the pool spins: never more spinners than CPUs the container may use, minus one for the HIP runtime's helper threads
+    threads_ = std::make_unique<ThreadPool>(std::max(1, std::min(cfg_.zero_num_threads, usableCpus() - 1)), cfg_.mz_cpu_base);
     const size_t GA = size_t(G_) * A_;
     rr_nc_.resize(G_); rr_action_.resize(GA); rr_bsize_.resize(G_);
     for (auto* v : {&rr_count_, &rr_mean_, &rr_policy_, &rr_logit_, &rr_noise_, &rr_value_, &rr_reward_}) { v->resize(GA); }
@@ -1052,6 +1079,8 @@ struct mz_net { mz::Net net; };
 struct mz_env { std::unique_ptr<mz::GameEnv> e; };
 
 extern "C" {
+
+int mz_usable_cpus(void) { return mz::usableCpus(); }
 
 mz_worker* mz_worker_create(int device, const char* conf, const mz_net_desc* desc, const float* weights, size_t count)
 {

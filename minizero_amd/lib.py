@@ -161,6 +161,10 @@ def device_count():
     return load().mz_device_count()
 
 
+def usable_cpus():
+    return load().mz_usable_cpus()
+
+
 def param_count(desc):
     return _check(load(), load().mz_net_param_count(C.byref(desc)))
 

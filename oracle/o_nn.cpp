@@ -17,6 +17,8 @@
 #include <cassert>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -43,7 +45,15 @@ public:
 private:
     NNPool()
     {
-        nt_ = std::max(1u, std::thread::hardware_concurrency());
+        // threads = CPUs this container may actually use (cgroup quota), else 256 runnable threads get throttled on a 16-CPU quota
+        nt_ = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = getenv("MZO_THREADS")) { nt_ = std::max(1, atoi(e)); }
+        else if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            double period = 100000;
+            if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { nt_ = std::max(1, std::min(nt_, static_cast<int>(atof(q) / period))); }
+            fclose(f);
+        }
         for (int t = 1; t < nt_; ++t) { std::thread([this] { uint64_t seen = 0; for (;;) { { std::unique_lock<std::mutex> l(mu_); cv_.wait(l, [&] { return epoch_ != seen; }); seen = epoch_; } work(); } }).detach(); }
     }
     void work()
