@@ -184,6 +184,24 @@ int mz_env_policy_size(const mz_env* e);
 int mz_env_feature_size(const mz_env* e);
 int mz_env_legal_mask(const mz_env* e, uint8_t* out);
 int mz_env_features(const mz_env* e, int rotation, float* out);
+/* the same planes bit-packed (the device format): channel c = ceil(P/32) words, bit p%32 of word p/32 */
+int mz_env_feature_bits(const mz_env* e, int rotation, uint32_t* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident leaf environment (AlphaZero Go): test access.  The worker uses it when
+ * mz_device_env=true (default) instead of replaying the path on a host copy of the root
+ * environment (ref actor/zero_actor.cpp:55,79,215-252; environment/go/go.cpp:132-308).
+ * mz_godev_playout plays actions[0..root_prefix) on the host engine (the root), then
+ * actions[root_prefix..count) one node per move on the DEVICE engine and returns, for the
+ * root (step 0) and after every device move, what the worker consumes: bit-packed planes under
+ * rotation rots[step], legal mask, terminal flag, Tromp-Taylor result, player to move.
+ * steps = count - root_prefix + 1; feat_out [steps][18*ceil(P/32)], legal_out [steps][P+1].
+ * mz_sort_candidates orders n policies like the reference's std::sort (policy descending,
+ * ref zero_actor.cpp:225-227) on the device, ties included: order_out[i] = index of the i-th.
+ * ------------------------------------------------------------------------------------------ */
+int mz_godev_playout(int device, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots,
+                     uint32_t* feat_out, uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out);
+int mz_sort_candidates(int device, const float* policy, int n, int* order_out);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 //   TicTacToe: two 9-bit masks.
 // All feature planes are written straight into caller memory (the worker's pinned staging buffer).
 #include "env.h"
+#include "go_dev.h"
 #include "common.h"
 #include <cstring>
 #include <map>
@@ -561,6 +562,45 @@ public:
         }
         uint32_t* t = out + (turn_ == 1 ? 16 : 17) * W32;
         for (int p = 0; p < P_; ++p) { t[p >> 5] |= 1u << (p & 31); }
+    }
+    bool hasDeviceTwin() const override { return true; }
+    const uint64_t* zobristKeys() const override
+    {
+        // [2][P_] contiguous copy of the [2][kMaxP] table
+        static std::mutex mu;
+        static std::map<int, std::vector<uint64_t>> cache;
+        std::lock_guard<std::mutex> lock(mu);
+        auto& k = cache[n_];
+        if (k.empty()) {
+            k.resize(size_t(2) * P_);
+            for (int c = 0; c < 2; ++c) { for (int p = 0; p < P_; ++p) { k[size_t(c) * P_ + p] = st_->key[c][p]; } }
+        }
+        return k.data();
+    }
+    void exportDeviceRoot(void* dst) const override
+    {
+        static_assert(kWords == kGoMaxW && kHashCap == kGoSeenCap && kMaxP == kGoMaxP, "device snapshot layout");
+        GoRootSnapshot& s = *static_cast<GoRootSnapshot*>(dst);
+        memcpy(s.stones, stones_, sizeof(s.stones));
+        memcpy(s.hist, hist_, sizeof(s.hist));
+        memcpy(s.seen, seen_, sizeof(s.seen));
+        s.hash = hash_;
+        s.hist_len = hist_len_;
+        s.turn = turn_;
+        s.nmoves = static_cast<int32_t>(action_ids_.size());
+        int passes = 0;
+        for (size_t k = action_ids_.size(); k > 0 && passes < 2 && action_ids_[k - 1] == P_; --k) { ++passes; }
+        s.passes = passes;
+        // group id per stone: the first point of the group in scan order
+        int16_t grp[kMaxP];
+        uint8_t done[kMaxP];
+        memset(done, 0, P_);
+        for (int p = 0; p < P_; ++p) {
+            if (board_[p] == 0 || done[p]) { s.lab[p] = board_[p] == 0 ? 0 : s.lab[p]; continue; }
+            int gs = 0;
+            (void)group(p, kMaxP + 1, grp, &gs, nullptr);
+            for (int i = 0; i < gs; ++i) { s.lab[grp[i]] = static_cast<uint16_t>(p); done[grp[i]] = 1; }
+        }
     }
     int numInputChannels() const override { return 18; }
     int boardSize() const override { return n_; }

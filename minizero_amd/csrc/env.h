@@ -46,6 +46,10 @@ public:
     virtual int numPlayers() const { return 2; }
     virtual std::string name() const = 0;
     virtual std::vector<std::pair<std::string, std::string>> loaderTags() const = 0;
+    // engines with a device twin (go_dev.hip): the root position in the device's format, once per move
+    virtual bool hasDeviceTwin() const { return false; }
+    virtual void exportDeviceRoot(void* /*GoRootSnapshot*/) const {}
+    virtual const uint64_t* zobristKeys() const { return nullptr; } // [2][points]
     int turn() const { return turn_; }
     int featureSize() const { return numInputChannels() * boardSize() * boardSize(); }
     const std::vector<int16_t>& actionIds() const { return action_ids_; }

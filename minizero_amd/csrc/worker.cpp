@@ -13,6 +13,7 @@
 #include "env.h"
 #include "net.h"
 #include "pool.h"
+#include "go_dev.h"
 #include <pthread.h>
 #include <sched.h>
 #include <unistd.h>
@@ -296,10 +297,16 @@ private:
         Pool::View<float> h_policy, h_logit, h_value, h_reward, d_policy, d_logit, d_value, d_reward;
         DevBuf<int> d_src_idx, d_dst_idx, d_action_ids;
         int signal_seq = 0; // last completion signal queued on this lane's stream
+        // device-resident leaf environment (AlphaZero Go): per-cycle rotations travel as a kernel argument
+        GoDevice godev;
+        RotPack rot{};
+        int cycles_since_signal = 0;
     };
     Lane& laneOf(int g) { return *lanes_[g / lane_size_ < int(lanes_.size()) ? g / lane_size_ : int(lanes_.size()) - 1]; }
     int phase1(Lane& L, bool root_expansion, bool done);
     int phase2(Lane& L);
+    int phase2Resident(Lane& L);
+    int uploadRoots(Lane& L);
     int cycle();
     int createActors();
     int resetAllSearches();
@@ -346,6 +353,7 @@ private:
     int flipping_player_ = 2;
     bool use_signal_ = true;  // wait on a pinned completion word written by a 1-thread kernel instead of hipStreamSynchronize
     bool feat_bits_ = false; // AlphaZero leaves travel host->device as bit-packed planes (all board-game planes are 0/1)
+    bool resident_ = false;  // the whole cycle runs on the device (go_dev.hip): the host only does the RNG-ordered per-move logic
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -416,7 +424,29 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     if (rcc) { return rcc; }
     feat_bits_ = (desc.type == 0) && net0().hasFusedTower();
     use_signal_ = cfg_.mz_signal_wait;
+    resident_ = cfg_.mz_device_env && desc.type == 0 && feat_bits_ && !cfg_.actor_use_gumbel && games_[0].env->hasDeviceTwin() &&
+                lane_size_ <= kRotPackGames;
+    if (resident_) {
+        const GameEnv& e = *games_[0].env;
+        const int* inv[8];
+        const int* fwd[8];
+        for (int r = 0; r < 8; ++r) { inv[r] = e.rot()->inv[r].data(); fwd[r] = e.rot()->fwd[r].data(); }
+        for (auto& L : lanes_) {
+            int rc = L->godev.init(device, L->n, e.boardSize(), cfg_.env_go_komi, A_, n_ + 1, L->pool.v_.max_depth, L->stream, inv, fwd, e.zobristKeys());
+            if (rc) { return rc; }
+            L->pool.v_.host_path_len = nullptr; // nobody on the host reads the paths any more
+            L->pool.v_.host_path_action = nullptr;
+            if ((rc = uploadRoots(*L))) { return rc; }
+        }
+    }
     return MZ_OK;
+}
+
+int Worker::uploadRoots(Lane& L)
+{
+    const int g0 = L.g0;
+    threads_->parallelFor(L.n, [this, &L, g0](int j) { games_[g0 + j].env->exportDeviceRoot(L.godev.hostSnap(j)); });
+    return L.godev.uploadRoots();
 }
 
 int Worker::createActors()
@@ -459,6 +489,7 @@ int Worker::resetAllSearches()
         for (int j = 0; j < L->n; ++j) { rp[j] = rootPlayerFor(games_[L->g0 + j]); }
         int rc = L->pool.resetSearch(nullptr, rp.data());
         if (rc) { return rc; }
+        if (resident_ && (rc = uploadRoots(*L))) { return rc; }
     }
     return MZ_OK;
 }
@@ -834,18 +865,22 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done)
     const int g0 = L.g0, g1 = L.g0 + L.n;
     double t0 = nowMs();
     if (pending_) {
-        if (use_signal_) { int rcw = L.pool.waitSignal(L.signal_seq); if (rcw) { return rcw; } }
-        else { MZ_HIP(hipStreamSynchronize(L.stream)); } // network outputs of this lane
-        double t1 = nowMs();
-        stats_.ms_forward += t1 - t0;
-        trace_.add(0, t1 - t0);
-        threads_->parallelFor(L.n, [this, g0](int j) { buildCandidates(g0 + j); });
-        const double tc = nowMs();
-        trace_.add(1, tc - t1);
-        int rc = L.pool.expandBackupStaged(az ? -1 : sim_pre_);
-        if (rc) { return rc; }
-        const double te = nowMs();
-        trace_.add(2, te - tc);
+        double t1 = t0, te = t0;
+        int rc = MZ_OK;
+        if (!resident_) { // resident: candidates + expand + backup were queued on the device right behind the heads (phase2Resident)
+            if (use_signal_) { int rcw = L.pool.waitSignal(L.signal_seq); if (rcw) { return rcw; } }
+            else { MZ_HIP(hipStreamSynchronize(L.stream)); } // network outputs of this lane
+            t1 = nowMs();
+            stats_.ms_forward += t1 - t0;
+            trace_.add(0, t1 - t0);
+            threads_->parallelFor(L.n, [this, g0](int j) { buildCandidates(g0 + j); });
+            const double tc = nowMs();
+            trace_.add(1, tc - t1);
+            rc = L.pool.expandBackupStaged(az ? -1 : sim_pre_);
+            if (rc) { return rc; }
+            te = nowMs();
+            trace_.add(2, te - tc);
+        }
         const bool want_noise = root_expansion && (cfg_.actor_use_dirichlet_noise || cfg_.actor_use_gumbel_noise);
         if (done || cfg_.actor_use_gumbel || want_noise) {
             // root statistics for the per-move host logic (sync point; also surfaces pool capacity errors)
@@ -901,6 +936,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done)
             std::vector<int> rp(L.n);
             for (int j = 0; j < L.n; ++j) { rp[j] = rootPlayerFor(games_[g0 + j]); }
             if ((rc = L.pool.resetSearch(nullptr, rp.data()))) { return rc; }
+            if (resident_ && (rc = uploadRoots(L))) { return rc; }
         }
         t0 = nowMs();
         stats_.ms_move += t0 - t2;
@@ -925,8 +961,14 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done)
         MZ_HIP(hipMemcpyAsync(L.pool.d_start_.p, L.pool.h_start_.p, L.n * sizeof(int), hipMemcpyHostToDevice, L.stream));
         d_start = L.pool.d_start_.p;
     }
+    if (resident_) { for (int g = g0; g < g1; ++g) { rotPackSet(L.rot, g - g0, games_[g].rot); } }
     int rc = L.pool.selectAsync(d_start);
     if (rc) { return rc; }
+    if (resident_) {
+        const double tz = nowMs();
+        stats_.ms_select += tz - t0;
+        return MZ_OK;
+    }
     if (!(cfg_.mz_zero_copy & 2)) {
         // one D2H: [path_len n] (+ [path_action n*max_depth] for AlphaZero, whose leaves need the moves for the replay)
         MZ_HIP(hipMemcpyAsync(L.pool.h_path_arena_.p, L.pool.d_path_arena_.p,
@@ -940,8 +982,29 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done)
 }
 
 // phase 2 of a lane: leaf positions + feature planes on the host, then the network (asynchronously).
+// device-resident cycle: leaf position + planes + legal mask, network, candidate lists, expand + backup — all queued, no host hop
+int Worker::phase2Resident(Lane& L)
+{
+    const double t0 = nowMs();
+    const int slot = sims_done_; // position slot of this simulation's leaf (slot 0 = the root)
+    int rc;
+    if ((rc = L.godev.leafAsync(L.pool.v_, L.rot, slot))) { return rc; }
+    if ((rc = L.net.forwardAZ(reinterpret_cast<const float*>(L.godev.v_.feat), L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, true))) { return rc; }
+    if ((rc = L.godev.candAsync(L.pool, L.d_policy.p, L.d_logit.p, L.d_value.p, L.rot))) { return rc; }
+    if ((rc = L.pool.expandBackupAsync(slot, false))) { return rc; }
+    // bound the host's run-ahead (kernel-argument ring, launch queue): a completion word every 32 cycles, wait for the one before
+    if (++L.cycles_since_signal >= 32) {
+        L.cycles_since_signal = 0;
+        if (L.signal_seq > 0 && (rc = L.pool.waitSignal(L.signal_seq))) { return rc; }
+        if ((rc = L.pool.signalAsync(++L.signal_seq))) { return rc; }
+    }
+    stats_.ms_forward += nowMs() - t0;
+    return MZ_OK;
+}
+
 int Worker::phase2(Lane& L)
 {
+    if (resident_) { return phase2Resident(L); }
     const bool az = desc_.type == 0;
     const int g0 = L.g0;
     const double t0 = nowMs();
@@ -1021,6 +1084,15 @@ int Worker::runCycles(int n)
     for (int i = 0; i < n; ++i) {
         int rc = cycle();
         if (rc) { return rc; }
+    }
+    if (resident_) { // the cycles above were only queued: the call returns when they have run
+        const double t0 = nowMs();
+        for (auto& L : lanes_) {
+            MZ_HIP(hipStreamSynchronize(L->stream));
+            int rc = L->pool.checkError();
+            if (rc) { return rc; }
+        }
+        stats_.ms_total += nowMs() - t0;
     }
     return n;
 }
@@ -1146,6 +1218,59 @@ int mz_env_features(const mz_env* e, int rotation, float* out)
 {
     if (rotation < 0 || rotation > 7) { mz::setError("rotation %d out of range", rotation); return MZ_ERR_ARG; }
     e->e->features(rotation, out);
+    return MZ_OK;
+}
+
+int mz_env_feature_bits(const mz_env* e, int rotation, uint32_t* out)
+{
+    if (rotation < 0 || rotation > 7) { mz::setError("rotation %d out of range", rotation); return MZ_ERR_ARG; }
+    e->e->featureBits(rotation, out);
+    return MZ_OK;
+}
+
+int mz_sort_candidates(int device, const float* policy, int n, int* order_out) { return mz::sortCandidatesOnDevice(device, policy, n, order_out); }
+
+int mz_godev_playout(int device, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots, uint32_t* feat_out,
+                     uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out)
+{
+    using namespace mz;
+    if (mz_device_count() < 1) { setError("mz_godev_playout: no GPU (libmzgpu has no CPU path)"); return MZ_ERR_DEVICE; }
+    if (!actions || !rots || count < 0 || root_prefix < 0 || root_prefix > count) { setError("mz_godev_playout: bad arguments"); return MZ_ERR_ARG; }
+    std::unique_ptr<GameEnv> env = createGameEnv("go", board_size, komi);
+    if (!env || !env->hasDeviceTwin()) { setError("mz_godev_playout: no device twin for this board"); return MZ_ERR_ARG; }
+    for (int i = 0; i < root_prefix; ++i) {
+        if (!env->act(actions[i], env->turn())) { setError("mz_godev_playout: illegal root action %d at move %d", actions[i], i); return MZ_ERR_ARG; }
+    }
+    const int steps = count - root_prefix + 1, A = env->policySize(), md = steps + 1;
+    const int* inv[8];
+    const int* fwd[8];
+    for (int r = 0; r < 8; ++r) { inv[r] = env->rot()->inv[r].data(); fwd[r] = env->rot()->fwd[r].data(); }
+    GoDevice gd;
+    int rc = gd.init(device, 1, env->boardSize(), komi, A, steps, md, nullptr, inv, fwd, env->zobristKeys());
+    if (rc) { return rc; }
+    env->exportDeviceRoot(gd.hostSnap(0));
+    if ((rc = gd.uploadRoots())) { return rc; }
+    // a one-game "tree" that is a single chain: node d = the position after d device moves, kept in slot d
+    DevBuf<int> d_i;
+    if (!d_i.alloc(size_t(1) + 3 * md)) { setError("mz_godev_playout: allocation failed"); return MZ_ERR_DEVICE; }
+    std::vector<int> h(size_t(1) + 3 * md, 0);
+    for (int d = 0; d < md; ++d) {
+        h[1 + d] = d;                                                                  // path
+        h[1 + md + d] = (d >= 1 && root_prefix + d - 1 < count) ? actions[root_prefix + d - 1] : -1; // path_action
+        h[1 + 2 * md + d] = d;                                                         // hslot
+    }
+    PoolView pv{};
+    pv.games = 1; pv.cap = md; pv.A = A; pv.max_depth = md;
+    pv.path_len = d_i.p; pv.path = d_i.p + 1; pv.path_action = d_i.p + 1 + md; pv.hslot = d_i.p + 1 + 2 * md;
+    const int W32 = (env->boardSize() * env->boardSize() + 31) / 32;
+    for (int d = 0; d < steps; ++d) {
+        h[0] = d + 1;
+        MZ_HIP(hipMemcpy(d_i.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+        RotPack rp{};
+        rotPackSet(rp, 0, rots[d] & 7);
+        if ((rc = gd.leafAsync(pv, rp, d))) { return rc; }
+        if ((rc = gd.readLeaf(feat_out + size_t(d) * 18 * W32, legal_out + size_t(d) * A, terminal_out + d, eval_out + d, player_out + d))) { return rc; }
+    }
     return MZ_OK;
 }
 

@@ -135,6 +135,9 @@ def load():
         L.mz_env_eval_score.argtypes = [vp, C.c_int]
         L.mz_env_legal_mask.argtypes = [vp, u8p]
         L.mz_env_features.argtypes = [vp, C.c_int, fp]
+        L.mz_env_feature_bits.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
+        L.mz_godev_playout.argtypes = [C.c_int, C.c_int, C.c_float, ip, C.c_int, C.c_int, ip, C.POINTER(C.c_uint32), u8p, ip, fp, ip]
+        L.mz_sort_candidates.argtypes = [C.c_int, fp, C.c_int, ip]
     _LIB = L
     return L
 
@@ -398,3 +401,37 @@ class Env:
         f = np.empty(self.L.mz_env_feature_size(self.h), np.float32)
         self.L.mz_env_features(self.h, rot, _f(f))
         return f
+
+    def feature_bits(self, rot, channels, points):
+        w = np.zeros(channels * ((points + 31) // 32), np.uint32)
+        _check(self.L, self.L.mz_env_feature_bits(self.h, rot, w.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return w
+
+
+def godev_playout(board_size, komi, actions, root_prefix, rots, device=0):
+    """Device Go engine: root = actions[:root_prefix] on the host engine, then one device move per remaining action.
+    Returns (feat_bits [steps][18*W32], legal [steps][A], terminal [steps], eval [steps], player [steps])."""
+    L = load()
+    P = board_size * board_size
+    acts = np.ascontiguousarray(actions, np.int32)
+    steps = len(acts) - root_prefix + 1
+    rots = np.ascontiguousarray(rots, np.int32)
+    assert len(rots) >= steps
+    W32 = (P + 31) // 32
+    feat = np.zeros((steps, 18 * W32), np.uint32)
+    legal = np.zeros((steps, P + 1), np.uint8)
+    term = np.zeros(steps, np.int32)
+    ev = np.zeros(steps, np.float32)
+    pl = np.zeros(steps, np.int32)
+    _check(L, L.mz_godev_playout(device, board_size, komi, _i(acts), len(acts), root_prefix, _i(rots), feat.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                 legal.ctypes.data_as(C.POINTER(C.c_uint8)), _i(term), _f(ev), _i(pl)))
+    return feat, legal, term, ev, pl
+
+
+def sort_candidates(policy, device=0):
+    """Order of candidates under the reference's std::sort(policy descending), computed by the device path."""
+    L = load()
+    p = np.ascontiguousarray(policy, np.float32)
+    order = np.zeros(len(p), np.int32)
+    _check(L, L.mz_sort_candidates(device, _f(p), len(p), _i(order)))
+    return order

@@ -1,0 +1,103 @@
+"""GPU tests of the device-resident Go leaf environment (go_dev.hip) and the device candidate sort.
+
+The device engine (one position slot per tree node: leaf = parent slot + one move, labels / liberties / superko set kept
+incrementally) is played move by move next to the host engine (env.cpp, itself differential-tested against the oracle's
+restatement of the reference in tests/test_env_parity.py): after every move the legal mask, the bit-packed feature planes
+under a random rotation, the terminal flag, the Tromp-Taylor result and the player to move must be identical (bit-exact:
+integer / bit work).  Small boards make captures, ko and positional-superko repeats frequent; 8x8 has P = 64 (the pass bit
+starts a new mask word); 19x19 is the maximum size."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _play_and_compare(mz, n, komi, seed, max_moves, pass_prob, root_prefix_frac):
+    rng = np.random.default_rng(seed)
+    conf = f"env_game=go:env_board_size={n}:env_go_komi={komi}"
+    P = n * n
+    env = mz.Env(conf)
+    actions = []
+    while not env.is_terminal() and len(actions) < max_moves:
+        legal = np.nonzero(env.legal_mask())[0]
+        board = legal[legal != P]
+        if len(board) == 0 or rng.random() < pass_prob:
+            a = P
+        else:
+            a = int(rng.choice(board))
+        assert env.act(a)
+        actions.append(a)
+    root_prefix = int(len(actions) * root_prefix_frac)
+    steps = len(actions) - root_prefix + 1
+    rots = rng.integers(0, 8, steps).astype(np.int32)
+    feat, legal, term, ev, pl = mz.godev_playout(n, komi, actions, root_prefix, rots)
+    ref = mz.Env(conf)
+    for a in actions[:root_prefix]:
+        assert ref.act(a)
+    captures = 0
+    for d in range(steps):
+        where = f"board {n} seed {seed} step {d} (root_prefix {root_prefix}) actions {actions[:root_prefix + d]}"
+        assert pl[d] == ref.turn(), where
+        assert bool(term[d]) == ref.is_terminal(), where
+        if ref.is_terminal():
+            assert ev[d] == ref.eval_score(), where
+        else:
+            assert np.array_equal(legal[d], ref.legal_mask()), where
+        assert np.array_equal(feat[d], ref.feature_bits(int(rots[d]), 18, P)), where
+        if d + 1 < steps:
+            assert ref.act(actions[root_prefix + d]), where
+    return len(actions), captures
+
+
+@pytest.mark.parametrize("n,games,max_moves", [(5, 40, 120), (7, 12, 200), (9, 10, 170), (8, 6, 140), (13, 3, 300), (19, 2, 500), (3, 20, 40)])
+def test_device_engine_matches_host_engine(mz, n, games, max_moves):
+    total = 0
+    for g in range(games):
+        moves, _ = _play_and_compare(mz, n, 7.0 if g % 2 == 0 else 6.5, 1000 * n + g, max_moves, pass_prob=0.03 if g % 3 else 0.15,
+                                     root_prefix_frac=[0.0, 0.3, 0.7][g % 3])
+        total += moves
+    assert total > games * 5
+
+
+def test_device_engine_long_9x9_game_to_the_move_cap(mz):
+    # no passes: runs into the 2 * 81 move cap (ref go.cpp:253-254), root at the start: every position comes from the device
+    moves, _ = _play_and_compare(mz, 9, 7.0, 77, 400, pass_prob=0.0, root_prefix_frac=0.0)
+    assert moves >= 100
+
+
+@pytest.fixture(scope="module")
+def ref_sort(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("refsort") / "libref_sort.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "csrc", "ref_sort.cpp")], check=True, timeout=120)
+    lib = ctypes.CDLL(so)
+    lib.ref_sort.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+
+    def run(policy):
+        p = np.ascontiguousarray(policy, np.float32)
+        out = np.zeros(len(p), np.int32)
+        lib.ref_sort(p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(p), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        return out
+    return run
+
+
+def test_device_candidate_sort_is_libstdcxx_sort(mz, ref_sort):
+    """The candidate order feeds child order -> PUCT tie-breaks and the ordered init-Q sum: with tied policies only the exact
+    introsort of libstdc++ reproduces the reference (ref zero_actor.cpp:225-227)."""
+    rng = np.random.default_rng(5)
+    cases = 0
+    for it in range(160):
+        n = int(rng.integers(1, 83)) if it % 5 else int(rng.integers(83, 363))
+        levels = int(rng.integers(1, 4)) if it % 2 else int(rng.integers(4, 2000))
+        p = (rng.integers(0, levels, n) / levels).astype(np.float32)
+        if it % 7 == 0:
+            p = np.sort(p)
+        if it % 9 == 0:
+            p = rng.random(n).astype(np.float32)  # no ties: the rank path
+        assert np.array_equal(mz.sort_candidates(p), ref_sort(p)), f"case {it}: n={n} levels={levels}"
+        cases += 1
+    assert cases == 160
