@@ -134,26 +134,35 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     for (int j = 0; j < PTW; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
     const float* wl = wp + size_t(ot) * 64 + lane;
     const size_t wstep = size_t(OT) * 64;
-    float a_cur[CG], a_nxt[CG];
+    // A-fragments are double-buffered by TAP in two register sets; the loop is unrolled by two taps so that no register copies
+    // tie the prefetch to the end of an iteration, and the fences keep the scheduler from sinking the global loads below the tap's
+    // MFMAs (it did: every tap paid an exposed L2 round trip) or hoisting all nine taps' loads (256 VGPRs + spills)
+    float a0[CG], a1[CG];
+    auto loadA = [&](float* a, int t) {
 #pragma unroll
-    for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = wl[size_t(cg) * wstep]; }
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-        const int tn = t < 8 ? t + 1 : 8;
-#pragma unroll
-        for (int cg = 0; cg < CG; ++cg) { a_nxt[cg] = wl[(size_t(tn) * CG + cg) * wstep]; }
+        for (int cg = 0; cg < CG; ++cg) { a[cg] = wl[(size_t(t) * CG + cg) * wstep]; }
+        asm volatile("" ::: "memory");
+    };
+    auto tap = [&](const float* a, int t) {
         const int tapoff = (t / 3) * PW + (t % 3);
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
 #pragma unroll
             for (int j = 0; j < PTW; ++j) {
                 float bv = tin[pixoff[j] + cg * 4 * CS + tapoff];
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[cg], bv, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg], bv, acc[j], 0, 0, 0);
             }
         }
+    };
+    loadA(a0, 0);
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = a_nxt[cg]; }
+    for (int t = 0; t < 8; t += 2) { // fully unrolled: s_waitcnt counts are exact only in straight-line code (a loop-carried prefetch gets vmcnt(0))
+        loadA(a1, t + 1);
+        tap(a0, t);
+        loadA(a0, t + 2);
+        tap(a1, t + 1);
     }
+    tap(a0, 8);
 #pragma unroll
     for (int j = 0; j < PTW; ++j) {
         const int pt = half * PTW + j;

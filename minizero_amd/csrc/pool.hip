@@ -52,6 +52,16 @@ __device__ __forceinline__ bool better(float s1, float p1, int i1, float s2, flo
     return (s1 > s2) || (s1 == s2 && (p1 > p2 || (p1 == p2 && i1 < i2)));
 }
 
+// one step of a DPP reduction with the PUCT order: lanes without a source lane (row edge / masked row) keep their own triple
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dppBest(float& rs, float& rp, int& ri)
+{
+    const float s2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(rs), __float_as_int(rs), CTRL, ROW_MASK, 0xF, false));
+    const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(rp), __float_as_int(rp), CTRL, ROW_MASK, 0xF, false));
+    const int i2 = __builtin_amdgcn_update_dpp(ri, ri, CTRL, ROW_MASK, 0xF, false);
+    if (better(s2, p2, i2, rs, rp, ri)) { rs = s2; rp = p2; ri = i2; }
+}
+
 __device__ __forceinline__ NodeRec loadRec(const NodeRec* p)
 {
     const float4 a = reinterpret_cast<const float4*>(p)[0];
@@ -61,6 +71,11 @@ __device__ __forceinline__ NodeRec loadRec(const NodeRec* p)
     n.first_child = b.x; n.num_children = b.y; n.action = b.z; n.players = b.w;
     return n;
 }
+
+// value of a wave-uniform lane: v_readlane_b32 (a few cycles) instead of the ds_bpermute_b32 that __shfl turns into (an LDS round
+// trip, ~100 cycles: the ordered init-Q sum walks up to A visited children one by one)
+__device__ __forceinline__ int laneI(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float laneF(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 // One wave64 per game.  Per level: every lane loads the 32-B records of its children (<= 2 per lane for A <= 128, a loop
 // beyond), all arithmetic runs from registers, and the winning lane's record supplies the next level's (first_child,
@@ -101,11 +116,11 @@ __global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __res
             const bool vis0 = has0 && c0.count != 0.0f;
             if (vis0) { q0 = normalizedMean(v, c0.reward, c0.mean, c0.count, cplayer, bsize, lo, hi); }
             unsigned long long m = __ballot(vis0);
-            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += __shfl(q0, j); sum += 1; }
+            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += laneF(q0, j); sum += 1; }
             const bool vis1 = has1 && c1.count != 0.0f;
             if (vis1) { q1 = normalizedMean(v, c1.reward, c1.mean, c1.count, cplayer, bsize, lo, hi); }
             m = __ballot(vis1);
-            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += __shfl(q1, j); sum += 1; }
+            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += laneF(q1, j); sum += 1; }
         }
         for (int cb = 128; cb < nc; cb += 64) { // wide nodes (A > 128): remaining chunks straight from memory
             const int i = cb + lane;
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __res
                 if (vis) { q = normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi); }
             }
             unsigned long long m = __ballot(vis);
-            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += __shfl(q, j); sum += 1; }
+            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += laneF(q, j); sum += 1; }
         }
         const float init_q = v.atari_init_q ? (sum > 0 ? sum_of_win / sum : 1.0f) : (sum_of_win - 1) / (sum + 1);
         // ---- pass 2: PUCT score + arg-max (ref mcts.cpp:55-61,181-198) ----
@@ -141,20 +156,23 @@ __global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __res
                 consider(c, q, i);
             }
         }
+        // wave arg-max on the DPP network (row_shr 1/2/4/8, row_bcast 15/31: lane 63 ends up with the best triple) — no LDS traffic
         float rs = bs, rp = bp;
         int ri = bi;
-        for (int o = 32; o > 0; o >>= 1) {
-            const float s2 = __shfl_xor(rs, o), p2 = __shfl_xor(rp, o);
-            const int i2 = __shfl_xor(ri, o);
-            if (better(s2, p2, i2, rs, rp, ri)) { rs = s2; rp = p2; ri = i2; }
-        }
+        dppBest<0x111, 0xF>(rs, rp, ri);
+        dppBest<0x112, 0xF>(rs, rp, ri);
+        dppBest<0x114, 0xF>(rs, rp, ri);
+        dppBest<0x118, 0xF>(rs, rp, ri);
+        dppBest<0x142, 0xA>(rs, rp, ri);
+        dppBest<0x143, 0xC>(rs, rp, ri);
+        ri = laneI(ri, 63);
         // the lane that holds the winner broadcasts its record: that is the next level's header
         const int owner = __builtin_ctzll(__ballot(bi == ri));
-        cur.count = __shfl(best.count, owner);
-        cur.first_child = __shfl(best.first_child, owner);
-        cur.num_children = __shfl(best.num_children, owner);
-        cur.action = __shfl(best.action, owner);
-        cur.players = __shfl(best.players, owner);
+        cur.count = laneF(best.count, owner);
+        cur.first_child = laneI(best.first_child, owner);
+        cur.num_children = laneI(best.num_children, owner);
+        cur.action = laneI(best.action, owner);
+        cur.players = laneI(best.players, owner);
         node = fc + ri;
         if (lane == 0) {
             path[depth] = node;
@@ -209,7 +227,43 @@ __global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int
         }
     }
     if (lane == 0 && hslot >= 0) { v.hslot[base + leaf] = hslot; }
-    // ---- backup (ref mcts.cpp:166-179): a serial leaf -> root dependence chain, done by lane 0 ----
+    // ---- backup (ref mcts.cpp:166-179) ----
+    if (!v.value_rescale) {
+        // The only leaf -> root dependence is `updated = r + gamma * updated`, which needs the rewards but not the means: the
+        // path's records are loaded by 64 lanes at once (one memory round trip per 64 levels instead of one per level — the
+        // deepest of the 256 paths sets the kernel time), the chain runs over registers, then every lane updates its own node.
+        const float val = value_in[g], rew = reward_in[g];
+        if (lane == 0) {
+            v.value[base + leaf] = val;
+            v.rec[base + leaf].reward = rew;
+        }
+        float updated = val;
+        for (int kb = 0; kb < len; kb += 64) {
+            const int k = kb + lane; // k-th node from the leaf
+            const bool act = k < len;
+            NodeRec* n = v.rec + base + (act ? path[len - 1 - k] : 0);
+            float mean = 0.0f, cnt = 0.0f, r = 0.0f;
+            if (act) {
+                mean = n->mean;
+                cnt = n->count;
+                r = (k == 0) ? rew : n->reward;
+            }
+            float mine = 0.0f;
+            const int m = len - kb < 64 ? len - kb : 64;
+            for (int j = 0; j < m; ++j) {
+                if (lane == j) { mine = updated; }
+                updated = laneF(r, j) + v.gamma * updated;
+            }
+            if (act) { // MCTSNode::add(value, 1.0f) (ref mcts.cpp:20-28)
+                cnt += 1.0f;
+                mean += 1.0f * (mine - mean) / cnt;
+                n->mean = mean;
+                n->count = cnt;
+            }
+        }
+        return;
+    }
+    // with value rescaling the value-bound multiset is updated node by node: a serial chain, done by lane 0
     if (lane != 0) { return; }
     int bsize = 0;
     float* bkey = lds;                                     // value-bound multiset, LDS copy (lane 0 only)
