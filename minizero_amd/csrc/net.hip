@@ -140,7 +140,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     float a0[CG], a1[CG];
     auto loadA = [&](float* a, int t) {
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg) { a[cg] = wl[(size_t(t) * CG + cg) * wstep]; }
+        for (int cg = 0; cg < CG; ++cg) { a[cg] = __builtin_nontemporal_load(&wl[(size_t(t) * CG + cg) * wstep]); } // streaming: keep the L2 for the search tree
         asm volatile("" ::: "memory");
     };
     auto tap = [&](const float* a, int t) {
@@ -174,7 +174,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
                 float v = acc[j][r] + bias[oc];
                 if (tskip) { v = v + tskip[oc * CS + pixdst[j]]; }
                 v = v > 0.0f ? v : 0.0f;
-                if (gout) { gout[oc * P + q] = v; } else { tout[oc * CS + pixdst[j]] = v; }
+                if (gout) { __builtin_nontemporal_store(v, &gout[oc * P + q]); } else { tout[oc * CS + pixdst[j]] = v; }
             }
         }
     }
