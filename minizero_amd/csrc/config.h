@@ -56,6 +56,7 @@ struct WorkerConfig {
     int mz_cpu_base = -1;
     // not a reference key: wait for the GPU on a pinned completion word (spin) instead of hipStreamSynchronize
     bool mz_signal_wait = true;
+    bool mz_sim_kernel = true; // with mz_device_env: whole runs of cycles as one launch of the per-game simulation kernel (sim.hip)
     bool mz_device_env = true; // AlphaZero Go without Gumbel: rules, planes, legal mask and candidate sort on the device (go_dev.hip)
     int mz_zero_copy = 3; // bit 0: kernels read their inputs from pinned host memory; bit 1: kernels write their outputs there
 

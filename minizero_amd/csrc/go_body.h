@@ -1,0 +1,427 @@
+// Device bodies of the device-resident Go leaf environment (see go_dev.h), shared by the stand-alone kernels (go_dev.hip) and the
+// per-game simulation kernel (sim.hip).  Each body is run by ONE wave64 for game `g`; waveSync() orders its LDS traffic.
+#pragma once
+#include "go_dev.h"
+#include "sort_emul.h"
+
+namespace mz {
+
+// single-wave phases: make the wave's LDS / global writes visible to its other lanes (no s_barrier: the other waves of a
+// 512-thread workgroup are parked at a real barrier while wave 0 runs the tree phases of the simulation kernel)
+__device__ __forceinline__ void waveSync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+inline size_t goLeafSmemBytes(const GoDevView& v, int max_depth) { return sizeof(uint64_t) * (size_t(v.Ppad) + max_depth + 18 * v.W) + size_t(v.Ppad) * (4 + 2 + 1); }
+
+struct Cand { int action; float policy, logit; };
+struct CandGreater { __host__ __device__ bool operator()(const Cand& l, const Cand& r) const { return l.policy > r.policy; } };
+using CandSort = StdSortEmul<Cand, CandGreater>;
+constexpr size_t kSortStackBytes = 3 * CandSort::kStack * sizeof(int);
+inline size_t azCandSmemBytes(int A) { return 2 * size_t(A) * sizeof(Cand) + kSortStackBytes + 16; }
+
+__device__ inline uint64_t shflXor64(uint64_t v, int o)
+{
+    const unsigned lo = __shfl_xor(static_cast<unsigned>(v), o), hi = __shfl_xor(static_cast<unsigned>(v >> 32), o);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+__device__ inline uint64_t waveXor64(uint64_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) { v ^= shflXor64(v, o); }
+    return v;
+}
+__device__ inline uint64_t normH(uint64_t h) { return h ? h : 1; }
+__device__ inline int rotOf(const RotPack& r, int g) { return (r.w[g / 10] >> (3 * (g % 10))) & 7; }
+
+// position + legal mask + feature planes of the leaf selected for game `g` (one wave64; `smem` as sized by goLeafSmemBytes)
+template <int CPL>
+__device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& pv, int rot, int slot, int g, int lane, uint64_t* __restrict__ smem)
+{
+    const int P = v.P, n = v.n, W = v.W, Ppad = v.Ppad, MD = pv.max_depth;
+    uint64_t* gh = smem;                                   // [Ppad] XOR of the keys of a group, by group id
+    uint64_t* ph = gh + Ppad;                              // [MD]   (normalised) hashes of the positions along the path
+    uint64_t* hb = ph + MD;                                // [8][2][W] stones k moves before the leaf
+    uint64_t* cur = hb + 16 * W;                           // [2][W] stones at the leaf
+    int* libs = reinterpret_cast<int*>(cur + 2 * W);       // [Ppad] liberties of a group, by group id
+    uint16_t* lab = reinterpret_cast<uint16_t*>(libs + Ppad); // [Ppad] group id per point
+    uint8_t* col = reinterpret_cast<uint8_t*>(lab + Ppad);  // [Ppad] 0 empty, 1 black, 2 white, 3 off board
+
+    const int len = pv.path_len[g];
+    const int* path = pv.path + size_t(g) * MD;
+    const int* pact = pv.path_action + size_t(g) * MD;
+    const int depth = len - 1;
+    const GoRootSnapshot& S = v.snap[g];
+    const int root_turn = S.turn, root_hist_len = S.hist_len;
+    const size_t sb = size_t(g) * v.slots;
+    const int* hs = pv.hslot + size_t(g) * pv.cap;
+    const int src = depth == 0 ? 0 : hs[path[len - 2]];
+
+    int c[CPL], l[CPL];
+    short nb[CPL][4];
+    uint64_t sbw[CPL], sww[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int p = i * 64 + lane;
+        sbw[i] = v.stones[((sb + src) * 2 + 0) * W + i];
+        sww[i] = v.stones[((sb + src) * 2 + 1) * W + i];
+        c[i] = 3;
+        l[i] = 0;
+        nb[i][0] = nb[i][1] = nb[i][2] = nb[i][3] = -1;
+        if (p < P) {
+            c[i] = ((sbw[i] >> lane) & 1) ? 1 : (((sww[i] >> lane) & 1) ? 2 : 0);
+            l[i] = v.lab[(sb + src) * Ppad + p];
+            const int x = p % n, y = p / n;
+            if (y + 1 < n) { nb[i][0] = static_cast<short>(p + n); }
+            if (x + 1 < n) { nb[i][1] = static_cast<short>(p + 1); }
+            if (y > 0) { nb[i][2] = static_cast<short>(p - n); }
+            if (x > 0) { nb[i][3] = static_cast<short>(p - 1); }
+        }
+        col[p] = static_cast<uint8_t>(c[i]);
+        lab[p] = static_cast<uint16_t>(l[i]);
+    }
+    uint64_t hash = v.hash[sb + src];
+    int nmoves = v.meta[(sb + src) * 2], passes = v.meta[(sb + src) * 2 + 1];
+    waveSync();
+    const int t = (depth & 1) ? 3 - root_turn : root_turn; // the player to move at the leaf
+
+    if (depth >= 1) { // leaf = parent + one move (ref go.cpp:132-190, observable effects only)
+        const int a = pact[len - 1], m = 3 - t;
+        ++nmoves;
+        if (a >= P) {
+            passes = passes + 1 > 2 ? 2 : passes + 1;
+        } else {
+            passes = 0;
+            const int ax = a % n, ay = a / n;
+            const int an[4] = {ay + 1 < n ? a + n : -1, ax + 1 < n ? a + 1 : -1, ay > 0 ? a - n : -1, ax > 0 ? a - 1 : -1};
+            int own[4], en[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                own[k] = -1;
+                en[k] = -1;
+                if (an[k] >= 0) {
+                    const int cq = col[an[k]];
+                    if (cq == m) { own[k] = lab[an[k]]; }
+                    else if (cq == 3 - m) { en[k] = lab[an[k]]; }
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                for (int j = 0; j < k; ++j) { if (en[j] == en[k]) { en[k] = -1; } }
+            }
+            waveSync();
+            // place the stone; the own groups it touches become one group whose id is the new point (unused as an id: it was empty)
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int p = i * 64 + lane;
+                if (p == a) { c[i] = m; l[i] = a; }
+                else if (c[i] == m && (l[i] == own[0] || l[i] == own[1] || l[i] == own[2] || l[i] == own[3])) { l[i] = a; }
+                col[p] = static_cast<uint8_t>(c[i]);
+                lab[p] = static_cast<uint16_t>(l[i]);
+            }
+            waveSync();
+            // which of the adjacent enemy groups still have a liberty
+            unsigned flags = 0;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                if (c[i] != 0) { continue; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = nb[i][k];
+                    if (q >= 0 && col[q] == 3 - m) {
+                        const int lq = lab[q];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { if (lq == en[j]) { flags |= 1u << j; } }
+                    }
+                }
+            }
+            bool cap[4], any_cap = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cap[j] = en[j] >= 0 && __ballot((flags >> j) & 1) == 0;
+                any_cap |= cap[j];
+            }
+            uint64_t hx = 0;
+            if (any_cap) {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    const int p = i * 64 + lane;
+                    if (c[i] == 3 - m && ((cap[0] && l[i] == en[0]) || (cap[1] && l[i] == en[1]) || (cap[2] && l[i] == en[2]) || (cap[3] && l[i] == en[3]))) {
+                        c[i] = 0;
+                        col[p] = 0;
+                        hx ^= v.key[size_t(2 - m) * P + p];
+                    }
+                }
+                hx = waveXor64(hx);
+            }
+            hash ^= v.key[size_t(m - 1) * P + a] ^ hx;
+            waveSync();
+        }
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int p = i * 64 + lane;
+            sbw[i] = __ballot(c[i] == 1);
+            sww[i] = __ballot(c[i] == 2);
+            if (lane == 0) {
+                v.stones[((sb + slot) * 2 + 0) * W + i] = sbw[i];
+                v.stones[((sb + slot) * 2 + 1) * W + i] = sww[i];
+            }
+            if (p < P) { v.lab[(sb + slot) * Ppad + p] = static_cast<uint16_t>(l[i]); }
+        }
+        if (lane == 0) {
+            v.hash[sb + slot] = hash;
+            v.meta[(sb + slot) * 2] = nmoves;
+            v.meta[(sb + slot) * 2 + 1] = passes;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        if (lane == 0) { cur[i] = sbw[i]; cur[W + i] = sww[i]; }
+    }
+    const bool terminal = passes >= 2 || nmoves > 2 * P; // ref go.cpp:246-257
+    // ---- hashes along the path (d = 1 .. depth; the root and everything before it is in the root's table) ----
+    for (int d = 1 + lane; d <= depth; d += 64) { ph[d - 1] = normH(d == depth ? hash : v.hash[sb + hs[path[d]]]); }
+    // ---- group liberties / key sums at the leaf ----
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { libs[i * 64 + lane] = 0; gh[i * 64 + lane] = 0; }
+    waveSync();
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        if (c[i] != 0) { continue; }
+        int seen_l[4], ns = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = nb[i][k];
+            if (q < 0 || col[q] == 0) { continue; }
+            const int lq = lab[q];
+            bool dup = false;
+            for (int j = 0; j < ns; ++j) { dup |= seen_l[j] == lq; }
+            if (!dup) { seen_l[ns++] = lq; atomicAdd(&libs[lq], 1); }
+        }
+    }
+    waveSync();
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int p = i * 64 + lane;
+        if (c[i] == 3 - t && libs[l[i]] == 1) { atomicXor(reinterpret_cast<unsigned long long*>(&gh[l[i]]), static_cast<unsigned long long>(v.key[size_t(2 - t) * P + p])); }
+    }
+    waveSync();
+    // ---- legal mask for the player to move (ref go.cpp:208-244): not occupied, not suicide, not a positional-superko repeat ----
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        bool bit = false;
+        if (c[i] == 0 && !terminal) {
+            const int p = i * 64 + lane;
+            bool ok = false;
+            uint64_t nh = hash ^ v.key[size_t(t - 1) * P + p];
+            int capl[4], ncap = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = nb[i][k];
+                if (q < 0) { continue; }
+                const int cq = col[q];
+                if (cq == 0) { ok = true; continue; }
+                const int lq = lab[q];
+                if (cq == t) {
+                    if (libs[lq] > 1) { ok = true; }
+                } else if (libs[lq] == 1) { // an enemy group in atari is captured: each group once
+                    bool dup = false;
+                    for (int j = 0; j < ncap; ++j) { dup |= capl[j] == lq; }
+                    if (!dup) { capl[ncap++] = lq; nh ^= gh[lq]; }
+                    ok = true;
+                }
+            }
+            if (ok) {
+                const uint64_t h = normH(nh);
+                bool rep = false;
+                for (uint32_t s = static_cast<uint32_t>(h) & (kGoSeenCap - 1);; s = (s + 1) & (kGoSeenCap - 1)) {
+                    const uint64_t e = S.seen[s];
+                    if (e == 0) { break; }
+                    if (e == h) { rep = true; break; }
+                }
+                for (int d = 0; d < depth && !rep; ++d) { rep = ph[d] == h; }
+                bit = !rep;
+            }
+        }
+        uint64_t w = __ballot(bit);
+        if (i == (P >> 6)) { w |= 1ull << (P & 63); } // pass is always legal
+        if (lane == 0) { v.legal[size_t(g) * v.LW + i] = w; }
+    }
+    if (v.LW > CPL && lane == 0) { v.legal[size_t(g) * v.LW + CPL] = (P >> 6) == CPL ? 1ull << (P & 63) : 0; } // P a multiple of 64
+    // ---- feature planes (ref go.cpp:280-308): planes 2k / 2k+1 = own / opponent stones k moves ago, 16 / 17 = black / white to move ----
+    const int avail = root_hist_len + depth;
+    for (int idx = lane; idx < 16 * W; idx += 64) {
+        const int k = idx / (2 * W), cw = idx % (2 * W);
+        uint64_t val = 0;
+        if (k < avail) {
+            if (k == 0) { val = cur[cw]; }
+            else if (k < depth) { val = v.stones[(sb + hs[path[len - 1 - k]]) * 2 * W + cw]; }
+            else { val = S.hist[(root_hist_len - 1 - (k - depth)) & 7][cw / W][cw % W]; }
+        }
+        hb[idx] = val;
+    }
+    waveSync();
+    {
+        const uint16_t* map = v.inv + size_t(rot) * P;
+        uint32_t* out = v.feat + size_t(g) * 18 * v.W32;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int p = i * 64 + lane;
+            const int q = p < P ? map[p] : 0;
+            uint64_t mine = 0; // lane ch keeps plane ch's word
+            for (int ch = 0; ch < 16; ++ch) {
+                const int k = ch >> 1, color = (ch & 1) == 0 ? t - 1 : 2 - t;
+                const bool bit = p < P && ((hb[(k * 2 + color) * W + (q >> 6)] >> (q & 63)) & 1);
+                const uint64_t bal = __ballot(bit);
+                if (lane == ch) { mine = bal; }
+            }
+            const uint64_t ones = __ballot(p < P);
+            if (lane == 16) { mine = t == 1 ? ones : 0; }
+            if (lane == 17) { mine = t == 2 ? ones : 0; }
+            if (lane < 18) {
+                if (2 * i < v.W32) { out[lane * v.W32 + 2 * i] = static_cast<uint32_t>(mine); }
+                if (2 * i + 1 < v.W32) { out[lane * v.W32 + 2 * i + 1] = static_cast<uint32_t>(mine >> 32); }
+            }
+        }
+    }
+    // ---- terminal: Tromp-Taylor area score + komi (ref go.cpp:259-278,703-723) ----
+    float eval = 0.0f;
+    if (terminal) {
+        waveSync();
+        uint16_t* rl = lab; // region id of the empty points: the smallest point of the region
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int p = i * 64 + lane;
+            rl[p] = static_cast<uint16_t>(p);
+            libs[p] = 0;
+            gh[p] = 0;
+        }
+        waveSync();
+        while (true) {
+            bool changed = false;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                if (c[i] != 0) { continue; }
+                const int p = i * 64 + lane;
+                int mn = rl[p];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = nb[i][k];
+                    if (q >= 0 && col[q] == 0 && rl[q] < mn) { mn = rl[q]; }
+                }
+                if (mn < rl[p]) { rl[p] = static_cast<uint16_t>(mn); changed = true; }
+            }
+            waveSync();
+            if (__ballot(changed) == 0) { break; }
+        }
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            if (c[i] != 0) { continue; }
+            const int p = i * 64 + lane, r = rl[p];
+            atomicAdd(&libs[r], 1);
+            unsigned long long border = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = nb[i][k];
+                if (q >= 0 && (col[q] == 1 || col[q] == 2)) { border |= col[q]; }
+            }
+            if (border) { atomicOr(reinterpret_cast<unsigned long long*>(&gh[r]), border); }
+        }
+        waveSync();
+        float t1 = 0.0f, t2 = 0.0f;
+        for (int i = 0; i < W; ++i) { t1 += static_cast<float>(__popcll(cur[i])); t2 += static_cast<float>(__popcll(cur[W + i])); }
+        t2 += v.komi;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { // regions in ascending order of their first point, like the host's scan
+            const int p = i * 64 + lane;
+            uint64_t roots = __ballot(c[i] == 0 && rl[p] == p);
+            while (roots) {
+                const int r = i * 64 + __builtin_ctzll(roots);
+                roots &= roots - 1;
+                const uint64_t border = gh[r];
+                const float size = static_cast<float>(libs[r]);
+                if ((border & 2) == 0) { t1 += size; }
+                else if ((border & 1) == 0) { t2 += size; }
+            }
+        }
+        eval = t1 > t2 ? 1.0f : (t1 < t2 ? -1.0f : 0.0f);
+    }
+    if (lane == 0) {
+        v.leaf_player[g] = t;
+        v.terminal[g] = terminal ? 1 : 0;
+        v.eval[g] = eval;
+    }
+}
+
+// order `k` candidates in cs[] like the reference's std::sort(policy descending): result in out[]
+__device__ void orderCandidates(Cand* cs, Cand* out, int* stack, int k, int lane, int* err)
+{
+    bool tie = false;
+    for (int i = lane; i < k; i += 64) {
+        const float pi = cs[i].policy;
+        int rank = 0;
+        for (int j = 0; j < k; ++j) {
+            const float pj = cs[j].policy;
+            rank += (pj > pi) || (pj == pi && j < i);
+            tie |= (pj == pi && j != i);
+        }
+        out[rank] = cs[i];
+    }
+    waveSync();
+    if (k > 16 && __ballot(tie) != 0) { // ties among > 16 elements: only the exact introsort gives the reference's order
+        if (lane == 0) {
+            StdSortEmul<Cand, CandGreater> s{cs, CandGreater()};
+            if (!s.sort(k, stack) && err) { atomicExch(err, MZ_ERR_CAPACITY); }
+        }
+        waveSync();
+        for (int i = lane; i < k; i += 64) { out[i] = cs[i]; }
+        waveSync();
+    }
+}
+
+// AlphaZero candidates of a leaf (ref zero_actor.cpp:215-245): legal actions in action order, policy / logit looked up through
+// the rotation, sorted by policy; a terminal leaf has no children and its value is the game result (zero_actor.cpp:85)
+__device__ __forceinline__ void azCandBody(const GoDevView& v, const float* __restrict__ policy, const float* __restrict__ logit,
+                                           const float* __restrict__ value, int rot, int* __restrict__ cand_count, int* __restrict__ cand_action,
+                                           float* __restrict__ cand_policy, float* __restrict__ cand_logit, int* __restrict__ cand_player,
+                                           float* __restrict__ value_out, float* __restrict__ reward_out, int* __restrict__ err, int g, int lane,
+                                           uint64_t* __restrict__ smem)
+{
+    Cand* cs = reinterpret_cast<Cand*>(smem);
+    Cand* out = cs + v.A;
+    int* stack = reinterpret_cast<int*>(out + v.A);
+    const int A = v.A;
+    const bool terminal = v.terminal[g] != 0;
+    int k = 0;
+    if (!terminal) {
+        const uint16_t* fwd = v.fwd + size_t(rot) * A;
+        for (int base = 0; base < A; base += 64) {
+            const int a = base + lane;
+            const bool leg = a < A && ((v.legal[size_t(g) * v.LW + (a >> 6)] >> (a & 63)) & 1);
+            const uint64_t m = __ballot(leg);
+            if (leg) {
+                const int pos = k + __popcll(m & ((1ull << lane) - 1));
+                const int f = fwd[a];
+                cs[pos] = Cand{a, policy[size_t(g) * A + f], logit[size_t(g) * A + f]};
+            }
+            k += __popcll(m);
+        }
+        waveSync();
+        orderCandidates(cs, out, stack, k, lane, err);
+        for (int i = lane; i < k; i += 64) {
+            cand_action[size_t(g) * A + i] = out[i].action;
+            cand_policy[size_t(g) * A + i] = out[i].policy;
+            cand_logit[size_t(g) * A + i] = out[i].logit;
+        }
+    }
+    if (lane == 0) {
+        cand_count[g] = k;
+        cand_player[g] = v.leaf_player[g];
+        value_out[g] = terminal ? v.eval[g] : value[g];
+        reward_out[g] = 0.0f;
+    }
+}
+
+} // namespace mz

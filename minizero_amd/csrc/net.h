@@ -38,6 +38,12 @@ bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<f
 
 float invertValueHost(float value); // 601-bin decode helper (ref utils/utils.h:102-108)
 
+struct TowerArgs;
+struct HeadParams;
+struct PoolView;
+struct GoDevView;
+class Pool;
+
 class Net {
 public:
     Net() = default;
@@ -58,6 +64,11 @@ public:
     int initial_any(const float* feat, int B, float* policy, float* logit, float* value, float* hidden, int where);
     int recurrent_any(const float* hidden_in, const float* action, int B, float* policy, float* logit, float* value, float* reward, float* hidden_out,
                       int where);
+    // the per-game simulation kernel (sim.hip): `nsims` whole simulations (select, leaf environment, tower, heads, candidates, expand +
+    // backup) of every game in ONE launch, each game advancing on its own workgroup.  *launched = false when no instance fits.
+    int simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_logit, float* d_value, const uint8_t* d_rot, int sim0, int nsims,
+                  bool* launched);
+    bool hasSimKernel(int board_n) const;
     int timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops);
     int timeTowerConv(int B, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch);
 
@@ -75,6 +86,8 @@ private:
     int launchConv(const ConvLayer& L, const float* in, const float* skip, float* out, int B);
     int launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits, bool has_stem = true);
     int launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden);
+    bool makeTowerArgs(const std::vector<ConvLayer>& t, bool in_bits, bool has_stem, TowerArgs* out, int* c0) const;
+    void makeHeadParams(HeadParams* out) const;
 
     DevBuf<float> params_;
     std::vector<ConvLayer> repr_, dyn_;
@@ -90,6 +103,11 @@ private:
     DevBuf<float> rec_in_;      // [B][C + a][P] dynamics input
     DevBuf<float> io_in_, io_in2_, io_policy_, io_logit_, io_value_, io_reward_, io_hidden_; // staging for MZ_HOST callers
     bool conv_only_ = false;    // timing mode: skip the heads
+    DevBuf<char> sim_args_;     // SimArgs block of sim_kernel in device memory + the host copy it was uploaded from
+    std::vector<char> sim_args_host_;
+    DevBuf<unsigned long long> sim_prof_; // MZ_SIM_PROF=1: per-phase tick counters of sim_kernel
+    void dumpSimProf();
+    DevBuf<unsigned> sim_sink_;
 public:
     bool use_fused_ = true;     // fused persistent tower kernel (same arithmetic as the per-layer kernels)
 };

@@ -14,7 +14,7 @@
 //                 fused in one workgroup per sample; for MuZero also the per-sample min/max rescale of
 //                 the hidden state (ref muzero_network.py:154-164) and its scatter into the HBM slab.
 #include "net.h"
-#include "net_dev.h"
+#include "net_body.h"
 #include <cmath>
 #include <cstring>
 
@@ -97,134 +97,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const float* __restrict__ in
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// tower_fused — the whole trunk (stem conv + 2*num_blocks residual convs) of one sample in ONE workgroup:
-// activations never leave LDS between layers.  Three zero-bordered LDS tiles [CMAX][CS] rotate as
-// (input, temp, output/skip); each layer is the same tap-major MFMA chain as conv3x3_mfma, its epilogue
-// (bias + skip + ReLU) writes straight into the interior of the next layer's padded tile.  8 wave64 per
-// workgroup (2 per SIMD): wave w owns output-channel tile (w & 3) and half of the pixel tiles, so MFMA issue of
-// one wave hides the LDS/global latency of its SIMD partner.  Weights stream from L2 (147 KB per layer), one
-// tap ahead in registers.  Removes 12 kernel boundaries, 12 LDS re-stagings and all inter-layer HBM traffic.
-// ---------------------------------------------------------------------------------------------
-struct TowerArgs {
-    int nlayers, cin0, C, OT; // C = hidden channels (== cout of every layer), OT = ceil(C/16)
-    int in_bits;              // input planes arrive bit-packed (1 bit per point, ceil(P/32) words per channel)
-    int has_stem;             // 1: layer 0 is a stem conv (cin0 -> C); 0: the input already has C channels and layer 0 starts a residual block
-    unsigned w_off[48], b_off[48];
-};
-
-template <int H, int W, int CG, int PTW>
-__device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
-                                            float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
-                                            int lane, int wave)
-{
-    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16;
-    const int ot = wave & 3, half = wave >> 2;
-    if (ot >= OT) { return; }
-    int pixoff[PTW], pixdst[PTW];
-#pragma unroll
-    for (int j = 0; j < PTW; ++j) {
-        int q = 16 * (half * PTW + j) + (lane & 15);
-        if (q >= P) { q = 0; }
-        pixdst[j] = (q / W + 1) * PW + (q % W) + 1;          // interior position in a padded plane
-        pixoff[j] = (lane >> 4) * CS + (q / W) * PW + (q % W); // top-left tap of the 3x3 window, channel (lane>>4)
-    }
-    f32x4 acc[PTW];
-#pragma unroll
-    for (int j = 0; j < PTW; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    const float* wl = wp + size_t(ot) * 64 + lane;
-    const size_t wstep = size_t(OT) * 64;
-    // A-fragments are double-buffered by TAP in two register sets; the loop is unrolled by two taps so that no register copies
-    // tie the prefetch to the end of an iteration, and the fences keep the scheduler from sinking the global loads below the tap's
-    // MFMAs (it did: every tap paid an exposed L2 round trip) or hoisting all nine taps' loads (256 VGPRs + spills)
-    float a0[CG], a1[CG];
-    auto loadA = [&](float* a, int t) {
-#pragma unroll
-        for (int cg = 0; cg < CG; ++cg) { a[cg] = __builtin_nontemporal_load(&wl[(size_t(t) * CG + cg) * wstep]); } // streaming: keep the L2 for the search tree
-        asm volatile("" ::: "memory");
-    };
-    auto tap = [&](const float* a, int t) {
-        const int tapoff = (t / 3) * PW + (t % 3);
-#pragma unroll
-        for (int cg = 0; cg < CG; ++cg) {
-#pragma unroll
-            for (int j = 0; j < PTW; ++j) {
-                float bv = tin[pixoff[j] + cg * 4 * CS + tapoff];
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg], bv, acc[j], 0, 0, 0);
-            }
-        }
-    };
-    loadA(a0, 0);
-#pragma unroll
-    for (int t = 0; t < 8; t += 2) { // fully unrolled: s_waitcnt counts are exact only in straight-line code (a loop-carried prefetch gets vmcnt(0))
-        loadA(a1, t + 1);
-        tap(a0, t);
-        loadA(a0, t + 2);
-        tap(a1, t + 1);
-    }
-    tap(a0, 8);
-#pragma unroll
-    for (int j = 0; j < PTW; ++j) {
-        const int pt = half * PTW + j;
-        const int q = 16 * pt + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oc = 16 * ot + 4 * (lane >> 4) + r;
-            if (pt < PT && q < P && oc < cout) {
-                float v = acc[j][r] + bias[oc];
-                if (tskip) { v = v + tskip[oc * CS + pixdst[j]]; }
-                v = v > 0.0f ? v : 0.0f;
-                if (gout) { __builtin_nontemporal_store(v, &gout[oc * P + q]); } else { tout[oc * CS + pixdst[j]] = v; }
-            }
-        }
-    }
-}
-
 template <int H, int W, int CIN0_PAD, int CPAD>
 __global__ __launch_bounds__(512) void tower_fused(const float* __restrict__ in, const float* __restrict__ params, TowerArgs ta,
                                                    float* __restrict__ out)
 {
-    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16, PTW = (PT + 1) / 2;
-    constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
     extern __shared__ __attribute__((aligned(16))) float tiles[]; // 3 x [CMAX][CS]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* T0 = tiles;
-    float* T1 = tiles + CMAX * CS;
-    float* T2 = tiles + 2 * CMAX * CS;
-    // zero all three tiles (borders and padding channels stay zero for the whole kernel), then the sample's planes into T0
-    for (int i = tid; i < 3 * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
-    __syncthreads();
-    float* Tin = ta.has_stem ? T0 : T1; // without a stem the input IS the first block's x
-    if (ta.in_bits) {
-        constexpr int W32 = (P + 31) / 32;
-        const unsigned* bits = reinterpret_cast<const unsigned*>(in) + size_t(b) * ta.cin0 * W32;
-        for (int i = tid; i < ta.cin0 * P; i += 512) {
-            const int c = i / P, p = i - c * P;
-            Tin[c * CS + (p / W + 1) * PW + (p % W) + 1] = ((bits[c * W32 + (p >> 5)] >> (p & 31)) & 1u) ? 1.0f : 0.0f;
-        }
-    } else {
-        const float* src = in + size_t(b) * ta.cin0 * P;
-        for (int i = tid; i < ta.cin0 * P; i += 512) {
-            const int c = i / P, p = i - c * P;
-            Tin[c * CS + (p / W + 1) * PW + (p % W) + 1] = src[i];
-        }
-    }
-    __syncthreads();
-    float* gout = out + size_t(b) * ta.C * P;
-    if (ta.has_stem) { // stem: T0 -> T1
-        tower_layer<H, W, CIN0_PAD / 4, PTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT,
-                                              lane, wave);
-        __syncthreads();
-    }
-    float *x = T1, *tmp = T0, *y = T2;
-    for (int l = ta.has_stem; l + 1 < ta.nlayers; l += 2) { // residual block: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x)
-        tower_layer<H, W, CPAD / 4, PTW>(x, nullptr, tmp, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, wave);
-        __syncthreads();
-        const bool last = (l + 2 >= ta.nlayers);
-        tower_layer<H, W, CPAD / 4, PTW>(tmp, x, y, last ? gout : nullptr, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, ta.OT, lane, wave);
-        __syncthreads();
-        float* s = x; x = y; y = s;
-    }
+    towerBody<H, W, CIN0_PAD, CPAD>(in, params, ta, out, blockIdx.x, threadIdx.x, tiles);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -247,100 +125,12 @@ __global__ void build_recurrent_input(const float* __restrict__ hidden, const in
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// fused heads (+ MuZero hidden-state rescale)
-// ---------------------------------------------------------------------------------------------
-struct HeadParams {
-    const float *pconv_w, *pconv_b, *pfc_wT, *pfc_b, *vconv_w, *vconv_b, *vfc1_wT, *vfc1_b, *vfc2_w, *vfc2_b;
-    int C, P, A, PC, VH;
-};
-
 __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ x, HeadParams hp, float* __restrict__ policy,
                                                     float* __restrict__ logit, float* __restrict__ value, float* __restrict__ hidden_dst,
                                                     const int* __restrict__ dst_idx, int scale_hidden)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC, VH = hp.VH;
-    float* xs = sm;                // [C*P]
-    float* pf = xs + C * P;        // [PC*P]
-    float* vf = pf + PC * P;       // [P]
-    float* h1 = vf + P;            // [VH]
-    float* lg = h1 + VH;           // [A] logits, then exp values
-    float* red = lg + A;           // [16] reduction scratch
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* src = x + size_t(b) * C * P;
-    for (int i = tid; i < C * P; i += 256) { xs[i] = src[i]; }
-    __syncthreads();
-
-    if (scale_hidden) { // min/max are order-free; (h - min) / scale is one IEEE op each
-        float mn = 3.4e38f, mx = -3.4e38f;
-        for (int i = tid; i < C * P; i += 256) { float v = xs[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-        for (int o = 32; o > 0; o >>= 1) {
-            float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
-            mn = m2 < mn ? m2 : mn;
-            mx = x2 > mx ? x2 : mx;
-        }
-        if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
-        __syncthreads();
-        mn = red[0]; mx = red[4];
-        for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
-        float scale = mx - mn;
-        if (scale < 1e-5f) { scale += 1e-5f; }
-        float* hd = hidden_dst + size_t(dst_idx ? dst_idx[b] : b) * C * P;
-        for (int i = tid; i < C * P; i += 256) {
-            float v = (xs[i] - mn) / scale;
-            xs[i] = v;
-            hd[i] = v;
-        }
-        __syncthreads();
-    }
-
-    // conv1x1 + folded BN + ReLU: PC policy planes and 1 value plane, one output element per thread
-    for (int i = tid; i < (PC + 1) * P; i += 256) {
-        const int j = i / P, p = i - j * P;
-        const float* w = (j < PC) ? hp.pconv_w + j * C : hp.vconv_w;
-        float acc = 0.0f;
-        for (int c = 0; c < C; ++c) { acc = __builtin_fmaf(xs[c * P + p], w[c], acc); }
-        float v = acc + ((j < PC) ? hp.pconv_b[j] : hp.vconv_b[0]);
-        v = v > 0.0f ? v : 0.0f;
-        if (j < PC) { pf[i] = v; } else { vf[p] = v; }
-    }
-    __syncthreads();
-
-    // policy FC (one logit per thread) and value FC1 (one hidden unit per thread)
-    for (int a = tid; a < A; a += 256) {
-        float acc = 0.0f;
-        const int n = PC * P;
-        for (int i = 0; i < n; ++i) { acc = __builtin_fmaf(pf[i], hp.pfc_wT[size_t(i) * A + a], acc); }
-        float v = acc + hp.pfc_b[a];
-        lg[a] = v;
-        logit[size_t(b) * A + a] = v;
-    }
-    for (int o = tid; o < VH; o += 256) {
-        float acc = 0.0f;
-        for (int p = 0; p < P; ++p) { acc = __builtin_fmaf(vf[p], hp.vfc1_wT[size_t(p) * VH + o], acc); }
-        float v = acc + hp.vfc1_b[o];
-        h1[o] = v > 0.0f ? v : 0.0f;
-    }
-    __syncthreads();
-
-    // value FC2 + tanh: one sequential chain (wave 1, lane 0) while wave 0 does the softmax
-    if (tid == 64) {
-        float acc = 0.0f;
-        for (int o = 0; o < VH; ++o) { acc = __builtin_fmaf(h1[o], hp.vfc2_w[o], acc); }
-        value[b] = mz_tanhf(acc + hp.vfc2_b[0]);
-    }
-    if (wave == 0) {
-        float m = -3.4e38f;
-        for (int a = lane; a < A; a += 64) { m = lg[a] > m ? lg[a] : m; }
-        for (int o = 32; o > 0; o >>= 1) { float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
-        for (int a = lane; a < A; a += 64) { lg[a] = mz_expf(lg[a] - m); }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float s = 0.0f;
-        for (int a = 0; a < A; ++a) { s += lg[a]; } // index-order sum, every lane redundantly (LDS broadcast)
-        for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lg[a] / s; }
-    }
+    headsBody(x, hp, policy, logit, value, hidden_dst, dst_idx, scale_hidden, blockIdx.x, threadIdx.x, 256, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -348,6 +138,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ x,
 // ---------------------------------------------------------------------------------------------
 Net::~Net()
 {
+    dumpSimProf();
     if (own_stream_ && stream_) { (void)hipStreamDestroy(stream_); }
 }
 
@@ -449,15 +240,14 @@ static int launchTowerT(const TowerArgs& ta, const float* params, const float* i
     return MZ_OK;
 }
 
-// returns MZ_OK and sets *launched when a fused instance exists for this trunk
-int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits, bool has_stem)
+// TowerArgs of a trunk that has the shape the fused kernel handles (false otherwise); *c0 = the CIN0_PAD template argument
+bool Net::makeTowerArgs(const std::vector<ConvLayer>& t, bool in_bits, bool has_stem, TowerArgs* out, int* c0) const
 {
-    *launched = false;
-    if (!use_fused_ || t.size() > 48 || t.empty() || (t.size() % 2) == (has_stem ? 0u : 1u)) { return MZ_OK; }
-    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
-    for (size_t i = has_stem ? 1 : 0; i < t.size(); ++i) { if (t[i].cin != C || t[i].cout != C) { return MZ_OK; } }
-    if (t[0].cout != C || C % 4 != 0) { return MZ_OK; }
-    TowerArgs ta;
+    if (!use_fused_ || t.size() > 48 || t.empty() || (t.size() % 2) == (has_stem ? 0u : 1u)) { return false; }
+    const int C = desc_.num_hidden_channels;
+    for (size_t i = has_stem ? 1 : 0; i < t.size(); ++i) { if (t[i].cin != C || t[i].cout != C) { return false; } }
+    if (t[0].cout != C || C % 4 != 0) { return false; }
+    TowerArgs& ta = *out;
     ta.nlayers = static_cast<int>(t.size());
     ta.cin0 = t[0].cin;
     ta.C = C;
@@ -465,7 +255,18 @@ int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* ou
     ta.in_bits = in_bits ? 1 : 0;
     ta.has_stem = has_stem ? 1 : 0;
     for (size_t i = 0; i < t.size(); ++i) { ta.w_off[i] = static_cast<unsigned>(t[i].w_off); ta.b_off[i] = static_cast<unsigned>(t[i].b_off); }
-    const int c0 = has_stem ? t[0].cin_pad : C; // without a stem the template's CIN0_PAD is unused: pick the C instance
+    *c0 = has_stem ? t[0].cin_pad : C; // without a stem the template's CIN0_PAD is unused: pick the C instance
+    return true;
+}
+
+// returns MZ_OK and sets *launched when a fused instance exists for this trunk
+int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits, bool has_stem)
+{
+    *launched = false;
+    TowerArgs ta;
+    int c0 = 0;
+    if (!makeTowerArgs(t, in_bits, has_stem, &ta, &c0)) { return MZ_OK; }
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
 #define MZ_TOWER_CASE(h, w, cin0, cpad) \
     if (H == h && W == w && c0 == cin0 && C == cpad) { *launched = true; return launchTowerT<h, w, cin0, cpad>(ta, params_.p, in, out, B, stream_); }
     MZ_TOWER_CASE(9, 9, 20, 64)  // Go AlphaZero / MuZero representation
@@ -505,14 +306,20 @@ int Net::runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, flo
     return MZ_OK;
 }
 
-int Net::launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden)
+void Net::makeHeadParams(HeadParams* out) const
 {
-    HeadParams hp;
+    HeadParams& hp = *out;
     const float* p = params_.p;
     hp.pconv_w = p + heads_.pconv_w; hp.pconv_b = p + heads_.pconv_b; hp.pfc_wT = p + heads_.pfc_wT; hp.pfc_b = p + heads_.pfc_b;
     hp.vconv_w = p + heads_.vconv_w; hp.vconv_b = p + heads_.vconv_b; hp.vfc1_wT = p + heads_.vfc1_wT; hp.vfc1_b = p + heads_.vfc1_b;
     hp.vfc2_w = p + heads_.vfc2_w; hp.vfc2_b = p + heads_.vfc2_b;
     hp.C = desc_.num_hidden_channels; hp.P = P(); hp.A = desc_.action_size; hp.PC = heads_.pc; hp.VH = desc_.num_value_hidden_channels;
+}
+
+int Net::launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden)
+{
+    HeadParams hp;
+    makeHeadParams(&hp);
     size_t lds = (size_t(hp.C) * hp.P + size_t(hp.PC) * hp.P + hp.P + hp.VH + hp.A + 16) * sizeof(float);
     if (lds > 48 * 1024) { MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); }
     hipLaunchKernelGGL(heads_kernel, dim3(B), dim3(256), lds, stream_, x, hp, policy, logit, value, hidden_dst, dst_idx, scale_hidden ? 1 : 0);

@@ -1,0 +1,236 @@
+// Device bodies of the network kernels that are shared by the stand-alone kernels (net.hip) and the per-game simulation
+// kernel (sim.hip): the fused residual tower and the fused heads.  gfx950, -ffp-contract=off; numerics contract in DESIGN.md §4.
+#pragma once
+#include "net_dev.h"
+
+namespace mz {
+
+// ---------------------------------------------------------------------------------------------
+// tower_fused — the whole trunk (stem conv + 2*num_blocks residual convs) of one sample in ONE workgroup:
+// activations never leave LDS between layers.  Three zero-bordered LDS tiles [CMAX][CS] rotate as
+// (input, temp, output/skip); each layer is the same tap-major MFMA chain as conv3x3_mfma, its epilogue
+// (bias + skip + ReLU) writes straight into the interior of the next layer's padded tile.  8 wave64 per
+// workgroup (2 per SIMD): wave w owns output-channel tile (w & 3) and half of the pixel tiles, so MFMA issue of
+// one wave hides the LDS/global latency of its SIMD partner.  Weights stream from L2 (147 KB per layer), one
+// tap ahead in registers.  Removes 12 kernel boundaries, 12 LDS re-stagings and all inter-layer HBM traffic.
+// ---------------------------------------------------------------------------------------------
+struct TowerArgs {
+    int nlayers, cin0, C, OT; // C = hidden channels (== cout of every layer), OT = ceil(C/16)
+    int in_bits;              // input planes arrive bit-packed (1 bit per point, ceil(P/32) words per channel)
+    int has_stem;             // 1: layer 0 is a stem conv (cin0 -> C); 0: the input already has C channels and layer 0 starts a residual block
+    unsigned w_off[48], b_off[48];
+};
+
+template <int H, int W, int CG, int PTW>
+__device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
+                                            float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
+                                            int lane, int wave)
+{
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16;
+    const int ot = wave & 3, half = wave >> 2;
+    if (ot >= OT) { return; }
+    int pixoff[PTW], pixdst[PTW];
+#pragma unroll
+    for (int j = 0; j < PTW; ++j) {
+        int q = 16 * (half * PTW + j) + (lane & 15);
+        if (q >= P) { q = 0; }
+        pixdst[j] = (q / W + 1) * PW + (q % W) + 1;          // interior position in a padded plane
+        pixoff[j] = (lane >> 4) * CS + (q / W) * PW + (q % W); // top-left tap of the 3x3 window, channel (lane>>4)
+    }
+    f32x4 acc[PTW];
+#pragma unroll
+    for (int j = 0; j < PTW; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const float* wl = wp + size_t(ot) * 64 + lane;
+    const size_t wstep = size_t(OT) * 64;
+    // A-fragments are double-buffered by TAP in two register sets; the loop is unrolled by two taps so that no register copies
+    // tie the prefetch to the end of an iteration, and the fences keep the scheduler from sinking the global loads below the tap's
+    // MFMAs (it did: every tap paid an exposed L2 round trip) or hoisting all nine taps' loads (256 VGPRs + spills)
+    float a0[CG], a1[CG];
+    auto loadA = [&](float* a, int t) {
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) { a[cg] = wl[(size_t(t) * CG + cg) * wstep]; }
+        asm volatile("" ::: "memory");
+    };
+    auto tap = [&](const float* a, int t) {
+        const int tapoff = (t / 3) * PW + (t % 3);
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+#pragma unroll
+            for (int j = 0; j < PTW; ++j) {
+                float bv = tin[pixoff[j] + cg * 4 * CS + tapoff];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg], bv, acc[j], 0, 0, 0);
+            }
+        }
+    };
+    loadA(a0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) { // fully unrolled: s_waitcnt counts are exact only in straight-line code (a loop-carried prefetch gets vmcnt(0))
+        loadA(a1, t + 1);
+        tap(a0, t);
+        loadA(a0, t + 2);
+        tap(a1, t + 1);
+    }
+    tap(a0, 8);
+#pragma unroll
+    for (int j = 0; j < PTW; ++j) {
+        const int pt = half * PTW + j;
+        const int q = 16 * pt + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = 16 * ot + 4 * (lane >> 4) + r;
+            if (pt < PT && q < P && oc < cout) {
+                float v = acc[j][r] + bias[oc];
+                if (tskip) { v = v + tskip[oc * CS + pixdst[j]]; }
+                v = v > 0.0f ? v : 0.0f;
+                if (gout) { __builtin_nontemporal_store(v, &gout[oc * P + q]); } else { tout[oc * CS + pixdst[j]] = v; }
+            }
+        }
+    }
+}
+
+// the body of tower_fused for sample `b`, run by all 512 threads of a workgroup (tid 0..511); `tiles` = 3 x [CMAX][CS] floats of LDS
+template <int H, int W, int CIN0_PAD, int CPAD>
+__device__ __forceinline__ void towerBody(const float* __restrict__ in, const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ out,
+                                          int b, int tid, float* __restrict__ tiles)
+{
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16, PTW = (PT + 1) / 2;
+    constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
+    const int lane = tid & 63, wave = tid >> 6;
+    float* T0 = tiles;
+    float* T1 = tiles + CMAX * CS;
+    float* T2 = tiles + 2 * CMAX * CS;
+    // zero all three tiles (borders and padding channels stay zero for the whole kernel), then the sample's planes into T0
+    for (int i = tid; i < 3 * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
+    __syncthreads();
+    float* Tin = ta.has_stem ? T0 : T1; // without a stem the input IS the first block's x
+    if (ta.in_bits) {
+        constexpr int W32 = (P + 31) / 32;
+        const unsigned* bits = reinterpret_cast<const unsigned*>(in) + size_t(b) * ta.cin0 * W32;
+        for (int i = tid; i < ta.cin0 * P; i += 512) {
+            const int c = i / P, p = i - c * P;
+            Tin[c * CS + (p / W + 1) * PW + (p % W) + 1] = ((bits[c * W32 + (p >> 5)] >> (p & 31)) & 1u) ? 1.0f : 0.0f;
+        }
+    } else {
+        const float* src = in + size_t(b) * ta.cin0 * P;
+        for (int i = tid; i < ta.cin0 * P; i += 512) {
+            const int c = i / P, p = i - c * P;
+            Tin[c * CS + (p / W + 1) * PW + (p % W) + 1] = src[i];
+        }
+    }
+    __syncthreads();
+    float* gout = out + size_t(b) * ta.C * P;
+    if (ta.has_stem) { // stem: T0 -> T1
+        tower_layer<H, W, CIN0_PAD / 4, PTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT,
+                                              lane, wave);
+        __syncthreads();
+    }
+    float *x = T1, *tmp = T0, *y = T2;
+    for (int l = ta.has_stem; l + 1 < ta.nlayers; l += 2) { // residual block: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x)
+        tower_layer<H, W, CPAD / 4, PTW>(x, nullptr, tmp, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, wave);
+        __syncthreads();
+        const bool last = (l + 2 >= ta.nlayers);
+        tower_layer<H, W, CPAD / 4, PTW>(tmp, x, y, last ? gout : nullptr, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, ta.OT, lane, wave);
+        __syncthreads();
+        float* s = x; x = y; y = s;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// fused heads (+ MuZero hidden-state rescale)
+// ---------------------------------------------------------------------------------------------
+struct HeadParams {
+    const float *pconv_w, *pconv_b, *pfc_wT, *pfc_b, *vconv_w, *vconv_b, *vfc1_wT, *vfc1_b, *vfc2_w, *vfc2_b;
+    int C, P, A, PC, VH;
+};
+
+// the body of heads_kernel for sample `b`, run by NT threads (a multiple of 64, >= 128); `sm` = (C*P + PC*P + P + VH + A + 16) floats of LDS
+__device__ __forceinline__ void headsBody(const float* __restrict__ x, const HeadParams& hp, float* __restrict__ policy, float* __restrict__ logit,
+                                          float* __restrict__ value, float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int scale_hidden,
+                                          int b, int tid, int NT, float* __restrict__ sm)
+{
+    const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC, VH = hp.VH;
+    float* xs = sm;                // [C*P]
+    float* pf = xs + C * P;        // [PC*P]
+    float* vf = pf + PC * P;       // [P]
+    float* h1 = vf + P;            // [VH]
+    float* lg = h1 + VH;           // [A] logits, then exp values
+    float* red = lg + A;           // [16] reduction scratch
+    const int lane = tid & 63, wave = tid >> 6, NW = NT >> 6;
+    const float* src = x + size_t(b) * C * P;
+    for (int i = tid; i < C * P; i += NT) { xs[i] = src[i]; }
+    __syncthreads();
+
+    if (scale_hidden) { // min/max are order-free; (h - min) / scale is one IEEE op each
+        float mn = 3.4e38f, mx = -3.4e38f;
+        for (int i = tid; i < C * P; i += NT) { float v = xs[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        for (int o = 32; o > 0; o >>= 1) {
+            float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
+            mn = m2 < mn ? m2 : mn;
+            mx = x2 > mx ? x2 : mx;
+        }
+        if (lane == 0) { red[wave] = mn; red[8 + wave] = mx; }
+        __syncthreads();
+        mn = red[0]; mx = red[8];
+        for (int w = 1; w < NW; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[8 + w] > mx ? red[8 + w] : mx; }
+        float scale = mx - mn;
+        if (scale < 1e-5f) { scale += 1e-5f; }
+        float* hd = hidden_dst + size_t(dst_idx ? dst_idx[b] : b) * C * P;
+        for (int i = tid; i < C * P; i += NT) {
+            float v = (xs[i] - mn) / scale;
+            xs[i] = v;
+            hd[i] = v;
+        }
+        __syncthreads();
+    }
+
+    // conv1x1 + folded BN + ReLU: PC policy planes and 1 value plane, one output element per thread
+    for (int i = tid; i < (PC + 1) * P; i += NT) {
+        const int j = i / P, p = i - j * P;
+        const float* w = (j < PC) ? hp.pconv_w + j * C : hp.vconv_w;
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) { acc = __builtin_fmaf(xs[c * P + p], w[c], acc); }
+        float v = acc + ((j < PC) ? hp.pconv_b[j] : hp.vconv_b[0]);
+        v = v > 0.0f ? v : 0.0f;
+        if (j < PC) { pf[i] = v; } else { vf[p] = v; }
+    }
+    __syncthreads();
+
+    // policy FC (one logit per thread) and value FC1 (one hidden unit per thread)
+    for (int a = tid; a < A; a += NT) {
+        float acc = 0.0f;
+        const int n = PC * P;
+        for (int i = 0; i < n; ++i) { acc = __builtin_fmaf(pf[i], hp.pfc_wT[size_t(i) * A + a], acc); }
+        float v = acc + hp.pfc_b[a];
+        lg[a] = v;
+        logit[size_t(b) * A + a] = v;
+    }
+    for (int o = tid; o < VH; o += NT) {
+        float acc = 0.0f;
+        for (int p = 0; p < P; ++p) { acc = __builtin_fmaf(vf[p], hp.vfc1_wT[size_t(p) * VH + o], acc); }
+        float v = acc + hp.vfc1_b[o];
+        h1[o] = v > 0.0f ? v : 0.0f;
+    }
+    __syncthreads();
+
+    // value FC2 + tanh: one sequential chain (wave 1, lane 0) while wave 0 does the softmax
+    if (tid == 64) {
+        float acc = 0.0f;
+        for (int o = 0; o < VH; ++o) { acc = __builtin_fmaf(h1[o], hp.vfc2_w[o], acc); }
+        value[b] = mz_tanhf(acc + hp.vfc2_b[0]);
+    }
+    if (wave == 0) {
+        float m = -3.4e38f;
+        for (int a = lane; a < A; a += 64) { m = lg[a] > m ? lg[a] : m; }
+        for (int o = 32; o > 0; o >>= 1) { float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
+        for (int a = lane; a < A; a += 64) { lg[a] = mz_expf(lg[a] - m); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float s = 0.0f;
+        for (int a = 0; a < A; ++a) { s += lg[a]; } // index-order sum, every lane redundantly (LDS broadcast)
+        for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lg[a] / s; }
+    }
+}
+
+
+} // namespace mz

@@ -5,7 +5,7 @@
 // Bit-exactness: built with -ffp-contract=off; the log()/sqrt() of the PUCT bias come from host-computed
 // tables indexed by N (ref mcts.cpp:57-58 uses the double libm functions); the init-Q sum is an ordered
 // f32 sum over the visited children in storage order; ties follow mcts.cpp:191.
-#include "pool.h"
+#include "pool_body.h"
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -31,161 +31,7 @@ __global__ void reset_kernel(PoolView v, const int* __restrict__ mask, const int
     v.bound_lo[g] = 0; v.bound_hi[g] = 0;
 }
 
-// normalized mean of a visited child (ref mcts.cpp:40-53 with virtual_loss == 0, which ActorGroup never uses)
-__device__ __forceinline__ float normalizedMean(const PoolView& v, float reward, float mean, float cnt, int player, int bsize, float lo, float hi)
-{
-    float value = reward + v.gamma * mean;
-    if (v.value_rescale) {
-        if (bsize < 2) { return 1.0f; }
-        value = (value - lo) / (hi - lo);
-        value = 2 * value - 1;
-        value = value < -1.0f ? -1.0f : value; // fmax(-1, .) then fmin(1, .), exact
-        value = value > 1.0f ? 1.0f : value;
-    }
-    value = (player == v.flipping_player) ? -value : value;
-    return (value * cnt - 0.0f) / (cnt + 0.0f);
-}
-
-__device__ __forceinline__ bool better(float s1, float p1, int i1, float s2, float p2, int i2)
-{
-    // (score, policy) lexicographic, first index wins full ties (ref mcts.cpp:189-195)
-    return (s1 > s2) || (s1 == s2 && (p1 > p2 || (p1 == p2 && i1 < i2)));
-}
-
-// one step of a DPP reduction with the PUCT order: lanes without a source lane (row edge / masked row) keep their own triple
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void dppBest(float& rs, float& rp, int& ri)
-{
-    const float s2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(rs), __float_as_int(rs), CTRL, ROW_MASK, 0xF, false));
-    const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(rp), __float_as_int(rp), CTRL, ROW_MASK, 0xF, false));
-    const int i2 = __builtin_amdgcn_update_dpp(ri, ri, CTRL, ROW_MASK, 0xF, false);
-    if (better(s2, p2, i2, rs, rp, ri)) { rs = s2; rp = p2; ri = i2; }
-}
-
-__device__ __forceinline__ NodeRec loadRec(const NodeRec* p)
-{
-    const float4 a = reinterpret_cast<const float4*>(p)[0];
-    const int4 b = reinterpret_cast<const int4*>(p)[1];
-    NodeRec n;
-    n.count = a.x; n.mean = a.y; n.policy = a.z; n.reward = a.w;
-    n.first_child = b.x; n.num_children = b.y; n.action = b.z; n.players = b.w;
-    return n;
-}
-
-// value of a wave-uniform lane: v_readlane_b32 (a few cycles) instead of the ds_bpermute_b32 that __shfl turns into (an LDS round
-// trip, ~100 cycles: the ordered init-Q sum walks up to A visited children one by one)
-__device__ __forceinline__ int laneI(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ float laneF(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
-
-// One wave64 per game.  Per level: every lane loads the 32-B records of its children (<= 2 per lane for A <= 128, a loop
-// beyond), all arithmetic runs from registers, and the winning lane's record supplies the next level's (first_child,
-// num_children, count) through shuffles — a single dependent memory round trip per level.
-__global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __restrict__ start)
-{
-    const int g = blockIdx.x, lane = threadIdx.x;
-    const NodeRec* recs = v.rec + size_t(g) * v.cap;
-    int* path = v.path + size_t(g) * v.max_depth;
-    int* pact = v.path_action + size_t(g) * v.max_depth;
-    int* hact = v.host_path_action ? v.host_path_action + size_t(g) * v.max_depth : nullptr;
-    const int bsize = v.bound_size[g];
-    const float lo = v.bound_lo[g], hi = v.bound_hi[g];
-    NodeRec cur = loadRec(recs); // root (uniform)
-    int node = 0, depth = 1;
-    if (lane == 0) { path[0] = 0; pact[0] = cur.action; if (hact) { hact[0] = cur.action; } }
-    const int st = start ? start[g] : 0;
-    if (st > 0) { // Gumbel: path = root + PUCT path below the chosen candidate (ref gumbel_zero.cpp:83-85)
-        node = st;
-        cur = loadRec(recs + st);
-        if (lane == 0) { path[1] = st; pact[1] = cur.action; if (hact) { hact[1] = cur.action; } }
-        depth = 2;
-    }
-    while (cur.num_children != 0 && depth < v.max_depth) {
-        const int nc = cur.num_children, fc = cur.first_child, cplayer = (cur.players >> 8) & 0xFF;
-        const int N = static_cast<int>(cur.count - 1);
-        const float bias = v.bias_tab[N];
-        const double sqrtN = v.sqrt_tab[N];
-        // ---- pass 1: init Q = ordered f32 sum over visited children (ref mcts.cpp:200-217); records stay in registers for A <= 128 ----
-        NodeRec c0, c1;
-        c0.count = 0; c1.count = 0;
-        const bool has0 = lane < nc, has1 = lane + 64 < nc;
-        if (has0) { c0 = loadRec(recs + fc + lane); }
-        if (has1) { c1 = loadRec(recs + fc + lane + 64); }
-        float sum_of_win = 0.0f, sum = 0.0f;
-        float q0 = 0.0f, q1 = 0.0f;
-        {
-            const bool vis0 = has0 && c0.count != 0.0f;
-            if (vis0) { q0 = normalizedMean(v, c0.reward, c0.mean, c0.count, cplayer, bsize, lo, hi); }
-            unsigned long long m = __ballot(vis0);
-            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += laneF(q0, j); sum += 1; }
-            const bool vis1 = has1 && c1.count != 0.0f;
-            if (vis1) { q1 = normalizedMean(v, c1.reward, c1.mean, c1.count, cplayer, bsize, lo, hi); }
-            m = __ballot(vis1);
-            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += laneF(q1, j); sum += 1; }
-        }
-        for (int cb = 128; cb < nc; cb += 64) { // wide nodes (A > 128): remaining chunks straight from memory
-            const int i = cb + lane;
-            float q = 0.0f;
-            bool vis = false;
-            if (i < nc) {
-                const NodeRec c = loadRec(recs + fc + i);
-                vis = c.count != 0.0f;
-                if (vis) { q = normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi); }
-            }
-            unsigned long long m = __ballot(vis);
-            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += laneF(q, j); sum += 1; }
-        }
-        const float init_q = v.atari_init_q ? (sum > 0 ? sum_of_win / sum : 1.0f) : (sum_of_win - 1) / (sum + 1);
-        // ---- pass 2: PUCT score + arg-max (ref mcts.cpp:55-61,181-198) ----
-        float bs = -FLT_MAX, bp = -FLT_MAX;
-        int bi = INT_MAX;
-        NodeRec best = c0;
-        auto consider = [&](const NodeRec& c, float q, int i) {
-            const float bpol = bias * c.policy;
-            const float value_u = static_cast<float>((static_cast<double>(bpol) * sqrtN) / static_cast<double>(1 + c.count));
-            const float value_q = (c.count == 0.0f) ? init_q : q;
-            const float score = value_u + value_q;
-            if (better(score, c.policy, i, bs, bp, bi)) { bs = score; bp = c.policy; bi = i; best = c; }
-        };
-        if (has0) { consider(c0, q0, lane); }
-        if (has1) { consider(c1, q1, lane + 64); }
-        for (int cb = 128; cb < nc; cb += 64) {
-            const int i = cb + lane;
-            if (i < nc) {
-                const NodeRec c = loadRec(recs + fc + i);
-                const float q = (c.count != 0.0f) ? normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi) : 0.0f;
-                consider(c, q, i);
-            }
-        }
-        // wave arg-max on the DPP network (row_shr 1/2/4/8, row_bcast 15/31: lane 63 ends up with the best triple) — no LDS traffic
-        float rs = bs, rp = bp;
-        int ri = bi;
-        dppBest<0x111, 0xF>(rs, rp, ri);
-        dppBest<0x112, 0xF>(rs, rp, ri);
-        dppBest<0x114, 0xF>(rs, rp, ri);
-        dppBest<0x118, 0xF>(rs, rp, ri);
-        dppBest<0x142, 0xA>(rs, rp, ri);
-        dppBest<0x143, 0xC>(rs, rp, ri);
-        ri = laneI(ri, 63);
-        // the lane that holds the winner broadcasts its record: that is the next level's header
-        const int owner = __builtin_ctzll(__ballot(bi == ri));
-        cur.count = laneF(best.count, owner);
-        cur.first_child = laneI(best.first_child, owner);
-        cur.num_children = laneI(best.num_children, owner);
-        cur.action = laneI(best.action, owner);
-        cur.players = laneI(best.players, owner);
-        node = fc + ri;
-        if (lane == 0) {
-            path[depth] = node;
-            pact[depth] = cur.action;
-            if (hact) { hact[depth] = cur.action; }
-        }
-        ++depth;
-    }
-    if (lane == 0) {
-        v.path_len[g] = depth;
-        if (v.host_path_len) { v.host_path_len[g] = depth; }
-    }
-}
+__global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __restrict__ start) { selectBody(v, start, blockIdx.x, threadIdx.x); }
 
 __global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int* __restrict__ cand_count, const int* __restrict__ cand_action,
                                                            const float* __restrict__ cand_policy, const float* __restrict__ cand_logit,
@@ -193,125 +39,7 @@ __global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int
                                                            const float* __restrict__ reward_in, int hslot, int* __restrict__ err)
 {
     extern __shared__ float lds[]; // value-bound multiset: keys [bound_cap] then counts [bound_cap] (only with value_rescale)
-    const int g = blockIdx.x, lane = threadIdx.x;
-    const size_t base = size_t(g) * v.cap;
-    const int len = v.path_len[g];
-    if (len <= 0) { return; }
-    const int* path = v.path + size_t(g) * v.max_depth;
-    const int leaf = path[len - 1];
-    const int k = cand_count[g];
-    // ---- expand (ref mcts.cpp:151-164, tree.h:71-77) ----
-    if (k > 0) {
-        const int fc = v.num_nodes[g];
-        if (fc + k > v.cap) {
-            if (lane == 0) { atomicExch(err, MZ_ERR_CAPACITY); }
-            return;
-        }
-        const int pl = cand_player[g];
-        for (int i = lane; i < k; i += 64) {
-            const size_t n = base + fc + i, c = size_t(g) * v.A + i;
-            NodeRec r;
-            r.count = 0; r.mean = 0; r.policy = cand_policy[c]; r.reward = 0;
-            r.first_child = -1; r.num_children = 0; r.action = cand_action[c]; r.players = pl;
-            reinterpret_cast<float4*>(v.rec + n)[0] = make_float4(r.count, r.mean, r.policy, r.reward);
-            reinterpret_cast<int4*>(v.rec + n)[1] = make_int4(r.first_child, r.num_children, r.action, r.players);
-            v.logit[n] = cand_logit[c];
-            v.noise[n] = 0; v.value[n] = 0; v.hslot[n] = -1;
-        }
-        if (lane == 0) {
-            NodeRec* l = v.rec + base + leaf;
-            l->first_child = fc;
-            l->num_children = k;
-            l->players = (l->players & 0xFF) | (pl << 8);
-            v.num_nodes[g] = fc + k;
-        }
-    }
-    if (lane == 0 && hslot >= 0) { v.hslot[base + leaf] = hslot; }
-    // ---- backup (ref mcts.cpp:166-179) ----
-    if (!v.value_rescale) {
-        // The only leaf -> root dependence is `updated = r + gamma * updated`, which needs the rewards but not the means: the
-        // path's records are loaded by 64 lanes at once (one memory round trip per 64 levels instead of one per level — the
-        // deepest of the 256 paths sets the kernel time), the chain runs over registers, then every lane updates its own node.
-        const float val = value_in[g], rew = reward_in[g];
-        if (lane == 0) {
-            v.value[base + leaf] = val;
-            v.rec[base + leaf].reward = rew;
-        }
-        float updated = val;
-        for (int kb = 0; kb < len; kb += 64) {
-            const int k = kb + lane; // k-th node from the leaf
-            const bool act = k < len;
-            NodeRec* n = v.rec + base + (act ? path[len - 1 - k] : 0);
-            float mean = 0.0f, cnt = 0.0f, r = 0.0f;
-            if (act) {
-                mean = n->mean;
-                cnt = n->count;
-                r = (k == 0) ? rew : n->reward;
-            }
-            float mine = 0.0f;
-            const int m = len - kb < 64 ? len - kb : 64;
-            for (int j = 0; j < m; ++j) {
-                if (lane == j) { mine = updated; }
-                updated = laneF(r, j) + v.gamma * updated;
-            }
-            if (act) { // MCTSNode::add(value, 1.0f) (ref mcts.cpp:20-28)
-                cnt += 1.0f;
-                mean += 1.0f * (mine - mean) / cnt;
-                n->mean = mean;
-                n->count = cnt;
-            }
-        }
-        return;
-    }
-    // with value rescaling the value-bound multiset is updated node by node: a serial chain, done by lane 0
-    if (lane != 0) { return; }
-    int bsize = 0;
-    float* bkey = lds;                                     // value-bound multiset, LDS copy (lane 0 only)
-    int* bcnt = reinterpret_cast<int*>(lds + v.bound_cap);
-    if (v.value_rescale) {
-        bsize = v.bound_size[g];
-        for (int j = 0; j < bsize; ++j) { bkey[j] = v.bound_key[size_t(g) * v.bound_cap + j]; bcnt[j] = v.bound_cnt[size_t(g) * v.bound_cap + j]; }
-    }
-    const float val = value_in[g], rew = reward_in[g];
-    v.value[base + leaf] = val;
-    v.rec[base + leaf].reward = rew;
-    float updated = val;
-    for (int i = len - 1; i >= 0; --i) {
-        NodeRec* n = v.rec + base + path[i];
-        const float r = (i == len - 1) ? rew : n->reward;
-        float mean = n->mean, cnt = n->count;
-        const float old_mean = r + v.gamma * mean;
-        // MCTSNode::add(value, 1.0f) (ref mcts.cpp:20-28); count + 1 <= 0 cannot happen for count >= 0
-        cnt += 1.0f;
-        mean += 1.0f * (updated - mean) / cnt;
-        n->mean = mean;
-        n->count = cnt;
-        if (v.value_rescale) { // updateTreeValueBound(old, new) (ref mcts.cpp:219-228): std::map<float,int> as an unordered array
-            const float new_mean = r + v.gamma * mean;
-            for (int j = 0; j < bsize; ++j) {
-                if (bkey[j] == old_mean) {
-                    if (--bcnt[j] == 0) { --bsize; bkey[j] = bkey[bsize]; bcnt[j] = bcnt[bsize]; }
-                    break;
-                }
-            }
-            int j = 0;
-            for (; j < bsize; ++j) { if (bkey[j] == new_mean) { ++bcnt[j]; break; } }
-            if (j == bsize && bsize < v.bound_cap) { bkey[bsize] = new_mean; bcnt[bsize] = 1; ++bsize; }
-        }
-        updated = r + v.gamma * updated;
-    }
-    if (v.value_rescale) {
-        float lo = 0.0f, hi = 0.0f;
-        for (int j = 0; j < bsize; ++j) {
-            v.bound_key[size_t(g) * v.bound_cap + j] = bkey[j];
-            v.bound_cnt[size_t(g) * v.bound_cap + j] = bcnt[j];
-            if (j == 0 || bkey[j] < lo) { lo = bkey[j]; }
-            if (j == 0 || bkey[j] > hi) { hi = bkey[j]; }
-        }
-        v.bound_size[g] = bsize;
-        v.bound_lo[g] = lo;
-        v.bound_hi[g] = hi;
-    }
+    expandBackupBody(v, cand_count, cand_action, cand_policy, cand_logit, cand_player, value_in, reward_in, hslot, err, blockIdx.x, threadIdx.x, lds);
 }
 
 __global__ __launch_bounds__(64) void root_set_noise_kernel(PoolView v, const int* __restrict__ mask, const float* __restrict__ policy,

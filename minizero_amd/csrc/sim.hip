@@ -1,0 +1,223 @@
+// sim_kernel — the per-game simulation kernel: workgroup g runs `nsims` complete MCTS simulations of game g without leaving
+// the GPU: PUCT selection, the leaf's Go position / planes / legal mask, the residual tower + heads on the 8 waves of the
+// workgroup, the candidate list and expand + backup.  The reference steps all games in lock-step, one batched forward per
+// cycle (ref actor/actor_group.cpp:81-114); nothing in a game depends on another game, so here every game advances at its own
+// pace: a simulation costs ITS path depth, not the deepest of the 256 paths, there are no kernel boundaries inside a move, and
+// the tower of one game overlaps the tree phases of the others.  The per-sample arithmetic is that of the stand-alone kernels
+// (same device bodies: net_body.h, pool_body.h, go_body.h), so results are bit-identical to the lock-step path.
+// The host draws the per-cycle feature rotations in the reference's order (cycle-major, actor-minor) before the launch.
+#include "net.h"
+#include "net_body.h"
+#include "pool_body.h"
+#include "go_body.h"
+#include <algorithm>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+
+namespace mz {
+
+struct SimArgs {
+    PoolView pv;
+    GoDevView gv;
+    TowerArgs ta;
+    HeadParams hp;
+    const float* params;
+    float* act;                       // [games][C][P] tower output (input of the heads)
+    float *policy, *logit, *value;    // heads outputs
+    int *cand_count, *cand_action, *cand_player;
+    float *cand_policy, *cand_logit, *value_io, *reward_io;
+    int* err;
+    unsigned* sink;                   // never-taken store target that keeps the prefetch loads alive
+    unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
+};
+
+// The tree phases are separate (non-inlined) functions: inlined next to the tower they push the kernel to 256 VGPRs with spills in
+// the MFMA loop.  SimArgs lives in device memory (not in 1.3 KB of kernel arguments pinned in SGPRs for the whole kernel).
+template <int CPL>
+__device__ __noinline__ void simSelectLeaf(const SimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles)
+{
+    unsigned long long t0 = 0;
+    if (a->prof) { t0 = wall_clock64(); }
+    selectBody(a->pv, nullptr, g, lane);
+    waveSync();
+    if (a->prof && lane == 0) {
+        a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
+        a->prof[size_t(g) * 8 + 6] += a->pv.path_len[g];
+    }
+    goLeafBody<CPL>(a->gv, a->pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles));
+}
+
+__device__ __noinline__ void simCandExpand(const SimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles)
+{
+    azCandBody(a->gv, a->policy, a->logit, a->value, rot, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io,
+               a->reward_io, a->err, g, lane, reinterpret_cast<uint64_t*>(tiles));
+    waveSync();
+    expandBackupBody(a->pv, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane,
+                     tiles);
+}
+
+// While wave 0 walks the tree, wave 1 pulls the children blocks along the PREVIOUS simulation's path into the L2: consecutive
+// simulations mostly share their upper path, the 32-B records of a level are a 2.6 KB block that the tower's traffic has evicted
+// (select: 26 % L2 hit rate), and the walk is one dependent memory round trip per level.  Pure hint: stale or torn path entries
+// are still node ids of this game.
+__device__ __noinline__ void simPrefetchPath(const SimArgs* __restrict__ a, int g, int lane)
+{
+    const PoolView& v = a->pv;
+    const int plen = v.path_len[g];
+    const int* path = v.path + size_t(g) * v.max_depth;
+    const NodeRec* recs = v.rec + size_t(g) * v.cap;
+    unsigned acc = 0;
+    for (int L = lane; L < plen; L += 64) {
+        const int node = path[L];
+        const int fc = recs[node].first_child, nc = recs[node].num_children;
+        if (nc <= 0) { continue; }
+        const char* base = reinterpret_cast<const char*>(recs + fc);
+        for (int off = 0; off < nc * int(sizeof(NodeRec)); off += 128) { acc ^= *reinterpret_cast<const unsigned*>(base + off); }
+    }
+    if (acc == 0x9e3779b9u && plen < 0) { *a->sink = acc; }
+}
+
+__device__ __noinline__ void simHeads(const SimArgs* __restrict__ a, int g, int tid, float* tiles)
+{
+    headsBody(a->act, a->hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles);
+}
+
+template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
+__global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a, const uint8_t* __restrict__ rot_tab, int sim0, int nsims)
+{
+    extern __shared__ __attribute__((aligned(16))) float tiles[];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int games = gridDim.x;
+    unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr;
+    for (int s = 0; s < nsims; ++s) {
+        const int slot = sim0 + s; // simulation index within the move = position slot of its leaf
+        const int rot = rot_tab[size_t(s) * games + g];
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (prof) { t0 = wall_clock64(); }
+        if (wave == 0) { simSelectLeaf<CPL>(a, rot, slot, g, lane, tiles); }
+        else if (wave == 1 && s + slot > 0) { simPrefetchPath(a, g, lane); }
+        __syncthreads();
+        if (prof) { t1 = wall_clock64(); }
+        towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, a->act, g, tid, tiles);
+        __syncthreads();
+        if (prof) { t2 = wall_clock64(); }
+        simHeads(a, g, tid, tiles);
+        __syncthreads();
+        if (prof) { t3 = wall_clock64(); }
+        if (wave == 0) { simCandExpand(a, rot, slot, g, lane, tiles); }
+        __syncthreads();
+        if (prof && tid == 0) {
+            t4 = wall_clock64();
+            prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
+        }
+    }
+}
+
+template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
+static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, size_t lds, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), dim3(games), dim3(512), lds, s, d_args, d_rot, sim0, nsims);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+#define MZ_SIM_CASES(X) \
+    X(9, 9, 20, 64, 2)  /* 9x9 Go, 64 channels (BASELINE configs[1]) */ \
+    X(9, 9, 20, 8, 2)   /* small 9x9 test nets */
+
+void Net::dumpSimProf()
+{
+    if (sim_prof_.n == 0) { return; }
+    std::vector<unsigned long long> h(sim_prof_.n);
+    if (hipMemcpy(h.data(), sim_prof_.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { return; }
+    const char* names[4] = {"select+leaf", "tower", "heads", "cand+expand"};
+    const size_t G = h.size() / 8;
+    double tot_all = 0, tot_max = 0;
+    for (int k = 0; k < 4; ++k) {
+        double sum = 0, mx = 0, sims = 0;
+        for (size_t g = 0; g < G; ++g) { sum += double(h[g * 8 + k]); mx = std::max(mx, double(h[g * 8 + k])); sims += double(h[g * 8 + 4]); }
+        fprintf(stderr, "[mz sim prof] %-12s avg %8.2f us per simulation (slowest game %8.2f us)\n", names[k], sum / std::max(1.0, sims) * 0.01,
+                mx / std::max(1.0, sims / G) * 0.01);
+        tot_all += sum / std::max(1.0, sims) * 0.01;
+    }
+    {
+        double sel = 0, lev = 0, sims = 0, maxlev = 0;
+        for (size_t g = 0; g < G; ++g) { sel += double(h[g * 8 + 5]); lev += double(h[g * 8 + 6]); sims += double(h[g * 8 + 4]); maxlev = std::max(maxlev, double(h[g * 8 + 6]) / std::max(1.0, double(h[g * 8 + 4]))); }
+        fprintf(stderr, "[mz sim prof] select alone avg %8.2f us, path length avg %.2f (deepest game avg %.2f) -> %.2f us per level\n", sel / std::max(1.0, sims) * 0.01,
+                lev / std::max(1.0, sims), maxlev, sel / std::max(1.0, lev) * 0.01);
+    }
+    for (size_t g = 0; g < G; ++g) { tot_max = std::max(tot_max, double(h[g * 8] + h[g * 8 + 1] + h[g * 8 + 2] + h[g * 8 + 3]) / std::max(1.0, double(h[g * 8 + 4])) * 0.01); }
+    fprintf(stderr, "[mz sim prof] total        avg %8.2f us per simulation (slowest game %8.2f us)\n", tot_all, tot_max);
+}
+
+bool Net::hasSimKernel(int board_n) const
+{
+    if (desc_.type != 0 || !use_fused_) { return false; }
+    TowerArgs ta;
+    int c0 = 0;
+    if (!makeTowerArgs(repr_, true, true, &ta, &c0)) { return false; }
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+#define MZ_SIM_HAS(h, w, cin0, cpad, cpl) \
+    if (H == h && W == w && c0 == cin0 && C == cpad && board_n == h && (h * w + 63) / 64 == cpl) { return true; }
+    MZ_SIM_CASES(MZ_SIM_HAS)
+#undef MZ_SIM_HAS
+    return false;
+}
+
+int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_logit, float* d_value, const uint8_t* d_rot, int sim0, int nsims,
+                   bool* launched)
+{
+    *launched = false;
+    if (desc_.type != 0) { return MZ_OK; }
+    SimArgs a;
+    memset(&a, 0, sizeof(a)); // compared bytewise below: no indeterminate padding
+    int c0 = 0;
+    if (!makeTowerArgs(repr_, true, true, &a.ta, &c0)) { return MZ_OK; }
+    int rc = ensureBatch(gv.games);
+    if (rc) { return rc; }
+    makeHeadParams(&a.hp);
+    a.pv = pool.v_;
+    a.gv = gv;
+    a.params = params_.p;
+    a.act = act_[0].p;
+    a.policy = d_policy; a.logit = d_logit; a.value = d_value;
+    a.cand_count = pool.d_cand_count_.p; a.cand_action = pool.d_cand_action_.p; a.cand_player = pool.d_cand_player_.p;
+    a.cand_policy = pool.d_cand_policy_.p; a.cand_logit = pool.d_cand_logit_.p; a.value_io = pool.d_value_.p; a.reward_io = pool.d_reward_.p;
+    a.err = pool.errFlag();
+    if (!sim_sink_.ensure(4)) { setError("hipMalloc failed"); return MZ_ERR_DEVICE; }
+    a.sink = sim_sink_.p;
+    if (getenv("MZ_SIM_PROF")) {
+        if (sim_prof_.n == 0) {
+            if (!sim_prof_.alloc(size_t(gv.games) * 8)) { setError("hipMalloc of the profile buffer failed"); return MZ_ERR_DEVICE; }
+            MZ_HIP(hipMemset(sim_prof_.p, 0, sim_prof_.n * sizeof(unsigned long long)));
+        }
+        a.prof = sim_prof_.p;
+    }
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+    const int cmax = c0 > C ? c0 : C;
+    size_t lds = size_t(3) * cmax * planeStride(H, W) * sizeof(float);
+    const size_t heads = (size_t(a.hp.C) * a.hp.P + size_t(a.hp.PC) * a.hp.P + a.hp.P + a.hp.VH + a.hp.A + 16) * sizeof(float);
+    lds = std::max(lds, std::max(heads, std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A))));
+    lds = std::max(lds, size_t(2) * pool.v_.bound_cap * sizeof(float));
+    // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
+    static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
+    if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
+        if (!sim_args_.ensure(sizeof(SimArgs))) { setError("hipMalloc of the simulation arguments failed"); return MZ_ERR_DEVICE; }
+        MZ_HIP(hipStreamSynchronize(stream_));
+        MZ_HIP(hipMemcpy(sim_args_.p, &a, sizeof(SimArgs), hipMemcpyHostToDevice));
+        sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
+    }
+#define MZ_SIM_LAUNCH(h, w, cin0, cpad, cpl) \
+    if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && gv.W == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, lds, stream_); }
+    MZ_SIM_CASES(MZ_SIM_LAUNCH)
+#undef MZ_SIM_LAUNCH
+    return MZ_OK;
+}
+
+} // namespace mz

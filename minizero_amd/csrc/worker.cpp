@@ -301,11 +301,14 @@ private:
         GoDevice godev;
         RotPack rot{};
         int cycles_since_signal = 0;
+        PinBuf<uint8_t> h_rot;   // per-game simulation kernel: rotations of a batch of cycles [cycle][game]
+        DevBuf<uint8_t> d_rot;
     };
     Lane& laneOf(int g) { return *lanes_[g / lane_size_ < int(lanes_.size()) ? g / lane_size_ : int(lanes_.size()) - 1]; }
-    int phase1(Lane& L, bool root_expansion, bool done);
+    int phase1(Lane& L, bool root_expansion, bool done, bool launch_select = true);
     int phase2(Lane& L);
     int phase2Resident(Lane& L);
+    int runCyclesSim(int n);
     int uploadRoots(Lane& L);
     int cycle();
     int createActors();
@@ -354,6 +357,7 @@ private:
     bool use_signal_ = true;  // wait on a pinned completion word written by a 1-thread kernel instead of hipStreamSynchronize
     bool feat_bits_ = false; // AlphaZero leaves travel host->device as bit-packed planes (all board-game planes are 0/1)
     bool resident_ = false;  // the whole cycle runs on the device (go_dev.hip): the host only does the RNG-ordered per-move logic
+    bool sim_kernel_ = false; // ... and whole runs of cycles are ONE launch of the per-game simulation kernel (sim.hip)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -437,6 +441,12 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             L->pool.v_.host_path_len = nullptr; // nobody on the host reads the paths any more
             L->pool.v_.host_path_action = nullptr;
             if ((rc = uploadRoots(*L))) { return rc; }
+        }
+        sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize());
+        if (sim_kernel_) {
+            for (auto& L : lanes_) {
+                if (!L->h_rot.alloc(size_t(n_ + 1) * L->n) || !L->d_rot.alloc(size_t(n_ + 1) * L->n)) { setError("worker: allocation failed (rot table)"); return MZ_ERR_DEVICE; }
+            }
         }
     }
     return MZ_OK;
@@ -859,7 +869,7 @@ void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor
 // ------------------------------------------------------------------------------------------------
 // phase 1 of a lane: consume the network outputs of the previous cycle (expand + backup), run the RNG-ordered serial
 // section for the lane's games, then launch the selection of the next simulation (asynchronously).
-int Worker::phase1(Lane& L, bool root_expansion, bool done)
+int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
 {
     const bool az = desc_.type == 0;
     const int g0 = L.g0, g1 = L.g0 + L.n;
@@ -961,6 +971,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done)
         MZ_HIP(hipMemcpyAsync(L.pool.d_start_.p, L.pool.h_start_.p, L.n * sizeof(int), hipMemcpyHostToDevice, L.stream));
         d_start = L.pool.d_start_.p;
     }
+    if (!launch_select) { return MZ_OK; } // per-game simulation kernel: selection is part of the launch (runCyclesSim)
     if (resident_) { for (int g = g0; g < g1; ++g) { rotPackSet(L.rot, g - g0, games_[g].rot); } }
     int rc = L.pool.selectAsync(d_start);
     if (rc) { return rc; }
@@ -1078,9 +1089,68 @@ int Worker::cycle()
     return MZ_OK;
 }
 
+// Device-resident cycles in batches: the host part of a cycle (per-move logic in RNG order, rotation draws) runs exactly as in
+// cycle(); every following cycle that needs nothing from the host but its rotation draws joins the same launch of the per-game
+// simulation kernel.  A 400-simulation move is two launches: the root expansion, then (after the root noise) the other 400.
+int Worker::runCyclesSim(int n)
+{
+    MZ_HIP(hipSetDevice(device_));
+    const bool noise_cfg = cfg_.actor_use_dirichlet_noise || cfg_.actor_use_gumbel_noise;
+    int i = 0;
+    while (i < n) {
+        const double t0 = nowMs();
+        sim_pre_ = sims_done_;
+        sim_post_ = sims_done_ + 1;
+        const bool root_expansion = pending_ && (sim_post_ == 1), done = pending_ && (sim_post_ == n_ + 1);
+        for (auto& L : lanes_) {
+            int rc = phase1(*L, root_expansion, done, false);
+            if (rc) { return rc; }
+            for (int j = 0; j < L->n; ++j) { L->h_rot.p[j] = static_cast<uint8_t>(games_[L->g0 + j].rot); }
+        }
+        if (pending_) { sims_done_ = done ? 0 : sim_post_; }
+        const int sim0 = sims_done_;
+        int batch = 1;
+        // cycles after this one: plain while they neither finish the search nor follow the root expansion of a noisy search
+        while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg)) {
+            for (auto& L : lanes_) { // the only RNG draws of a plain cycle: one rotation per actor, in actor order (zero_actor.cpp:56)
+                for (int j = 0; j < L->n; ++j) {
+                    Game& gm = games_[L->g0 + j];
+                    gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
+                    L->h_rot.p[size_t(batch) * L->n + j] = static_cast<uint8_t>(gm.rot);
+                }
+            }
+            ++batch;
+        }
+        for (auto& L : lanes_) {
+            MZ_HIP(hipMemcpyAsync(L->d_rot.p, L->h_rot.p, size_t(batch) * L->n, hipMemcpyHostToDevice, L->stream));
+            bool launched = false;
+            int rc = L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched);
+            if (rc) { return rc; }
+            if (!launched) { setError("worker: no simulation-kernel instance for this network"); return MZ_ERR_STATE; }
+        }
+        sims_done_ = sim0 + batch - 1;
+        pending_ = true;
+        stats_.cycles += batch;
+        stats_.leaf_evals += uint64_t(G_) * batch;
+        i += batch;
+        stats_.ms_total += nowMs() - t0;
+        // the rotation table is rewritten by the next batch: it must have been copied (the next host part usually syncs anyway)
+        if (i < n) { for (auto& L : lanes_) { MZ_HIP(hipStreamSynchronize(L->stream)); } }
+    }
+    const double t0 = nowMs();
+    for (auto& L : lanes_) {
+        MZ_HIP(hipStreamSynchronize(L->stream));
+        int rc = L->pool.checkError();
+        if (rc) { return rc; }
+    }
+    stats_.ms_total += nowMs() - t0;
+    return n;
+}
+
 int Worker::runCycles(int n)
 {
     if (!running_) { return 0; }
+    if (sim_kernel_) { return runCyclesSim(n); }
     for (int i = 0; i < n; ++i) {
         int rc = cycle();
         if (rc) { return rc; }

@@ -130,3 +130,36 @@ def test_small_atari_gumbel_muzero(mz, oracle):
     for i, (a, b) in enumerate(zip(lines, olines)):
         assert a == b, f"line {i} differs:\n  hip   : {a[:300]}\n  oracle: {b[:300]}"
     assert len(lines) == len(olines)
+
+
+def _lines_of(mz, conf, desc_args, chunks, total):
+    kw = dict(vh=desc_args[10], dv=desc_args[11], type_name=desc_args[12])
+    d = mz.make_desc(*desc_args[:10], **kw)
+    wk = mz.Worker(conf + ":program_seed=11:nn_file_name=x.pt:zero_num_threads=2", d, mz.generate_weights(d, 3))
+    wk.command("start")
+    done, k = 0, 0
+    while done < total:
+        c = min(chunks[k % len(chunks)], total - done)
+        assert wk.run_cycles(c) == c
+        done += c
+        k += 1
+    st = wk.stats()
+    assert st["cycles"] == total and st["leaf_evals"] == total * 5
+    return wk.pop_lines()
+
+
+@pytest.mark.parametrize("noise", ["true", "false"])
+def test_go_execution_modes_are_equivalent(mz, noise):
+    """Host leaf environment (lock-step, host hops), device-resident lock-step kernels, and the per-game simulation kernel
+    (whole runs of cycles in one launch, batches cut at arbitrary run_cycles boundaries) must emit identical records."""
+    conf = f"env_game=go:env_board_size=9:actor_num_simulation=12:zero_num_parallel_games=5:actor_use_dirichlet_noise={noise}"
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    total = 13 * 200
+    host = _lines_of(mz, conf + ":mz_device_env=false", args, [total], total)
+    resident = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=false", args, [7, 1, 30], total)
+    sim_whole = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [total], total)
+    sim_chunks = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [1, 2, 5, 13, 3, 40, 12, 14], total)
+    assert len(host) >= 5
+    assert host == resident
+    assert host == sim_whole
+    assert host == sim_chunks
