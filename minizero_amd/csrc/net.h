@@ -10,6 +10,7 @@ namespace mz {
 struct ConvLayer {
     int cin, cin_pad, cout, cout_pad;
     size_t w_off, b_off; // offsets (floats) into Net::params_
+    size_t w4_off;       // the same A-fragments, four channel groups interleaved per lane (one dwordx4 load = 4 k-steps): the fused tower's layout
 };
 
 struct HeadOffsets {

@@ -254,7 +254,7 @@ bool Net::makeTowerArgs(const std::vector<ConvLayer>& t, bool in_bits, bool has_
     ta.OT = t[0].cout_pad / 16;
     ta.in_bits = in_bits ? 1 : 0;
     ta.has_stem = has_stem ? 1 : 0;
-    for (size_t i = 0; i < t.size(); ++i) { ta.w_off[i] = static_cast<unsigned>(t[i].w_off); ta.b_off[i] = static_cast<unsigned>(t[i].b_off); }
+    for (size_t i = 0; i < t.size(); ++i) { ta.w_off[i] = static_cast<unsigned>(t[i].w4_off); ta.b_off[i] = static_cast<unsigned>(t[i].b_off); }
     *c0 = has_stem ? t[0].cin_pad : C; // without a stem the template's CIN0_PAD is unused: pick the C instance
     return true;
 }

@@ -21,6 +21,32 @@ struct TowerArgs {
     unsigned w_off[48], b_off[48];
 };
 
+// Which 16 pixels form MFMA pixel tile t.  The B operand of v_mfma_f32_16x16x4_f32 is one ds_read_b32 per lane with
+// lane = 16 * k + n reading channel plane k at the padded position of pixel n.  The four planes sit 16 banks apart (plane stride
+// % 32 == 16), so the read is conflict-free iff the 16 positions are distinct mod 16.  16 CONSECUTIVE pixels of a W-wide board
+// span up to 16 + 2 * (rows crossed) padded positions, i.e. always collide (measured: SQ_LDS_BANK_CONFLICT = 50 % of the LDS
+// cycles).  Instead tile t takes, for each residue n, the t-th pixel whose padded position is n mod 16: lane n always touches
+// bank (16 k + n + tap offset) mod 64.  Works when no residue class has more than ceil(P/16) pixels (9x9, 8x8, 6x6, 3x3, 19x19);
+// other shapes keep the consecutive tiling.
+template <int H, int W>
+struct TileMap {
+    static constexpr int P = H * W, PW = W + 2, PT = (P + 15) / 16;
+    short q[PT * 16];
+    constexpr TileMap() : q{}
+    {
+        int cnt[16] = {};
+        bool spread = true;
+        for (int i = 0; i < P; ++i) { const int r = ((i / W + 1) * PW + (i % W) + 1) & 15; if (++cnt[r] > PT) { spread = false; } }
+        for (int i = 0; i < PT * 16; ++i) { q[i] = spread ? short(-1) : short(i < P ? i : -1); }
+        if (spread) {
+            int seen[16] = {};
+            for (int i = 0; i < P; ++i) { const int r = ((i / W + 1) * PW + (i % W) + 1) & 15; q[seen[r]++ * 16 + r] = short(i); }
+        }
+    }
+};
+template <int H, int W>
+__device__ const TileMap<H, W> kTileMap{};
+
 template <int H, int W, int CG, int PTW>
 __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
                                             float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
@@ -29,26 +55,35 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16;
     const int ot = wave & 3, half = wave >> 2;
     if (ot >= OT) { return; }
-    int pixoff[PTW], pixdst[PTW];
+    int pixoff[PTW], pixdst[PTW], pixq[PTW];
 #pragma unroll
     for (int j = 0; j < PTW; ++j) {
-        int q = 16 * (half * PTW + j) + (lane & 15);
-        if (q >= P) { q = 0; }
+        const int pt = half * PTW + j;
+        pixq[j] = pt < PT ? kTileMap<H, W>.q[pt * 16 + (lane & 15)] : -1; // -1: padding column of the tile
+        const int q = pixq[j] < 0 ? 0 : pixq[j];
         pixdst[j] = (q / W + 1) * PW + (q % W) + 1;          // interior position in a padded plane
         pixoff[j] = (lane >> 4) * CS + (q / W) * PW + (q % W); // top-left tap of the 3x3 window, channel (lane>>4)
     }
     f32x4 acc[PTW];
 #pragma unroll
     for (int j = 0; j < PTW; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    const float* wl = wp + size_t(ot) * 64 + lane;
-    const size_t wstep = size_t(OT) * 64;
-    // A-fragments are double-buffered by TAP in two register sets; the loop is unrolled by two taps so that no register copies
-    // tie the prefetch to the end of an iteration, and the fences keep the scheduler from sinking the global loads below the tap's
-    // MFMAs (it did: every tap paid an exposed L2 round trip) or hoisting all nine taps' loads (256 VGPRs + spills)
+    // A-fragments in the interleaved layout of weights.cpp (w4_off): for (tap, oc-tile) CG * 64 contiguous floats
+    constexpr int CG4 = CG / 4;
+    const float* wl = wp + size_t(ot) * CG * 64;
+    const size_t wstep = size_t(OT) * CG * 64; // per tap
+    // A-fragments are double-buffered by TAP in two register sets; the loop is fully unrolled (exact s_waitcnt counts: a loop-carried
+    // prefetch gets vmcnt(0)) and the fences keep the scheduler from sinking the global loads below the tap's MFMAs (it did: every
+    // tap paid an exposed L2 round trip) or hoisting all nine taps' loads (256 VGPRs + spills).  Prefetching the B operand (LDS) a tap
+    // ahead the same way does not work: under that register pressure the compiler re-materialises the loads next to their uses.
     float a0[CG], a1[CG];
     auto loadA = [&](float* a, int t) {
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg) { a[cg] = wl[(size_t(t) * CG + cg) * wstep]; }
+        for (int c4 = 0; c4 < CG4; ++c4) {
+            const float4 w = *reinterpret_cast<const float4*>(wl + size_t(t) * wstep + c4 * 256 + lane * 4);
+            a[4 * c4] = w.x; a[4 * c4 + 1] = w.y; a[4 * c4 + 2] = w.z; a[4 * c4 + 3] = w.w;
+        }
+#pragma unroll
+        for (int cg = 4 * CG4; cg < CG; ++cg) { a[cg] = wl[size_t(t) * wstep + CG4 * 256 + (cg - 4 * CG4) * 64 + lane]; }
         asm volatile("" ::: "memory");
     };
     auto tap = [&](const float* a, int t) {
@@ -64,7 +99,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     };
     loadA(a0, 0);
 #pragma unroll
-    for (int t = 0; t < 8; t += 2) { // fully unrolled: s_waitcnt counts are exact only in straight-line code (a loop-carried prefetch gets vmcnt(0))
+    for (int t = 0; t < 8; t += 2) {
         loadA(a1, t + 1);
         tap(a0, t);
         loadA(a0, t + 2);
@@ -73,12 +108,11 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     tap(a0, 8);
 #pragma unroll
     for (int j = 0; j < PTW; ++j) {
-        const int pt = half * PTW + j;
-        const int q = 16 * pt + (lane & 15);
+        const int q = pixq[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int oc = 16 * ot + 4 * (lane >> 4) + r;
-            if (pt < PT && q < P && oc < cout) {
+            if (q >= 0 && oc < cout) {
                 float v = acc[j][r] + bias[oc];
                 if (tskip) { v = v + tskip[oc * CS + pixdst[j]]; }
                 v = v > 0.0f ? v : 0.0f;

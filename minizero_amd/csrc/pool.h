@@ -30,6 +30,7 @@ struct PoolView { // device pointers, passed to kernels by value
     // PUCT tables indexed by N = total_simulation (host-computed with the host libm: bit-exact by construction)
     const float* bias_tab;
     const double* sqrt_tab;
+    const double* rcp_tab; // [n + 4] correctly rounded 1/i (index 0 unused): the divisions by visit counts in select_kernel
     float gamma;
     int value_rescale, flipping_player, atari_init_q;
 };
@@ -97,7 +98,7 @@ private:
     DevBuf<int> bound_cnt_;
     DevBuf<float> bound_key_, game_f_;
     DevBuf<float> bias_tab_;
-    DevBuf<double> sqrt_tab_;
+    DevBuf<double> sqrt_tab_, rcp_tab_;
 };
 
 } // namespace mz

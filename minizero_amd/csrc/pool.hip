@@ -142,7 +142,7 @@ int Pool::init(int device, int games, int nodes_per_game, int action_size, const
     MZ_ALLOC(rec_, NN); MZ_ALLOC(f_nodes_, NN * 3); MZ_ALLOC(i_nodes_, NN);
     MZ_ALLOC(game_i_, G * 3 + 1); MZ_ALLOC(game_f_, G * 2);
     MZ_ALLOC(bound_key_, G * bound_cap); MZ_ALLOC(bound_cnt_, G * bound_cap);
-    MZ_ALLOC(bias_tab_, cfg.num_simulation + 3); MZ_ALLOC(sqrt_tab_, cfg.num_simulation + 3);
+    MZ_ALLOC(bias_tab_, cfg.num_simulation + 3); MZ_ALLOC(sqrt_tab_, cfg.num_simulation + 3); MZ_ALLOC(rcp_tab_, cfg.num_simulation + 5);
     v_.games = games; v_.cap = nodes_per_game; v_.A = action_size; v_.max_depth = max_depth;
     float* f = f_nodes_.p;
     v_.rec = rec_.p;
@@ -172,6 +172,10 @@ int Pool::init(int device, int games, int nodes_per_game, int action_size, const
     MZ_HIP(hipMemcpy(sqrt_tab_.p, sq.data(), sq.size() * sizeof(double), hipMemcpyHostToDevice));
     v_.bias_tab = bias_tab_.p;
     v_.sqrt_tab = sqrt_tab_.p;
+    std::vector<double> rcp(cfg.num_simulation + 5, 0.0); // correctly rounded reciprocals of the visit counts (host IEEE division)
+    for (size_t i = 1; i < rcp.size(); ++i) { rcp[i] = 1.0 / static_cast<double>(i); }
+    MZ_HIP(hipMemcpy(rcp_tab_.p, rcp.data(), rcp.size() * sizeof(double), hipMemcpyHostToDevice));
+    v_.rcp_tab = rcp_tab_.p;
     MZ_HIP(hipMemset(game_i_.p, 0, game_i_.n * sizeof(int)));
 
     // staging

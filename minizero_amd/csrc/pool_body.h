@@ -53,6 +53,56 @@ __device__ __forceinline__ NodeRec loadRec(const NodeRec* p)
 __device__ __forceinline__ int laneI(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float laneF(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
+// ---- fast PUCT level (nodes of <= 128 children, no value rescaling: every board game) ----
+// The walk is ONE wave executing a long dependent instruction stream per level (measured: ~390 cycles waiting for the children
+// records, ~2900 cycles of arithmetic), so the level is written for instruction count:
+//  * both IEEE divisions of the reference's formulas go through a host-built table of correctly rounded reciprocals of the
+//    (integer) visit counts: f32 a / c == (float)((double)a * RN64(1/c)) (the double product is within 2^-52 of a/c, a float
+//    rounding boundary is never that close to a quotient of a float by an integer <= 4096 unless the quotient is subnormal ->
+//    guarded), f64 x / d == fma(fma(-d, q0, x), r, q0) with q0 = x * r (Markstein's correction step, exact for r = RN(1/d));
+//    tests/test_div_tricks.py checks both against real division;
+//  * the arg-max reduces order-preserving integer keys with one DPP max/min per step instead of a three-value compare-and-select.
+__device__ __forceinline__ unsigned orderedKey(float f)
+{
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); // unsigned order == float order (no NaNs, no negative zeros here)
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dppMaxStep(unsigned v)
+{
+    const unsigned o = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, ROW_MASK, 0xF, false));
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned waveMaxU32(unsigned v) // result in every lane
+{
+    v = dppMaxStep<0x111, 0xF>(v);
+    v = dppMaxStep<0x112, 0xF>(v);
+    v = dppMaxStep<0x114, 0xF>(v);
+    v = dppMaxStep<0x118, 0xF>(v);
+    v = dppMaxStep<0x142, 0xA>(v);
+    v = dppMaxStep<0x143, 0xC>(v);
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
+struct LevelEval { float q, score; };
+// q = normalized mean of a visited child (ref mcts.cpp:40-53), u = PUCT exploration term (mcts.cpp:55-61); rc = {RN(1/count), RN(1/(1+count))}
+__device__ __forceinline__ LevelEval evalChild(const PoolView& v, const NodeRec& c, int cplayer, float bias, double sqrtN, double rc0, double rc1, bool* tiny)
+{
+    float value = c.reward + v.gamma * c.mean;
+    value = (cplayer == v.flipping_player) ? -value : value;
+    const float a = value * c.count - 0.0f;
+    LevelEval e;
+    e.q = static_cast<float>(static_cast<double>(a) * rc0); // == a / (count + 0.0f) unless the quotient is subnormal
+    *tiny = (a != 0.0f) && (__builtin_fabsf(a) < 0x1p-100f);
+    const float bpol = bias * c.policy;
+    const double x = static_cast<double>(bpol) * sqrtN;
+    const double d = static_cast<double>(1 + c.count);
+    const double q0 = x * rc1;
+    const double y = __builtin_fma(__builtin_fma(-d, q0, x), rc1, q0); // == x / d
+    e.score = static_cast<float>(y);
+    return e;
+}
+
 // One wave64 per game.  Per level: every lane loads the 32-B records of its children (<= 2 per lane for A <= 128, a loop
 // beyond), all arithmetic runs from registers, and the winning lane's record supplies the next level's (first_child,
 // num_children, count) through shuffles — a single dependent memory round trip per level.
@@ -79,6 +129,60 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
         const int N = static_cast<int>(cur.count - 1);
         const float bias = v.bias_tab[N];
         const double sqrtN = v.sqrt_tab[N];
+        if (nc <= 128 && !v.value_rescale) {
+            const bool two = nc > 64; // wave-uniform
+            const bool has0 = lane < nc, has1 = lane + 64 < nc;
+            NodeRec c0 = loadRec(recs + fc + (has0 ? lane : nc - 1)), c1 = c0;
+            if (two) { c1 = loadRec(recs + fc + (has1 ? lane + 64 : nc - 1)); }
+            const double* r0p = v.rcp_tab + static_cast<int>(c0.count);
+            const double r00 = r0p[0], r01 = r0p[1];
+            double r10 = r00, r11 = r01;
+            if (two) { const double* r1p = v.rcp_tab + static_cast<int>(c1.count); r10 = r1p[0]; r11 = r1p[1]; }
+            bool tiny0 = false, tiny1 = false;
+            LevelEval e0 = evalChild(v, c0, cplayer, bias, sqrtN, r00, r01, &tiny0), e1 = e0;
+            const bool vis0 = has0 && c0.count != 0.0f;
+            bool vis1 = false;
+            if (two) { e1 = evalChild(v, c1, cplayer, bias, sqrtN, r10, r11, &tiny1); vis1 = has1 && c1.count != 0.0f; }
+            if (__ballot((vis0 && tiny0) || (vis1 && tiny1)) != 0) { // subnormal quotient: the reference's division (never seen in practice)
+                e0.q = normalizedMean(v, c0.reward, c0.mean, c0.count, cplayer, bsize, lo, hi);
+                e1.q = normalizedMean(v, c1.reward, c1.mean, c1.count, cplayer, bsize, lo, hi);
+            }
+            // init Q: ordered f32 sum over the visited children in storage order (ref mcts.cpp:200-217)
+            float sum_of_win = 0.0f, sum = 0.0f;
+            unsigned long long m = __ballot(vis0);
+            while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += laneF(e0.q, j); sum += 1; }
+            if (two) {
+                m = __ballot(vis1);
+                while (m) { const int j = __builtin_ctzll(m); m &= m - 1; sum_of_win += laneF(e1.q, j); sum += 1; }
+            }
+            const float init_q = v.atari_init_q ? (sum > 0 ? sum_of_win / sum : 1.0f) : (sum_of_win - 1) / (sum + 1);
+            const float s0 = e0.score + (c0.count == 0.0f ? init_q : e0.q);
+            const float s1 = e1.score + (c1.count == 0.0f ? init_q : e1.q);
+            // per-lane best of its (at most) two children, then the wave arg-max: score, then prior, then the lower index (mcts.cpp:189-195)
+            const bool take1 = has1 && better(s1, c1.policy, lane + 64, s0, c0.policy, lane);
+            const NodeRec best = take1 ? c1 : c0;
+            const int bi = take1 ? lane + 64 : lane;
+            const unsigned ks = has0 ? orderedKey(take1 ? s1 : s0) : 0u;
+            const unsigned smax = waveMaxU32(ks);
+            const unsigned kp = (has0 && ks == smax) ? orderedKey(best.policy) : 0u;
+            const unsigned pmax = waveMaxU32(kp);
+            const unsigned ki = (has0 && ks == smax && kp == pmax) ? ~static_cast<unsigned>(bi) : 0u; // max of ~index = lowest index
+            const int ri = static_cast<int>(~waveMaxU32(ki));
+            const int owner = ri & 63;
+            cur.count = laneF(best.count, owner);
+            cur.first_child = laneI(best.first_child, owner);
+            cur.num_children = laneI(best.num_children, owner);
+            cur.action = laneI(best.action, owner);
+            cur.players = laneI(best.players, owner);
+            node = fc + ri;
+            if (lane == 0) {
+                path[depth] = node;
+                pact[depth] = cur.action;
+                if (hact) { hact[depth] = cur.action; }
+            }
+            ++depth;
+            continue;
+        }
         // ---- pass 1: init Q = ordered f32 sum over visited children (ref mcts.cpp:200-217); records stay in registers for A <= 128 ----
         NodeRec c0, c1;
         c0.count = 0; c1.count = 0;

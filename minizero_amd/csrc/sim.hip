@@ -98,10 +98,11 @@ __global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a,
         if (wave == 0) { simSelectLeaf<CPL>(a, rot, slot, g, lane, tiles); }
         else if (wave == 1 && s + slot > 0) { simPrefetchPath(a, g, lane); }
         __syncthreads();
-        if (prof) { t1 = wall_clock64(); }
+        unsigned long long c1 = 0;
+        if (prof) { t1 = wall_clock64(); c1 = clock64(); }
         towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, a->act, g, tid, tiles);
         __syncthreads();
-        if (prof) { t2 = wall_clock64(); }
+        if (prof) { t2 = wall_clock64(); if (tid == 0) { prof[7] += clock64() - c1; } }
         simHeads(a, g, tid, tiles);
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
@@ -136,6 +137,7 @@ void Net::dumpSimProf()
     if (sim_prof_.n == 0) { return; }
     std::vector<unsigned long long> h(sim_prof_.n);
     if (hipMemcpy(h.data(), sim_prof_.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { return; }
+    { double cyc = 0, tk = 0; for (size_t g = 0; g < h.size() / 8; ++g) { cyc += double(h[g * 8 + 7]); tk += double(h[g * 8 + 1]); } fprintf(stderr, "[mz sim prof] shader clock during the tower: %.3f GHz (clock64 / wall_clock64)\n", cyc / std::max(1.0, tk) * 0.1); }
     const char* names[4] = {"select+leaf", "tower", "heads", "cand+expand"};
     const size_t G = h.size() / 8;
     double tot_all = 0, tot_max = 0;

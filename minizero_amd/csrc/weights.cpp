@@ -180,6 +180,22 @@ ConvLayer packConv3(std::vector<float>& dst, const Folded& f)
                     if (oc < f.cout && c < f.cin) { wp[((size_t(t) * CG + cg) * OT + ot) * 64 + l] = f.w[(size_t(oc) * f.cin + c) * 9 + t]; }
                 }
     L.w_off = append(dst, wp);
+    // fused-tower layout: for (tap, oc-tile) the CG fragments are contiguous; groups of four channel groups are interleaved per lane so
+    // that one global_load_dwordx4 brings a lane its A values of four k-steps; the CG % 4 remaining fragments follow as plain 64-float rows
+    {
+        std::vector<float> w4(wp.size(), 0.0f);
+        const int CG4 = CG / 4;
+        for (int t = 0; t < 9; ++t)
+            for (int ot = 0; ot < OT; ++ot)
+                for (int cg = 0; cg < CG; ++cg)
+                    for (int l = 0; l < 64; ++l) {
+                        const size_t base = (size_t(t) * OT + ot) * CG * 64;
+                        const size_t idx = cg < 4 * CG4 ? base + size_t(cg >> 2) * 256 + size_t(l) * 4 + (cg & 3)
+                                                        : base + size_t(CG4) * 256 + size_t(cg - 4 * CG4) * 64 + l;
+                        w4[idx] = wp[((size_t(t) * CG + cg) * OT + ot) * 64 + l];
+                    }
+        L.w4_off = append(dst, w4);
+    }
     std::vector<float> b(L.cout_pad, 0.0f);
     for (int oc = 0; oc < f.cout; ++oc) { b[oc] = f.b[oc]; }
     L.b_off = append(dst, b);
