@@ -124,8 +124,9 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
 
 // the body of tower_fused for sample `b`, run by all 512 threads of a workgroup (tid 0..511); `tiles` = 3 x [CMAX][CS] floats of LDS
 template <int H, int W, int CIN0_PAD, int CPAD>
-__device__ __forceinline__ void towerBody(const float* __restrict__ in, const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ out,
-                                          int b, int tid, float* __restrict__ tiles)
+// out == nullptr: the last layer's activations stay in LDS; the returned pointer is that tile ([C][CS] padded planes)
+__device__ __forceinline__ float* towerBody(const float* __restrict__ in, const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ out,
+                                            int b, int tid, float* __restrict__ tiles)
 {
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16, PTW = (PT + 1) / 2;
     constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void towerBody(const float* __restrict__ in, const fl
         }
     }
     __syncthreads();
-    float* gout = out + size_t(b) * ta.C * P;
+    float* gout = out ? out + size_t(b) * ta.C * P : nullptr;
     if (ta.has_stem) { // stem: T0 -> T1
         tower_layer<H, W, CIN0_PAD / 4, PTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT,
                                               lane, wave);
@@ -167,6 +168,7 @@ __device__ __forceinline__ void towerBody(const float* __restrict__ in, const fl
         __syncthreads();
         float* s = x; x = y; y = s;
     }
+    return x;
 }
 
 
@@ -178,22 +180,47 @@ struct HeadParams {
     int C, P, A, PC, VH;
 };
 
+// acc = fmaf(x[i * xs], w[i * ws], acc) for i = 0 .. n-1 IN ORDER (one f32 chain), with the weights of CH steps loaded
+// ahead of the CH dependent fmas: the chain is latency-bound, and with the load issued next to each fma every step paid an L2 trip
+template <int CH>
+__device__ __forceinline__ float dotChain(const float* __restrict__ x, int xs, const float* __restrict__ w, size_t ws, int n)
+{
+    float acc = 0.0f;
+    int i0 = 0;
+    for (; i0 + CH <= n; i0 += CH) {
+        float wv[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) { wv[k] = w[size_t(i0 + k) * ws]; }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) { acc = __builtin_fmaf(x[(i0 + k) * xs], wv[k], acc); }
+    }
+    for (; i0 < n; ++i0) { acc = __builtin_fmaf(x[i0 * xs], w[size_t(i0) * ws], acc); }
+    return acc;
+}
+
 // the body of heads_kernel for sample `b`, run by NT threads (a multiple of 64, >= 128); `sm` = (C*P + PC*P + P + VH + A + 16) floats of LDS
 __device__ __forceinline__ void headsBody(const float* __restrict__ x, const HeadParams& hp, float* __restrict__ policy, float* __restrict__ logit,
                                           float* __restrict__ value, float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int scale_hidden,
-                                          int b, int tid, int NT, float* __restrict__ sm)
+                                          int b, int tid, int NT, float* __restrict__ sm, const float* __restrict__ xlds = nullptr, int xcs = 0,
+                                          int xpw = 0)
 {
+    // xlds != nullptr: the activations are already in LDS as padded planes (channel stride xcs, row stride xpw, 1-pixel border): no copy,
+    // `sm` then only holds the scratch (PC*P + P + VH + A + 16 floats); not combined with scale_hidden
     const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC, VH = hp.VH;
     float* xs = sm;                // [C*P]
-    float* pf = xs + C * P;        // [PC*P]
+    float* pf = xlds ? sm : xs + C * P; // [PC*P]
     float* vf = pf + PC * P;       // [P]
     float* h1 = vf + P;            // [VH]
     float* lg = h1 + VH;           // [A] logits, then exp values
     float* red = lg + A;           // [16] reduction scratch
     const int lane = tid & 63, wave = tid >> 6, NW = NT >> 6;
-    const float* src = x + size_t(b) * C * P;
-    for (int i = tid; i < C * P; i += NT) { xs[i] = src[i]; }
-    __syncthreads();
+    if (!xlds) {
+        const float* src = x + size_t(b) * C * P;
+        for (int i = tid; i < C * P; i += NT) { xs[i] = src[i]; }
+        __syncthreads();
+    }
+    const float* xrd = xlds ? xlds : xs;
+    const int xstride = xlds ? xcs : P;
 
     if (scale_hidden) { // min/max are order-free; (h - min) / scale is one IEEE op each
         float mn = 3.4e38f, mx = -3.4e38f;
@@ -222,35 +249,32 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
     for (int i = tid; i < (PC + 1) * P; i += NT) {
         const int j = i / P, p = i - j * P;
         const float* w = (j < PC) ? hp.pconv_w + j * C : hp.vconv_w;
-        float acc = 0.0f;
-        for (int c = 0; c < C; ++c) { acc = __builtin_fmaf(xs[c * P + p], w[c], acc); }
+        const int xo = xlds ? (p / (xpw - 2) + 1) * xpw + p % (xpw - 2) + 1 : p;
+        const float acc = dotChain<16>(xrd + xo, xstride, w, 1, C);
         float v = acc + ((j < PC) ? hp.pconv_b[j] : hp.vconv_b[0]);
         v = v > 0.0f ? v : 0.0f;
         if (j < PC) { pf[i] = v; } else { vf[p] = v; }
     }
     __syncthreads();
 
-    // policy FC (one logit per thread) and value FC1 (one hidden unit per thread)
+    // policy FC (one logit per thread, waves 0..) and value FC1 (one hidden unit per thread, on other waves when there are enough)
     for (int a = tid; a < A; a += NT) {
-        float acc = 0.0f;
-        const int n = PC * P;
-        for (int i = 0; i < n; ++i) { acc = __builtin_fmaf(pf[i], hp.pfc_wT[size_t(i) * A + a], acc); }
-        float v = acc + hp.pfc_b[a];
+        const float v = dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
         lg[a] = v;
         logit[size_t(b) * A + a] = v;
     }
-    for (int o = tid; o < VH; o += NT) {
-        float acc = 0.0f;
-        for (int p = 0; p < P; ++p) { acc = __builtin_fmaf(vf[p], hp.vfc1_wT[size_t(p) * VH + o], acc); }
-        float v = acc + hp.vfc1_b[o];
-        h1[o] = v > 0.0f ? v : 0.0f;
+    {
+        const int vo = (NT >= 256 && A <= 128) ? 128 : 0; // first thread of the value FC1 group
+        for (int o = (tid - vo + NT) % NT; o < VH; o += NT) {
+            const float v = dotChain<16>(vf, 1, hp.vfc1_wT + o, VH, P) + hp.vfc1_b[o];
+            h1[o] = v > 0.0f ? v : 0.0f;
+        }
     }
     __syncthreads();
 
     // value FC2 + tanh: one sequential chain (wave 1, lane 0) while wave 0 does the softmax
     if (tid == 64) {
-        float acc = 0.0f;
-        for (int o = 0; o < VH; ++o) { acc = __builtin_fmaf(h1[o], hp.vfc2_w[o], acc); }
+        const float acc = dotChain<16>(h1, 1, hp.vfc2_w, 1, VH);
         value[b] = mz_tanhf(acc + hp.vfc2_b[0]);
     }
     if (wave == 0) {

@@ -78,9 +78,10 @@ __device__ __noinline__ void simPrefetchPath(const SimArgs* __restrict__ a, int 
     if (acc == 0x9e3779b9u && plen < 0) { *a->sink = acc; }
 }
 
-__device__ __noinline__ void simHeads(const SimArgs* __restrict__ a, int g, int tid, float* tiles)
+// the heads read the tower's last activations where they are (an LDS tile); tile 0 (the blocks' temporary) is free for their scratch
+__device__ __noinline__ void simHeads(const SimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
 {
-    headsBody(a->act, a->hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles);
+    headsBody(nullptr, a->hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
 }
 
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
@@ -100,10 +101,10 @@ __global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a,
         __syncthreads();
         unsigned long long c1 = 0;
         if (prof) { t1 = wall_clock64(); c1 = clock64(); }
-        towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, a->act, g, tid, tiles);
+        const float* xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, nullptr, g, tid, tiles);
         __syncthreads();
         if (prof) { t2 = wall_clock64(); if (tid == 0) { prof[7] += clock64() - c1; } }
-        simHeads(a, g, tid, tiles);
+        simHeads(a, g, tid, tiles, xt, planeStride(H, W), W + 2);
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
         if (wave == 0) { simCandExpand(a, rot, slot, g, lane, tiles); }
