@@ -303,6 +303,8 @@ private:
         int cycles_since_signal = 0;
         PinBuf<uint8_t> h_rot;   // per-game simulation kernel: rotations of a batch of cycles [cycle][game]
         DevBuf<uint8_t> d_rot;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr; // GPU time of the simulation-kernel launches (stats: ms_forward)
+        ~Lane() { if (ev0) { (void)hipEventDestroy(ev0); } if (ev1) { (void)hipEventDestroy(ev1); } }
     };
     Lane& laneOf(int g) { return *lanes_[g / lane_size_ < int(lanes_.size()) ? g / lane_size_ : int(lanes_.size()) - 1]; }
     int phase1(Lane& L, bool root_expansion, bool done, bool launch_select = true);
@@ -446,6 +448,8 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         if (sim_kernel_) {
             for (auto& L : lanes_) {
                 if (!L->h_rot.alloc(size_t(n_ + 1) * L->n) || !L->d_rot.alloc(size_t(n_ + 1) * L->n)) { setError("worker: allocation failed (rot table)"); return MZ_ERR_DEVICE; }
+                MZ_HIP(hipEventCreate(&L->ev0));
+                MZ_HIP(hipEventCreate(&L->ev1));
             }
         }
     }
@@ -1124,26 +1128,32 @@ int Worker::runCyclesSim(int n)
         for (auto& L : lanes_) {
             MZ_HIP(hipMemcpyAsync(L->d_rot.p, L->h_rot.p, size_t(batch) * L->n, hipMemcpyHostToDevice, L->stream));
             bool launched = false;
+            MZ_HIP(hipEventRecord(L->ev0, L->stream));
             int rc = L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched);
             if (rc) { return rc; }
             if (!launched) { setError("worker: no simulation-kernel instance for this network"); return MZ_ERR_STATE; }
+            MZ_HIP(hipEventRecord(L->ev1, L->stream));
         }
         sims_done_ = sim0 + batch - 1;
         pending_ = true;
         stats_.cycles += batch;
         stats_.leaf_evals += uint64_t(G_) * batch;
         i += batch;
+        // the batch has to finish before the next host part (root statistics) or the return; its GPU time goes to ms_forward
+        float ms_gpu = 0.0f;
+        for (auto& L : lanes_) {
+            MZ_HIP(hipStreamSynchronize(L->stream));
+            float ms = 0.0f;
+            MZ_HIP(hipEventElapsedTime(&ms, L->ev0, L->ev1));
+            ms_gpu = std::max(ms_gpu, ms);
+        }
+        stats_.ms_forward += ms_gpu;
         stats_.ms_total += nowMs() - t0;
-        // the rotation table is rewritten by the next batch: it must have been copied (the next host part usually syncs anyway)
-        if (i < n) { for (auto& L : lanes_) { MZ_HIP(hipStreamSynchronize(L->stream)); } }
     }
-    const double t0 = nowMs();
     for (auto& L : lanes_) {
-        MZ_HIP(hipStreamSynchronize(L->stream));
         int rc = L->pool.checkError();
         if (rc) { return rc; }
     }
-    stats_.ms_total += nowMs() - t0;
     return n;
 }
 
