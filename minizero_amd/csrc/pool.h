@@ -58,6 +58,7 @@ public:
     int hiddenIndexAsync(int slots_per_game, int dst_slot, int* d_src_idx, int* d_dst_idx, int* d_action_ids); // MuZero: slots of the last select
     int checkError();                              // device-side error flag (capacity)
     int* errFlag() { return game_i_.p + size_t(v_.games) * 3; }
+    int rcpEntries() const { return static_cast<int>(rcp_tab_.n); }
     // low-latency completion: a 1-thread kernel stores `value` into a pinned host word behind everything already queued on
     // the stream; the host spins on that word instead of going through hipStreamSynchronize (falls back to it after 20 ms)
     int signalAsync(int value);

@@ -31,7 +31,7 @@ __global__ void reset_kernel(PoolView v, const int* __restrict__ mask, const int
     v.bound_lo[g] = 0; v.bound_hi[g] = 0;
 }
 
-__global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __restrict__ start) { selectBody(v, start, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void select_kernel(PoolView v, const int* __restrict__ start) { selectBody(v, start, blockIdx.x, threadIdx.x, v.rcp_tab); }
 
 __global__ __launch_bounds__(64) void expand_backup_kernel(PoolView v, const int* __restrict__ cand_count, const int* __restrict__ cand_action,
                                                            const float* __restrict__ cand_policy, const float* __restrict__ cand_logit,

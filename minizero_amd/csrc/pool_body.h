@@ -106,7 +106,10 @@ __device__ __forceinline__ LevelEval evalChild(const PoolView& v, const NodeRec&
 // One wave64 per game.  Per level: every lane loads the 32-B records of its children (<= 2 per lane for A <= 128, a loop
 // beyond), all arithmetic runs from registers, and the winning lane's record supplies the next level's (first_child,
 // num_children, count) through shuffles — a single dependent memory round trip per level.
-__device__ __forceinline__ void selectBody(const PoolView& v, const int* __restrict__ start, int g, int lane)
+// rcp: the reciprocal table RN64(1/i) — v.rcp_tab (global) or an LDS copy of it (the simulation kernel: the table lookup is on the
+// per-level critical path, right behind the children records)
+template <class RcpPtr>
+__device__ __forceinline__ void selectBody(const PoolView& v, const int* __restrict__ start, int g, int lane, RcpPtr rcp)
 {
     const NodeRec* recs = v.rec + size_t(g) * v.cap;
     int* path = v.path + size_t(g) * v.max_depth;
@@ -134,10 +137,10 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
             const bool has0 = lane < nc, has1 = lane + 64 < nc;
             NodeRec c0 = loadRec(recs + fc + (has0 ? lane : nc - 1)), c1 = c0;
             if (two) { c1 = loadRec(recs + fc + (has1 ? lane + 64 : nc - 1)); }
-            const double* r0p = v.rcp_tab + static_cast<int>(c0.count);
+            const RcpPtr r0p = rcp + static_cast<int>(c0.count);
             const double r00 = r0p[0], r01 = r0p[1];
             double r10 = r00, r11 = r01;
-            if (two) { const double* r1p = v.rcp_tab + static_cast<int>(c1.count); r10 = r1p[0]; r11 = r1p[1]; }
+            if (two) { const RcpPtr r1p = rcp + static_cast<int>(c1.count); r10 = r1p[0]; r11 = r1p[1]; }
             bool tiny0 = false, tiny1 = false;
             LevelEval e0 = evalChild(v, c0, cplayer, bias, sqrtN, r00, r01, &tiny0), e1 = e0;
             const bool vis0 = has0 && c0.count != 0.0f;

@@ -28,18 +28,21 @@ struct SimArgs {
     int *cand_count, *cand_action, *cand_player;
     float *cand_policy, *cand_logit, *value_io, *reward_io;
     int* err;
+    int rcp_n;                        // entries of pv.rcp_tab
     unsigned* sink;                   // never-taken store target that keeps the prefetch loads alive
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
 
 // The tree phases are separate (non-inlined) functions: inlined next to the tower they push the kernel to 256 VGPRs with spills in
 // the MFMA loop.  SimArgs lives in device memory (not in 1.3 KB of kernel arguments pinned in SGPRs for the whole kernel).
+typedef __attribute__((address_space(3))) const double LdsCDouble;
+
 template <int CPL>
-__device__ __noinline__ void simSelectLeaf(const SimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles)
+__device__ __noinline__ void simSelectLeaf(const SimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp)
 {
     unsigned long long t0 = 0;
     if (a->prof) { t0 = wall_clock64(); }
-    selectBody(a->pv, nullptr, g, lane);
+    selectBody(a->pv, nullptr, g, lane, rcp);
     waveSync();
     if (a->prof && lane == 0) {
         a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
@@ -90,13 +93,19 @@ __global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a,
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int games = gridDim.x;
+    // the reciprocal table of the PUCT divisions lives in LDS above the three tower tiles for the whole launch
+    constexpr int kTileFloats = 3 * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W);
+    double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
+    for (int i = tid; i < a->rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
+    __syncthreads();
+    LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr;
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = position slot of its leaf
         const int rot = rot_tab[size_t(s) * games + g];
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (prof) { t0 = wall_clock64(); }
-        if (wave == 0) { simSelectLeaf<CPL>(a, rot, slot, g, lane, tiles); }
+        if (wave == 0) { simSelectLeaf<CPL>(a, rot, slot, g, lane, tiles, rcp_lds); }
         else if (wave == 1 && s + slot > 0) { simPrefetchPath(a, g, lane); }
         __syncthreads();
         unsigned long long c1 = 0;
@@ -193,6 +202,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     a.cand_count = pool.d_cand_count_.p; a.cand_action = pool.d_cand_action_.p; a.cand_player = pool.d_cand_player_.p;
     a.cand_policy = pool.d_cand_policy_.p; a.cand_logit = pool.d_cand_logit_.p; a.value_io = pool.d_value_.p; a.reward_io = pool.d_reward_.p;
     a.err = pool.errFlag();
+    a.rcp_n = pool.rcpEntries();
     if (!sim_sink_.ensure(4)) { setError("hipMalloc failed"); return MZ_ERR_DEVICE; }
     a.sink = sim_sink_.p;
     if (getenv("MZ_SIM_PROF")) {
@@ -208,6 +218,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     const size_t heads = (size_t(a.hp.C) * a.hp.P + size_t(a.hp.PC) * a.hp.P + a.hp.P + a.hp.VH + a.hp.A + 16) * sizeof(float);
     lds = std::max(lds, std::max(heads, std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A))));
     lds = std::max(lds, size_t(2) * pool.v_.bound_cap * sizeof(float));
+    lds = size_t(3) * cmax * planeStride(H, W) * sizeof(float) + size_t(a.rcp_n) * sizeof(double) > lds ? size_t(3) * cmax * planeStride(H, W) * sizeof(float) + size_t(a.rcp_n) * sizeof(double) : lds;
     // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
     static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
