@@ -47,10 +47,14 @@ struct TileMap {
 template <int H, int W>
 __device__ const TileMap<H, W> kTileMap{};
 
-template <int H, int W, int CG, int PTW>
+// a_first / have_first: this layer's tap-0 A-fragments if the previous layer already fetched them; next_wp / a_next: the NEXT layer's
+// weights (nullptr: none) whose tap-0 fragments are fetched during this layer's last tap, so that the layer boundary (epilogue,
+// barrier) does not end with an exposed L2 round trip; the bias values are fetched at the start of the layer for the same reason
+template <int H, int W, int CG, int PTW, int CGN>
 __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
                                             float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
-                                            int lane, int wave)
+                                            int lane, int wave, bool have_first, float (&a_first)[CG], const float* __restrict__ next_wp,
+                                            float (&a_next)[CGN])
 {
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16;
     const int ot = wave & 3, half = wave >> 2;
@@ -67,6 +71,8 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     f32x4 acc[PTW];
 #pragma unroll
     for (int j = 0; j < PTW; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const float4 bias4 = *reinterpret_cast<const float4*>(bias + 16 * ot + 4 * (lane >> 4)); // the 4 output channels of this lane's accumulators
+    const float biasv[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
     // A-fragments in the interleaved layout of weights.cpp (w4_off): for (tap, oc-tile) CG * 64 contiguous floats
     constexpr int CG4 = CG / 4;
     const float* wl = wp + size_t(ot) * CG * 64;
@@ -76,16 +82,17 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     // tap paid an exposed L2 round trip) or hoisting all nine taps' loads (256 VGPRs + spills).  Prefetching the B operand (LDS) a tap
     // ahead the same way does not work: under that register pressure the compiler re-materialises the loads next to their uses.
     float a0[CG], a1[CG];
-    auto loadA = [&](float* a, int t) {
+    auto loadFrom = [&](float* a, const float* base) { // base = first float of a (tap, oc-tile) block of CG * 64 floats
 #pragma unroll
         for (int c4 = 0; c4 < CG4; ++c4) {
-            const float4 w = *reinterpret_cast<const float4*>(wl + size_t(t) * wstep + c4 * 256 + lane * 4);
+            const float4 w = *reinterpret_cast<const float4*>(base + c4 * 256 + lane * 4);
             a[4 * c4] = w.x; a[4 * c4 + 1] = w.y; a[4 * c4 + 2] = w.z; a[4 * c4 + 3] = w.w;
         }
 #pragma unroll
-        for (int cg = 4 * CG4; cg < CG; ++cg) { a[cg] = wl[size_t(t) * wstep + CG4 * 256 + (cg - 4 * CG4) * 64 + lane]; }
+        for (int cg = 4 * CG4; cg < CG; ++cg) { a[cg] = base[CG4 * 256 + (cg - 4 * CG4) * 64 + lane]; }
         asm volatile("" ::: "memory");
     };
+    auto loadA = [&](float* a, int t) { loadFrom(a, wl + size_t(t) * wstep); };
     auto tap = [&](const float* a, int t) {
         const int tapoff = (t / 3) * PW + (t % 3);
 #pragma unroll
@@ -97,13 +104,30 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
             }
         }
     };
-    loadA(a0, 0);
+    if (have_first) {
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) { a0[cg] = a_first[cg]; }
+    } else {
+        loadA(a0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < 8; t += 2) {
         loadA(a1, t + 1);
         tap(a0, t);
         loadA(a0, t + 2);
         tap(a1, t + 1);
+    }
+    if (next_wp) { // the next layer's first tap (its block of this wave's oc-tile): in flight during the last tap, the epilogue and the barrier
+        constexpr int CGN4 = CGN / 4;
+        const float* nb = next_wp + size_t(ot) * CGN * 64;
+#pragma unroll
+        for (int c4 = 0; c4 < CGN4; ++c4) {
+            const float4 w = *reinterpret_cast<const float4*>(nb + c4 * 256 + lane * 4);
+            a_next[4 * c4] = w.x; a_next[4 * c4 + 1] = w.y; a_next[4 * c4 + 2] = w.z; a_next[4 * c4 + 3] = w.w;
+        }
+#pragma unroll
+        for (int cg = 4 * CGN4; cg < CGN; ++cg) { a_next[cg] = nb[CGN4 * 256 + (cg - 4 * CGN4) * 64 + lane]; }
+        asm volatile("" ::: "memory");
     }
     tap(a0, 8);
 #pragma unroll
@@ -113,7 +137,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
         for (int r = 0; r < 4; ++r) {
             const int oc = 16 * ot + 4 * (lane >> 4) + r;
             if (q >= 0 && oc < cout) {
-                float v = acc[j][r] + bias[oc];
+                float v = acc[j][r] + biasv[r];
                 if (tskip) { v = v + tskip[oc * CS + pixdst[j]]; }
                 v = v > 0.0f ? v : 0.0f;
                 if (gout) { __builtin_nontemporal_store(v, &gout[oc * P + q]); } else { tout[oc * CS + pixdst[j]] = v; }
@@ -154,17 +178,25 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     }
     __syncthreads();
     float* gout = out ? out + size_t(b) * ta.C * P : nullptr;
+    // tap-0 A-fragments of the next layer travel from layer to layer in registers (aA / aB alternate)
+    float aS[CIN0_PAD / 4], aA[CPAD / 4], aB[CPAD / 4];
+    bool have = false;
     if (ta.has_stem) { // stem: T0 -> T1
-        tower_layer<H, W, CIN0_PAD / 4, PTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT,
-                                              lane, wave);
+        const float* nw = ta.nlayers > 1 ? params + ta.w_off[1] : nullptr;
+        tower_layer<H, W, CIN0_PAD / 4, PTW, CPAD / 4>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C,
+                                                         ta.OT, lane, wave, false, aS, nw, aA);
+        have = nw != nullptr;
         __syncthreads();
     }
     float *x = T1, *tmp = T0, *y = T2;
     for (int l = ta.has_stem; l + 1 < ta.nlayers; l += 2) { // residual block: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x)
-        tower_layer<H, W, CPAD / 4, PTW>(x, nullptr, tmp, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, wave);
+        tower_layer<H, W, CPAD / 4, PTW, CPAD / 4>(x, nullptr, tmp, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, wave, have, aA,
+                                                     params + ta.w_off[l + 1], aB);
         __syncthreads();
         const bool last = (l + 2 >= ta.nlayers);
-        tower_layer<H, W, CPAD / 4, PTW>(tmp, x, y, last ? gout : nullptr, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, ta.OT, lane, wave);
+        tower_layer<H, W, CPAD / 4, PTW, CPAD / 4>(tmp, x, y, last ? gout : nullptr, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, ta.OT, lane,
+                                                     wave, true, aB, last ? nullptr : params + ta.w_off[l + 2], aA);
+        have = !last;
         __syncthreads();
         float* s = x; x = y; y = s;
     }
