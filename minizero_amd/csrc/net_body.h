@@ -129,6 +129,14 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
         for (int cg = 4 * CGN4; cg < CGN; ++cg) { a_next[cg] = nb[CGN4 * 256 + (cg - 4 * CGN4) * 64 + lane]; }
         asm volatile("" ::: "memory");
     }
+    // the residual inputs of the epilogue are read while the last tap's MFMAs run
+    float skv[PTW][4];
+#pragma unroll
+    for (int j = 0; j < PTW; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { skv[j][r] = tskip ? tskip[(16 * ot + 4 * (lane >> 4) + r) * CS + pixdst[j]] : 0.0f; }
+    }
+    asm volatile("" ::: "memory");
     tap(a0, 8);
 #pragma unroll
     for (int j = 0; j < PTW; ++j) {
@@ -138,7 +146,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
             const int oc = 16 * ot + 4 * (lane >> 4) + r;
             if (q >= 0 && oc < cout) {
                 float v = acc[j][r] + biasv[r];
-                if (tskip) { v = v + tskip[oc * CS + pixdst[j]]; }
+                if (tskip) { v = v + skv[j][r]; }
                 v = v > 0.0f ? v : 0.0f;
                 if (gout) { __builtin_nontemporal_store(v, &gout[oc * P + q]); } else { tout[oc * CS + pixdst[j]] = v; }
             }
