@@ -59,6 +59,11 @@ long mz_net_param_count(const mz_net_desc* desc);
  * of BASELINE.json).  out must hold mz_net_param_count() floats. */
 int mz_net_generate_weights(const mz_net_desc* desc, uint64_t seed, float* out);
 
+/* Network::loadModel's torch::jit::load (ref network/network.h:18-37), without LibTorch: reads the TorchScript archive the
+ * reference's trainer writes (learner/train.py:127) and returns the 12 hyper-parameters and the flat weight blob described
+ * above.  Call with weights_out == NULL to get *count_out; capacity = floats available in weights_out. */
+int mz_net_read_pt(const char* path, mz_net_desc* desc_out, float* weights_out, size_t capacity, size_t* count_out);
+
 /* createNetwork(file, gpu_id) (ref network/create_network.h:11-30): here the caller hands the parsed
  * blob; device must be a valid GPU ordinal (gpu_id == -1 / CPU is NOT supported: MZ_ERR_DEVICE). */
 mz_net* mz_net_create(int device, const mz_net_desc* desc, const float* weights, size_t count);

@@ -4,6 +4,8 @@
 #include "pool.h"
 #include <cstring>
 #include <memory>
+#include <string>
+#include <vector>
 
 namespace mz {
 static thread_local char g_err[1024] = "";
@@ -41,6 +43,28 @@ int mz_net_generate_weights(const mz_net_desc* desc, uint64_t seed, float* out)
 {
     if (!desc || !out || !mz::netValidateDesc(*desc)) { return MZ_ERR_ARG; }
     return mz::netGenerate(*desc, seed, out) ? MZ_OK : MZ_ERR_ARG;
+}
+
+int mz_net_read_pt(const char* path, mz_net_desc* desc_out, float* weights_out, size_t capacity, size_t* count_out)
+{
+    if (!path) { mz::setError("mz_net_read_pt: NULL path"); return MZ_ERR_ARG; }
+    mz_net_desc d;
+    std::vector<float> w;
+    std::string err;
+    if (!mz::readTorchScript(path, &d, &w, &err)) { mz::setError("%s", err.c_str()); return MZ_ERR_ARG; }
+    if (!mz::netValidateDesc(d)) { return MZ_ERR_ARG; }
+    if (static_cast<long>(w.size()) != mz::netParamCount(d)) {
+        mz::setError("%s: %zu floating-point values in the archive, the %d-block network of its hyper-parameters has %ld", path, w.size(), d.num_blocks,
+                     mz::netParamCount(d));
+        return MZ_ERR_ARG;
+    }
+    if (desc_out) { *desc_out = d; }
+    if (count_out) { *count_out = w.size(); }
+    if (weights_out) {
+        if (capacity < w.size()) { mz::setError("mz_net_read_pt: buffer of %zu floats, %zu needed", capacity, w.size()); return MZ_ERR_ARG; }
+        memcpy(weights_out, w.data(), w.size() * sizeof(float));
+    }
+    return MZ_OK;
 }
 
 mz_net* mz_net_create(int device, const mz_net_desc* desc, const float* weights, size_t count)

@@ -4,6 +4,7 @@
 // muzero_network.py:137-164.  Arithmetic order is specified in DESIGN.md §"Network numerics".
 #pragma once
 #include "common.h"
+#include <string>
 
 namespace mz {
 
@@ -36,6 +37,8 @@ bool netGenerate(const mz_net_desc& d, uint64_t seed, float* out);
 bool netValidateDesc(const mz_net_desc& d);
 bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<float>& packed, std::vector<ConvLayer>& repr, std::vector<ConvLayer>& dyn,
                  HeadOffsets& h, AtariLayers& at);
+
+bool readTorchScript(const std::string& path, mz_net_desc* desc, std::vector<float>* weights, std::string* err); // ptfile.cpp
 
 float invertValueHost(float value); // 601-bin decode helper (ref utils/utils.h:102-108)
 

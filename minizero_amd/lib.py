@@ -89,6 +89,7 @@ def load():
     L.mz_net_param_count.restype = C.c_long
     L.mz_net_param_count.argtypes = [C.POINTER(NetDesc)]
     L.mz_net_generate_weights.argtypes = [C.POINTER(NetDesc), C.c_uint64, fp]
+    L.mz_net_read_pt.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mz_net_create.restype = vp
     L.mz_net_create.argtypes = [C.c_int, C.POINTER(NetDesc), fp, C.c_size_t]
     L.mz_net_reload.argtypes = [vp, fp, C.c_size_t]
@@ -166,6 +167,17 @@ def device_count():
 
 def usable_cpus():
     return load().mz_usable_cpus()
+
+
+def read_pt(path):
+    """(desc, weights) of a TorchScript file written by the reference's trainer — native parser, no torch."""
+    L = load()
+    d = NetDesc()
+    n = C.c_size_t(0)
+    _check(L, L.mz_net_read_pt(path.encode(), C.byref(d), None, 0, C.byref(n)))
+    w = np.empty(n.value, np.float32)
+    _check(L, L.mz_net_read_pt(path.encode(), C.byref(d), _f(w), n.value, C.byref(n)))
+    return d, w
 
 
 def param_count(desc):
