@@ -70,8 +70,9 @@ public:
                       int where);
     // the per-game simulation kernel (sim.hip): `nsims` whole simulations (select, leaf environment, tower, heads, candidates, expand +
     // backup) of every game in ONE launch, each game advancing on its own workgroup.  *launched = false when no instance fits.
+    // d_root_noise ([games][A], nullable): Dirichlet noise applied to the root children before simulation 1
     int simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_logit, float* d_value, const uint8_t* d_rot, int sim0, int nsims,
-                  bool* launched);
+                  bool* launched, const float* d_root_noise = nullptr, float noise_eps = 0.0f);
     bool hasSimKernel(int board_n) const;
     int timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops);
     int timeTowerConv(int B, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch);

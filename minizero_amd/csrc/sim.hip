@@ -29,6 +29,8 @@ struct SimArgs {
     float *cand_policy, *cand_logit, *value_io, *reward_io;
     int* err;
     int rcp_n;                        // entries of pv.rcp_tab
+    const float* root_noise;          // [games][A] Dirichlet noise of the root children (host RNG), applied before simulation 1; nullptr: none
+    float noise_eps;
     unsigned* sink;                   // never-taken store target that keeps the prefetch loads alive
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
@@ -58,6 +60,23 @@ __device__ __noinline__ void simCandExpand(const SimArgs* __restrict__ a, int ro
     waveSync();
     expandBackupBody(a->pv, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane,
                      tiles);
+}
+
+// Root exploration noise (ref zero_actor.cpp:194-213): policy = (1 - eps) * policy + eps * noise for the root's children, in storage
+// order; the noise values were drawn on the host in the reference's RNG order (their count only depends on the number of legal moves)
+__device__ __noinline__ void simApplyRootNoise(const SimArgs* __restrict__ a, int g, int lane)
+{
+    const PoolView& v = a->pv;
+    const size_t base = size_t(g) * v.cap;
+    const int nc = v.rec[base].num_children;
+    const size_t fc = base + v.rec[base].first_child;
+    const float eps = a->noise_eps;
+    for (int i = lane; i < nc; i += 64) {
+        const float nz = a->root_noise[size_t(g) * v.A + i];
+        v.rec[fc + i].policy = (1 - eps) * v.rec[fc + i].policy + eps * nz;
+        v.noise[fc + i] = nz;
+    }
+    waveSync();
 }
 
 // While wave 0 walks the tree, wave 1 pulls the children blocks along the PREVIOUS simulation's path into the L2: consecutive
@@ -105,7 +124,10 @@ __global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a,
         const int rot = rot_tab[size_t(s) * games + g];
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (prof) { t0 = wall_clock64(); }
-        if (wave == 0) { simSelectLeaf<CPL>(a, rot, slot, g, lane, tiles, rcp_lds); }
+        if (wave == 0) {
+            if (slot == 1 && a->root_noise) { simApplyRootNoise(a, g, lane); }
+            simSelectLeaf<CPL>(a, rot, slot, g, lane, tiles, rcp_lds);
+        }
         else if (wave == 1 && s + slot > 0) { simPrefetchPath(a, g, lane); }
         __syncthreads();
         unsigned long long c1 = 0;
@@ -183,7 +205,7 @@ bool Net::hasSimKernel(int board_n) const
 }
 
 int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_logit, float* d_value, const uint8_t* d_rot, int sim0, int nsims,
-                   bool* launched)
+                   bool* launched, const float* d_root_noise, float noise_eps)
 {
     *launched = false;
     if (desc_.type != 0) { return MZ_OK; }
@@ -203,6 +225,8 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     a.cand_policy = pool.d_cand_policy_.p; a.cand_logit = pool.d_cand_logit_.p; a.value_io = pool.d_value_.p; a.reward_io = pool.d_reward_.p;
     a.err = pool.errFlag();
     a.rcp_n = pool.rcpEntries();
+    a.root_noise = d_root_noise;
+    a.noise_eps = noise_eps;
     if (!sim_sink_.ensure(4)) { setError("hipMalloc failed"); return MZ_ERR_DEVICE; }
     a.sink = sim_sink_.p;
     if (getenv("MZ_SIM_PROF")) {

@@ -303,6 +303,8 @@ private:
         int cycles_since_signal = 0;
         PinBuf<uint8_t> h_rot;   // per-game simulation kernel: rotations of a batch of cycles [cycle][game]
         DevBuf<uint8_t> d_rot;
+        PinBuf<float> h_noise;   // Dirichlet noise of the root children drawn ahead of the launch [game][A]
+        DevBuf<float> d_noise;
         hipEvent_t ev0 = nullptr, ev1 = nullptr; // GPU time of the simulation-kernel launches (stats: ms_forward)
         ~Lane() { if (ev0) { (void)hipEventDestroy(ev0); } if (ev1) { (void)hipEventDestroy(ev1); } }
     };
@@ -359,6 +361,11 @@ private:
     bool use_signal_ = true;  // wait on a pinned completion word written by a 1-thread kernel instead of hipStreamSynchronize
     bool feat_bits_ = false; // AlphaZero leaves travel host->device as bit-packed planes (all board-game planes are 0/1)
     bool resident_ = false;  // the whole cycle runs on the device (go_dev.hip): the host only does the RNG-ordered per-move logic
+    struct DeferredInfo { int g, mover; size_t index; };
+    std::vector<float> noise_scratch_;
+    std::vector<DeferredInfo> deferred_; // record strings of the last move, built while the next launch runs
+    bool defer_info_ = false;
+    void flushDeferred();
     bool sim_kernel_ = false; // ... and whole runs of cycles are ONE launch of the per-game simulation kernel (sim.hip)
 };
 
@@ -445,9 +452,11 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             if ((rc = uploadRoots(*L))) { return rc; }
         }
         sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize());
+        defer_info_ = sim_kernel_;
         if (sim_kernel_) {
             for (auto& L : lanes_) {
                 if (!L->h_rot.alloc(size_t(n_ + 1) * L->n) || !L->d_rot.alloc(size_t(n_ + 1) * L->n)) { setError("worker: allocation failed (rot table)"); return MZ_ERR_DEVICE; }
+                if (!L->h_noise.alloc(size_t(L->n) * A_) || !L->d_noise.alloc(size_t(L->n) * A_)) { setError("worker: allocation failed (noise)"); return MZ_ERR_DEVICE; }
                 MZ_HIP(hipEventCreate(&L->ev0));
                 MZ_HIP(hipEventCreate(&L->ev1));
             }
@@ -663,9 +672,11 @@ std::string Worker::searchDistributionString(int g) const // ref mcts.cpp:126-13
 {
     const size_t off = size_t(g) * A_;
     std::ostringstream oss;
+    bool first = true;
     for (int i = 0; i < rr_nc_[g]; ++i) {
         if (rr_count_[off + i] == 0) { continue; }
-        oss << (oss.str().empty() ? "" : ",") << rr_action_[off + i] << ":" << rr_count_[off + i];
+        oss << (first ? "" : ",") << rr_action_[off + i] << ":" << rr_count_[off + i];
+        first = false;
     }
     return oss.str();
 }
@@ -850,24 +861,44 @@ void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor
     Game& gm = games_[g];
     const size_t off = size_t(g) * A_;
     const bool resign = isResign(g);
+    bool acted = false;
+    int mover = 0;
     if (!resign) {
         const int action = rr_action_[off + gm.selected];
-        const int mover = gm.env->turn(); // == the player of every root child
+        mover = gm.env->turn(); // == the player of every root child
         if (gm.env->act(action, mover)) {
             gm.action_info_history.resize(gm.env->actionIds().size());
-            gm.action_info_history.back() = actionInfo(g, mover);
+            acted = true;
         }
     }
     ++stats_.moves;
     const bool is_endgame = (resign || gm.env->isTerminal());
+    const int game_length = static_cast<int>(gm.env->actionIds().size());
+    const int seq = cfg_.zero_actor_intermediate_sequence_length;
+    const bool intermediate = !is_endgame && seq > 0 && game_length >= seq &&
+                              (game_length - cfg_.learner_n_step_return - cfg_.learner_muzero_unrolling_step) % seq == 0;
+    if (acted) {
+        // the P/V/R strings of this move (no RNG involved) are only needed when the game is printed: for every other game they are
+        // built after the next launch has been queued, off the critical path (the root statistics stay valid until the next root read)
+        if (defer_info_ && !is_endgame && !intermediate) { deferred_.push_back({g, mover, gm.action_info_history.size() - 1}); }
+        else { gm.action_info_history.back() = actionInfo(g, mover); }
+    }
     if (is_endgame) {
         outputGame(gm);
         resetGame(gm, rng_);
-    } else {
-        const int game_length = static_cast<int>(gm.env->actionIds().size());
-        const int seq = cfg_.zero_actor_intermediate_sequence_length;
-        if (seq > 0 && game_length >= seq && (game_length - cfg_.learner_n_step_return - cfg_.learner_muzero_unrolling_step) % seq == 0) { outputGame(gm); }
+    } else if (intermediate) {
+        outputGame(gm);
     }
+}
+
+void Worker::flushDeferred()
+{
+    if (deferred_.empty()) { return; }
+    threads_->parallelFor(static_cast<int>(deferred_.size()), [this](int k) {
+        const DeferredInfo& d = deferred_[k];
+        games_[d.g].action_info_history[d.index] = actionInfo(d.g, d.mover);
+    });
+    deferred_.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1114,26 +1145,43 @@ int Worker::runCyclesSim(int n)
         if (pending_) { sims_done_ = done ? 0 : sim_post_; }
         const int sim0 = sims_done_;
         int batch = 1;
-        // cycles after this one: plain while they neither finish the search nor follow the root expansion of a noisy search
-        while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg)) {
-            for (auto& L : lanes_) { // the only RNG draws of a plain cycle: one rotation per actor, in actor order (zero_actor.cpp:56)
+        // Cycles after this one join the launch while they need nothing from the host but RNG draws.  The cycle behind the root
+        // expansion (sim index 1) needs the Dirichlet noise of the root children: its values only depend on the RNG stream and on
+        // the NUMBER of root children = legal moves of the root position, which the host engine knows, so they are drawn here in the
+        // reference's order ([noise][rotation] per actor, zero_actor.cpp:194-213 then :56) and applied by the kernel before simulation 1.
+        const bool device_noise = cfg_.actor_use_dirichlet_noise && !cfg_.actor_use_gumbel_noise;
+        bool noise_in_batch = false;
+        while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg && !device_noise)) {
+            const bool noise_cycle = (sim0 + batch == 1) && noise_cfg;
+            for (auto& L : lanes_) {
                 for (int j = 0; j < L->n; ++j) {
                     Game& gm = games_[L->g0 + j];
-                    gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
+                    if (noise_cycle) {
+                        gm.env->legalMask(gm.legal.data());
+                        int k = 0;
+                        for (int a = 0; a < A_; ++a) { k += gm.legal[a] != 0; }
+                        rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise_scratch_);
+                        memcpy(L->h_noise.p + size_t(j) * A_, noise_scratch_.data(), size_t(k) * sizeof(float));
+                    }
+                    gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0; // the only draw of a plain cycle (zero_actor.cpp:56)
                     L->h_rot.p[size_t(batch) * L->n + j] = static_cast<uint8_t>(gm.rot);
                 }
             }
+            noise_in_batch |= noise_cycle;
             ++batch;
         }
         for (auto& L : lanes_) {
             MZ_HIP(hipMemcpyAsync(L->d_rot.p, L->h_rot.p, size_t(batch) * L->n, hipMemcpyHostToDevice, L->stream));
+            if (noise_in_batch) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, L->stream)); }
             bool launched = false;
             MZ_HIP(hipEventRecord(L->ev0, L->stream));
-            int rc = L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched);
+            int rc = L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched,
+                                      noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon);
             if (rc) { return rc; }
             if (!launched) { setError("worker: no simulation-kernel instance for this network"); return MZ_ERR_STATE; }
             MZ_HIP(hipEventRecord(L->ev1, L->stream));
         }
+        flushDeferred(); // the record strings of the move just decided: built while the launch runs
         sims_done_ = sim0 + batch - 1;
         pending_ = true;
         stats_.cycles += batch;
