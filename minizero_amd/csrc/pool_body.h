@@ -67,20 +67,25 @@ __device__ __forceinline__ unsigned orderedKey(float f)
     const unsigned b = __float_as_uint(f);
     return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); // unsigned order == float order (no NaNs, no negative zeros here)
 }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dppMaxStep(unsigned v)
+// wave-wide unsigned max, result in every lane: six v_max_u32 with the DPP operand folded in (row_shr 1/2/4/8 scan inside the rows of
+// 16, then row_bcast 15 / 31 across rows; lanes without a source read 0, the identity), written in assembly because the compiler
+// emits v_mov_dpp + s_nop + v_max per step; the s_nop 1 is the VALU-write -> DPP-read hazard (2 wait states)
+__device__ __forceinline__ unsigned waveMaxU32(unsigned v)
 {
-    const unsigned o = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, ROW_MASK, 0xF, false));
-    return o > v ? o : v;
-}
-__device__ __forceinline__ unsigned waveMaxU32(unsigned v) // result in every lane
-{
-    v = dppMaxStep<0x111, 0xF>(v);
-    v = dppMaxStep<0x112, 0xF>(v);
-    v = dppMaxStep<0x114, 0xF>(v);
-    v = dppMaxStep<0x118, 0xF>(v);
-    v = dppMaxStep<0x142, 0xA>(v);
-    v = dppMaxStep<0x143, 0xC>(v);
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
     return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
@@ -117,13 +122,27 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
     int* hact = v.host_path_action ? v.host_path_action + size_t(g) * v.max_depth : nullptr;
     const int bsize = v.bound_size[g];
     const float lo = v.bound_lo[g], hi = v.bound_hi[g];
-    NodeRec cur = loadRec(recs); // root (uniform)
+    // the node header travels down the walk in SCALAR registers: every lane loads the same record, readfirstlane tells the compiler so
+    // (otherwise the whole loop is compiled as divergent: exec-mask loop control, per-level v_mov round trips of the header)
+    auto uniformRec = [](NodeRec r) {
+        NodeRec u;
+        u.count = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r.count)));
+        u.mean = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r.mean)));
+        u.policy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r.policy)));
+        u.reward = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(r.reward)));
+        u.first_child = __builtin_amdgcn_readfirstlane(r.first_child);
+        u.num_children = __builtin_amdgcn_readfirstlane(r.num_children);
+        u.action = __builtin_amdgcn_readfirstlane(r.action);
+        u.players = __builtin_amdgcn_readfirstlane(r.players);
+        return u;
+    };
+    NodeRec cur = uniformRec(loadRec(recs)); // root
     int node = 0, depth = 1;
     if (lane == 0) { path[0] = 0; pact[0] = cur.action; if (hact) { hact[0] = cur.action; } }
-    const int st = start ? start[g] : 0;
+    const int st = start ? __builtin_amdgcn_readfirstlane(start[g]) : 0;
     if (st > 0) { // Gumbel: path = root + PUCT path below the chosen candidate (ref gumbel_zero.cpp:83-85)
         node = st;
-        cur = loadRec(recs + st);
+        cur = uniformRec(loadRec(recs + st));
         if (lane == 0) { path[1] = st; pact[1] = cur.action; if (hact) { hact[1] = cur.action; } }
         depth = 2;
     }
@@ -133,10 +152,15 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
         const float bias = v.bias_tab[N];
         const double sqrtN = v.sqrt_tab[N];
         if (nc <= 128 && !v.value_rescale) {
-            const bool two = nc > 64; // wave-uniform
-            const bool has0 = lane < nc, has1 = lane + 64 < nc;
-            NodeRec c0 = loadRec(recs + fc + (has0 ? lane : nc - 1)), c1 = c0;
-            if (two) { c1 = loadRec(recs + fc + (has1 ? lane + 64 : nc - 1)); }
+            // Children are stored in descending prior order and an unvisited child can only be chosen while every child before it has
+            // been visited (equal init-Q, u monotone in the prior, ties go to the higher prior / lower index), so the visited children
+            // of a node are a PREFIX of its children and the arg-max is among that prefix plus the first unvisited child.  The prefix
+            // length is kept in the upper half of `players` (expandBackupBody).  Not at the root: the root noise re-orders its priors.
+            const int ne = node == 0 ? nc : min(nc, static_cast<int>(static_cast<unsigned>(cur.players) >> 16) + 1); // children that need a look
+            const bool two = ne > 64; // wave-uniform
+            const bool has0 = lane < ne, has1 = lane + 64 < ne;
+            NodeRec c0 = loadRec(recs + fc + (has0 ? lane : ne - 1)), c1 = c0;
+            if (two) { c1 = loadRec(recs + fc + (has1 ? lane + 64 : ne - 1)); }
             const RcpPtr r0p = rcp + static_cast<int>(c0.count);
             const double r00 = r0p[0], r01 = r0p[1];
             double r10 = r00, r11 = r01;
@@ -290,8 +314,10 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
             return;
         }
         const int pl = cand_player[g];
+        bool unsorted = false; // select's visited-prefix shortcut needs the priors in descending order (the actor always sorts them)
         for (int i = lane; i < k; i += 64) {
             const size_t n = base + fc + i, c = size_t(g) * v.A + i;
+            if (i > 0 && cand_policy[c - 1] < cand_policy[c]) { unsorted = true; }
             NodeRec r;
             r.count = 0; r.mean = 0; r.policy = cand_policy[c]; r.reward = 0;
             r.first_child = -1; r.num_children = 0; r.action = cand_action[c]; r.players = pl;
@@ -300,11 +326,13 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
             v.logit[n] = cand_logit[c];
             v.noise[n] = 0; v.value[n] = 0; v.hslot[n] = -1;
         }
+        const bool any_unsorted = __ballot(unsorted) != 0;
         if (lane == 0) {
             NodeRec* l = v.rec + base + leaf;
             l->first_child = fc;
             l->num_children = k;
-            l->players = (l->players & 0xFF) | (pl << 8);
+            // bits 16..31: number of visited children (0xFFFF = unknown order: select looks at every child)
+            l->players = (l->players & 0xFF) | (pl << 8) | (any_unsorted ? static_cast<int>(0xFFFF0000u) : 0);
             v.num_nodes[g] = fc + k;
         }
     }
@@ -330,6 +358,7 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
                 cnt = n->count;
                 r = (k == 0) ? rew : n->reward;
             }
+            if (kb == 0 && len >= 2 && laneF(cnt, 0) == 0.0f && lane == 1 && (static_cast<unsigned>(n->players) >> 16) != 0xFFFFu) { n->players += 1 << 16; } // the leaf's parent: one more visited child (select's prefix)
             float mine = 0.0f;
             const int m = len - kb < 64 ? len - kb : 64;
             for (int j = 0; j < m; ++j) {
@@ -357,6 +386,9 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
     const float val = value_in[g], rew = reward_in[g];
     v.value[base + leaf] = val;
     v.rec[base + leaf].reward = rew;
+    if (len >= 2 && v.rec[base + leaf].count == 0.0f && (static_cast<unsigned>(v.rec[base + path[len - 2]].players) >> 16) != 0xFFFFu) {
+        v.rec[base + path[len - 2]].players += 1 << 16;
+    }
     float updated = val;
     for (int i = len - 1; i >= 0; --i) {
         NodeRec* n = v.rec + base + path[i];
