@@ -21,56 +21,70 @@ struct TowerArgs {
     unsigned w_off[48], b_off[48];
 };
 
-// Which 16 pixels form MFMA pixel tile t.  The B operand of v_mfma_f32_16x16x4_f32 is one ds_read_b32 per lane with
-// lane = 16 * k + n reading channel plane k at the padded position of pixel n.  The four planes sit 16 banks apart (plane stride
-// % 32 == 16), so the read is conflict-free iff the 16 positions are distinct mod 16.  16 CONSECUTIVE pixels of a W-wide board
-// span up to 16 + 2 * (rows crossed) padded positions, i.e. always collide (measured: SQ_LDS_BANK_CONFLICT = 50 % of the LDS
-// cycles).  Instead tile t takes, for each residue n, the t-th pixel whose padded position is n mod 16: lane n always touches
-// bank (16 k + n + tap offset) mod 64.  Works when no residue class has more than ceil(P/16) pixels (9x9, 8x8, 6x6, 3x3, 19x19);
-// other shapes keep the consecutive tiling.
+// Which pixels form MFMA pixel tile t.
+//  * The B operand of v_mfma_f32_16x16x4_f32 is one ds_read_b32 per lane with lane = 16 * k + n reading channel plane k at the padded
+//    position of pixel n.  The four planes sit 16 banks apart (plane stride % 32 == 16), so the read is conflict-free iff the 16
+//    positions are distinct mod 16.  16 CONSECUTIVE pixels of a W-wide board span up to 16 + 2 * (rows crossed) padded positions, i.e.
+//    always collide (measured: SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles), so tile t takes, for each residue n, the t-th pixel whose
+//    padded position is n mod 16 (pixels that do not fit fill the free slots).
+//  * A board of 16 m + 1 points (9x9 = 81) needs m + 1 tiles, the last one with a single real column.  That column is made the
+//    top-right CORNER pixel: only 4 of its 9 taps are inside the board, the other 5 read zero padding for every channel, and
+//    a k-step whose B operand is all zero leaves the accumulator as it is (the chain starts at +0 and fma(a, 0, acc) = acc), so the
+//    last tile issues 4 / 9 of its MFMAs (9x9: 784 instead of 864 MFMAs per SIMD and layer).
+//    (Computing that pixel on the vector ALUs instead — 5 full tiles, 150 us per launch without it — was tried: the 256 dependent
+//    fmas + 256 LDS reads per layer cost more issue slots beside the MFMAs than the tile saves: 181 us.)
 template <int H, int W>
 struct TileMap {
-    static constexpr int P = H * W, PW = W + 2, PT = (P + 15) / 16;
+    static constexpr int P = H * W, PW = W + 2;
+    static constexpr int PT = (P + 15) / 16;                  // MFMA pixel tiles
+    static constexpr bool kCorner = (P % 16 == 1) && H > 1 && W > 1 && PT >= 2;
+    static constexpr int VQ = kCorner ? W - 1 : -1;           // the corner pixel (0, W - 1), alone in the last tile
+    static constexpr int PT0 = (PT + 1) / 2, PT1 = PT - PT0;  // tiles of waves 0-3 / waves 4-7
     short q[PT * 16];
     constexpr TileMap() : q{}
     {
+        for (int i = 0; i < PT * 16; ++i) { q[i] = -1; }
+        constexpr int full = kCorner ? PT - 1 : PT; // tiles filled by residue class
         int cnt[16] = {};
-        bool spread = true;
-        for (int i = 0; i < P; ++i) { const int r = ((i / W + 1) * PW + (i % W) + 1) & 15; if (++cnt[r] > PT) { spread = false; } }
-        for (int i = 0; i < PT * 16; ++i) { q[i] = spread ? short(-1) : short(i < P ? i : -1); }
-        if (spread) {
-            int seen[16] = {};
-            for (int i = 0; i < P; ++i) { const int r = ((i / W + 1) * PW + (i % W) + 1) & 15; q[seen[r]++ * 16 + r] = short(i); }
+        short over[P + 1] = {};
+        int nover = 0;
+        for (int i = 0; i < P; ++i) {
+            if (i == VQ) { continue; }
+            const int r = ((i / W + 1) * PW + (i % W) + 1) & 15;
+            if (cnt[r] < full) { q[cnt[r]++ * 16 + r] = short(i); } else { over[nover++] = short(i); }
         }
+        for (int s = 0, k = 0; s < full * 16 && k < nover; ++s) { if (q[s] < 0) { q[s] = over[k++]; } }
+        if (kCorner) { q[(PT - 1) * 16 + (((0 + 1) * PW + (W - 1) + 1) & 15)] = short(VQ); }
     }
 };
 template <int H, int W>
 __device__ const TileMap<H, W> kTileMap{};
 
+// taps of the 3x3 window that are inside the board for the corner pixel (0, W - 1): (dy, dx) in {0, +1} x {-1, 0}
+__host__ __device__ constexpr bool cornerTapInside(int t) { return t == 3 || t == 4 || t == 6 || t == 7; }
+
+// One conv3x3 layer for the NT pixel tiles [tile0, tile0 + NT) and oc-tile `ot` of this wave; CORNER: the last of them is the corner tile.
 // a_first / have_first: this layer's tap-0 A-fragments if the previous layer already fetched them; next_wp / a_next: the NEXT layer's
 // weights (nullptr: none) whose tap-0 fragments are fetched during this layer's last tap, so that the layer boundary (epilogue,
-// barrier) does not end with an exposed L2 round trip; the bias values are fetched at the start of the layer for the same reason
-template <int H, int W, int CG, int PTW, int CGN>
+// barrier) does not end with an exposed L2 round trip; the bias values are fetched at the start of the layer for the same reason.
+template <int H, int W, int CG, int NT, int CGN, bool CORNER>
 __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
                                             float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
-                                            int lane, int wave, bool have_first, float (&a_first)[CG], const float* __restrict__ next_wp,
+                                            int lane, int ot, int tile0, bool have_first, float (&a_first)[CG], const float* __restrict__ next_wp,
                                             float (&a_next)[CGN])
 {
-    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16;
-    const int ot = wave & 3, half = wave >> 2;
-    if (ot >= OT) { return; }
-    int pixoff[PTW], pixdst[PTW], pixq[PTW];
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
+    int pixoff[NT], pixdst[NT], pixq[NT];
 #pragma unroll
-    for (int j = 0; j < PTW; ++j) {
-        const int pt = half * PTW + j;
-        pixq[j] = pt < PT ? kTileMap<H, W>.q[pt * 16 + (lane & 15)] : -1; // -1: padding column of the tile
+    for (int j = 0; j < NT; ++j) {
+        pixq[j] = kTileMap<H, W>.q[(tile0 + j) * 16 + (lane & 15)]; // -1: padding column of the tile
         const int q = pixq[j] < 0 ? 0 : pixq[j];
         pixdst[j] = (q / W + 1) * PW + (q % W) + 1;          // interior position in a padded plane
         pixoff[j] = (lane >> 4) * CS + (q / W) * PW + (q % W); // top-left tap of the 3x3 window, channel (lane>>4)
     }
-    f32x4 acc[PTW];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int j = 0; j < PTW; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    for (int j = 0; j < NT; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
     const float4 bias4 = *reinterpret_cast<const float4*>(bias + 16 * ot + 4 * (lane >> 4)); // the 4 output channels of this lane's accumulators
     const float biasv[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
     // A-fragments in the interleaved layout of weights.cpp (w4_off): for (tap, oc-tile) CG * 64 contiguous floats
@@ -98,7 +112,8 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
 #pragma unroll
-            for (int j = 0; j < PTW; ++j) {
+            for (int j = 0; j < NT; ++j) {
+                if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; } // all-zero B operand: the k-step leaves the accumulator unchanged
                 float bv = tin[pixoff[j] + cg * 4 * CS + tapoff];
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg], bv, acc[j], 0, 0, 0);
             }
@@ -130,16 +145,16 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
         asm volatile("" ::: "memory");
     }
     // the residual inputs of the epilogue are read while the last tap's MFMAs run
-    float skv[PTW][4];
+    float skv[NT][4];
 #pragma unroll
-    for (int j = 0; j < PTW; ++j) {
+    for (int j = 0; j < NT; ++j) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { skv[j][r] = tskip ? tskip[(16 * ot + 4 * (lane >> 4) + r) * CS + pixdst[j]] : 0.0f; }
     }
     asm volatile("" ::: "memory");
     tap(a0, 8);
 #pragma unroll
-    for (int j = 0; j < PTW; ++j) {
+    for (int j = 0; j < NT; ++j) {
         const int q = pixq[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -154,13 +169,32 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     }
 }
 
+// wave -> (oc-tile, pixel tiles): waves 0-3 take tiles [0, PT0), waves 4-7 tiles [PT0, PT) (the last one may be the corner tile)
+template <int H, int W, int CG, int CGN>
+__device__ __forceinline__ void towerLayerOfWave(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
+                                                 float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
+                                                 int lane, int wave, bool have_first, float (&a_first)[CG], const float* __restrict__ next_wp,
+                                                 float (&a_next)[CGN])
+{
+    using TM = TileMap<H, W>;
+    const int ot = wave & 3, half = wave >> 2;
+    if (ot >= OT) { return; }
+    if (half == 0) {
+        tower_layer<H, W, CG, TM::PT0, CGN, (TM::kCorner && TM::PT1 == 0)>(tin, tskip, tout, gout, wp, bias, cout, OT, lane, ot, 0, have_first, a_first,
+                                                                            next_wp, a_next);
+    } else if constexpr (TM::PT1 > 0) {
+        tower_layer<H, W, CG, TM::PT1, CGN, TM::kCorner>(tin, tskip, tout, gout, wp, bias, cout, OT, lane, ot, TM::PT0, have_first, a_first, next_wp,
+                                                         a_next);
+    }
+}
+
 // the body of tower_fused for sample `b`, run by all 512 threads of a workgroup (tid 0..511); `tiles` = 3 x [CMAX][CS] floats of LDS
-template <int H, int W, int CIN0_PAD, int CPAD>
 // out == nullptr: the last layer's activations stay in LDS; the returned pointer is that tile ([C][CS] padded planes)
+template <int H, int W, int CIN0_PAD, int CPAD>
 __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ out,
                                             int b, int tid, float* __restrict__ tiles)
 {
-    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W), PT = (P + 15) / 16, PTW = (PT + 1) / 2;
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
     constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
     const int lane = tid & 63, wave = tid >> 6;
     float* T0 = tiles;
@@ -186,27 +220,27 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     }
     __syncthreads();
     float* gout = out ? out + size_t(b) * ta.C * P : nullptr;
-    // tap-0 A-fragments of the next layer travel from layer to layer in registers (aA / aB alternate)
+    // tap-0 A-fragments of the next layer travel from layer to layer in registers
     float aS[CIN0_PAD / 4], aA[CPAD / 4], aB[CPAD / 4];
     bool have = false;
     if (ta.has_stem) { // stem: T0 -> T1
         const float* nw = ta.nlayers > 1 ? params + ta.w_off[1] : nullptr;
-        tower_layer<H, W, CIN0_PAD / 4, PTW, CPAD / 4>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C,
-                                                         ta.OT, lane, wave, false, aS, nw, aA);
+        towerLayerOfWave<H, W, CIN0_PAD / 4, CPAD / 4>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C,
+                                                        ta.OT, lane, wave, false, aS, nw, aA);
         have = nw != nullptr;
         __syncthreads();
     }
     float *x = T1, *tmp = T0, *y = T2;
-    for (int l = ta.has_stem; l + 1 < ta.nlayers; l += 2) { // residual block: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x)
-        tower_layer<H, W, CPAD / 4, PTW, CPAD / 4>(x, nullptr, tmp, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, wave, have, aA,
-                                                     params + ta.w_off[l + 1], aB);
-        __syncthreads();
-        const bool last = (l + 2 >= ta.nlayers);
-        tower_layer<H, W, CPAD / 4, PTW, CPAD / 4>(tmp, x, y, last ? gout : nullptr, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, ta.OT, lane,
-                                                     wave, true, aB, last ? nullptr : params + ta.w_off[l + 2], aA);
+#pragma unroll 1
+    for (int l = ta.has_stem; l < ta.nlayers; ++l) { // residual blocks: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x) — one code copy for both convs
+        const bool second = ((l - ta.has_stem) & 1) != 0, last = l + 1 == ta.nlayers;
+        towerLayerOfWave<H, W, CPAD / 4, CPAD / 4>(second ? tmp : x, second ? x : nullptr, second ? y : tmp, last ? gout : nullptr, params + ta.w_off[l],
+                                                    params + ta.b_off[l], ta.C, ta.OT, lane, wave, have, aA, last ? nullptr : params + ta.w_off[l + 1], aB);
+#pragma unroll
+        for (int cg = 0; cg < CPAD / 4; ++cg) { aA[cg] = aB[cg]; }
         have = !last;
         __syncthreads();
-        float* s = x; x = y; y = s;
+        if (second) { float* s2 = x; x = y; y = s2; }
     }
     return x;
 }
