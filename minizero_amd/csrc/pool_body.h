@@ -157,6 +157,42 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
             // of a node are a PREFIX of its children and the arg-max is among that prefix plus the first unvisited child.  The prefix
             // length is kept in the upper half of `players` (expandBackupBody).  Not at the root: the root noise re-orders its priors.
             const int ne = node == 0 ? nc : min(nc, static_cast<int>(static_cast<unsigned>(cur.players) >> 16) + 1); // children that need a look
+            if (node != 0 && ne <= 3) {
+                // 96 % of the levels of a 400-simulation search: one or two visited children plus the first unvisited one.  Same
+                // arithmetic, but the handful of values is compared through readlanes: no wave reductions, no loops.
+                const bool has = lane < ne;
+                const NodeRec c = loadRec(recs + fc + (has ? lane : ne - 1));
+                const RcpPtr rp = rcp + static_cast<int>(c.count);
+                bool tiny = false;
+                LevelEval e = evalChild(v, c, cplayer, bias, sqrtN, rp[0], rp[1], &tiny);
+                const bool vis = has && c.count != 0.0f;
+                const unsigned long long vm = __ballot(vis);
+                if (__ballot(vis && tiny) != 0) { e.q = normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi); }
+                // ordered sum over the visited children (adding +0 for an unvisited one changes nothing: the sum is never -0)
+                float sum_of_win = 0.0f, sum = 0.0f;
+                sum_of_win += (vm & 1) ? laneF(e.q, 0) : 0.0f; sum += (vm & 1) ? 1.0f : 0.0f;
+                sum_of_win += (vm & 2) ? laneF(e.q, 1) : 0.0f; sum += (vm & 2) ? 1.0f : 0.0f;
+                sum_of_win += (vm & 4) ? laneF(e.q, 2) : 0.0f; sum += (vm & 4) ? 1.0f : 0.0f;
+                const float init_q = v.atari_init_q ? (sum > 0 ? sum_of_win / sum : 1.0f) : (sum_of_win - 1) / (sum + 1);
+                const float sc = e.score + (c.count == 0.0f ? init_q : e.q);
+                float bs = laneF(sc, 0), bp = laneF(c.policy, 0);
+                int ri = 0;
+                if (ne > 1) { const float s1 = laneF(sc, 1), p1 = laneF(c.policy, 1); if (better(s1, p1, 1, bs, bp, ri)) { bs = s1; bp = p1; ri = 1; } }
+                if (ne > 2) { const float s2 = laneF(sc, 2), p2 = laneF(c.policy, 2); if (better(s2, p2, 2, bs, bp, ri)) { bs = s2; bp = p2; ri = 2; } }
+                cur.count = laneF(c.count, ri);
+                cur.first_child = laneI(c.first_child, ri);
+                cur.num_children = laneI(c.num_children, ri);
+                cur.action = laneI(c.action, ri);
+                cur.players = laneI(c.players, ri);
+                node = fc + ri;
+                if (lane == 0) {
+                    path[depth] = node;
+                    pact[depth] = cur.action;
+                    if (hact) { hact[depth] = cur.action; }
+                }
+                ++depth;
+                continue;
+            }
             const bool two = ne > 64; // wave-uniform
             const bool has0 = lane < ne, has1 = lane + 64 < ne;
             NodeRec c0 = loadRec(recs + fc + (has0 ? lane : ne - 1)), c1 = c0;
