@@ -191,8 +191,10 @@ __device__ __forceinline__ void towerLayerOfWave(const float* __restrict__ tin, 
 // the body of tower_fused for sample `b`, run by all 512 threads of a workgroup (tid 0..511); `tiles` = 3 x [CMAX][CS] floats of LDS
 // out == nullptr: the last layer's activations stay in LDS; the returned pointer is that tile ([C][CS] padded planes)
 template <int H, int W, int CIN0_PAD, int CPAD>
+// hidden_src != nullptr (MuZero dynamics, ref muzero_network.py:32): the input is cat(hidden_src[C][P], one-hot plane of `action`)
+// instead of sample b of `in` (a pass / out-of-board action gives an all-zero plane, ref go.cpp:310-315)
 __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ out,
-                                            int b, int tid, float* __restrict__ tiles)
+                                            int b, int tid, float* __restrict__ tiles, const float* __restrict__ hidden_src = nullptr, int action = -1)
 {
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
     constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
@@ -204,7 +206,14 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     for (int i = tid; i < 3 * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
     __syncthreads();
     float* Tin = ta.has_stem ? T0 : T1; // without a stem the input IS the first block's x
-    if (ta.in_bits) {
+    if (hidden_src) {
+        const int CH = ta.cin0 - 1;
+        for (int i = tid; i < CH * P; i += 512) {
+            const int c = i / P, p = i - c * P;
+            Tin[c * CS + (p / W + 1) * PW + (p % W) + 1] = hidden_src[i];
+        }
+        if (tid == 0 && action >= 0 && action < P) { Tin[CH * CS + (action / W + 1) * PW + (action % W) + 1] = 1.0f; }
+    } else if (ta.in_bits) {
         constexpr int W32 = (P + 31) / 32;
         const unsigned* bits = reinterpret_cast<const unsigned*>(in) + size_t(b) * ta.cin0 * W32;
         for (int i = tid; i < ta.cin0 * P; i += 512) {
@@ -279,7 +288,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
                                           int xpw = 0)
 {
     // xlds != nullptr: the activations are already in LDS as padded planes (channel stride xcs, row stride xpw, 1-pixel border): no copy,
-    // `sm` then only holds the scratch (PC*P + P + VH + A + 16 floats); not combined with scale_hidden
+    // `sm` then only holds the scratch (PC*P + P + VH + A + 16 floats); with scale_hidden the tile is rescaled in place
     const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC, VH = hp.VH;
     float* xs = sm;                // [C*P]
     float* pf = xlds ? sm : xs + C * P; // [PC*P]
@@ -297,8 +306,14 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
     const int xstride = xlds ? xcs : P;
 
     if (scale_hidden) { // min/max are order-free; (h - min) / scale is one IEEE op each
+        float* xw = xlds ? const_cast<float*>(xlds) : xs;
+        auto xidx = [&](int i) {
+            if (!xlds) { return i; }
+            const int c = i / P, p = i - c * P;
+            return c * xcs + (p / (xpw - 2) + 1) * xpw + p % (xpw - 2) + 1;
+        };
         float mn = 3.4e38f, mx = -3.4e38f;
-        for (int i = tid; i < C * P; i += NT) { float v = xs[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        for (int i = tid; i < C * P; i += NT) { float v = xw[xidx(i)]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
         for (int o = 32; o > 0; o >>= 1) {
             float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
             mn = m2 < mn ? m2 : mn;
@@ -312,8 +327,9 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
         if (scale < 1e-5f) { scale += 1e-5f; }
         float* hd = hidden_dst + size_t(dst_idx ? dst_idx[b] : b) * C * P;
         for (int i = tid; i < C * P; i += NT) {
-            float v = (xs[i] - mn) / scale;
-            xs[i] = v;
+            const int k = xidx(i);
+            float v = (xw[k] - mn) / scale;
+            xw[k] = v;
             hd[i] = v;
         }
         __syncthreads();

@@ -29,6 +29,13 @@ struct SimArgs {
     float *cand_policy, *cand_logit, *value_io, *reward_io;
     int* err;
     int rcp_n;                        // entries of pv.rcp_tab
+    // MuZero (sim_kernel_mz): dynamics trunk, hidden-state slab, root planes / legal mask / player from the host engine
+    TowerArgs ta_dyn;
+    float* hidden;                    // [games][slots][C * P]
+    const unsigned* root_feat;        // [games][cin * ceil(P / 32)] bit-packed planes of the root position
+    const unsigned long long* root_legal; // [games][LW] legal mask of the root position
+    const int* root_turn;             // [games] player to move at the root
+    int slots, A, LW, num_players;
     const float* root_noise;          // [games][A] Dirichlet noise of the root children (host RNG), applied before simulation 1; nullptr: none
     float noise_eps;
     unsigned* sink;                   // never-taken store target that keeps the prefetch loads alive
@@ -147,6 +154,107 @@ __global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a,
     }
 }
 
+// ---- MuZero (board games; ref muzero_network.h:97-178, zero_actor.cpp:215-245): no leaf environment.  The leaf is evaluated from
+// its parent's hidden state (slab slot `hslot[parent]`) and the move; its children are ALL actions (the root: the legal ones) in
+// the reference's sort order; the new hidden state is rescaled to [0, 1] per sample and written to the slab slot of this simulation.
+__device__ __noinline__ void simMzCandExpand(const SimArgs* __restrict__ a, int slot, int g, int lane, float* tiles)
+{
+    const PoolView& v = a->pv;
+    const int A = a->A, len = v.path_len[g], depth = len - 1;
+    Cand* cs = reinterpret_cast<Cand*>(tiles);
+    Cand* out = cs + A;
+    int* stack = reinterpret_cast<int*>(out + A);
+    int k = 0;
+    for (int base = 0; base < A; base += 64) {
+        const int ac = base + lane;
+        const bool leg = ac < A && (depth > 0 || ((a->root_legal[size_t(g) * a->LW + (ac >> 6)] >> (ac & 63)) & 1)); // legality is only known at the root (zero_actor.cpp:238)
+        const unsigned long long m = __ballot(leg);
+        if (leg) { cs[k + __popcll(m & ((1ull << lane) - 1))] = Cand{ac, a->policy[size_t(g) * A + ac], a->logit[size_t(g) * A + ac]}; }
+        k += __popcll(m);
+    }
+    waveSync();
+    orderCandidates(cs, out, stack, k, lane, a->err);
+    for (int i = lane; i < k; i += 64) {
+        a->cand_action[size_t(g) * A + i] = out[i].action;
+        a->cand_policy[size_t(g) * A + i] = out[i].policy;
+        a->cand_logit[size_t(g) * A + i] = out[i].logit;
+    }
+    if (lane == 0) {
+        const int rt = a->root_turn[g];
+        a->cand_count[g] = k;
+        a->cand_player[g] = (a->num_players == 2 && (depth & 1)) ? 3 - rt : rt; // the children are moved by the player to move at the leaf
+        a->value_io[g] = a->value[g];
+        a->reward_io[g] = 0.0f; // board games have no reward head (ref muzero_network.h:129)
+    }
+    waveSync();
+    expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles);
+}
+
+__device__ __noinline__ void simMzSelect(const SimArgs* __restrict__ a, int slot, int g, int lane, LdsCDouble* rcp)
+{
+    if (slot == 1 && a->root_noise) { simApplyRootNoise(a, g, lane); }
+    selectBody(a->pv, nullptr, g, lane, rcp);
+}
+
+__device__ __noinline__ void simMzHeads(const SimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
+{
+    // hidden_dst + g * C * P must be the slab slot (g, slot): headsBody indexes its outputs with the sample index
+    float* hd = a->hidden + (size_t(g) * a->slots + slot - g) * size_t(a->hp.C) * a->hp.P;
+    headsBody(nullptr, a->hp, a->policy, a->logit, a->value, hd, nullptr, 1, g, tid, 512, tiles, xtile, xcs, xpw);
+}
+
+template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
+__global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a, int sim0, int nsims)
+{
+    extern __shared__ __attribute__((aligned(16))) float tiles[];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int CM = CIN0_PAD > CDYN_PAD ? (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) : (CDYN_PAD > CPAD ? CDYN_PAD : CPAD);
+    constexpr int kTileFloats = 3 * CM * planeStride(H, W);
+    double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
+    for (int i = tid; i < a->rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
+    __syncthreads();
+    LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
+    const PoolView& v = a->pv;
+    for (int s = 0; s < nsims; ++s) {
+        const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
+        if (wave == 0) { simMzSelect(a, slot, g, lane, rcp_lds); }
+        __syncthreads();
+        const float* xt;
+        if (slot == 0) { // initial inference: representation trunk on the root planes
+            xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, a->ta, nullptr, g, tid, tiles);
+        } else { // recurrent inference: dynamics trunk on (parent hidden state, move)
+            const int len = v.path_len[g];
+            const int* path = v.path + size_t(g) * v.max_depth;
+            const int src = v.hslot[size_t(g) * v.cap + path[len - 2]];
+            const int action = v.path_action[size_t(g) * v.max_depth + len - 1];
+            const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;
+            xt = towerBody<H, W, CDYN_PAD, CPAD>(nullptr, a->params, a->ta_dyn, nullptr, g, tid, tiles, hsrc, action);
+        }
+        __syncthreads();
+        simMzHeads(a, slot, g, tid, tiles, xt, planeStride(H, W), W + 2);
+        __syncthreads();
+        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles); }
+        __syncthreads();
+    }
+}
+
+template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
+static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, size_t lds, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), dim3(games), dim3(512), lds, s, d_args, sim0, nsims);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+#define MZ_SIM_MZ_CASES(X) \
+    X(9, 9, 20, 68, 64)  /* 9x9 Go MuZero, 64 channels (BASELINE configs[3]) */ \
+    X(9, 9, 20, 12, 8)   /* small 9x9 test nets */
+
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
 static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, size_t lds, hipStream_t s)
 {
@@ -255,6 +363,60 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && gv.W == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, lds, stream_); }
     MZ_SIM_CASES(MZ_SIM_LAUNCH)
 #undef MZ_SIM_LAUNCH
+    return MZ_OK;
+}
+
+bool Net::hasSimKernelMz() const
+{
+    if (desc_.type != 1 || !use_fused_) { return false; }
+    TowerArgs t1, t2;
+    int c0 = 0, cd = 0;
+    if (!makeTowerArgs(repr_, true, true, &t1, &c0) || !makeTowerArgs(dyn_, false, true, &t2, &cd)) { return false; }
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+#define MZ_SIM_MZ_HAS(h, w, cin0, cdyn, cpad) \
+    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { return true; }
+    MZ_SIM_MZ_CASES(MZ_SIM_MZ_HAS)
+#undef MZ_SIM_MZ_HAS
+    return false;
+}
+
+int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
+                     int num_players, float* d_policy, float* d_logit, float* d_value, int sim0, int nsims, bool* launched, const float* d_root_noise,
+                     float noise_eps)
+{
+    *launched = false;
+    if (desc_.type != 1) { return MZ_OK; }
+    SimArgs a;
+    memset(&a, 0, sizeof(a));
+    int c0 = 0, cd = 0;
+    if (!makeTowerArgs(repr_, true, true, &a.ta, &c0) || !makeTowerArgs(dyn_, false, true, &a.ta_dyn, &cd)) { return MZ_OK; }
+    makeHeadParams(&a.hp);
+    a.pv = pool.v_;
+    a.params = params_.p;
+    a.policy = d_policy; a.logit = d_logit; a.value = d_value;
+    a.cand_count = pool.d_cand_count_.p; a.cand_action = pool.d_cand_action_.p; a.cand_player = pool.d_cand_player_.p;
+    a.cand_policy = pool.d_cand_policy_.p; a.cand_logit = pool.d_cand_logit_.p; a.value_io = pool.d_value_.p; a.reward_io = pool.d_reward_.p;
+    a.err = pool.errFlag();
+    a.rcp_n = pool.rcpEntries();
+    a.hidden = d_hidden; a.slots = slots; a.root_feat = d_root_feat; a.root_legal = d_root_legal; a.root_turn = d_root_turn;
+    a.A = desc_.action_size; a.LW = (desc_.action_size + 63) / 64; a.num_players = num_players;
+    a.root_noise = d_root_noise;
+    a.noise_eps = noise_eps;
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+    const int cmax = std::max(std::max(c0, cd), C);
+    const size_t tile_bytes = size_t(3) * cmax * planeStride(H, W) * sizeof(float);
+    size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double);
+    lds = std::max(lds, azCandSmemBytes(a.A));
+    if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
+        if (!sim_args_.ensure(sizeof(SimArgs))) { setError("hipMalloc of the simulation arguments failed"); return MZ_ERR_DEVICE; }
+        MZ_HIP(hipStreamSynchronize(stream_));
+        MZ_HIP(hipMemcpy(sim_args_.p, &a, sizeof(SimArgs), hipMemcpyHostToDevice));
+        sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
+    }
+#define MZ_SIM_MZ_LAUNCH(h, w, cin0, cdyn, cpad) \
+    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, lds, stream_); }
+    MZ_SIM_MZ_CASES(MZ_SIM_MZ_LAUNCH)
+#undef MZ_SIM_MZ_LAUNCH
     return MZ_OK;
 }
 

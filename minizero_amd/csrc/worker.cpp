@@ -303,6 +303,10 @@ private:
         int cycles_since_signal = 0;
         PinBuf<uint8_t> h_rot;   // per-game simulation kernel: rotations of a batch of cycles [cycle][game]
         DevBuf<uint8_t> d_rot;
+        // MuZero simulation kernel: root planes (bit-packed), legal mask and player of every game, refreshed once per move
+        PinBuf<uint32_t> h_rootfeat; DevBuf<uint32_t> d_rootfeat;
+        PinBuf<unsigned long long> h_rootlegal; DevBuf<unsigned long long> d_rootlegal;
+        PinBuf<int> h_rootturn; DevBuf<int> d_rootturn;
         PinBuf<float> h_noise;   // Dirichlet noise of the root children drawn ahead of the launch [game][A]
         DevBuf<float> d_noise;
         hipEvent_t ev0 = nullptr, ev1 = nullptr; // GPU time of the simulation-kernel launches (stats: ms_forward)
@@ -366,6 +370,7 @@ private:
     std::vector<DeferredInfo> deferred_; // record strings of the last move, built while the next launch runs
     bool defer_info_ = false;
     void flushDeferred();
+    bool sim_mz_ = false;     // MuZero board game on sim_kernel_mz (no device rules needed: the leaves have no environment)
     bool sim_kernel_ = false; // ... and whole runs of cycles are ONE launch of the per-game simulation kernel (sim.hip)
 };
 
@@ -462,12 +467,46 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             }
         }
     }
+    sim_mz_ = !resident_ && cfg_.mz_sim_kernel && desc.type == 1 && !cfg_.actor_use_gumbel && !cfg_.actor_mcts_value_rescale && net0().hasSimKernelMz();
+    if (sim_mz_) {
+        sim_kernel_ = true;
+        defer_info_ = true;
+        const int fw = games_[0].env->featureWords(), LW = (A_ + 63) / 64;
+        for (auto& L : lanes_) {
+            if (!L->h_rootfeat.alloc(size_t(L->n) * fw) || !L->d_rootfeat.alloc(size_t(L->n) * fw) || !L->h_rootlegal.alloc(size_t(L->n) * LW) ||
+                !L->d_rootlegal.alloc(size_t(L->n) * LW) || !L->h_rootturn.alloc(L->n) || !L->d_rootturn.alloc(L->n) ||
+                !L->h_noise.alloc(size_t(L->n) * A_) || !L->d_noise.alloc(size_t(L->n) * A_) || !L->h_rot.alloc(size_t(n_ + 1) * L->n) ||
+                !L->d_rot.alloc(size_t(n_ + 1) * L->n)) {
+                setError("worker: allocation failed (MuZero root staging)");
+                return MZ_ERR_DEVICE;
+            }
+            MZ_HIP(hipEventCreate(&L->ev0));
+            MZ_HIP(hipEventCreate(&L->ev1));
+            int rc = uploadRoots(*L);
+            if (rc) { return rc; }
+        }
+    }
     return MZ_OK;
 }
 
 int Worker::uploadRoots(Lane& L)
 {
     const int g0 = L.g0;
+    if (sim_mz_) { // MuZero: what the initial inference and the root expansion need from the host engine
+        const int fw = games_[0].env->featureWords(), LW = (A_ + 63) / 64;
+        threads_->parallelFor(L.n, [this, &L, g0, fw, LW](int j) {
+            Game& gm = games_[g0 + j];
+            gm.env->featureBits(0, L.h_rootfeat.p + size_t(j) * fw);
+            gm.env->legalMask(gm.legal.data());
+            for (int w = 0; w < LW; ++w) { L.h_rootlegal.p[size_t(j) * LW + w] = 0; }
+            for (int a = 0; a < A_; ++a) { if (gm.legal[a]) { L.h_rootlegal.p[size_t(j) * LW + (a >> 6)] |= 1ull << (a & 63); } }
+            L.h_rootturn.p[j] = gm.env->turn();
+        });
+        MZ_HIP(hipMemcpyAsync(L.d_rootfeat.p, L.h_rootfeat.p, L.h_rootfeat.n * sizeof(uint32_t), hipMemcpyHostToDevice, L.stream));
+        MZ_HIP(hipMemcpyAsync(L.d_rootlegal.p, L.h_rootlegal.p, L.h_rootlegal.n * sizeof(unsigned long long), hipMemcpyHostToDevice, L.stream));
+        MZ_HIP(hipMemcpyAsync(L.d_rootturn.p, L.h_rootturn.p, L.h_rootturn.n * sizeof(int), hipMemcpyHostToDevice, L.stream));
+        return MZ_OK;
+    }
     threads_->parallelFor(L.n, [this, &L, g0](int j) { games_[g0 + j].env->exportDeviceRoot(L.godev.hostSnap(j)); });
     return L.godev.uploadRoots();
 }
@@ -512,7 +551,7 @@ int Worker::resetAllSearches()
         for (int j = 0; j < L->n; ++j) { rp[j] = rootPlayerFor(games_[L->g0 + j]); }
         int rc = L->pool.resetSearch(nullptr, rp.data());
         if (rc) { return rc; }
-        if (resident_ && (rc = uploadRoots(*L))) { return rc; }
+        if ((resident_ || sim_mz_) && (rc = uploadRoots(*L))) { return rc; }
     }
     return MZ_OK;
 }
@@ -912,7 +951,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
     if (pending_) {
         double t1 = t0, te = t0;
         int rc = MZ_OK;
-        if (!resident_) { // resident: candidates + expand + backup were queued on the device right behind the heads (phase2Resident)
+        if (!resident_ && !sim_mz_) { // resident: candidates + expand + backup were queued on the device right behind the heads (phase2Resident)
             if (use_signal_) { int rcw = L.pool.waitSignal(L.signal_seq); if (rcw) { return rcw; } }
             else { MZ_HIP(hipStreamSynchronize(L.stream)); } // network outputs of this lane
             t1 = nowMs();
@@ -981,7 +1020,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
             std::vector<int> rp(L.n);
             for (int j = 0; j < L.n; ++j) { rp[j] = rootPlayerFor(games_[g0 + j]); }
             if ((rc = L.pool.resetSearch(nullptr, rp.data()))) { return rc; }
-            if (resident_ && (rc = uploadRoots(L))) { return rc; }
+            if ((resident_ || sim_mz_) && (rc = uploadRoots(L))) { return rc; }
         }
         t0 = nowMs();
         stats_.ms_move += t0 - t2;
@@ -1163,8 +1202,10 @@ int Worker::runCyclesSim(int n)
                         rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise_scratch_);
                         memcpy(L->h_noise.p + size_t(j) * A_, noise_scratch_.data(), size_t(k) * sizeof(float));
                     }
-                    gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0; // the only draw of a plain cycle (zero_actor.cpp:56)
-                    L->h_rot.p[size_t(batch) * L->n + j] = static_cast<uint8_t>(gm.rot);
+                    if (desc_.type == 0) { // AlphaZero: the only draw of a plain cycle (zero_actor.cpp:56); MuZero draws nothing
+                        gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
+                        L->h_rot.p[size_t(batch) * L->n + j] = static_cast<uint8_t>(gm.rot);
+                    }
                 }
             }
             noise_in_batch |= noise_cycle;
@@ -1175,8 +1216,11 @@ int Worker::runCyclesSim(int n)
             if (noise_in_batch) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, L->stream)); }
             bool launched = false;
             MZ_HIP(hipEventRecord(L->ev0, L->stream));
-            int rc = L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched,
-                                      noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon);
+            int rc = sim_mz_ ? L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
+                                                  games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, sim0, batch, &launched,
+                                                  noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon)
+                              : L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched,
+                                                 noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon);
             if (rc) { return rc; }
             if (!launched) { setError("worker: no simulation-kernel instance for this network"); return MZ_ERR_STATE; }
             MZ_HIP(hipEventRecord(L->ev1, L->stream));

@@ -163,3 +163,17 @@ def test_go_execution_modes_are_equivalent(mz, noise):
     assert host == resident
     assert host == sim_whole
     assert host == sim_chunks
+
+
+def test_go_muzero_execution_modes_are_equivalent(mz):
+    """MuZero: lock-step kernels with host candidate lists vs the per-game simulation kernel (initial + recurrent inference, hidden-state
+    slab, candidate sort and expand + backup in one launch per run of cycles)."""
+    conf = "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=10:zero_num_parallel_games=5"
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "muzero")
+    total = 11 * 180
+    lockstep = _lines_of(mz, conf + ":mz_sim_kernel=false", args, [total], total)
+    sim_whole = _lines_of(mz, conf + ":mz_sim_kernel=true", args, [total], total)
+    sim_chunks = _lines_of(mz, conf + ":mz_sim_kernel=true", args, [1, 2, 5, 11, 3, 40, 12, 10], total)
+    assert len(lockstep) >= 5
+    assert lockstep == sim_whole
+    assert lockstep == sim_chunks
