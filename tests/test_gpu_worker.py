@@ -177,3 +177,13 @@ def test_go_muzero_execution_modes_are_equivalent(mz):
     assert len(lockstep) >= 5
     assert lockstep == sim_whole
     assert lockstep == sim_chunks
+
+
+def test_go_full_games_to_the_end(mz, oracle):
+    """Whole 9x9 games (captures, ko and superko late in the game, passes, the 2 * 81 move cap, Tromp-Taylor results in the records) through
+    the default execution mode — device rules engine + per-game simulation kernel — against the oracle's records."""
+    conf = "env_game=go:env_board_size=9:actor_num_simulation=4:zero_num_parallel_games=6"
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    lines, olines, st = run_both(mz, oracle, conf, args, 5 * 164 * 3, threads=2, seed=5)
+    check(lines, olines, 12)
+    assert st["games"] >= 12
