@@ -1,0 +1,99 @@
+// Gumbel root logic on the device (ref actor/gumbel_zero.cpp:74-137): sequential halving of the sampled root candidates and the
+// choice of the root child the next simulation starts from.  Run by ONE wave64 for game `g` between two simulations of the per-game
+// simulation kernel.  Everything here is deterministic given the root statistics (the only random input, the Gumbel noise of the
+// root logits, is drawn on the host in the reference's RNG order and applied by simApplyRootNoise); the three std::sort calls of
+// the reference are replayed with sort_emul.h, so ties fall the way libstdc++ lets them fall.  The host's own copy of this logic
+// (worker.cpp gumbelSequentialHalving / gumbelSortByScore) stays in charge of the move decision: it reads the state back.
+#pragma once
+#include "gumbel.h"
+#include "pool_body.h"
+#include "sort_emul.h"
+
+namespace mz {
+
+struct GumbelByLogit { // candidates by logit, descending (gumbel_zero.cpp:97)
+    const float* lg;
+    __device__ bool operator()(int l, int r) const { return lg[l] > lg[r]; }
+};
+struct GumbelByScore { // gumbel_zero.cpp:121-137
+    const float* score;
+    __device__ bool operator()(int l, int r) const { return score[l] > score[r]; }
+};
+struct GumbelByCount { // fewest visits first, then the larger logit (gumbel_zero.cpp:78-81)
+    const float *cnt, *lg;
+    __device__ bool operator()(int l, int r) const { return cnt[l] < cnt[r] || (cnt[l] == cnt[r] && lg[l] > lg[r]); }
+};
+
+inline size_t gumbelSmemBytes(int A) { return size_t(A) * (3 * sizeof(float) + sizeof(int)) + (kGumbelMaxSample + 3 * 40) * sizeof(int) + 64; }
+
+// sim_post = simulations of this search completed so far (>= 1).  Returns the node the next selection starts from.
+__device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelView& gv, int sim_post, int g, int lane, float* smem)
+{
+    const size_t base = size_t(g) * v.cap;
+    const NodeRec root = v.rec[base];
+    const int nc = root.num_children, fc = root.first_child, cplayer = (root.players >> 8) & 0xFF;
+    float* cnt = smem;              // [nc]
+    float* lg = cnt + v.A;          // [nc]
+    float* score = lg + v.A;        // [nc]
+    int* idx = reinterpret_cast<int*>(score + v.A); // [nc] scratch for the first sort
+    int* cand = idx + v.A;                           // [kGumbelMaxSample] the candidates, sorted in LDS
+    int* stack = cand + kGumbelMaxSample;            // sort_emul range stack
+    int* st = gv.state + size_t(g) * (3 + kGumbelMaxSample);
+    const int bsize = v.bound_size[g];
+    const float lo = v.bound_lo[g], hi = v.bound_hi[g];
+    float mx = 0.0f;
+    for (int i = lane; i < nc; i += 64) {
+        const NodeRec c = v.rec[base + fc + i];
+        cnt[i] = c.count;
+        lg[i] = v.logit[base + fc + i];
+        mx = c.count > mx ? c.count : mx;
+        // score of gumbelSortByScore: logit + (c_visit + max count) * c_scale * normalized mean; the max count is added below
+        score[i] = c.count > 0.0f ? normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi) : 0.0f;
+        idx[i] = i;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(mx, o); mx = m2 > mx ? m2 : mx; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int start = 0;
+    if (lane == 0) {
+        int ncand = st[0], sample = st[1], budget = st[2];
+        if (sim_post != 1) { for (int i = 0; i < ncand; ++i) { cand[i] = st[3 + i]; } }
+        if (sim_post == 1) { // the root has just been expanded: sample the top-m children by (noisy) logit
+            StdSortEmul<int, GumbelByLogit> s{idx, GumbelByLogit{lg}};
+            s.sort(nc, stack);
+            ncand = nc < gv.sample_size ? nc : gv.sample_size;
+            for (int i = 0; i < ncand; ++i) { cand[i] = idx[i]; }
+            sample = gv.sample_size;
+            budget = gv.budget0;
+        } else {
+            bool all = true;
+            for (int i = 0; i < ncand; ++i) { if (!(cnt[cand[i]] >= static_cast<float>(budget))) { all = false; break; } }
+            if (all) {
+                int lg2 = 0;
+                while ((1 << (lg2 + 1)) <= sample) { ++lg2; }
+                const int next_budget = gv.next_budget[lg2 < 8 ? lg2 : 7];
+                if (next_budget > 0 && sample > 2) {
+                    sample /= 2;
+                    for (int i = 0; i < nc; ++i) {
+                        const float value = score[i];
+                        const float sc = lg[i] + (gv.sigma_visit_c + mx) * gv.sigma_scale_c * value;
+                        score[i] = cnt[i] > 0.0f ? sc : -3.402823466e+38f;
+                    }
+                    StdSortEmul<int, GumbelByScore> s{cand, GumbelByScore{score}};
+                    s.sort(ncand, stack);
+                    if (ncand > sample) { ncand = sample; }
+                    budget = static_cast<int>(cnt[cand[0]] + static_cast<float>(next_budget));
+                }
+            }
+        }
+        StdSortEmul<int, GumbelByCount> s2{cand, GumbelByCount{cnt, lg}};
+        s2.sort(ncand, stack);
+        st[0] = ncand; st[1] = sample; st[2] = budget;
+        for (int i = 0; i < ncand; ++i) { st[3 + i] = cand[i]; }
+        start = fc + cand[0];
+    }
+    return __builtin_amdgcn_readfirstlane(start);
+}
+
+} // namespace mz

@@ -46,6 +46,7 @@ struct TowerArgs;
 struct HeadParams;
 struct PoolView;
 struct GoDevView;
+struct GumbelView;
 class Pool;
 
 class Net {
@@ -71,8 +72,11 @@ public:
     // the per-game simulation kernel (sim.hip): `nsims` whole simulations (select, leaf environment, tower, heads, candidates, expand +
     // backup) of every game in ONE launch, each game advancing on its own workgroup.  *launched = false when no instance fits.
     // d_root_noise ([games][A], nullable): Dirichlet noise applied to the root children before simulation 1
+    // noise_kind 1: Dirichlet on the priors, 2: Gumbel on the logits; gum != nullptr: Gumbel root logic on the device (d_start: [games] scratch;
+    // host_start: the first simulation starts from d_start as uploaded by the host)
     int simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_logit, float* d_value, const uint8_t* d_rot, int sim0, int nsims,
-                  bool* launched, const float* d_root_noise = nullptr, float noise_eps = 0.0f);
+                  bool* launched, const float* d_root_noise = nullptr, float noise_eps = 0.0f, int noise_kind = 1, const struct GumbelView* gum = nullptr,
+                  int* d_start = nullptr, bool host_start = false);
     bool hasSimKernel(int board_n) const;
     // MuZero (board games): the same for initial + recurrent inference; hidden states live in the caller's slab [games][slots][C * P]
     int simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,

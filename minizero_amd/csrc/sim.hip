@@ -10,6 +10,7 @@
 #include "net_body.h"
 #include "pool_body.h"
 #include "go_body.h"
+#include "gumbel_body.h"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -36,8 +37,12 @@ struct SimArgs {
     const unsigned long long* root_legal; // [games][LW] legal mask of the root position
     const int* root_turn;             // [games] player to move at the root
     int slots, A, LW, num_players;
-    const float* root_noise;          // [games][A] Dirichlet noise of the root children (host RNG), applied before simulation 1; nullptr: none
+    const float* root_noise;          // [games][A] noise of the root children (host RNG), applied before simulation 1; nullptr: none
     float noise_eps;
+    int noise_kind;                   // 1: Dirichlet on the priors, 2: Gumbel on the logits (ref zero_actor.cpp:194-213)
+    int use_gumbel;                   // Gumbel root logic (sequential halving + start node) between simulations
+    GumbelView gum;
+    int* start;                       // [games] start node of the next selection (written by the Gumbel step or by the host)
     unsigned* sink;                   // never-taken store target that keeps the prefetch loads alive
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
@@ -51,7 +56,7 @@ __device__ __noinline__ void simSelectLeaf(const SimArgs* __restrict__ a, int ro
 {
     unsigned long long t0 = 0;
     if (a->prof) { t0 = wall_clock64(); }
-    selectBody(a->pv, nullptr, g, lane, rcp);
+    selectBody(a->pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
     waveSync();
     if (a->prof && lane == 0) {
         a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
@@ -80,9 +85,21 @@ __device__ __noinline__ void simApplyRootNoise(const SimArgs* __restrict__ a, in
     const float eps = a->noise_eps;
     for (int i = lane; i < nc; i += 64) {
         const float nz = a->root_noise[size_t(g) * v.A + i];
-        v.rec[fc + i].policy = (1 - eps) * v.rec[fc + i].policy + eps * nz;
+        if (a->noise_kind == 1) { v.rec[fc + i].policy = (1 - eps) * v.rec[fc + i].policy + eps * nz; }
+        else { v.logit[fc + i] = v.logit[fc + i] + nz; }
         v.noise[fc + i] = nz;
     }
+    waveSync();
+}
+
+// Gumbel: sequential halving + the root child the next simulation starts from (slot >= 1); the first simulation of a launch takes the
+// start node the host computed when it ran this step itself (it does at every launch boundary, reading the state back first)
+__device__ __noinline__ void simGumbelStart(const SimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles)
+{
+    if (host_start && slot >= 1) { return; } // a->start[g] was uploaded by the host
+    int st = 0;
+    if (slot >= 1 && !host_start) { st = gumbelStepBody(a->pv, a->gum, slot, g, lane, tiles); }
+    if (lane == 0) { a->start[g] = st; }
     waveSync();
 }
 
@@ -114,7 +131,7 @@ __device__ __noinline__ void simHeads(const SimArgs* __restrict__ a, int g, int 
 }
 
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
-__global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a, const uint8_t* __restrict__ rot_tab, int sim0, int nsims)
+__global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a, const uint8_t* __restrict__ rot_tab, int sim0, int nsims, int host_start)
 {
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,6 +150,7 @@ __global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a,
         if (prof) { t0 = wall_clock64(); }
         if (wave == 0) {
             if (slot == 1 && a->root_noise) { simApplyRootNoise(a, g, lane); }
+            if (a->use_gumbel) { simGumbelStart(a, slot, s == 0 && host_start != 0, g, lane, tiles); }
             simSelectLeaf<CPL>(a, rot, slot, g, lane, tiles, rcp_lds);
         }
         else if (wave == 1 && s + slot > 0) { simPrefetchPath(a, g, lane); }
@@ -256,14 +274,14 @@ static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, s
     X(9, 9, 20, 12, 8)   /* small 9x9 test nets */
 
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
-static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, size_t lds, hipStream_t s)
+static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         attr_set = true;
     }
-    hipLaunchKernelGGL((sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), dim3(games), dim3(512), lds, s, d_args, d_rot, sim0, nsims);
+    hipLaunchKernelGGL((sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), dim3(games), dim3(512), lds, s, d_args, d_rot, sim0, nsims, host_start);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
@@ -313,7 +331,7 @@ bool Net::hasSimKernel(int board_n) const
 }
 
 int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_logit, float* d_value, const uint8_t* d_rot, int sim0, int nsims,
-                   bool* launched, const float* d_root_noise, float noise_eps)
+                   bool* launched, const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start)
 {
     *launched = false;
     if (desc_.type != 0) { return MZ_OK; }
@@ -335,6 +353,10 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     a.rcp_n = pool.rcpEntries();
     a.root_noise = d_root_noise;
     a.noise_eps = noise_eps;
+    a.noise_kind = noise_kind;
+    a.use_gumbel = gum ? 1 : 0;
+    if (gum) { a.gum = *gum; }
+    a.start = d_start;
     if (!sim_sink_.ensure(4)) { setError("hipMalloc failed"); return MZ_ERR_DEVICE; }
     a.sink = sim_sink_.p;
     if (getenv("MZ_SIM_PROF")) {
@@ -350,6 +372,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     const size_t heads = (size_t(a.hp.C) * a.hp.P + size_t(a.hp.PC) * a.hp.P + a.hp.P + a.hp.VH + a.hp.A + 16) * sizeof(float);
     lds = std::max(lds, std::max(heads, std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A))));
     lds = std::max(lds, size_t(2) * pool.v_.bound_cap * sizeof(float));
+    lds = std::max(lds, gumbelSmemBytes(gv.A));
     lds = size_t(3) * cmax * planeStride(H, W) * sizeof(float) + size_t(a.rcp_n) * sizeof(double) > lds ? size_t(3) * cmax * planeStride(H, W) * sizeof(float) + size_t(a.rcp_n) * sizeof(double) : lds;
     // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
     static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
@@ -360,7 +383,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
         sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
     }
 #define MZ_SIM_LAUNCH(h, w, cin0, cpad, cpl) \
-    if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && gv.W == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, lds, stream_); }
+    if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && gv.W == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
     MZ_SIM_CASES(MZ_SIM_LAUNCH)
 #undef MZ_SIM_LAUNCH
     return MZ_OK;
@@ -402,6 +425,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.A = desc_.action_size; a.LW = (desc_.action_size + 63) / 64; a.num_players = num_players;
     a.root_noise = d_root_noise;
     a.noise_eps = noise_eps;
+    a.noise_kind = 1;
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
     const int cmax = std::max(std::max(c0, cd), C);
     const size_t tile_bytes = size_t(3) * cmax * planeStride(H, W) * sizeof(float);

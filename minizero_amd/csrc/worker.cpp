@@ -14,6 +14,7 @@
 #include "net.h"
 #include "pool.h"
 #include "go_dev.h"
+#include "gumbel.h"
 #include <pthread.h>
 #include <sched.h>
 #include <unistd.h>
@@ -307,6 +308,7 @@ private:
         PinBuf<uint32_t> h_rootfeat; DevBuf<uint32_t> d_rootfeat;
         PinBuf<unsigned long long> h_rootlegal; DevBuf<unsigned long long> d_rootlegal;
         PinBuf<int> h_rootturn; DevBuf<int> d_rootturn;
+        PinBuf<int> h_gum; DevBuf<int> d_gum; // Gumbel state of every game (gumbel.h): the device runs the halving between simulations
         PinBuf<float> h_noise;   // Dirichlet noise of the root children drawn ahead of the launch [game][A]
         DevBuf<float> d_noise;
         hipEvent_t ev0 = nullptr, ev1 = nullptr; // GPU time of the simulation-kernel launches (stats: ms_forward)
@@ -370,6 +372,9 @@ private:
     std::vector<DeferredInfo> deferred_; // record strings of the last move, built while the next launch runs
     bool defer_info_ = false;
     void flushDeferred();
+    GumbelView gum_{};        // constants of the device-side Gumbel step (state pointer set per lane)
+    bool dev_gumbel_ = false; // AlphaZero Go + Gumbel on the simulation kernel
+    int syncGumbel(Lane& L, bool to_device);
     bool sim_mz_ = false;     // MuZero board game on sim_kernel_mz (no device rules needed: the leaves have no environment)
     bool sim_kernel_ = false; // ... and whole runs of cycles are ONE launch of the per-game simulation kernel (sim.hip)
 };
@@ -442,8 +447,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     if (rcc) { return rcc; }
     feat_bits_ = (desc.type == 0) && net0().hasFusedTower();
     use_signal_ = cfg_.mz_signal_wait;
-    resident_ = cfg_.mz_device_env && desc.type == 0 && feat_bits_ && !cfg_.actor_use_gumbel && games_[0].env->hasDeviceTwin() &&
-                lane_size_ <= kRotPackGames;
+    resident_ = cfg_.mz_device_env && desc.type == 0 && feat_bits_ && games_[0].env->hasDeviceTwin() && lane_size_ <= kRotPackGames;
     if (resident_) {
         const GameEnv& e = *games_[0].env;
         const int* inv[8];
@@ -456,7 +460,23 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             L->pool.v_.host_path_action = nullptr;
             if ((rc = uploadRoots(*L))) { return rc; }
         }
-        sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize());
+        sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize()) &&
+                      (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 1 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
+        dev_gumbel_ = sim_kernel_ && cfg_.actor_use_gumbel;
+        if (dev_gumbel_) { // the constants of gumbel_zero.cpp:101,110 in the host's double arithmetic
+            const int m = cfg_.actor_gumbel_sample_size;
+            gum_.sample_size = m;
+            gum_.sigma_visit_c = cfg_.actor_gumbel_sigma_visit_c;
+            gum_.sigma_scale_c = cfg_.actor_gumbel_sigma_scale_c;
+            gum_.budget0 = static_cast<int>(std::max(1.0, std::floor(cfg_.actor_num_simulation / (std::log2(m) * m))));
+            for (int k = 0; k < 8; ++k) { gum_.next_budget[k] = static_cast<int>(std::floor(cfg_.actor_num_simulation / (std::log2(m) * (1 << k) / 2))); }
+            for (auto& L : lanes_) {
+                const size_t n = size_t(L->n) * (3 + kGumbelMaxSample);
+                if (!L->h_gum.alloc(n) || !L->d_gum.alloc(n)) { setError("worker: allocation failed (gumbel state)"); return MZ_ERR_DEVICE; }
+                memset(L->h_gum.p, 0, n * sizeof(int));
+                MZ_HIP(hipMemset(L->d_gum.p, 0, n * sizeof(int)));
+            }
+        }
         defer_info_ = sim_kernel_;
         if (sim_kernel_) {
             for (auto& L : lanes_) {
@@ -1163,6 +1183,34 @@ int Worker::cycle()
     return MZ_OK;
 }
 
+// Gumbel state of the lane's games between host (Game::candidates / sample_size / simulation_budget) and device (gumbel.h layout)
+int Worker::syncGumbel(Lane& L, bool to_device)
+{
+    const int stride = 3 + kGumbelMaxSample;
+    if (to_device) {
+        for (int j = 0; j < L.n; ++j) {
+            const Game& gm = games_[L.g0 + j];
+            int* st = L.h_gum.p + size_t(j) * stride;
+            st[0] = static_cast<int>(gm.candidates.size());
+            st[1] = gm.sample_size;
+            st[2] = gm.simulation_budget;
+            for (size_t i = 0; i < gm.candidates.size() && i < size_t(kGumbelMaxSample); ++i) { st[3 + i] = gm.candidates[i]; }
+        }
+        MZ_HIP(hipMemcpyAsync(L.d_gum.p, L.h_gum.p, L.h_gum.n * sizeof(int), hipMemcpyHostToDevice, L.stream));
+        return MZ_OK;
+    }
+    MZ_HIP(hipMemcpyAsync(L.h_gum.p, L.d_gum.p, L.h_gum.n * sizeof(int), hipMemcpyDeviceToHost, L.stream));
+    MZ_HIP(hipStreamSynchronize(L.stream));
+    for (int j = 0; j < L.n; ++j) {
+        Game& gm = games_[L.g0 + j];
+        const int* st = L.h_gum.p + size_t(j) * stride;
+        gm.candidates.assign(st + 3, st + 3 + std::max(0, std::min(st[0], kGumbelMaxSample)));
+        gm.sample_size = st[1];
+        gm.simulation_budget = st[2];
+    }
+    return MZ_OK;
+}
+
 // Device-resident cycles in batches: the host part of a cycle (per-move logic in RNG order, rotation draws) runs exactly as in
 // cycle(); every following cycle that needs nothing from the host but its rotation draws joins the same launch of the per-game
 // simulation kernel.  A 400-simulation move is two launches: the root expansion, then (after the root noise) the other 400.
@@ -1176,9 +1224,12 @@ int Worker::runCyclesSim(int n)
         sim_pre_ = sims_done_;
         sim_post_ = sims_done_ + 1;
         const bool root_expansion = pending_ && (sim_post_ == 1), done = pending_ && (sim_post_ == n_ + 1);
+        const bool host_gumbel = dev_gumbel_ && pending_; // the host runs this cycle's Gumbel step itself: state down, step, state up
         for (auto& L : lanes_) {
-            int rc = phase1(*L, root_expansion, done, false);
-            if (rc) { return rc; }
+            int rc = MZ_OK;
+            if (host_gumbel && (rc = syncGumbel(*L, false))) { return rc; }
+            if ((rc = phase1(*L, root_expansion, done, false))) { return rc; }
+            if (host_gumbel && (rc = syncGumbel(*L, true))) { return rc; }
             for (int j = 0; j < L->n; ++j) { L->h_rot.p[j] = static_cast<uint8_t>(games_[L->g0 + j].rot); }
         }
         if (pending_) { sims_done_ = done ? 0 : sim_post_; }
@@ -1188,7 +1239,7 @@ int Worker::runCyclesSim(int n)
         // expansion (sim index 1) needs the Dirichlet noise of the root children: its values only depend on the RNG stream and on
         // the NUMBER of root children = legal moves of the root position, which the host engine knows, so they are drawn here in the
         // reference's order ([noise][rotation] per actor, zero_actor.cpp:194-213 then :56) and applied by the kernel before simulation 1.
-        const bool device_noise = cfg_.actor_use_dirichlet_noise && !cfg_.actor_use_gumbel_noise;
+        const bool device_noise = cfg_.actor_use_dirichlet_noise || (cfg_.actor_use_gumbel_noise && !sim_mz_); // the kernel applies either kind
         bool noise_in_batch = false;
         while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg && !device_noise)) {
             const bool noise_cycle = (sim0 + batch == 1) && noise_cfg;
@@ -1199,7 +1250,8 @@ int Worker::runCyclesSim(int n)
                         gm.env->legalMask(gm.legal.data());
                         int k = 0;
                         for (int a = 0; a < A_; ++a) { k += gm.legal[a] != 0; }
-                        rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise_scratch_);
+                        if (cfg_.actor_use_dirichlet_noise) { rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise_scratch_); }
+                        else { rng_.gumbel(k, noise_scratch_); }
                         memcpy(L->h_noise.p + size_t(j) * A_, noise_scratch_.data(), size_t(k) * sizeof(float));
                     }
                     if (desc_.type == 0) { // AlphaZero: the only draw of a plain cycle (zero_actor.cpp:56); MuZero draws nothing
@@ -1219,8 +1271,13 @@ int Worker::runCyclesSim(int n)
             int rc = sim_mz_ ? L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
                                                   games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, sim0, batch, &launched,
                                                   noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon)
-                              : L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched,
-                                                 noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon);
+                              : [&]() {
+                                    GumbelView gv = gum_;
+                                    gv.state = L->d_gum.p;
+                                    return L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched,
+                                                            noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon,
+                                                            cfg_.actor_use_dirichlet_noise ? 1 : 2, dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, host_gumbel);
+                                }();
             if (rc) { return rc; }
             if (!launched) { setError("worker: no simulation-kernel instance for this network"); return MZ_ERR_STATE; }
             MZ_HIP(hipEventRecord(L->ev1, L->stream));

@@ -187,3 +187,30 @@ def test_go_full_games_to_the_end(mz, oracle):
     lines, olines, st = run_both(mz, oracle, conf, args, 5 * 164 * 3, threads=2, seed=5)
     check(lines, olines, 12)
     assert st["games"] >= 12
+
+
+GO_GUMBEL = ("env_game=go:env_board_size=9:actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:"
+             "actor_gumbel_sample_size=16:actor_gumbel_sigma_visit_c=50:actor_gumbel_sigma_scale_c=1:zero_num_parallel_games=5")
+
+
+@pytest.mark.parametrize("n", [16, 50])
+def test_go_gumbel_on_the_device_matches_oracle(mz, oracle, n):
+    """Gumbel root logic (noise on the logits, top-m sampling, sequential halving, start node of every simulation) inside the simulation
+    kernel, records against the oracle."""
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    lines, olines, _ = run_both(mz, oracle, GO_GUMBEL + f":actor_num_simulation={n}", args, (n + 1) * 200, threads=2, seed=9)
+    check(lines, olines, 3)
+
+
+def test_go_gumbel_execution_modes_are_equivalent(mz):
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    conf = GO_GUMBEL + ":actor_num_simulation=20:actor_select_action_by_count=true:actor_select_action_by_softmax_count=false"
+    total = 21 * 200
+    host = _lines_of(mz, conf + ":mz_device_env=false", args, [total], total)
+    resident = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=false", args, [9, 1, 30], total)
+    sim_whole = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [total], total)
+    sim_chunks = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [1, 2, 5, 21, 3, 40, 20, 22, 7], total)
+    assert len(host) >= 3
+    assert host == resident
+    assert host == sim_whole
+    assert host == sim_chunks
