@@ -246,6 +246,21 @@ public:
             out[3 * P + p] = turn_ == 2 ? 1.0f : 0.0f;
         }
     }
+    bool hasDeviceTwin() const override { return n_ <= 8; }
+    int deviceKind() const override { return 1; }
+    void exportDeviceRoot(void* dst) const override // the fields of GoRootSnapshot the Othello device engine reads (go_body.h othLeafBody)
+    {
+        GoRootSnapshot& s = *static_cast<GoRootSnapshot*>(dst);
+        s.stones[0][0] = s_[0];
+        s.stones[1][0] = s_[1];
+        s.hash = 0;
+        s.hist_len = 0;
+        s.turn = turn_;
+        s.nmoves = static_cast<int32_t>(action_ids_.size());
+        int passes = 0;
+        for (size_t k = action_ids_.size(); k > 0 && passes < 2 && action_ids_[k - 1] == n_ * n_; --k) { ++passes; }
+        s.passes = passes;
+    }
     int numInputChannels() const override { return 4; }
     int boardSize() const override { return n_; }
     int policySize() const override { return n_ * n_ + 1; }

@@ -48,6 +48,7 @@ public:
     virtual std::vector<std::pair<std::string, std::string>> loaderTags() const = 0;
     // engines with a device twin (go_dev.hip): the root position in the device's format, once per move
     virtual bool hasDeviceTwin() const { return false; }
+    virtual int deviceKind() const { return 0; } // GoDevView::kind (0 Go, 1 Othello)
     virtual void exportDeviceRoot(void* /*GoRootSnapshot*/) const {}
     virtual const uint64_t* zobristKeys() const { return nullptr; } // [2][points]
     int turn() const { return turn_; }

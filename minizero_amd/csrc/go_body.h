@@ -355,6 +355,125 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     }
 }
 
+// ---- Othello (ref environment/othello/othello.cpp:61-140,195-255): the whole position is two 64-bit boards, so every lane carries
+// it and the rules are scalar bit arithmetic; only the rotated feature planes are built with ballots.  Slot layout: the `stones`
+// words of the Go slab hold the two boards, `meta` (moves played, trailing passes).
+struct OthMasks { unsigned long long full, not_left, not_right; int n; };
+__device__ __forceinline__ unsigned long long othShift(const OthMasks& k, unsigned long long b, int d)
+{
+    switch (d) {
+    case 0: return (b << k.n) & k.full;
+    case 1: return b >> k.n;
+    case 2: return (b & k.not_left) >> 1;
+    case 3: return ((b & k.not_right) << 1) & k.full;
+    case 4: return ((b & k.not_left) << (k.n - 1)) & k.full;
+    case 5: return ((b & k.not_right) << (k.n + 1)) & k.full;
+    case 6: return (b & k.not_right) >> (k.n - 1);
+    default: return (b & k.not_left) >> (k.n + 1);
+    }
+}
+__device__ __forceinline__ unsigned long long othMoves(const OthMasks& k, unsigned long long me, unsigned long long op)
+{
+    const unsigned long long empty = k.full & ~(me | op);
+    unsigned long long m = 0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        unsigned long long x = othShift(k, me, d) & op;
+        for (int i = 0; i < k.n - 3; ++i) { x |= othShift(k, x, d) & op; }
+        m |= othShift(k, x, d) & empty;
+    }
+    return m;
+}
+
+__device__ __forceinline__ void othLeafBody(const GoDevView& v, const PoolView& pv, int rot, int slot, int g, int lane)
+{
+    const int P = v.P, n = v.n, MD = pv.max_depth;
+    OthMasks k;
+    k.n = n;
+    k.full = P == 64 ? ~0ull : ((1ull << P) - 1);
+    k.not_left = 0; k.not_right = 0;
+    for (int y = 0; y < n; ++y) {
+        const unsigned long long row = ((1ull << n) - 1) << (y * n);
+        k.not_left |= row & ~(1ull << (y * n));
+        k.not_right |= row & ~(1ull << (y * n + n - 1));
+    }
+    const int len = pv.path_len[g];
+    const int* path = pv.path + size_t(g) * MD;
+    const int* pact = pv.path_action + size_t(g) * MD;
+    const int depth = len - 1;
+    const GoRootSnapshot& S = v.snap[g];
+    const int root_turn = S.turn;
+    const size_t sb = size_t(g) * v.slots;
+    const int* hs = pv.hslot + size_t(g) * pv.cap;
+    const int src = depth == 0 ? 0 : hs[path[len - 2]];
+    unsigned long long s[2] = {v.stones[((sb + src) * 2 + 0) * v.W], v.stones[((sb + src) * 2 + 1) * v.W]};
+    int nmoves = v.meta[(sb + src) * 2], passes = v.meta[(sb + src) * 2 + 1];
+    const int t = (depth & 1) ? 3 - root_turn : root_turn; // the player to move at the leaf
+    if (depth >= 1) {
+        const int a = pact[len - 1], m = 3 - t;
+        ++nmoves;
+        if (a >= P) {
+            passes = passes + 1 > 2 ? 2 : passes + 1;
+        } else {
+            passes = 0;
+            unsigned long long& me = s[m - 1];
+            unsigned long long& op = s[2 - m];
+            const unsigned long long placed = 1ull << a;
+            unsigned long long flip = 0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                unsigned long long line = 0, x = othShift(k, placed, d);
+                for (int i = 0; i < n && (x & op); ++i) { line |= x; x = othShift(k, x, d); }
+                if (x & me) { flip |= line; }
+            }
+            me |= placed | flip;
+            op &= ~flip;
+        }
+        if (lane == 0) {
+            v.stones[((sb + slot) * 2 + 0) * v.W] = s[0];
+            v.stones[((sb + slot) * 2 + 1) * v.W] = s[1];
+            v.meta[(sb + slot) * 2] = nmoves;
+            v.meta[(sb + slot) * 2 + 1] = passes;
+        }
+    }
+    const bool terminal = passes >= 2; // ref othello.cpp: two consecutive passes
+    const unsigned long long mv = terminal ? 0ull : othMoves(k, s[t - 1], s[2 - t]);
+    if (lane == 0) { // legal mask: the moves, or pass when there is none (ref othello.cpp:195-201)
+        unsigned long long w0 = mv, w1 = 0;
+        if (!terminal && mv == 0) { if (P < 64) { w0 |= 1ull << P; } else { w1 = 1ull; } }
+        v.legal[size_t(g) * v.LW] = w0;
+        if (v.LW > 1) { v.legal[size_t(g) * v.LW + 1] = w1; }
+    }
+    { // planes (ref othello.cpp:238-262): own, opponent, black to move, white to move — under the cycle's rotation
+        const uint16_t* map = v.inv + size_t(rot) * P;
+        const int q = lane < P ? map[lane] : 0;
+        const unsigned long long own = __ballot(lane < P && ((s[t - 1] >> q) & 1)), opp = __ballot(lane < P && ((s[2 - t] >> q) & 1));
+        const unsigned long long ones = __ballot(lane < P);
+        unsigned long long mine = 0;
+        if (lane == 0) { mine = own; }
+        if (lane == 1) { mine = opp; }
+        if (lane == 2) { mine = t == 1 ? ones : 0; }
+        if (lane == 3) { mine = t == 2 ? ones : 0; }
+        uint32_t* out = v.feat + size_t(g) * 4 * v.W32;
+        if (lane < 4) {
+            out[lane * v.W32] = static_cast<uint32_t>(mine);
+            if (v.W32 > 1) { out[lane * v.W32 + 1] = static_cast<uint32_t>(mine >> 32); }
+        }
+    }
+    float eval = 0.0f;
+    if (terminal) { // ref othello.cpp:211-236: a winner only once neither side can move
+        if (othMoves(k, s[0], s[1]) == 0 && othMoves(k, s[1], s[0]) == 0) {
+            const int b = __popcll(s[0]), w = __popcll(s[1]);
+            eval = b > w ? 1.0f : (b < w ? -1.0f : 0.0f);
+        }
+    }
+    if (lane == 0) {
+        v.leaf_player[g] = t;
+        v.terminal[g] = terminal ? 1 : 0;
+        v.eval[g] = eval;
+    }
+}
+
 // order `k` candidates in cs[] like the reference's std::sort(policy descending): result in out[]
 __device__ void orderCandidates(Cand* cs, Cand* out, int* stack, int k, int lane, int* err)
 {

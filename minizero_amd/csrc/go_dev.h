@@ -32,6 +32,8 @@ struct RotPack { uint32_t w[kRotPackGames / 10]; }; // per-game feature rotation
 inline void rotPackSet(RotPack& r, int g, int rot) { r.w[g / 10] = (r.w[g / 10] & ~(7u << (3 * (g % 10)))) | (uint32_t(rot) << (3 * (g % 10))); }
 
 struct GoDevView {
+    int kind;                  // 0: Go, 1: Othello (two bitboards + pass count per slot, no hash / group ids; same outputs)
+    int channels;              // feature planes of the game (Go 18, Othello 4)
     int games, n, P, W, A, slots, Ppad, W32, LW;
     float komi;
     uint64_t* stones;          // [games][slots][2][W]
@@ -51,8 +53,9 @@ struct GoDevView {
 
 class GoDevice {
 public:
+    // kind 0: Go (keys = Zobrist table [2][P]); kind 1: Othello (board_n <= 8, keys unused)
     int init(int device, int games, int board_n, float komi, int action_size, int slots, int max_depth, hipStream_t stream, const int* const inv[8],
-             const int* const fwd[8], const uint64_t* keys);
+             const int* const fwd[8], const uint64_t* keys, int kind = 0);
     GoRootSnapshot* hostSnap(int g) { return h_snap_.p + g; }
     int uploadRoots();                                                   // snapshots H2D + slot 0 of every game
     int leafAsync(const PoolView& pv, const RotPack& rot, int slot);      // position + planes + legal mask of the selected leaves

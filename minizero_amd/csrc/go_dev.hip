@@ -32,6 +32,11 @@ __global__ __launch_bounds__(64) void go_leaf_kernel(GoDevView v, PoolView pv, R
     goLeafBody<CPL>(v, pv, rotOf(rp, blockIdx.x), slot, blockIdx.x, threadIdx.x, smem);
 }
 
+__global__ __launch_bounds__(64) void oth_leaf_kernel(GoDevView v, PoolView pv, RotPack rp, int slot)
+{
+    othLeafBody(v, pv, rotOf(rp, blockIdx.x), slot, blockIdx.x, threadIdx.x);
+}
+
 __global__ __launch_bounds__(64) void az_cand_kernel(GoDevView v, const float* __restrict__ policy, const float* __restrict__ logit,
                                                      const float* __restrict__ value, RotPack rp, int* __restrict__ cand_count,
                                                      int* __restrict__ cand_action, float* __restrict__ cand_policy, float* __restrict__ cand_logit,
@@ -60,8 +65,9 @@ __global__ __launch_bounds__(64) void sort_test_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 int GoDevice::init(int device, int games, int board_n, float komi, int action_size, int slots, int max_depth, hipStream_t stream, const int* const inv[8],
-                   const int* const fwd[8], const uint64_t* keys)
+                   const int* const fwd[8], const uint64_t* keys, int kind)
 {
+    if (kind == 1 && board_n > 8) { setError("GoDevice: Othello boards up to 8x8"); return MZ_ERR_ARG; }
     if (board_n < 2 || board_n > kGoMaxN || games < 1 || games > kRotPackGames || action_size != board_n * board_n + 1) {
         setError("GoDevice: unsupported shape (board %d, %d games, %d actions)", board_n, games, action_size);
         return MZ_ERR_ARG;
@@ -71,12 +77,13 @@ int GoDevice::init(int device, int games, int board_n, float komi, int action_si
     max_depth_ = max_depth;
     MZ_HIP(hipSetDevice(device));
     GoDevView& v = v_;
+    v.kind = kind; v.channels = kind == 1 ? 4 : 18;
     v.games = games; v.n = board_n; v.P = board_n * board_n; v.W = (v.P + 63) / 64; v.A = action_size; v.slots = slots;
     v.Ppad = 64 * v.W; v.W32 = (v.P + 31) / 32; v.LW = (v.A + 63) / 64; v.komi = komi;
     const size_t GS = size_t(games) * slots;
     if (!h_snap_.alloc(games) || !d_snap_.alloc(games) || !stones_.alloc(GS * 2 * v.W) || !hash_.alloc(GS) || !meta_.alloc(GS * 2) ||
         !lab_.alloc(GS * v.Ppad) || !key_.alloc(size_t(2) * v.P) || !inv_.alloc(size_t(8) * v.P) || !fwd_.alloc(size_t(8) * v.A) ||
-        !feat_.alloc(size_t(games) * 18 * v.W32) || !legal_.alloc(size_t(games) * v.LW) || !misc_i_.alloc(size_t(games) * 2) || !eval_.alloc(games)) {
+        !feat_.alloc(size_t(games) * v.channels * v.W32) || !legal_.alloc(size_t(games) * v.LW) || !misc_i_.alloc(size_t(games) * 2) || !eval_.alloc(games)) {
         setError("GoDevice: allocation failed");
         return MZ_ERR_DEVICE;
     }
@@ -88,7 +95,7 @@ int GoDevice::init(int device, int games, int board_n, float komi, int action_si
     MZ_HIP(hipMemcpy(inv_.p, t.data(), size_t(8) * v.P * sizeof(uint16_t), hipMemcpyHostToDevice));
     for (int r = 0; r < 8; ++r) { for (int a = 0; a < v.A; ++a) { t[size_t(r) * v.A + a] = static_cast<uint16_t>(fwd[r][a]); } }
     MZ_HIP(hipMemcpy(fwd_.p, t.data(), size_t(8) * v.A * sizeof(uint16_t), hipMemcpyHostToDevice));
-    MZ_HIP(hipMemcpy(key_.p, keys, size_t(2) * v.P * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (keys) { MZ_HIP(hipMemcpy(key_.p, keys, size_t(2) * v.P * sizeof(uint64_t), hipMemcpyHostToDevice)); }
     v.stones = stones_.p; v.hash = hash_.p; v.meta = meta_.p; v.lab = lab_.p; v.snap = d_snap_.p; v.key = key_.p; v.inv = inv_.p; v.fwd = fwd_.p;
     v.feat = feat_.p; v.legal = legal_.p; v.leaf_player = misc_i_.p; v.terminal = misc_i_.p + games; v.eval = eval_.p;
     return MZ_OK;
@@ -106,6 +113,11 @@ int GoDevice::uploadRoots()
 int GoDevice::leafAsync(const PoolView& pv, const RotPack& rot, int slot)
 {
     if (slot < 0 || slot >= v_.slots) { setError("GoDevice::leafAsync: slot %d out of range", slot); return MZ_ERR_ARG; }
+    if (v_.kind == 1) {
+        hipLaunchKernelGGL(oth_leaf_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, pv, rot, slot);
+        MZ_HIP(hipGetLastError());
+        return MZ_OK;
+    }
     const size_t smem = goLeafSmemBytes(v_, pv.max_depth);
 #define MZ_GO_CASE(K) \
     case K: hipLaunchKernelGGL(go_leaf_kernel<K>, dim3(v_.games), dim3(64), smem, stream_, v_, pv, rot, slot); break;
@@ -133,7 +145,7 @@ int GoDevice::readLeaf(uint32_t* feat, uint8_t* legal, int* terminal, float* eva
     MZ_HIP(hipSetDevice(device_));
     MZ_HIP(hipStreamSynchronize(stream_));
     const int G = v_.games;
-    if (feat) { MZ_HIP(hipMemcpy(feat, v_.feat, size_t(G) * 18 * v_.W32 * sizeof(uint32_t), hipMemcpyDeviceToHost)); }
+    if (feat) { MZ_HIP(hipMemcpy(feat, v_.feat, size_t(G) * v_.channels * v_.W32 * sizeof(uint32_t), hipMemcpyDeviceToHost)); }
     if (legal) {
         std::vector<uint64_t> w(size_t(G) * v_.LW);
         MZ_HIP(hipMemcpy(w.data(), v_.legal, w.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));

@@ -77,7 +77,7 @@ public:
     int simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_logit, float* d_value, const uint8_t* d_rot, int sim0, int nsims,
                   bool* launched, const float* d_root_noise = nullptr, float noise_eps = 0.0f, int noise_kind = 1, const struct GumbelView* gum = nullptr,
                   int* d_start = nullptr, bool host_start = false);
-    bool hasSimKernel(int board_n) const;
+    bool hasSimKernel(int board_n, int env_kind = 0) const; // env_kind: GoDevView::kind
     // MuZero (board games): the same for initial + recurrent inference; hidden states live in the caller's slab [games][slots][C * P]
     int simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                     int num_players, float* d_policy, float* d_logit, float* d_value, int sim0, int nsims, bool* launched,

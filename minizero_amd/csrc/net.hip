@@ -229,7 +229,7 @@ template <int H, int W, int CIN0_PAD, int CPAD>
 static int launchTowerT(const TowerArgs& ta, const float* params, const float* in, float* out, int B, hipStream_t s)
 {
     constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
-    constexpr size_t lds = size_t(3) * CMAX * planeStride(H, W) * sizeof(float);
+    constexpr size_t lds = size_t(kTowerTiles) * CMAX * planeStride(H, W) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fused<H, W, CIN0_PAD, CPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));

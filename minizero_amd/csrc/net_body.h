@@ -201,9 +201,8 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     const int lane = tid & 63, wave = tid >> 6;
     float* T0 = tiles;
     float* T1 = tiles + CMAX * CS;
-    float* T2 = tiles + 2 * CMAX * CS;
-    // zero all three tiles (borders and padding channels stay zero for the whole kernel), then the sample's planes into T0
-    for (int i = tid; i < 3 * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
+    // zero both tiles (borders and padding channels stay zero for the whole kernel), then the sample's planes into T0
+    for (int i = tid; i < kTowerTiles * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
     __syncthreads();
     float* Tin = ta.has_stem ? T0 : T1; // without a stem the input IS the first block's x
     if (hidden_src) {
@@ -239,17 +238,16 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
         have = nw != nullptr;
         __syncthreads();
     }
-    float *x = T1, *tmp = T0, *y = T2;
+    float *x = T1, *tmp = T0;
 #pragma unroll 1
     for (int l = ta.has_stem; l < ta.nlayers; ++l) { // residual blocks: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x) — one code copy for both convs
         const bool second = ((l - ta.has_stem) & 1) != 0, last = l + 1 == ta.nlayers;
-        towerLayerOfWave<H, W, CPAD / 4, CPAD / 4>(second ? tmp : x, second ? x : nullptr, second ? y : tmp, last ? gout : nullptr, params + ta.w_off[l],
+        towerLayerOfWave<H, W, CPAD / 4, CPAD / 4>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, last ? gout : nullptr, params + ta.w_off[l],
                                                     params + ta.b_off[l], ta.C, ta.OT, lane, wave, have, aA, last ? nullptr : params + ta.w_off[l + 1], aB);
 #pragma unroll
         for (int cg = 0; cg < CPAD / 4; ++cg) { aA[cg] = aB[cg]; }
         have = !last;
         __syncthreads();
-        if (second) { float* s2 = x; x = y; y = s2; }
     }
     return x;
 }

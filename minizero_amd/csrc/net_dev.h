@@ -6,6 +6,10 @@ namespace mz {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// LDS tiles of the fused tower: the blocks' input/output x (the second conv writes y over x: every lane reads the skip value and writes
+// the result at ITS OWN (channel, pixel), the conv itself reads the temporary) and the temporary (also the stem's input)
+constexpr int kTowerTiles = 2;
+
 __host__ __device__ constexpr int planeStride(int H, int W)
 {
     // padded plane (H+2)*(W+2) rounded up so that stride % 32 == 16: the two 16-lane channel groups

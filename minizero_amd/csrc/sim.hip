@@ -51,7 +51,7 @@ struct SimArgs {
 // the MFMA loop.  SimArgs lives in device memory (not in 1.3 KB of kernel arguments pinned in SGPRs for the whole kernel).
 typedef __attribute__((address_space(3))) const double LdsCDouble;
 
-template <int CPL>
+template <int CPL, int WPE>
 __device__ __noinline__ void simSelectLeaf(const SimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp)
 {
     unsigned long long t0 = 0;
@@ -62,9 +62,11 @@ __device__ __noinline__ void simSelectLeaf(const SimArgs* __restrict__ a, int ro
         a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
         a->prof[size_t(g) * 8 + 6] += a->pv.path_len[g];
     }
-    goLeafBody<CPL>(a->gv, a->pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles));
+    if constexpr (CPL == 0) { othLeafBody(a->gv, a->pv, rot, slot, g, lane); } // CPL 0: Othello (go_body.h)
+    else { goLeafBody<CPL>(a->gv, a->pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles)); }
 }
 
+template <int WPE>
 __device__ __noinline__ void simCandExpand(const SimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles)
 {
     azCandBody(a->gv, a->policy, a->logit, a->value, rot, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io,
@@ -76,6 +78,7 @@ __device__ __noinline__ void simCandExpand(const SimArgs* __restrict__ a, int ro
 
 // Root exploration noise (ref zero_actor.cpp:194-213): policy = (1 - eps) * policy + eps * noise for the root's children, in storage
 // order; the noise values were drawn on the host in the reference's RNG order (their count only depends on the number of legal moves)
+template <int WPE>
 __device__ __noinline__ void simApplyRootNoise(const SimArgs* __restrict__ a, int g, int lane)
 {
     const PoolView& v = a->pv;
@@ -94,6 +97,7 @@ __device__ __noinline__ void simApplyRootNoise(const SimArgs* __restrict__ a, in
 
 // Gumbel: sequential halving + the root child the next simulation starts from (slot >= 1); the first simulation of a launch takes the
 // start node the host computed when it ran this step itself (it does at every launch boundary, reading the state back first)
+template <int WPE>
 __device__ __noinline__ void simGumbelStart(const SimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles)
 {
     if (host_start && slot >= 1) { return; } // a->start[g] was uploaded by the host
@@ -107,6 +111,7 @@ __device__ __noinline__ void simGumbelStart(const SimArgs* __restrict__ a, int s
 // simulations mostly share their upper path, the 32-B records of a level are a 2.6 KB block that the tower's traffic has evicted
 // (select: 26 % L2 hit rate), and the walk is one dependent memory round trip per level.  Pure hint: stale or torn path entries
 // are still node ids of this game.
+template <int WPE>
 __device__ __noinline__ void simPrefetchPath(const SimArgs* __restrict__ a, int g, int lane)
 {
     const PoolView& v = a->pv;
@@ -125,19 +130,34 @@ __device__ __noinline__ void simPrefetchPath(const SimArgs* __restrict__ a, int 
 }
 
 // the heads read the tower's last activations where they are (an LDS tile); tile 0 (the blocks' temporary) is free for their scratch
+template <int WPE>
 __device__ __noinline__ void simHeads(const SimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
 {
     headsBody(nullptr, a->hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
 }
 
+// 8x8 boards: three tower tiles are 80 KB of LDS, so TWO games share a CU (16 waves) if the kernel stays within 128 VGPRs: one game's
+// tree phases and barrier bubbles are filled by the other's tower
+// waves per SIMD the kernel is compiled for: 4 (= two resident workgroups per CU, 128 VGPRs) for boards up to 64 points, whose tower
+// fits that register budget; 9x9 Go keeps 2 (its 6 pixel tiles per wave pair need ~166 VGPRs, and BASELINE's 256 games are one per CU)
+template <int H, int W, int CIN0_PAD, int CPAD>
+constexpr int simWavesPerEu() { return (H * W <= 64 && kTowerTiles * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W) * 4 <= 76 * 1024) ? 4 : 2; }
+
+template <int H, int W, int CIN0_PAD, int CPAD>
+__device__ __noinline__ const float* simTower(const SimArgs* __restrict__ a, int g, int tid, float* tiles)
+{
+    return towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, nullptr, g, tid, tiles);
+}
+
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
-__global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a, const uint8_t* __restrict__ rot_tab, int sim0, int nsims, int host_start)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPerEu<H, W, CIN0_PAD, CPAD>(), 4))) void sim_kernel(const SimArgs* __restrict__ a, const uint8_t* __restrict__ rot_tab, int sim0, int nsims, int host_start)
 {
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int games = gridDim.x;
+    constexpr int WPE = simWavesPerEu<H, W, CIN0_PAD, CPAD>();
     // the reciprocal table of the PUCT divisions lives in LDS above the three tower tiles for the whole launch
-    constexpr int kTileFloats = 3 * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W);
+    constexpr int kTileFloats = kTowerTiles * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W);
     double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
     for (int i = tid; i < a->rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
     __syncthreads();
@@ -149,21 +169,23 @@ __global__ __launch_bounds__(512) void sim_kernel(const SimArgs* __restrict__ a,
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (prof) { t0 = wall_clock64(); }
         if (wave == 0) {
-            if (slot == 1 && a->root_noise) { simApplyRootNoise(a, g, lane); }
-            if (a->use_gumbel) { simGumbelStart(a, slot, s == 0 && host_start != 0, g, lane, tiles); }
-            simSelectLeaf<CPL>(a, rot, slot, g, lane, tiles, rcp_lds);
+            if (slot == 1 && a->root_noise) { simApplyRootNoise<WPE>(a, g, lane); }
+            if (a->use_gumbel) { simGumbelStart<WPE>(a, slot, s == 0 && host_start != 0, g, lane, tiles); }
+            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds);
         }
-        else if (wave == 1 && s + slot > 0) { simPrefetchPath(a, g, lane); }
+        else if (wave == 1 && s + slot > 0) { simPrefetchPath<WPE>(a, g, lane); }
         __syncthreads();
         unsigned long long c1 = 0;
         if (prof) { t1 = wall_clock64(); c1 = clock64(); }
-        const float* xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, nullptr, g, tid, tiles);
+        const float* xt;
+        if constexpr (WPE == 4) { xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles); } // its own function: its own register budget
+        else { xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, nullptr, g, tid, tiles); }
         __syncthreads();
         if (prof) { t2 = wall_clock64(); if (tid == 0) { prof[7] += clock64() - c1; } }
-        simHeads(a, g, tid, tiles, xt, planeStride(H, W), W + 2);
+        simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2);
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
-        if (wave == 0) { simCandExpand(a, rot, slot, g, lane, tiles); }
+        if (wave == 0) { simCandExpand<WPE>(a, rot, slot, g, lane, tiles); }
         __syncthreads();
         if (prof && tid == 0) {
             t4 = wall_clock64();
@@ -210,7 +232,7 @@ __device__ __noinline__ void simMzCandExpand(const SimArgs* __restrict__ a, int 
 
 __device__ __noinline__ void simMzSelect(const SimArgs* __restrict__ a, int slot, int g, int lane, LdsCDouble* rcp)
 {
-    if (slot == 1 && a->root_noise) { simApplyRootNoise(a, g, lane); }
+    if (slot == 1 && a->root_noise) { simApplyRootNoise<2>(a, g, lane); }
     selectBody(a->pv, nullptr, g, lane, rcp);
 }
 
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int CM = CIN0_PAD > CDYN_PAD ? (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) : (CDYN_PAD > CPAD ? CDYN_PAD : CPAD);
-    constexpr int kTileFloats = 3 * CM * planeStride(H, W);
+    constexpr int kTileFloats = kTowerTiles * CM * planeStride(H, W);
     double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
     for (int i = tid; i < a->rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
     __syncthreads();
@@ -288,7 +310,9 @@ static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, in
 
 #define MZ_SIM_CASES(X) \
     X(9, 9, 20, 64, 2)  /* 9x9 Go, 64 channels (BASELINE configs[1]) */ \
-    X(9, 9, 20, 8, 2)   /* small 9x9 test nets */
+    X(9, 9, 20, 8, 2)   /* small 9x9 test nets */ \
+    X(8, 8, 4, 64, 0)   /* 8x8 Othello, 64 channels (BASELINE configs[2]); CPL 0 = the Othello rules */ \
+    X(8, 8, 4, 8, 0)    /* small 8x8 Othello test nets */
 
 void Net::dumpSimProf()
 {
@@ -316,7 +340,7 @@ void Net::dumpSimProf()
     fprintf(stderr, "[mz sim prof] total        avg %8.2f us per simulation (slowest game %8.2f us)\n", tot_all, tot_max);
 }
 
-bool Net::hasSimKernel(int board_n) const
+bool Net::hasSimKernel(int board_n, int env_kind) const
 {
     if (desc_.type != 0 || !use_fused_) { return false; }
     TowerArgs ta;
@@ -324,7 +348,7 @@ bool Net::hasSimKernel(int board_n) const
     if (!makeTowerArgs(repr_, true, true, &ta, &c0)) { return false; }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
 #define MZ_SIM_HAS(h, w, cin0, cpad, cpl) \
-    if (H == h && W == w && c0 == cin0 && C == cpad && board_n == h && (h * w + 63) / 64 == cpl) { return true; }
+    if (H == h && W == w && c0 == cin0 && C == cpad && board_n == h && (env_kind == 1 ? 0 : (h * w + 63) / 64) == cpl) { return true; }
     MZ_SIM_CASES(MZ_SIM_HAS)
 #undef MZ_SIM_HAS
     return false;
@@ -368,12 +392,13 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
     const int cmax = c0 > C ? c0 : C;
-    size_t lds = size_t(3) * cmax * planeStride(H, W) * sizeof(float);
-    const size_t heads = (size_t(a.hp.C) * a.hp.P + size_t(a.hp.PC) * a.hp.P + a.hp.P + a.hp.VH + a.hp.A + 16) * sizeof(float);
-    lds = std::max(lds, std::max(heads, std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A))));
-    lds = std::max(lds, size_t(2) * pool.v_.bound_cap * sizeof(float));
-    lds = std::max(lds, gumbelSmemBytes(gv.A));
-    lds = size_t(3) * cmax * planeStride(H, W) * sizeof(float) + size_t(a.rcp_n) * sizeof(double) > lds ? size_t(3) * cmax * planeStride(H, W) * sizeof(float) + size_t(a.rcp_n) * sizeof(double) : lds;
+    // LDS: the tower tiles, and above them the reciprocal table; the heads and wave 0's tree phases take their scratch from the tiles
+    const size_t tile_bytes = size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float);
+    const size_t heads = (size_t(a.hp.PC) * a.hp.P + a.hp.P + a.hp.VH + a.hp.A + 16) * sizeof(float); // in tile 0 (the activations stay in tile 1)
+    size_t scratch = std::max(std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A)), gumbelSmemBytes(gv.A));
+    scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
+    if (scratch > tile_bytes || heads > tile_bytes / kTowerTiles) { return MZ_OK; } // not launched: the caller falls back to the lock-step kernels
+    const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double);
     // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
     static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
@@ -383,7 +408,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
         sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
     }
 #define MZ_SIM_LAUNCH(h, w, cin0, cpad, cpl) \
-    if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && gv.W == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
+    if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && (gv.kind == 1 ? 0 : gv.W) == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
     MZ_SIM_CASES(MZ_SIM_LAUNCH)
 #undef MZ_SIM_LAUNCH
     return MZ_OK;
@@ -428,9 +453,9 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.noise_kind = 1;
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
     const int cmax = std::max(std::max(c0, cd), C);
-    const size_t tile_bytes = size_t(3) * cmax * planeStride(H, W) * sizeof(float);
-    size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double);
-    lds = std::max(lds, azCandSmemBytes(a.A));
+    const size_t tile_bytes = size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float);
+    if (azCandSmemBytes(a.A) > tile_bytes) { return MZ_OK; }
+    const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double);
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
         if (!sim_args_.ensure(sizeof(SimArgs))) { setError("hipMalloc of the simulation arguments failed"); return MZ_ERR_DEVICE; }
         MZ_HIP(hipStreamSynchronize(stream_));

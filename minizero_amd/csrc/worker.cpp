@@ -454,13 +454,14 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         const int* fwd[8];
         for (int r = 0; r < 8; ++r) { inv[r] = e.rot()->inv[r].data(); fwd[r] = e.rot()->fwd[r].data(); }
         for (auto& L : lanes_) {
-            int rc = L->godev.init(device, L->n, e.boardSize(), cfg_.env_go_komi, A_, n_ + 1, L->pool.v_.max_depth, L->stream, inv, fwd, e.zobristKeys());
+            int rc = L->godev.init(device, L->n, e.boardSize(), cfg_.env_go_komi, A_, n_ + 1, L->pool.v_.max_depth, L->stream, inv, fwd, e.zobristKeys(),
+                                   e.deviceKind());
             if (rc) { return rc; }
             L->pool.v_.host_path_len = nullptr; // nobody on the host reads the paths any more
             L->pool.v_.host_path_action = nullptr;
             if ((rc = uploadRoots(*L))) { return rc; }
         }
-        sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize()) &&
+        sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize(), e.deviceKind()) &&
                       (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 1 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
         dev_gumbel_ = sim_kernel_ && cfg_.actor_use_gumbel;
         if (dev_gumbel_) { // the constants of gumbel_zero.cpp:101,110 in the host's double arithmetic

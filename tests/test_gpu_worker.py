@@ -214,3 +214,32 @@ def test_go_gumbel_execution_modes_are_equivalent(mz):
     assert host == resident
     assert host == sim_whole
     assert host == sim_chunks
+
+
+OTHELLO_ARGS = ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65, 16, 1, "alphazero")
+
+
+@pytest.mark.parametrize("gumbel", ["true", "false"])
+def test_othello_execution_modes_are_equivalent(mz, gumbel):
+    """Othello's device rules engine (go_body.h othLeafBody: bitboard flips, forced passes, two-pass end, disc-count result) in the
+    lock-step kernels and inside the simulation kernel, against the host engine."""
+    conf = ("env_game=othello:env_board_size=8:actor_num_simulation=10:zero_num_parallel_games=5:"
+            f"actor_use_gumbel={gumbel}:actor_use_gumbel_noise={gumbel}:actor_use_dirichlet_noise={'false' if gumbel == 'true' else 'true'}:"
+            "actor_gumbel_sample_size=8")
+    total = 11 * 150
+    host = _lines_of(mz, conf + ":mz_device_env=false", OTHELLO_ARGS, [total], total)
+    resident = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=false", OTHELLO_ARGS, [7, 1, 30], total)
+    sim_whole = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", OTHELLO_ARGS, [total], total)
+    sim_chunks = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", OTHELLO_ARGS, [1, 2, 5, 11, 3, 40, 12, 10], total)
+    assert len(host) >= 5
+    assert host == resident
+    assert host == sim_whole
+    assert host == sim_chunks
+
+
+def test_othello_full_games_to_the_end(mz, oracle):
+    """Whole 8x8 Othello games through the default mode (device rules + simulation kernel): end-game passes and results vs the oracle."""
+    conf = "env_game=othello:env_board_size=8:actor_num_simulation=4:zero_num_parallel_games=6"
+    lines, olines, st = run_both(mz, oracle, conf, OTHELLO_ARGS, 5 * 62 * 3, threads=2, seed=11)
+    check(lines, olines, 12)
+    assert st["games"] >= 12
