@@ -67,21 +67,44 @@ __host__ __device__ constexpr bool cornerTapInside(int t) { return t == 3 || t =
 // a_first / have_first: this layer's tap-0 A-fragments if the previous layer already fetched them; next_wp / a_next: the NEXT layer's
 // weights (nullptr: none) whose tap-0 fragments are fetched during this layer's last tap, so that the layer boundary (epilogue,
 // barrier) does not end with an exposed L2 round trip; the bias values are fetched at the start of the layer for the same reason.
+#ifndef MZ_TPROF
+#define MZ_TPROF(slot) // tools/tower_prof.hip defines it: time stamps of wave phases inside a layer
+#endif
+
+// per-lane geometry of a wave's pixel tiles, computed once per tower (the tile map is a table in constant memory: fetching it at the start of
+// every layer cost ~800 cycles of exposed latency per layer)
+template <int NT>
+struct PixSet {
+    int off[NT];  // top-left tap of the 3x3 window in the padded plane, channel (lane >> 4)
+    int dst[NT];  // interior position of the pixel in a padded plane; padding columns of a tile: the plane's first spare float (never read)
+    int q[NT];    // pixel index, -1: padding column of the tile
+};
+template <int H, int W, int NT>
+__device__ __forceinline__ PixSet<NT> makePixSet(int lane, int tile0)
+{
+    constexpr int PW = W + 2, CS = planeStride(H, W);
+    static_assert(CS > (H + 2) * (W + 2), "the plane stride leaves a spare float behind the padded plane");
+    PixSet<NT> px;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        px.q[j] = kTileMap<H, W>.q[(tile0 + j) * 16 + (lane & 15)];
+        const int q = px.q[j] < 0 ? 0 : px.q[j];
+        px.dst[j] = px.q[j] < 0 ? (H + 2) * (W + 2) : (q / W + 1) * PW + (q % W) + 1;
+        px.off[j] = (lane >> 4) * CS + (q / W) * PW + (q % W);
+    }
+    return px;
+}
+
 template <int H, int W, int CG, int NT, int CGN, bool CORNER>
 __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
                                             float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
-                                            int lane, int ot, int tile0, bool have_first, float (&a_first)[CG], const float* __restrict__ next_wp,
-                                            float (&a_next)[CGN])
+                                            int lane, int ot, const PixSet<NT>& px, bool have_first, float (&a_first)[CG],
+                                            const float* __restrict__ next_wp, float (&a_next)[CGN])
 {
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
-    int pixoff[NT], pixdst[NT], pixq[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        pixq[j] = kTileMap<H, W>.q[(tile0 + j) * 16 + (lane & 15)]; // -1: padding column of the tile
-        const int q = pixq[j] < 0 ? 0 : pixq[j];
-        pixdst[j] = (q / W + 1) * PW + (q % W) + 1;          // interior position in a padded plane
-        pixoff[j] = (lane >> 4) * CS + (q / W) * PW + (q % W); // top-left tap of the 3x3 window, channel (lane>>4)
-    }
+    const int (&pixoff)[NT] = px.off;
+    const int (&pixdst)[NT] = px.dst;
+    const int (&pixq)[NT] = px.q;
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
@@ -107,18 +130,37 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
         asm volatile("" ::: "memory");
     };
     auto loadA = [&](float* a, int t) { loadFrom(a, wl + size_t(t) * wstep); };
-    auto tap = [&](const float* a, int t) {
+    // B operand (one ds_read_b32 per MFMA): the values of k-group (t, cg + 1) are read BEFORE the MFMAs of group (t, cg) are issued and
+    // the order is pinned with sched_barrier: left to itself the scheduler puts every read right in front of its MFMA, which costs nothing
+    // while the SIMD's other wave fills the pipe, but a wave that is alone on its SIMD (the other one finished its tiles: tools/tower_prof)
+    // then issues one MFMA per LDS round trip (85 cycles instead of 32)
+    auto bload = [&](float (&b)[NT], int t, int cg) {
         const int tapoff = (t / 3) * PW + (t % 3);
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; } // all-zero B operand: the k-step leaves the accumulator unchanged
-                float bv = tin[pixoff[j] + cg * 4 * CS + tapoff];
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg], bv, acc[j], 0, 0, 0);
-            }
+        for (int j = 0; j < NT; ++j) {
+            if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; } // all-zero B operand: the k-step leaves the accumulator unchanged
+            b[j] = tin[pixoff[j] + cg * 4 * CS + tapoff];
         }
     };
+    float bc[NT];
+    auto tap = [&](const float* a, int t) { // bc = the B values of group (t, 0) on entry, of group (t + 1, 0) on exit
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+            float bn[NT];
+            if (cg + 1 < CG) { bload(bn, t, cg + 1); } else if (t < 8) { bload(bn, t + 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; }
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg], bc[j], acc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { bc[j] = bn[j]; }
+        }
+    };
+    bload(bc, 0, 0);
+    MZ_TPROF(0);
     if (have_first) {
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) { a0[cg] = a_first[cg]; }
@@ -144,48 +186,86 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
         for (int cg = 4 * CGN4; cg < CGN; ++cg) { a_next[cg] = nb[CGN4 * 256 + (cg - 4 * CGN4) * 64 + lane]; }
         asm volatile("" ::: "memory");
     }
-    // the residual inputs of the epilogue are read while the last tap's MFMAs run
+    // the residual inputs of the epilogue are read while the last tap's MFMAs run (unconditionally, from a readable tile: no branches)
+    const bool has_skip = tskip != nullptr;
+    const float* sk = has_skip ? tskip : tin;
+    const int ocb = 16 * ot + 4 * (lane >> 4); // the 4 output channels of this lane's accumulators: ocb .. ocb + 3
     float skv[NT][4];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { skv[j][r] = tskip ? tskip[(16 * ot + 4 * (lane >> 4) + r) * CS + pixdst[j]] : 0.0f; }
+        for (int r = 0; r < 4; ++r) { skv[j][r] = sk[(ocb + r) * CS + pixdst[j]]; }
     }
     asm volatile("" ::: "memory");
     tap(a0, 8);
+    MZ_TPROF(1);
+    if (gout) { // stand-alone launch, last layer: NCHW to HBM
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int q = pixq[j];
+        for (int j = 0; j < NT; ++j) {
+            const int q = pixq[j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oc = 16 * ot + 4 * (lane >> 4) + r;
-            if (q >= 0 && oc < cout) {
+            for (int r = 0; r < 4; ++r) {
                 float v = acc[j][r] + biasv[r];
-                if (tskip) { v = v + skv[j][r]; }
+                v = v + (has_skip ? skv[j][r] : 0.0f); // without a skip: + 0 only turns -0 into +0, which the ReLU does anyway
                 v = v > 0.0f ? v : 0.0f;
-                if (gout) { __builtin_nontemporal_store(v, &gout[oc * P + q]); } else { tout[oc * CS + pixdst[j]] = v; }
+                if (q >= 0 && ocb + r < cout) { __builtin_nontemporal_store(v, &gout[(ocb + r) * P + q]); }
+            }
+        }
+    } else { // into the next layer's tile: straight-line ds_write_b32 with immediate offsets; lanes of padding columns write the plane's
+             // spare float, channels beyond cout (networks narrower than an oc-tile) the spare float of the lane's first channel
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float* dstp = tout + ocb * CS + pixdst[j];
+            float* dump = tout + ocb * CS + (H + 2) * (W + 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[j][r] + biasv[r];
+                v = v + (has_skip ? skv[j][r] : 0.0f);
+                v = v > 0.0f ? v : 0.0f;
+                float* d = (ocb + r < cout) ? dstp + r * CS : dump;
+                *d = v;
             }
         }
     }
+    MZ_TPROF(2);
 }
 
-// wave -> (oc-tile, pixel tiles): waves 0-3 take tiles [0, PT0), waves 4-7 tiles [PT0, PT) (the last one may be the corner tile)
-template <int H, int W, int CG, int CGN>
-__device__ __forceinline__ void towerLayerOfWave(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
-                                                 float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
-                                                 int lane, int wave, bool have_first, float (&a_first)[CG], const float* __restrict__ next_wp,
-                                                 float (&a_next)[CGN])
+// the layer sequence of one wave: oc-tile `ot` x the NT pixel tiles from `tile0` (CORNER: the last of them is the corner tile); T0 = the
+// temporary (holds the stem's input on entry), T1 = x.  Every wave of the workgroup passes the same number of barriers (towerIdle).
+template <int H, int W, int CIN0_PAD, int CPAD, int NT, bool CORNER>
+__device__ __forceinline__ void towerRun(const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ T0, float* __restrict__ T1,
+                                         float* __restrict__ gout, int lane, int ot, int tile0)
 {
-    using TM = TileMap<H, W>;
-    const int ot = wave & 3, half = wave >> 2;
-    if (ot >= OT) { return; }
-    if (half == 0) {
-        tower_layer<H, W, CG, TM::PT0, CGN, (TM::kCorner && TM::PT1 == 0)>(tin, tskip, tout, gout, wp, bias, cout, OT, lane, ot, 0, have_first, a_first,
-                                                                            next_wp, a_next);
-    } else if constexpr (TM::PT1 > 0) {
-        tower_layer<H, W, CG, TM::PT1, CGN, TM::kCorner>(tin, tskip, tout, gout, wp, bias, cout, OT, lane, ot, TM::PT0, have_first, a_first, next_wp,
-                                                         a_next);
+    const PixSet<NT> px = makePixSet<H, W, NT>(lane, tile0);
+    // tap-0 A-fragments of the next layer travel from layer to layer in registers
+    float aS[CIN0_PAD / 4], aA[CPAD / 4], aB[CPAD / 4];
+    bool have = false;
+    if (ta.has_stem) { // stem: T0 -> T1
+        const float* nw = ta.nlayers > 1 ? params + ta.w_off[1] : nullptr;
+        tower_layer<H, W, CIN0_PAD / 4, NT, CPAD / 4, CORNER>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0],
+                                                             ta.C, ta.OT, lane, ot, px, false, aS, nw, aA);
+        have = nw != nullptr;
+        __syncthreads();
     }
+    float *x = T1, *tmp = T0;
+#pragma unroll 1
+    for (int l = ta.has_stem; l < ta.nlayers; ++l) { // residual blocks: tmp = relu(conv1(x)); x = relu(conv2(tmp) + x) — one code copy for both convs
+        const bool second = ((l - ta.has_stem) & 1) != 0, last = l + 1 == ta.nlayers;
+        tower_layer<H, W, CPAD / 4, NT, CPAD / 4, CORNER>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, last ? gout : nullptr,
+                                                         params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, ot, px, have, aA,
+                                                         last ? nullptr : params + ta.w_off[l + 1], aB);
+#pragma unroll
+        for (int cg = 0; cg < CPAD / 4; ++cg) { aA[cg] = aB[cg]; }
+        have = !last;
+        __syncthreads();
+        MZ_TPROF(3);
+    }
+}
+
+// waves without tiles (oc-tiles beyond the network's width, boards of a single pixel tile) only keep the barrier count
+__device__ __forceinline__ void towerIdle(const TowerArgs& ta)
+{
+    for (int l = 0; l < ta.nlayers; ++l) { __syncthreads(); }
 }
 
 // the body of tower_fused for sample `b`, run by all 512 threads of a workgroup (tid 0..511); `tiles` = 3 x [CMAX][CS] floats of LDS
@@ -228,27 +308,17 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     }
     __syncthreads();
     float* gout = out ? out + size_t(b) * ta.C * P : nullptr;
-    // tap-0 A-fragments of the next layer travel from layer to layer in registers
-    float aS[CIN0_PAD / 4], aA[CPAD / 4], aB[CPAD / 4];
-    bool have = false;
-    if (ta.has_stem) { // stem: T0 -> T1
-        const float* nw = ta.nlayers > 1 ? params + ta.w_off[1] : nullptr;
-        towerLayerOfWave<H, W, CIN0_PAD / 4, CPAD / 4>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C,
-                                                        ta.OT, lane, wave, false, aS, nw, aA);
-        have = nw != nullptr;
-        __syncthreads();
+    // wave -> (oc-tile, pixel tiles): waves 0-3 take tiles [0, PT0), waves 4-7 tiles [PT0, PT) (the last one may be the corner tile)
+    using TM = TileMap<H, W>;
+    const int ot = wave & 3, half = wave >> 2;
+    if (ot < ta.OT && half == 0) {
+        towerRun<H, W, CIN0_PAD, CPAD, TM::PT0, (TM::kCorner && TM::PT1 == 0)>(params, ta, T0, T1, gout, lane, ot, 0);
+    } else if (ot < ta.OT && TM::PT1 > 0) {
+        if constexpr (TM::PT1 > 0) { towerRun<H, W, CIN0_PAD, CPAD, TM::PT1, TM::kCorner>(params, ta, T0, T1, gout, lane, ot, TM::PT0); }
+    } else {
+        towerIdle(ta);
     }
-    float *x = T1, *tmp = T0;
-#pragma unroll 1
-    for (int l = ta.has_stem; l < ta.nlayers; ++l) { // residual blocks: tmp = relu(conv1(x)); y = relu(conv2(tmp) + x) — one code copy for both convs
-        const bool second = ((l - ta.has_stem) & 1) != 0, last = l + 1 == ta.nlayers;
-        towerLayerOfWave<H, W, CPAD / 4, CPAD / 4>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, last ? gout : nullptr, params + ta.w_off[l],
-                                                    params + ta.b_off[l], ta.C, ta.OT, lane, wave, have, aA, last ? nullptr : params + ta.w_off[l + 1], aB);
-#pragma unroll
-        for (int cg = 0; cg < CPAD / 4; ++cg) { aA[cg] = aB[cg]; }
-        have = !last;
-        __syncthreads();
-    }
+    float* x = T1;
     return x;
 }
 

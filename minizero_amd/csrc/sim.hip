@@ -7,11 +7,24 @@
 // (same device bodies: net_body.h, pool_body.h, go_body.h), so results are bit-identical to the lock-step path.
 // The host draws the per-cycle feature rotations in the reference's order (cycle-major, actor-minor) before the launch.
 #include "net.h"
+#ifdef MZ_SIM_TPROF // experiment: cycles per tower layer inside the simulation kernel (game 0, wave 0), printed by dumpSimProf
+__device__ unsigned long long g_tp[64];
+__shared__ unsigned long long s_tp_prev;
+__shared__ int s_tp_idx;
+#define MZ_TPROF(slot)                                                                         \
+    do {                                                                                       \
+        if ((slot) == 3 && threadIdx.x == 0 && blockIdx.x == 0) {                              \
+            const unsigned long long t_ = clock64();                                           \
+            g_tp[s_tp_idx & 63] += t_ - s_tp_prev; s_tp_prev = t_; ++s_tp_idx;                 \
+        }                                                                                      \
+    } while (0)
+#endif
 #include "net_body.h"
 #include "pool_body.h"
 #include "go_body.h"
 #include "gumbel_body.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstring>
 #include <cstdlib>
 #include <vector>
@@ -47,41 +60,64 @@ struct SimArgs {
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
 
+// SimArgs never changes during a launch: the device functions read it through the CONSTANT address space, i.e. with scalar loads whose
+// results are wave-uniform and can be kept / re-used across stores.  Through a generic pointer every field was a flat load (divergent for
+// the compiler, since a flat address may be private memory: the whole selection loop was compiled with exec-mask control flow) that had
+// to be repeated after every store — the PUCT walk waited for such a reload on every level.
+typedef __attribute__((address_space(4))) const SimArgs CSimArgs;
+template <class T>
+__device__ __forceinline__ T ldc(__attribute__((address_space(4))) const T* p) // by-value copy of a sub-structure (SGPRs after SROA)
+{
+    static_assert(sizeof(T) % 4 == 0 && std::is_trivially_copyable<T>::value, "word-copied");
+    typedef __attribute__((address_space(4))) const unsigned CU;
+    CU* s = (CU*)p;
+    unsigned w[sizeof(T) / 4];
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) { w[i] = s[i]; }
+    T t;
+    __builtin_memcpy(&t, w, sizeof(T));
+    return t;
+}
+
 // The tree phases are separate (non-inlined) functions: inlined next to the tower they push the kernel to 256 VGPRs with spills in
 // the MFMA loop.  SimArgs lives in device memory (not in 1.3 KB of kernel arguments pinned in SGPRs for the whole kernel).
 typedef __attribute__((address_space(3))) const double LdsCDouble;
 
 template <int CPL, int WPE>
-__device__ __noinline__ void simSelectLeaf(const SimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp)
+__device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp)
 {
     unsigned long long t0 = 0;
     if (a->prof) { t0 = wall_clock64(); }
-    selectBody(a->pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
+    const PoolView pv = ldc(&a->pv);
+    selectBody(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
     waveSync();
     if (a->prof && lane == 0) {
         a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
-        a->prof[size_t(g) * 8 + 6] += a->pv.path_len[g];
+        a->prof[size_t(g) * 8 + 6] += pv.path_len[g];
     }
-    if constexpr (CPL == 0) { othLeafBody(a->gv, a->pv, rot, slot, g, lane); } // CPL 0: Othello (go_body.h)
-    else { goLeafBody<CPL>(a->gv, a->pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles)); }
+    const GoDevView gv = ldc(&a->gv);
+    if constexpr (CPL == 0) { othLeafBody(gv, pv, rot, slot, g, lane); } // CPL 0: Othello (go_body.h)
+    else { goLeafBody<CPL>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles)); }
 }
 
 template <int WPE>
-__device__ __noinline__ void simCandExpand(const SimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles)
+__device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles)
 {
-    azCandBody(a->gv, a->policy, a->logit, a->value, rot, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io,
+    const GoDevView gv = ldc(&a->gv);
+    const PoolView pv = ldc(&a->pv);
+    azCandBody(gv, a->policy, a->logit, a->value, rot, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io,
                a->reward_io, a->err, g, lane, reinterpret_cast<uint64_t*>(tiles));
     waveSync();
-    expandBackupBody(a->pv, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane,
+    expandBackupBody(pv, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane,
                      tiles);
 }
 
 // Root exploration noise (ref zero_actor.cpp:194-213): policy = (1 - eps) * policy + eps * noise for the root's children, in storage
 // order; the noise values were drawn on the host in the reference's RNG order (their count only depends on the number of legal moves)
 template <int WPE>
-__device__ __noinline__ void simApplyRootNoise(const SimArgs* __restrict__ a, int g, int lane)
+__device__ __noinline__ void simApplyRootNoise(CSimArgs* __restrict__ a, int g, int lane)
 {
-    const PoolView& v = a->pv;
+    const PoolView v = ldc(&a->pv);
     const size_t base = size_t(g) * v.cap;
     const int nc = v.rec[base].num_children;
     const size_t fc = base + v.rec[base].first_child;
@@ -98,11 +134,11 @@ __device__ __noinline__ void simApplyRootNoise(const SimArgs* __restrict__ a, in
 // Gumbel: sequential halving + the root child the next simulation starts from (slot >= 1); the first simulation of a launch takes the
 // start node the host computed when it ran this step itself (it does at every launch boundary, reading the state back first)
 template <int WPE>
-__device__ __noinline__ void simGumbelStart(const SimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles)
+__device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles)
 {
     if (host_start && slot >= 1) { return; } // a->start[g] was uploaded by the host
     int st = 0;
-    if (slot >= 1 && !host_start) { st = gumbelStepBody(a->pv, a->gum, slot, g, lane, tiles); }
+    if (slot >= 1 && !host_start) { const PoolView pv = ldc(&a->pv); const GumbelView gum = ldc(&a->gum); st = gumbelStepBody(pv, gum, slot, g, lane, tiles); }
     if (lane == 0) { a->start[g] = st; }
     waveSync();
 }
@@ -112,9 +148,9 @@ __device__ __noinline__ void simGumbelStart(const SimArgs* __restrict__ a, int s
 // (select: 26 % L2 hit rate), and the walk is one dependent memory round trip per level.  Pure hint: stale or torn path entries
 // are still node ids of this game.
 template <int WPE>
-__device__ __noinline__ void simPrefetchPath(const SimArgs* __restrict__ a, int g, int lane)
+__device__ __noinline__ void simPrefetchPath(CSimArgs* __restrict__ a, int g, int lane)
 {
-    const PoolView& v = a->pv;
+    const PoolView v = ldc(&a->pv);
     const int plen = v.path_len[g];
     const int* path = v.path + size_t(g) * v.max_depth;
     const NodeRec* recs = v.rec + size_t(g) * v.cap;
@@ -131,9 +167,10 @@ __device__ __noinline__ void simPrefetchPath(const SimArgs* __restrict__ a, int 
 
 // the heads read the tower's last activations where they are (an LDS tile); tile 0 (the blocks' temporary) is free for their scratch
 template <int WPE>
-__device__ __noinline__ void simHeads(const SimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
+__device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
 {
-    headsBody(nullptr, a->hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
+    const HeadParams hp = ldc(&a->hp);
+    headsBody(nullptr, hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
 }
 
 // 8x8 boards: three tower tiles are 80 KB of LDS, so TWO games share a CU (16 waves) if the kernel stays within 128 VGPRs: one game's
@@ -144,14 +181,18 @@ template <int H, int W, int CIN0_PAD, int CPAD>
 constexpr int simWavesPerEu() { return (H * W <= 64 && kTowerTiles * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W) * 4 <= 76 * 1024) ? 4 : 2; }
 
 template <int H, int W, int CIN0_PAD, int CPAD>
-__device__ __noinline__ const float* simTower(const SimArgs* __restrict__ a, int g, int tid, float* tiles)
+__device__ __noinline__ const float* simTower(CSimArgs* __restrict__ a, int g, int tid, float* tiles)
 {
-    return towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, nullptr, g, tid, tiles);
+#ifdef MZ_SIM_TPROF
+    if (tid == 0 && g == 0) { s_tp_prev = clock64(); s_tp_idx = 0; g_tp[63] += 1; }
+#endif
+    return towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
 }
 
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPerEu<H, W, CIN0_PAD, CPAD>(), 4))) void sim_kernel(const SimArgs* __restrict__ a, const uint8_t* __restrict__ rot_tab, int sim0, int nsims, int host_start)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPerEu<H, W, CIN0_PAD, CPAD>(), 4))) void sim_kernel(const SimArgs* __restrict__ a_, const uint8_t* __restrict__ rot_tab, int sim0, int nsims, int host_start)
 {
+    CSimArgs* a = (CSimArgs*)a_;
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int games = gridDim.x;
@@ -178,8 +219,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         unsigned long long c1 = 0;
         if (prof) { t1 = wall_clock64(); c1 = clock64(); }
         const float* xt;
-        if constexpr (WPE == 4) { xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles); } // its own function: its own register budget
-        else { xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, a->ta, nullptr, g, tid, tiles); }
+        if constexpr (true) { xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles); } // its own function: its own register budget
+        else { xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles); }
         __syncthreads();
         if (prof) { t2 = wall_clock64(); if (tid == 0) { prof[7] += clock64() - c1; } }
         simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2);
@@ -197,9 +238,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
 // ---- MuZero (board games; ref muzero_network.h:97-178, zero_actor.cpp:215-245): no leaf environment.  The leaf is evaluated from
 // its parent's hidden state (slab slot `hslot[parent]`) and the move; its children are ALL actions (the root: the legal ones) in
 // the reference's sort order; the new hidden state is rescaled to [0, 1] per sample and written to the slab slot of this simulation.
-__device__ __noinline__ void simMzCandExpand(const SimArgs* __restrict__ a, int slot, int g, int lane, float* tiles)
+__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles)
 {
-    const PoolView& v = a->pv;
+    const PoolView v = ldc(&a->pv);
     const int A = a->A, len = v.path_len[g], depth = len - 1;
     Cand* cs = reinterpret_cast<Cand*>(tiles);
     Cand* out = cs + A;
@@ -230,22 +271,25 @@ __device__ __noinline__ void simMzCandExpand(const SimArgs* __restrict__ a, int 
     expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles);
 }
 
-__device__ __noinline__ void simMzSelect(const SimArgs* __restrict__ a, int slot, int g, int lane, LdsCDouble* rcp)
+__device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, int g, int lane, LdsCDouble* rcp)
 {
     if (slot == 1 && a->root_noise) { simApplyRootNoise<2>(a, g, lane); }
-    selectBody(a->pv, nullptr, g, lane, rcp);
+    const PoolView pv = ldc(&a->pv);
+    selectBody(pv, nullptr, g, lane, rcp);
 }
 
-__device__ __noinline__ void simMzHeads(const SimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
+__device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
 {
     // hidden_dst + g * C * P must be the slab slot (g, slot): headsBody indexes its outputs with the sample index
     float* hd = a->hidden + (size_t(g) * a->slots + slot - g) * size_t(a->hp.C) * a->hp.P;
-    headsBody(nullptr, a->hp, a->policy, a->logit, a->value, hd, nullptr, 1, g, tid, 512, tiles, xtile, xcs, xpw);
+    const HeadParams hp = ldc(&a->hp);
+    headsBody(nullptr, hp, a->policy, a->logit, a->value, hd, nullptr, 1, g, tid, 512, tiles, xtile, xcs, xpw);
 }
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
-__global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a, int sim0, int nsims)
+__global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a_, int sim0, int nsims)
 {
+    CSimArgs* a = (CSimArgs*)a_;
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int CM = CIN0_PAD > CDYN_PAD ? (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) : (CDYN_PAD > CPAD ? CDYN_PAD : CPAD);
@@ -254,21 +298,21 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     for (int i = tid; i < a->rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
     __syncthreads();
     LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
-    const PoolView& v = a->pv;
+    const PoolView v = ldc(&a->pv);
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
         if (wave == 0) { simMzSelect(a, slot, g, lane, rcp_lds); }
         __syncthreads();
         const float* xt;
         if (slot == 0) { // initial inference: representation trunk on the root planes
-            xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, a->ta, nullptr, g, tid, tiles);
+            xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
         } else { // recurrent inference: dynamics trunk on (parent hidden state, move)
             const int len = v.path_len[g];
             const int* path = v.path + size_t(g) * v.max_depth;
             const int src = v.hslot[size_t(g) * v.cap + path[len - 2]];
             const int action = v.path_action[size_t(g) * v.max_depth + len - 1];
             const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;
-            xt = towerBody<H, W, CDYN_PAD, CPAD>(nullptr, a->params, a->ta_dyn, nullptr, g, tid, tiles, hsrc, action);
+            xt = towerBody<H, W, CDYN_PAD, CPAD>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action);
         }
         __syncthreads();
         simMzHeads(a, slot, g, tid, tiles, xt, planeStride(H, W), W + 2);
@@ -316,6 +360,16 @@ static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, in
 
 void Net::dumpSimProf()
 {
+#ifdef MZ_SIM_TPROF
+    {
+        unsigned long long h[64];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tp), sizeof(h)) == hipSuccess && h[63]) {
+            fprintf(stderr, "[mz sim tprof] cycles per layer (game 0, avg over %llu towers):", h[63]);
+            for (int i = 0; i < 14; ++i) { fprintf(stderr, " %.0f", double(h[i]) / double(h[63])); }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     if (sim_prof_.n == 0) { return; }
     std::vector<unsigned long long> h(sim_prof_.n);
     if (hipMemcpy(h.data(), sim_prof_.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { return; }
