@@ -38,6 +38,21 @@ __device__ __forceinline__ void dppBest(float& rs, float& rp, int& ri)
     if (better(s2, p2, i2, rs, rp, ri)) { rs = s2; rp = p2; ri = i2; }
 }
 
+// global-address-space views of pool memory: `global_load` with a scalar base instead of `flat_load` with a 64-bit VGPR address (a generic
+// pointer may point to LDS or scratch, so the compiler has to use the slower flat path and per-lane 64-bit address arithmetic)
+#define MZ_GLOBAL __attribute__((address_space(1)))
+typedef MZ_GLOBAL const NodeRec GNodeRec;
+__device__ __forceinline__ NodeRec loadRec(GNodeRec* p)
+{
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    typedef int vi4 __attribute__((ext_vector_type(4)));
+    const vf4 a = ((MZ_GLOBAL const vf4*)p)[0];
+    const vi4 b = ((MZ_GLOBAL const vi4*)p)[1];
+    NodeRec n;
+    n.count = a.x; n.mean = a.y; n.policy = a.z; n.reward = a.w;
+    n.first_child = b.x; n.num_children = b.y; n.action = b.z; n.players = b.w;
+    return n;
+}
 __device__ __forceinline__ NodeRec loadRec(const NodeRec* p)
 {
     const float4 a = reinterpret_cast<const float4*>(p)[0];
@@ -116,10 +131,12 @@ __device__ __forceinline__ LevelEval evalChild(const PoolView& v, const NodeRec&
 template <class RcpPtr>
 __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restrict__ start, int g, int lane, RcpPtr rcp)
 {
-    const NodeRec* recs = v.rec + size_t(g) * v.cap;
-    int* path = v.path + size_t(g) * v.max_depth;
-    int* pact = v.path_action + size_t(g) * v.max_depth;
-    int* hact = v.host_path_action ? v.host_path_action + size_t(g) * v.max_depth : nullptr;
+    GNodeRec* recs = (GNodeRec*)(v.rec + size_t(g) * v.cap);
+    MZ_GLOBAL int* path = (MZ_GLOBAL int*)(v.path + size_t(g) * v.max_depth);
+    MZ_GLOBAL int* pact = (MZ_GLOBAL int*)(v.path_action + size_t(g) * v.max_depth);
+    MZ_GLOBAL int* hact = v.host_path_action ? (MZ_GLOBAL int*)(v.host_path_action + size_t(g) * v.max_depth) : nullptr;
+    MZ_GLOBAL const float* bias_tab = (MZ_GLOBAL const float*)v.bias_tab;
+    MZ_GLOBAL const double* sqrt_tab = (MZ_GLOBAL const double*)v.sqrt_tab;
     const int bsize = v.bound_size[g];
     const float lo = v.bound_lo[g], hi = v.bound_hi[g];
     // the node header travels down the walk in SCALAR registers: every lane loads the same record, readfirstlane tells the compiler so
@@ -146,11 +163,21 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
         if (lane == 0) { path[1] = st; pact[1] = cur.action; if (hact) { hact[1] = cur.action; } }
         depth = 2;
     }
-    while (cur.num_children != 0 && depth < v.max_depth) {
+    const int max_depth = __builtin_amdgcn_readfirstlane(v.max_depth);
+    for (;;) {
+        // the loop-carried header is wave-uniform by construction (readlane results); saying so again at the top of every level keeps the
+        // loop control and the per-level branches scalar (without it the compiler builds the walk with exec-mask control flow)
+        cur.count = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cur.count)));
+        cur.first_child = __builtin_amdgcn_readfirstlane(cur.first_child);
+        cur.num_children = __builtin_amdgcn_readfirstlane(cur.num_children);
+        cur.players = __builtin_amdgcn_readfirstlane(cur.players);
+        depth = __builtin_amdgcn_readfirstlane(depth);
+        node = __builtin_amdgcn_readfirstlane(node);
+        if (!(cur.num_children != 0 && depth < max_depth)) { break; }
         const int nc = cur.num_children, fc = cur.first_child, cplayer = (cur.players >> 8) & 0xFF;
         const int N = static_cast<int>(cur.count - 1);
-        const float bias = v.bias_tab[N];
-        const double sqrtN = v.sqrt_tab[N];
+        const float bias = bias_tab[N];
+        const double sqrtN = sqrt_tab[N];
         if (nc <= 128 && !v.value_rescale) {
             // Children are stored in descending prior order and an unvisited child can only be chosen while every child before it has
             // been visited (equal init-Q, u monotone in the prior, ties go to the higher prior / lower index), so the visited children

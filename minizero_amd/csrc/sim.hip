@@ -86,9 +86,18 @@ typedef __attribute__((address_space(3))) const double LdsCDouble;
 template <int CPL, int WPE>
 __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    rot = __builtin_amdgcn_readfirstlane(rot);
     unsigned long long t0 = 0;
     if (a->prof) { t0 = wall_clock64(); }
     const PoolView pv = ldc(&a->pv);
+#ifdef MZ_SELECT_TWICE // experiment: the walk again, now with its records in the caches -> the profile shows the arithmetic-only time
+    selectBody(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
+    waveSync();
+    if (a->prof) { t0 = wall_clock64(); }
+#endif
     selectBody(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
     waveSync();
     if (a->prof && lane == 0) {
@@ -103,6 +112,10 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
 template <int WPE>
 __device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    rot = __builtin_amdgcn_readfirstlane(rot);
     const GoDevView gv = ldc(&a->gv);
     const PoolView pv = ldc(&a->pv);
     azCandBody(gv, a->policy, a->logit, a->value, rot, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io,
@@ -117,6 +130,8 @@ __device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, in
 template <int WPE>
 __device__ __noinline__ void simApplyRootNoise(CSimArgs* __restrict__ a, int g, int lane)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
     const PoolView v = ldc(&a->pv);
     const size_t base = size_t(g) * v.cap;
     const int nc = v.rec[base].num_children;
@@ -136,6 +151,9 @@ __device__ __noinline__ void simApplyRootNoise(CSimArgs* __restrict__ a, int g, 
 template <int WPE>
 __device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
     if (host_start && slot >= 1) { return; } // a->start[g] was uploaded by the host
     int st = 0;
     if (slot >= 1 && !host_start) { const PoolView pv = ldc(&a->pv); const GumbelView gum = ldc(&a->gum); st = gumbelStepBody(pv, gum, slot, g, lane, tiles); }
@@ -150,6 +168,8 @@ __device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, 
 template <int WPE>
 __device__ __noinline__ void simPrefetchPath(CSimArgs* __restrict__ a, int g, int lane)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
     const PoolView v = ldc(&a->pv);
     const int plen = v.path_len[g];
     const int* path = v.path + size_t(g) * v.max_depth;
@@ -169,6 +189,10 @@ __device__ __noinline__ void simPrefetchPath(CSimArgs* __restrict__ a, int g, in
 template <int WPE>
 __device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    xcs = __builtin_amdgcn_readfirstlane(xcs);
+    xpw = __builtin_amdgcn_readfirstlane(xpw);
     const HeadParams hp = ldc(&a->hp);
     headsBody(nullptr, hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
 }
@@ -183,6 +207,8 @@ constexpr int simWavesPerEu() { return (H * W <= 64 && kTowerTiles * (CIN0_PAD >
 template <int H, int W, int CIN0_PAD, int CPAD>
 __device__ __noinline__ const float* simTower(CSimArgs* __restrict__ a, int g, int tid, float* tiles)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
 #ifdef MZ_SIM_TPROF
     if (tid == 0 && g == 0) { s_tp_prev = clock64(); s_tp_idx = 0; g_tp[63] += 1; }
 #endif
@@ -240,6 +266,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
 // the reference's sort order; the new hidden state is rescaled to [0, 1] per sample and written to the slab slot of this simulation.
 __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
     const PoolView v = ldc(&a->pv);
     const int A = a->A, len = v.path_len[g], depth = len - 1;
     Cand* cs = reinterpret_cast<Cand*>(tiles);
@@ -273,6 +302,9 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
 
 __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, int g, int lane, LdsCDouble* rcp)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
     if (slot == 1 && a->root_noise) { simApplyRootNoise<2>(a, g, lane); }
     const PoolView pv = ldc(&a->pv);
     selectBody(pv, nullptr, g, lane, rcp);
@@ -280,6 +312,11 @@ __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, int
 
 __device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
 {
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    xcs = __builtin_amdgcn_readfirstlane(xcs);
+    xpw = __builtin_amdgcn_readfirstlane(xpw);
     // hidden_dst + g * C * P must be the slab slot (g, slot): headsBody indexes its outputs with the sample index
     float* hd = a->hidden + (size_t(g) * a->slots + slot - g) * size_t(a->hp.C) * a->hp.P;
     const HeadParams hp = ldc(&a->hp);
