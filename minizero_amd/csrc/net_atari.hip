@@ -11,6 +11,7 @@
 //                   the 601-way softmax expectation is computed in index order; invertValue stays on the host (double libm).
 #include "net.h"
 #include "net_dev.h"
+#include "net_body.h"
 
 namespace mz {
 
@@ -103,126 +104,144 @@ struct AtariHeadParams {
     int C, P, A, PC;
 };
 
-// DiscreteValueNetwork + softmax expectation on the LDS-resident activations xs[C][P]; result (transformed space) -> *out
-__device__ void discreteHead(const DiscreteParams& d, const float* xs, int C, int P, float* f, float* h1, float* lg, float* red, float* out, int tid)
+// DiscreteValueNetwork + softmax expectation on the LDS-resident activations xs[C][P]; result (transformed space) -> *out.
+// Run by one HALF of the workgroup (512 threads, `t` = 0..511): the reward and the value head of a sample are independent and run
+// side by side on the two halves.  Both halves pass the same barriers; `active` = false: barriers only.  Every sum is the reference's
+// sequential f32 chain (dotChain: the weights of 16 steps are loaded ahead of the 16 dependent fmas); the 601 quotients of the
+// expectation are independent and computed by all threads, only the two index-ordered sums are serial.
+__device__ void discreteHead(const DiscreteParams& d, bool active, const float* xs, int C, int P, float* f, float* h1, float* lg, float* red,
+                             float* out, int t)
 {
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < d.hc * P; i += 256) {
-        const int j = i / P, p = i - j * P;
-        const float* w = d.conv_w + j * C;
-        float acc = 0.0f;
-        for (int c = 0; c < C; ++c) { acc = __builtin_fmaf(xs[c * P + p], w[c], acc); }
-        const float v = acc + d.conv_b[j];
-        f[i] = v > 0.0f ? v : 0.0f;
+    constexpr int NT = 512;
+    const int lane = t & 63, wave = t >> 6;
+    if (active) {
+        for (int i = t; i < d.hc * P; i += NT) {
+            const int j = i / P, p = i - j * P;
+            const float v = dotChain<16>(xs + p, P, d.conv_w + j * C, 1, C) + d.conv_b[j];
+            f[i] = v > 0.0f ? v : 0.0f;
+        }
     }
     __syncthreads();
-    const int n1 = d.hc * P;
-    for (int o = tid; o < d.hidden; o += 256) {
-        float acc = 0.0f;
-        for (int i = 0; i < n1; ++i) { acc = __builtin_fmaf(f[i], d.fc1_wT[size_t(i) * d.hidden + o], acc); }
-        const float v = acc + d.fc1_b[o];
-        h1[o] = v > 0.0f ? v : 0.0f;
+    if (active) {
+        const int n1 = d.hc * P;
+        for (int o = t; o < d.hidden; o += NT) {
+            const float v = dotChain<16>(f, 1, d.fc1_wT + o, d.hidden, n1) + d.fc1_b[o];
+            h1[o] = v > 0.0f ? v : 0.0f;
+        }
     }
     __syncthreads();
     float m = -3.4e38f;
-    for (int o = tid; o < d.size; o += 256) {
-        float acc = 0.0f;
-        for (int i = 0; i < d.hidden; ++i) { acc = __builtin_fmaf(h1[i], d.fc2_wT[size_t(i) * d.size + o], acc); }
-        const float v = acc + d.fc2_b[o];
-        lg[o] = v;
-        m = v > m ? v : m;
+    if (active) {
+        for (int o = t; o < d.size; o += NT) {
+            const float v = dotChain<16>(h1, 1, d.fc2_wT + o, d.size, d.hidden) + d.fc2_b[o];
+            lg[o] = v;
+            m = v > m ? v : m;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
+        if (lane == 0) { red[wave] = m; }
     }
-    for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
-    if (lane == 0) { red[wave] = m; }
     __syncthreads();
-    m = red[0];
-    for (int w = 1; w < 4; ++w) { m = red[w] > m ? red[w] : m; }
-    for (int o = tid; o < d.size; o += 256) { lg[o] = mz_expf(lg[o] - m); }
+    if (active) {
+        m = red[0];
+        for (int w = 1; w < NT / 64; ++w) { m = red[w] > m ? red[w] : m; }
+        for (int o = t; o < d.size; o += NT) { lg[o] = mz_expf(lg[o] - m); }
+    }
     __syncthreads();
-    if (tid == 0) { // index-ordered sums (ref muzero_network.h:157-162: accumulate(sum + value * start_value++))
+    if (active && t == 0) { // index-ordered sum of the exponentials (ref muzero_network.h:157-162)
         float s = 0.0f;
         for (int i = 0; i < d.size; ++i) { s += lg[i]; }
+        red[8] = s;
+    }
+    __syncthreads();
+    if (active) {
+        const float s = red[8];
+        const int start_value = -d.size / 2;
+        for (int o = t; o < d.size; o += NT) { lg[o] = (lg[o] / s) * static_cast<float>(start_value + o); } // value * start_value++ (int -> float, exact)
+    }
+    __syncthreads();
+    if (active && t == 0) { // accumulate(sum + value * start_value++), in index order
         float e = 0.0f;
-        int start_value = -d.size / 2;
-        for (int i = 0; i < d.size; ++i) { e = e + (lg[i] / s) * start_value++; }
+        for (int i = 0; i < d.size; ++i) { e = e + lg[i]; }
         *out = e;
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void heads_atari_kernel(const float* __restrict__ x, AtariHeadParams hp, float* __restrict__ policy,
-                                                          float* __restrict__ logit, float* __restrict__ value, float* __restrict__ reward,
-                                                          float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int do_reward)
+__global__ __launch_bounds__(1024) void heads_atari_kernel(const float* __restrict__ x, AtariHeadParams hp, float* __restrict__ policy,
+                                                           float* __restrict__ logit, float* __restrict__ value, float* __restrict__ reward,
+                                                           float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int do_reward)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC;
     const int hcmax = hp.value.hc > hp.reward.hc ? hp.value.hc : hp.reward.hc;
     const int hidmax = hp.value.hidden > hp.reward.hidden ? hp.value.hidden : hp.reward.hidden;
-    float* xs = sm;                     // [C*P]
-    float* f = xs + C * P;              // [hcmax*P]
+    const int sizemax = hp.value.size > hp.reward.size ? hp.value.size : hp.reward.size;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = tid >> 9, t = tid & 511;
+    const int per_half = hcmax * P + hidmax + sizemax + 16;
+    float* xr = sm;                     // [C*P] the trunk's output (the reward head reads the UNscaled hidden state)
+    float* xs = xr + C * P;             // [C*P] the rescaled hidden state (policy and value heads, and the slab)
+    float* pf = xs + C * P;             // [PC*P]
+    float* lgp = pf + PC * P;           // [A]
+    float* redp = lgp + A;              // [32]
+    float* hb = redp + 32 + half * per_half; // this half's head scratch
+    float* f = hb;                      // [hcmax*P]
     float* h1 = f + hcmax * P;          // [hidmax]
-    float* lg = h1 + hidmax;            // [max(size, A)]
-    float* pf = lg + (hp.value.size > A ? hp.value.size : A); // [PC*P]
-    float* red = pf + PC * P;           // [16]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* lg = h1 + hidmax;            // [sizemax]
+    float* red = lg + sizemax;          // [16]
     const float* src = x + size_t(b) * C * P;
-    for (int i = tid; i < C * P; i += 256) { xs[i] = src[i]; }
+    for (int i = tid; i < C * P; i += 1024) { xr[i] = src[i]; }
     __syncthreads();
-    if (do_reward) { discreteHead(hp.reward, xs, C, P, f, h1, lg, red, reward + b, tid); }
     // scale_hidden_state (ref muzero_atari_network.py:189-198)
     {
         float mn = 3.4e38f, mx = -3.4e38f;
-        for (int i = tid; i < C * P; i += 256) { const float v = xs[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        for (int i = tid; i < C * P; i += 1024) { const float v = xr[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
         for (int o = 32; o > 0; o >>= 1) {
             const float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
             mn = m2 < mn ? m2 : mn;
             mx = x2 > mx ? x2 : mx;
         }
-        if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+        if (lane == 0) { redp[wave] = mn; redp[16 + wave] = mx; }
         __syncthreads();
-        mn = red[0]; mx = red[4];
-        for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
+        mn = redp[0]; mx = redp[16];
+        for (int w = 1; w < 16; ++w) { mn = redp[w] < mn ? redp[w] : mn; mx = redp[16 + w] > mx ? redp[16 + w] : mx; }
         float scale = mx - mn;
         if (scale < 1e-5f) { scale += 1e-5f; }
         float* hd = hidden_dst + size_t(dst_idx ? dst_idx[b] : b) * C * P;
-        __syncthreads();
-        for (int i = tid; i < C * P; i += 256) {
-            const float v = (xs[i] - mn) / scale;
+        for (int i = tid; i < C * P; i += 1024) {
+            const float v = (xr[i] - mn) / scale;
             xs[i] = v;
             hd[i] = v;
         }
         __syncthreads();
     }
-    // policy head
-    for (int i = tid; i < PC * P; i += 256) {
+    // half 0: reward head on the unscaled state (ref muzero_atari_network.py: dynamics -> reward before the rescale);
+    // half 1: value head on the rescaled state
+    discreteHead(half == 0 ? hp.reward : hp.value, half == 0 ? do_reward != 0 : true, half == 0 ? xr : xs, C, P, f, h1, lg, red,
+                 half == 0 ? reward + b : value + b, t);
+    // policy head (all threads; its barriers come after the discrete heads')
+    for (int i = tid; i < PC * P; i += 1024) {
         const int j = i / P, p = i - j * P;
-        float acc = 0.0f;
-        for (int c = 0; c < C; ++c) { acc = __builtin_fmaf(xs[c * P + p], hp.pconv_w[j * C + c], acc); }
-        const float v = acc + hp.pconv_b[j];
+        const float v = dotChain<16>(xs + p, P, hp.pconv_w + j * C, 1, C) + hp.pconv_b[j];
         pf[i] = v > 0.0f ? v : 0.0f;
     }
     __syncthreads();
-    for (int a = tid; a < A; a += 256) {
-        float acc = 0.0f;
-        for (int i = 0; i < PC * P; ++i) { acc = __builtin_fmaf(pf[i], hp.pfc_wT[size_t(i) * A + a], acc); }
-        const float v = acc + hp.pfc_b[a];
-        lg[a] = v;
+    for (int a = tid; a < A; a += 1024) {
+        const float v = dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
+        lgp[a] = v;
         logit[size_t(b) * A + a] = v;
     }
     __syncthreads();
     if (wave == 0) {
         float m = -3.4e38f;
-        for (int a = lane; a < A; a += 64) { m = lg[a] > m ? lg[a] : m; }
+        for (int a = lane; a < A; a += 64) { m = lgp[a] > m ? lgp[a] : m; }
         for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
-        for (int a = lane; a < A; a += 64) { lg[a] = mz_expf(lg[a] - m); }
+        for (int a = lane; a < A; a += 64) { lgp[a] = mz_expf(lgp[a] - m); }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         float s = 0.0f;
-        for (int a = 0; a < A; ++a) { s += lg[a]; }
-        for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lg[a] / s; }
+        for (int a = 0; a < A; ++a) { s += lgp[a]; }
+        for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lgp[a] / s; }
     }
-    __syncthreads();
-    discreteHead(hp.value, xs, C, P, f, h1, lg, red, value + b, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -277,8 +296,14 @@ static int launchAtariHeads(const Net& net, const float* params, const HeadOffse
     hp.pconv_w = params + h.pconv_w; hp.pconv_b = params + h.pconv_b; hp.pfc_wT = params + h.pfc_wT; hp.pfc_b = params + h.pfc_b;
     hp.C = net.desc_.num_hidden_channels; hp.P = net.P(); hp.A = net.desc_.action_size; hp.PC = h.pc;
     const int hcmax = std::max(at.value.hc, at.reward.hc), hidmax = std::max(at.value.hidden, at.reward.hidden);
-    const size_t lds = (size_t(hp.C) * hp.P + size_t(hcmax) * hp.P + hidmax + std::max(at.value.size, hp.A) + size_t(hp.PC) * hp.P + 16) * sizeof(float);
-    hipLaunchKernelGGL(heads_atari_kernel, dim3(B), dim3(256), lds, s, x, hp, policy, logit, value, reward, hidden_dst, dst_idx, do_reward ? 1 : 0);
+    const int sizemax = std::max(at.value.size, at.reward.size);
+    const size_t lds = (size_t(2) * hp.C * hp.P + size_t(hp.PC) * hp.P + hp.A + 32 + size_t(2) * (size_t(hcmax) * hp.P + hidmax + sizemax + 16)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_atari_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(heads_atari_kernel, dim3(B), dim3(1024), lds, s, x, hp, policy, logit, value, reward, hidden_dst, dst_idx, do_reward ? 1 : 0);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
