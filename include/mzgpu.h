@@ -203,10 +203,13 @@ int mz_env_feature_bits(const mz_env* e, int rotation, uint32_t* out);
  * steps = count - root_prefix + 1; feat_out [steps][18*ceil(P/32)], legal_out [steps][P+1].
  * mz_sort_candidates orders n policies like the reference's std::sort (policy descending,
  * ref zero_actor.cpp:225-227) on the device, ties included: order_out[i] = index of the i-th.
+ * mz_invert_values_device applies the 601-bin decode (ref utils/utils.h:102-108 invertValue) to n values with the device
+ * function the simulation kernel uses for muzero_atari (mz_invert_value is the host function of the lock-step path).
  * ------------------------------------------------------------------------------------------ */
 int mz_godev_playout(int device, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots,
                      uint32_t* feat_out, uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out);
 int mz_sort_candidates(int device, const float* policy, int n, int* order_out);
+int mz_invert_values_device(int device, const float* values, int n, float* out);
 
 #ifdef __cplusplus
 }

@@ -41,9 +41,11 @@ bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<f
 bool readTorchScript(const std::string& path, mz_net_desc* desc, std::vector<float>* weights, std::string* err); // ptfile.cpp
 
 float invertValueHost(float value); // 601-bin decode helper (ref utils/utils.h:102-108)
+int invertValuesOnDevice(int device, const float* values, int n, float* out); // the device twin (net_atari_body.h), test access
 
 struct TowerArgs;
 struct HeadParams;
+struct AtariHeadParams;
 struct PoolView;
 struct GoDevView;
 struct GumbelView;
@@ -79,10 +81,13 @@ public:
                   int* d_start = nullptr, bool host_start = false);
     bool hasSimKernel(int board_n, int env_kind = 0) const; // env_kind: GoDevView::kind
     // MuZero (board games): the same for initial + recurrent inference; hidden states live in the caller's slab [games][slots][C * P]
+    // nsims simulations (slots sim0 ..) of every game in one launch of sim_kernel_mz; muzero_atari: sim0 >= 1 (the root's 96x96 representation
+    // runs as stand-alone kernels), value / reward come out of the kernel in game scale (d_reward: [games])
     int simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
-                    int num_players, float* d_policy, float* d_logit, float* d_value, int sim0, int nsims, bool* launched,
-                    const float* d_root_noise = nullptr, float noise_eps = 0.0f);
+                    int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
+                    const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start);
     bool hasSimKernelMz() const;
+    void makeAtariHeadParams(AtariHeadParams* out) const; // net_atari.hip
     int timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops);
     int timeTowerConv(int B, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch);
 

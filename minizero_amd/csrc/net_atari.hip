@@ -12,6 +12,7 @@
 #include "net.h"
 #include "net_dev.h"
 #include "net_body.h"
+#include "net_atari_body.h"
 
 namespace mz {
 
@@ -97,151 +98,14 @@ __global__ void avgpool3s2_kernel(const float* __restrict__ in, int C, int H, in
     }
 }
 
-struct DiscreteParams { const float *conv_w, *conv_b, *fc1_wT, *fc1_b, *fc2_wT, *fc2_b; int hc, hidden, size; };
-struct AtariHeadParams {
-    DiscreteParams reward, value;
-    const float *pconv_w, *pconv_b, *pfc_wT, *pfc_b;
-    int C, P, A, PC;
-};
-
-// DiscreteValueNetwork + softmax expectation on the LDS-resident activations xs[C][P]; result (transformed space) -> *out.
-// Run by one HALF of the workgroup (512 threads, `t` = 0..511): the reward and the value head of a sample are independent and run
-// side by side on the two halves.  Both halves pass the same barriers; `active` = false: barriers only.  Every sum is the reference's
-// sequential f32 chain (dotChain: the weights of 16 steps are loaded ahead of the 16 dependent fmas); the 601 quotients of the
-// expectation are independent and computed by all threads, only the two index-ordered sums are serial.
-__device__ void discreteHead(const DiscreteParams& d, bool active, const float* xs, int C, int P, float* f, float* h1, float* lg, float* red,
-                             float* out, int t)
-{
-    constexpr int NT = 512;
-    const int lane = t & 63, wave = t >> 6;
-    if (active) {
-        for (int i = t; i < d.hc * P; i += NT) {
-            const int j = i / P, p = i - j * P;
-            const float v = dotChain<16>(xs + p, P, d.conv_w + j * C, 1, C) + d.conv_b[j];
-            f[i] = v > 0.0f ? v : 0.0f;
-        }
-    }
-    __syncthreads();
-    if (active) {
-        const int n1 = d.hc * P;
-        for (int o = t; o < d.hidden; o += NT) {
-            const float v = dotChain<16>(f, 1, d.fc1_wT + o, d.hidden, n1) + d.fc1_b[o];
-            h1[o] = v > 0.0f ? v : 0.0f;
-        }
-    }
-    __syncthreads();
-    float m = -3.4e38f;
-    if (active) {
-        for (int o = t; o < d.size; o += NT) {
-            const float v = dotChain<16>(h1, 1, d.fc2_wT + o, d.size, d.hidden) + d.fc2_b[o];
-            lg[o] = v;
-            m = v > m ? v : m;
-        }
-        for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
-        if (lane == 0) { red[wave] = m; }
-    }
-    __syncthreads();
-    if (active) {
-        m = red[0];
-        for (int w = 1; w < NT / 64; ++w) { m = red[w] > m ? red[w] : m; }
-        for (int o = t; o < d.size; o += NT) { lg[o] = mz_expf(lg[o] - m); }
-    }
-    __syncthreads();
-    if (active && t == 0) { // index-ordered sum of the exponentials (ref muzero_network.h:157-162)
-        float s = 0.0f;
-        for (int i = 0; i < d.size; ++i) { s += lg[i]; }
-        red[8] = s;
-    }
-    __syncthreads();
-    if (active) {
-        const float s = red[8];
-        const int start_value = -d.size / 2;
-        for (int o = t; o < d.size; o += NT) { lg[o] = (lg[o] / s) * static_cast<float>(start_value + o); } // value * start_value++ (int -> float, exact)
-    }
-    __syncthreads();
-    if (active && t == 0) { // accumulate(sum + value * start_value++), in index order
-        float e = 0.0f;
-        for (int i = 0; i < d.size; ++i) { e = e + lg[i]; }
-        *out = e;
-    }
-    __syncthreads();
-}
-
 __global__ __launch_bounds__(1024) void heads_atari_kernel(const float* __restrict__ x, AtariHeadParams hp, float* __restrict__ policy,
                                                            float* __restrict__ logit, float* __restrict__ value, float* __restrict__ reward,
                                                            float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int do_reward)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC;
-    const int hcmax = hp.value.hc > hp.reward.hc ? hp.value.hc : hp.reward.hc;
-    const int hidmax = hp.value.hidden > hp.reward.hidden ? hp.value.hidden : hp.reward.hidden;
-    const int sizemax = hp.value.size > hp.reward.size ? hp.value.size : hp.reward.size;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = tid >> 9, t = tid & 511;
-    const int per_half = hcmax * P + hidmax + sizemax + 16;
-    float* xr = sm;                     // [C*P] the trunk's output (the reward head reads the UNscaled hidden state)
-    float* xs = xr + C * P;             // [C*P] the rescaled hidden state (policy and value heads, and the slab)
-    float* pf = xs + C * P;             // [PC*P]
-    float* lgp = pf + PC * P;           // [A]
-    float* redp = lgp + A;              // [32]
-    float* hb = redp + 32 + half * per_half; // this half's head scratch
-    float* f = hb;                      // [hcmax*P]
-    float* h1 = f + hcmax * P;          // [hidmax]
-    float* lg = h1 + hidmax;            // [sizemax]
-    float* red = lg + sizemax;          // [16]
-    const float* src = x + size_t(b) * C * P;
-    for (int i = tid; i < C * P; i += 1024) { xr[i] = src[i]; }
-    __syncthreads();
-    // scale_hidden_state (ref muzero_atari_network.py:189-198)
-    {
-        float mn = 3.4e38f, mx = -3.4e38f;
-        for (int i = tid; i < C * P; i += 1024) { const float v = xr[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-        for (int o = 32; o > 0; o >>= 1) {
-            const float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
-            mn = m2 < mn ? m2 : mn;
-            mx = x2 > mx ? x2 : mx;
-        }
-        if (lane == 0) { redp[wave] = mn; redp[16 + wave] = mx; }
-        __syncthreads();
-        mn = redp[0]; mx = redp[16];
-        for (int w = 1; w < 16; ++w) { mn = redp[w] < mn ? redp[w] : mn; mx = redp[16 + w] > mx ? redp[16 + w] : mx; }
-        float scale = mx - mn;
-        if (scale < 1e-5f) { scale += 1e-5f; }
-        float* hd = hidden_dst + size_t(dst_idx ? dst_idx[b] : b) * C * P;
-        for (int i = tid; i < C * P; i += 1024) {
-            const float v = (xr[i] - mn) / scale;
-            xs[i] = v;
-            hd[i] = v;
-        }
-        __syncthreads();
-    }
-    // half 0: reward head on the unscaled state (ref muzero_atari_network.py: dynamics -> reward before the rescale);
-    // half 1: value head on the rescaled state
-    discreteHead(half == 0 ? hp.reward : hp.value, half == 0 ? do_reward != 0 : true, half == 0 ? xr : xs, C, P, f, h1, lg, red,
-                 half == 0 ? reward + b : value + b, t);
-    // policy head (all threads; its barriers come after the discrete heads')
-    for (int i = tid; i < PC * P; i += 1024) {
-        const int j = i / P, p = i - j * P;
-        const float v = dotChain<16>(xs + p, P, hp.pconv_w + j * C, 1, C) + hp.pconv_b[j];
-        pf[i] = v > 0.0f ? v : 0.0f;
-    }
-    __syncthreads();
-    for (int a = tid; a < A; a += 1024) {
-        const float v = dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
-        lgp[a] = v;
-        logit[size_t(b) * A + a] = v;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float m = -3.4e38f;
-        for (int a = lane; a < A; a += 64) { m = lgp[a] > m ? lgp[a] : m; }
-        for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
-        for (int a = lane; a < A; a += 64) { lgp[a] = mz_expf(lgp[a] - m); }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float s = 0.0f;
-        for (int a = 0; a < A; ++a) { s += lgp[a]; }
-        for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lgp[a] / s; }
-    }
+    const int b = blockIdx.x;
+    float* hd = hidden_dst + size_t(dst_idx ? dst_idx[b] : b) * hp.C * hp.P;
+    atariHeadsBody<512>(x + size_t(b) * hp.C * hp.P, nullptr, 0, 0, hp, policy, logit, value, reward, hd, do_reward, 0, b, threadIdx.x, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -287,17 +151,22 @@ static DiscreteParams discreteParams(const float* p, const DiscreteHeadOffsets& 
     return DiscreteParams{p + o.conv_w, p + o.conv_b, p + o.fc1_wT, p + o.fc1_b, p + o.fc2_wT, p + o.fc2_b, o.hc, o.hidden, o.size};
 }
 
+void Net::makeAtariHeadParams(AtariHeadParams* out) const
+{
+    AtariHeadParams& hp = *out;
+    const float* params = params_.p;
+    hp.reward = discreteParams(params, at_.reward);
+    hp.value = discreteParams(params, at_.value);
+    hp.pconv_w = params + heads_.pconv_w; hp.pconv_b = params + heads_.pconv_b; hp.pfc_wT = params + heads_.pfc_wT; hp.pfc_b = params + heads_.pfc_b;
+    hp.C = desc_.num_hidden_channels; hp.P = P(); hp.A = desc_.action_size; hp.PC = heads_.pc;
+}
+
 static int launchAtariHeads(const Net& net, const float* params, const HeadOffsets& h, const AtariLayers& at, const float* x, int B, float* policy,
                             float* logit, float* value, float* reward, float* hidden_dst, const int* dst_idx, bool do_reward, hipStream_t s)
 {
     AtariHeadParams hp;
-    hp.reward = discreteParams(params, at.reward);
-    hp.value = discreteParams(params, at.value);
-    hp.pconv_w = params + h.pconv_w; hp.pconv_b = params + h.pconv_b; hp.pfc_wT = params + h.pfc_wT; hp.pfc_b = params + h.pfc_b;
-    hp.C = net.desc_.num_hidden_channels; hp.P = net.P(); hp.A = net.desc_.action_size; hp.PC = h.pc;
-    const int hcmax = std::max(at.value.hc, at.reward.hc), hidmax = std::max(at.value.hidden, at.reward.hidden);
-    const int sizemax = std::max(at.value.size, at.reward.size);
-    const size_t lds = (size_t(2) * hp.C * hp.P + size_t(hp.PC) * hp.P + hp.A + 32 + size_t(2) * (size_t(hcmax) * hp.P + hidmax + sizemax + 16)) * sizeof(float);
+    net.makeAtariHeadParams(&hp);
+    const size_t lds = atariHeadsSmemFloats(hp) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_atari_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -382,6 +251,25 @@ int Net::recurrentAtari(const float* d_hidden_src, const int* d_src_idx, const f
     if (!launched) { setError("no fused tower instance for the muzero_atari dynamics network"); return MZ_ERR_ARG; }
     if (conv_only_) { return MZ_OK; }
     return launchAtariHeads(*this, params_.p, heads_, at_, act_[0].p, B, d_policy, d_logit, d_value, d_reward, d_hidden_dst, d_dst_idx, true, stream_);
+}
+
+__global__ void invert_value_kernel(const float* __restrict__ in, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[i] = invertValueDev(in[i]); }
+}
+
+int invertValuesOnDevice(int device, const float* values, int n, float* out)
+{
+    if (n <= 0) { return MZ_OK; }
+    MZ_HIP(hipSetDevice(device));
+    DevBuf<float> d_in, d_out;
+    if (!d_in.alloc(n) || !d_out.alloc(n)) { setError("invertValuesOnDevice: allocation failed"); return MZ_ERR_DEVICE; }
+    MZ_HIP(hipMemcpy(d_in.p, values, size_t(n) * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(invert_value_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, d_in.p, n, d_out.p);
+    MZ_HIP(hipGetLastError());
+    MZ_HIP(hipMemcpy(out, d_out.p, size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+    return MZ_OK;
 }
 
 } // namespace mz

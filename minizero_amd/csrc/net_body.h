@@ -271,10 +271,12 @@ __device__ __forceinline__ void towerIdle(const TowerArgs& ta)
 // the body of tower_fused for sample `b`, run by all 512 threads of a workgroup (tid 0..511); `tiles` = 3 x [CMAX][CS] floats of LDS
 // out == nullptr: the last layer's activations stay in LDS; the returned pointer is that tile ([C][CS] padded planes)
 template <int H, int W, int CIN0_PAD, int CPAD>
-// hidden_src != nullptr (MuZero dynamics, ref muzero_network.py:32): the input is cat(hidden_src[C][P], one-hot plane of `action`)
+// hidden_src != nullptr (MuZero dynamics, ref muzero_network.py:32): the input is cat(hidden_src[C][P], one-hot plane of `action`;
+// action_planes > 1: that many planes, plane `action` all ones)
 // instead of sample b of `in` (a pass / out-of-board action gives an all-zero plane, ref go.cpp:310-315)
 __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ out,
-                                            int b, int tid, float* __restrict__ tiles, const float* __restrict__ hidden_src = nullptr, int action = -1)
+                                            int b, int tid, float* __restrict__ tiles, const float* __restrict__ hidden_src = nullptr, int action = -1,
+                                            int action_planes = 1)
 {
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
     constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
@@ -286,12 +288,17 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     __syncthreads();
     float* Tin = ta.has_stem ? T0 : T1; // without a stem the input IS the first block's x
     if (hidden_src) {
-        const int CH = ta.cin0 - 1;
+        const int CH = ta.cin0 - (action_planes > 1 ? action_planes : 1);
         for (int i = tid; i < CH * P; i += 512) {
             const int c = i / P, p = i - c * P;
             Tin[c * CS + (p / W + 1) * PW + (p % W) + 1] = hidden_src[i];
         }
-        if (tid == 0 && action >= 0 && action < P) { Tin[CH * CS + (action / W + 1) * PW + (action % W) + 1] = 1.0f; }
+        if (action_planes > 1) { // Atari: one plane per action, the chosen action's plane all ones (ref atari.cpp:124-130)
+            const int CH0 = ta.cin0 - action_planes;
+            if (action >= 0 && action < action_planes) {
+                for (int p = tid; p < P; p += 512) { Tin[(CH0 + action) * CS + (p / W + 1) * PW + (p % W) + 1] = 1.0f; }
+            }
+        } else if (tid == 0 && action >= 0 && action < P) { Tin[CH * CS + (action / W + 1) * PW + (action % W) + 1] = 1.0f; }
     } else if (ta.in_bits) {
         constexpr int W32 = (P + 31) / 32;
         const unsigned* bits = reinterpret_cast<const unsigned*>(in) + size_t(b) * ta.cin0 * W32;

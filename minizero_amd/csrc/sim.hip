@@ -20,6 +20,7 @@ __shared__ int s_tp_idx;
     } while (0)
 #endif
 #include "net_body.h"
+#include "net_atari_body.h"
 #include "pool_body.h"
 #include "go_body.h"
 #include "gumbel_body.h"
@@ -56,6 +57,10 @@ struct SimArgs {
     int use_gumbel;                   // Gumbel root logic (sequential halving + start node) between simulations
     GumbelView gum;
     int* start;                       // [games] start node of the next selection (written by the Gumbel step or by the host)
+    // muzero_atari (sim_kernel_mz, simulations >= 1; the 96x96 representation of the root runs as stand-alone kernels)
+    int atari, action_planes;
+    AtariHeadParams ahp;
+    float* reward;                    // [games] reward head output (game scale)
     unsigned* sink;                   // never-taken store target that keeps the prefetch loads alive
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
@@ -294,29 +299,37 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
         a->cand_count[g] = k;
         a->cand_player[g] = (a->num_players == 2 && (depth & 1)) ? 3 - rt : rt; // the children are moved by the player to move at the leaf
         a->value_io[g] = a->value[g];
-        a->reward_io[g] = 0.0f; // board games have no reward head (ref muzero_network.h:129)
+        a->reward_io[g] = a->atari ? a->reward[g] : 0.0f; // board games have no reward head (ref muzero_network.h:129)
     }
     waveSync();
     expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles);
 }
 
-__device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, int g, int lane, LdsCDouble* rcp)
+__device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
-    g = __builtin_amdgcn_readfirstlane(g);
     slot = __builtin_amdgcn_readfirstlane(slot);
+    g = __builtin_amdgcn_readfirstlane(g);
     if (slot == 1 && a->root_noise) { simApplyRootNoise<2>(a, g, lane); }
+    if (a->use_gumbel) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
     const PoolView pv = ldc(&a->pv);
-    selectBody(pv, nullptr, g, lane, rcp);
+    selectBody(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
 }
 
-__device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
+__device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, float* scratch, const float* xtile, int xcs,
+                                        int xpw)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
-    g = __builtin_amdgcn_readfirstlane(g);
     slot = __builtin_amdgcn_readfirstlane(slot);
+    g = __builtin_amdgcn_readfirstlane(g);
     xcs = __builtin_amdgcn_readfirstlane(xcs);
     xpw = __builtin_amdgcn_readfirstlane(xpw);
+    if (a->atari) { // 601-bin value / reward heads, rescaled hidden state to the slab slot of this simulation, value and reward in game scale
+        const AtariHeadParams hp = ldc(&a->ahp);
+        float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
+        atariHeadsBody<256>(nullptr, xtile, xcs, xpw, hp, a->policy, a->logit, a->value, a->reward, hd, 1, 1, g, tid, scratch);
+        return;
+    }
     // hidden_dst + g * C * P must be the slab slot (g, slot): headsBody indexes its outputs with the sample index
     float* hd = a->hidden + (size_t(g) * a->slots + slot - g) * size_t(a->hp.C) * a->hp.P;
     const HeadParams hp = ldc(&a->hp);
@@ -324,24 +337,27 @@ __device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int 
 }
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
-__global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a_, int sim0, int nsims)
+__global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start)
 {
     CSimArgs* a = (CSimArgs*)a_;
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int CM = CIN0_PAD > CDYN_PAD ? (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) : (CDYN_PAD > CPAD ? CDYN_PAD : CPAD);
     constexpr int kTileFloats = kTowerTiles * CM * planeStride(H, W);
+    // LDS: the tower tiles | the reciprocal table | (muzero_atari) the scratch of the 601-bin heads
     double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
-    for (int i = tid; i < a->rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
+    const int rcp_n = a->rcp_n;
+    for (int i = tid; i < rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
     __syncthreads();
     LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
+    float* head_scratch = reinterpret_cast<float*>(rcp_w + rcp_n);
     const PoolView v = ldc(&a->pv);
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
-        if (wave == 0) { simMzSelect(a, slot, g, lane, rcp_lds); }
+        if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds); }
         __syncthreads();
         const float* xt;
-        if (slot == 0) { // initial inference: representation trunk on the root planes
+        if (slot == 0) { // initial inference: representation trunk on the root planes (board games; muzero_atari roots never come here)
             xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
         } else { // recurrent inference: dynamics trunk on (parent hidden state, move)
             const int len = v.path_len[g];
@@ -349,10 +365,10 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             const int src = v.hslot[size_t(g) * v.cap + path[len - 2]];
             const int action = v.path_action[size_t(g) * v.max_depth + len - 1];
             const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;
-            xt = towerBody<H, W, CDYN_PAD, CPAD>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action);
+            xt = towerBody<H, W, CDYN_PAD, CPAD>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action, a->action_planes);
         }
         __syncthreads();
-        simMzHeads(a, slot, g, tid, tiles, xt, planeStride(H, W), W + 2);
+        simMzHeads(a, slot, g, tid, tiles, head_scratch, xt, planeStride(H, W), W + 2);
         __syncthreads();
         if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles); }
         __syncthreads();
@@ -360,21 +376,23 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
 }
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
-static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, size_t lds, hipStream_t s)
+static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         attr_set = true;
     }
-    hipLaunchKernelGGL((sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), dim3(games), dim3(512), lds, s, d_args, sim0, nsims);
+    hipLaunchKernelGGL((sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), dim3(games), dim3(512), lds, s, d_args, sim0, nsims, host_start);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
 
 #define MZ_SIM_MZ_CASES(X) \
     X(9, 9, 20, 68, 64)  /* 9x9 Go MuZero, 64 channels (BASELINE configs[3]) */ \
-    X(9, 9, 20, 12, 8)   /* small 9x9 test nets */
+    X(9, 9, 20, 12, 8)   /* small 9x9 test nets */ \
+    X(6, 6, 64, 84, 64)  /* muzero_atari dynamics, 64 channels + 18 action planes (BASELINE configs[4]); the representation runs stand-alone */ \
+    X(6, 6, 32, 52, 32)  /* small muzero_atari test nets */
 
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
 static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
@@ -507,10 +525,12 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
 
 bool Net::hasSimKernelMz() const
 {
-    if (desc_.type != 1 || !use_fused_) { return false; }
+    if ((desc_.type != 1 && desc_.type != 2) || !use_fused_) { return false; }
     TowerArgs t1, t2;
     int c0 = 0, cd = 0;
-    if (!makeTowerArgs(repr_, true, true, &t1, &c0) || !makeTowerArgs(dyn_, false, true, &t2, &cd)) { return false; }
+    if (desc_.type == 2) { c0 = desc_.num_hidden_channels; } // the root's representation never runs in the kernel: the CIN0_PAD = C instance
+    else if (!makeTowerArgs(repr_, true, true, &t1, &c0)) { return false; }
+    if (!makeTowerArgs(dyn_, false, true, &t2, &cd)) { return false; }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
 #define MZ_SIM_MZ_HAS(h, w, cin0, cdyn, cpad) \
     if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { return true; }
@@ -520,19 +540,35 @@ bool Net::hasSimKernelMz() const
 }
 
 int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
-                     int num_players, float* d_policy, float* d_logit, float* d_value, int sim0, int nsims, bool* launched, const float* d_root_noise,
-                     float noise_eps)
+                     int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
+                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start)
 {
     *launched = false;
-    if (desc_.type != 1) { return MZ_OK; }
+    const bool atari = desc_.type == 2;
+    if (desc_.type != 1 && !atari) { return MZ_OK; }
+    if (atari && sim0 < 1) { setError("simLaunchMz: the muzero_atari root is evaluated by the stand-alone kernels"); return MZ_ERR_ARG; }
     SimArgs a;
     memset(&a, 0, sizeof(a));
     int c0 = 0, cd = 0;
-    if (!makeTowerArgs(repr_, true, true, &a.ta, &c0) || !makeTowerArgs(dyn_, false, true, &a.ta_dyn, &cd)) { return MZ_OK; }
-    makeHeadParams(&a.hp);
+    if (atari) { c0 = desc_.num_hidden_channels; }
+    else if (!makeTowerArgs(repr_, true, true, &a.ta, &c0)) { return MZ_OK; }
+    if (!makeTowerArgs(dyn_, false, true, &a.ta_dyn, &cd)) { return MZ_OK; }
+    int rc = ensureBatch(pool.v_.games);
+    if (rc) { return rc; }
+    size_t head_floats = 0;
+    if (atari) {
+        makeAtariHeadParams(&a.ahp);
+        a.atari = 1;
+        a.action_planes = desc_.num_action_feature_channels;
+        a.hp.C = a.ahp.C; a.hp.P = a.ahp.P; // the slab geometry (sim_kernel_mz reads it from hp)
+        head_floats = atariHeadsSmemFloats(a.ahp);
+    } else {
+        makeHeadParams(&a.hp);
+        a.action_planes = 1;
+    }
     a.pv = pool.v_;
     a.params = params_.p;
-    a.policy = d_policy; a.logit = d_logit; a.value = d_value;
+    a.policy = d_policy; a.logit = d_logit; a.value = d_value; a.reward = d_reward;
     a.cand_count = pool.d_cand_count_.p; a.cand_action = pool.d_cand_action_.p; a.cand_player = pool.d_cand_player_.p;
     a.cand_policy = pool.d_cand_policy_.p; a.cand_logit = pool.d_cand_logit_.p; a.value_io = pool.d_value_.p; a.reward_io = pool.d_reward_.p;
     a.err = pool.errFlag();
@@ -541,12 +577,18 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.A = desc_.action_size; a.LW = (desc_.action_size + 63) / 64; a.num_players = num_players;
     a.root_noise = d_root_noise;
     a.noise_eps = noise_eps;
-    a.noise_kind = 1;
+    a.noise_kind = noise_kind;
+    a.use_gumbel = gum ? 1 : 0;
+    if (gum) { a.gum = *gum; }
+    a.start = d_start;
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
     const int cmax = std::max(std::max(c0, cd), C);
     const size_t tile_bytes = size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float);
-    if (azCandSmemBytes(a.A) > tile_bytes) { return MZ_OK; }
-    const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double);
+    size_t scratch = std::max(azCandSmemBytes(a.A), gumbelSmemBytes(a.A));
+    scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
+    if (scratch > tile_bytes) { return MZ_OK; }
+    const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) + head_floats * sizeof(float);
+    if (lds > 160 * 1024) { return MZ_OK; }
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
         if (!sim_args_.ensure(sizeof(SimArgs))) { setError("hipMalloc of the simulation arguments failed"); return MZ_ERR_DEVICE; }
         MZ_HIP(hipStreamSynchronize(stream_));
@@ -554,7 +596,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
         sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
     }
 #define MZ_SIM_MZ_LAUNCH(h, w, cin0, cdyn, cpad) \
-    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, lds, stream_); }
+    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
     MZ_SIM_MZ_CASES(MZ_SIM_MZ_LAUNCH)
 #undef MZ_SIM_MZ_LAUNCH
     return MZ_OK;

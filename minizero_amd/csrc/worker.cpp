@@ -320,6 +320,7 @@ private:
     int phase2Resident(Lane& L);
     int runCyclesSim(int n);
     int uploadRoots(Lane& L);
+    int setupDeviceGumbel();
     int cycle();
     int createActors();
     int resetAllSearches();
@@ -373,7 +374,9 @@ private:
     bool defer_info_ = false;
     void flushDeferred();
     GumbelView gum_{};        // constants of the device-side Gumbel step (state pointer set per lane)
-    bool dev_gumbel_ = false; // AlphaZero Go + Gumbel on the simulation kernel
+    bool dev_gumbel_ = false; // Gumbel root logic inside the simulation kernel
+    bool sim_root_host_ = false;    // muzero_atari on sim_kernel_mz: the root (96x96 representation) is evaluated by a lock-step cycle
+    bool root_host_pending_ = false; // ... whose outputs the next phase1 still has to turn into the root's children (host candidate lists)
     int syncGumbel(Lane& L, bool to_device);
     bool sim_mz_ = false;     // MuZero board game on sim_kernel_mz (no device rules needed: the leaves have no environment)
     bool sim_kernel_ = false; // ... and whole runs of cycles are ONE launch of the per-game simulation kernel (sim.hip)
@@ -463,21 +466,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         }
         sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize(), e.deviceKind()) &&
                       (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 1 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
-        dev_gumbel_ = sim_kernel_ && cfg_.actor_use_gumbel;
-        if (dev_gumbel_) { // the constants of gumbel_zero.cpp:101,110 in the host's double arithmetic
-            const int m = cfg_.actor_gumbel_sample_size;
-            gum_.sample_size = m;
-            gum_.sigma_visit_c = cfg_.actor_gumbel_sigma_visit_c;
-            gum_.sigma_scale_c = cfg_.actor_gumbel_sigma_scale_c;
-            gum_.budget0 = static_cast<int>(std::max(1.0, std::floor(cfg_.actor_num_simulation / (std::log2(m) * m))));
-            for (int k = 0; k < 8; ++k) { gum_.next_budget[k] = static_cast<int>(std::floor(cfg_.actor_num_simulation / (std::log2(m) * (1 << k) / 2))); }
-            for (auto& L : lanes_) {
-                const size_t n = size_t(L->n) * (3 + kGumbelMaxSample);
-                if (!L->h_gum.alloc(n) || !L->d_gum.alloc(n)) { setError("worker: allocation failed (gumbel state)"); return MZ_ERR_DEVICE; }
-                memset(L->h_gum.p, 0, n * sizeof(int));
-                MZ_HIP(hipMemset(L->d_gum.p, 0, n * sizeof(int)));
-            }
-        }
+        { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
         defer_info_ = sim_kernel_;
         if (sim_kernel_) {
             for (auto& L : lanes_) {
@@ -488,11 +477,14 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             }
         }
     }
-    sim_mz_ = !resident_ && cfg_.mz_sim_kernel && desc.type == 1 && !cfg_.actor_use_gumbel && !cfg_.actor_mcts_value_rescale && net0().hasSimKernelMz();
+    sim_mz_ = !resident_ && cfg_.mz_sim_kernel && (desc.type == 1 || desc.type == 2) && net0().hasSimKernelMz() &&
+              (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 1 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
     if (sim_mz_) {
         sim_kernel_ = true;
         defer_info_ = true;
-        const int fw = games_[0].env->featureWords(), LW = (A_ + 63) / 64;
+        sim_root_host_ = desc.type == 2;
+        { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
+        const int fw = sim_root_host_ ? 1 : games_[0].env->featureWords(), LW = (A_ + 63) / 64;
         for (auto& L : lanes_) {
             if (!L->h_rootfeat.alloc(size_t(L->n) * fw) || !L->d_rootfeat.alloc(size_t(L->n) * fw) || !L->h_rootlegal.alloc(size_t(L->n) * LW) ||
                 !L->d_rootlegal.alloc(size_t(L->n) * LW) || !L->h_rootturn.alloc(L->n) || !L->d_rootturn.alloc(L->n) ||
@@ -510,14 +502,34 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     return MZ_OK;
 }
 
+int Worker::setupDeviceGumbel() // the constants of the device-side Gumbel step + its per-lane state buffers
+{
+    dev_gumbel_ = sim_kernel_ && cfg_.actor_use_gumbel;
+    if (dev_gumbel_) { // the constants of gumbel_zero.cpp:101,110 in the host's double arithmetic
+        const int m = cfg_.actor_gumbel_sample_size;
+        gum_.sample_size = m;
+        gum_.sigma_visit_c = cfg_.actor_gumbel_sigma_visit_c;
+        gum_.sigma_scale_c = cfg_.actor_gumbel_sigma_scale_c;
+        gum_.budget0 = static_cast<int>(std::max(1.0, std::floor(cfg_.actor_num_simulation / (std::log2(m) * m))));
+        for (int k = 0; k < 8; ++k) { gum_.next_budget[k] = static_cast<int>(std::floor(cfg_.actor_num_simulation / (std::log2(m) * (1 << k) / 2))); }
+        for (auto& L : lanes_) {
+            const size_t n = size_t(L->n) * (3 + kGumbelMaxSample);
+            if (!L->h_gum.alloc(n) || !L->d_gum.alloc(n)) { setError("worker: allocation failed (gumbel state)"); return MZ_ERR_DEVICE; }
+            memset(L->h_gum.p, 0, n * sizeof(int));
+            MZ_HIP(hipMemset(L->d_gum.p, 0, n * sizeof(int)));
+        }
+    }
+    return MZ_OK;
+}
+
 int Worker::uploadRoots(Lane& L)
 {
     const int g0 = L.g0;
     if (sim_mz_) { // MuZero: what the initial inference and the root expansion need from the host engine
-        const int fw = games_[0].env->featureWords(), LW = (A_ + 63) / 64;
+        const int fw = sim_root_host_ ? 1 : games_[0].env->featureWords(), LW = (A_ + 63) / 64;
         threads_->parallelFor(L.n, [this, &L, g0, fw, LW](int j) {
             Game& gm = games_[g0 + j];
-            gm.env->featureBits(0, L.h_rootfeat.p + size_t(j) * fw);
+            if (!sim_root_host_) { gm.env->featureBits(0, L.h_rootfeat.p + size_t(j) * fw); }
             gm.env->legalMask(gm.legal.data());
             for (int w = 0; w < LW; ++w) { L.h_rootlegal.p[size_t(j) * LW + w] = 0; }
             for (int a = 0; a < A_; ++a) { if (gm.legal[a]) { L.h_rootlegal.p[size_t(j) * LW + (a >> 6)] |= 1ull << (a & 63); } }
@@ -972,7 +984,8 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
     if (pending_) {
         double t1 = t0, te = t0;
         int rc = MZ_OK;
-        if (!resident_ && !sim_mz_) { // resident: candidates + expand + backup were queued on the device right behind the heads (phase2Resident)
+        if (!resident_ && (!sim_mz_ || root_host_pending_)) { // resident / simulation kernel: candidates + expand + backup already ran on the device
+            root_host_pending_ = false;
             if (use_signal_) { int rcw = L.pool.waitSignal(L.signal_seq); if (rcw) { return rcw; } }
             else { MZ_HIP(hipStreamSynchronize(L.stream)); } // network outputs of this lane
             t1 = nowMs();
@@ -1226,21 +1239,38 @@ int Worker::runCyclesSim(int n)
         sim_post_ = sims_done_ + 1;
         const bool root_expansion = pending_ && (sim_post_ == 1), done = pending_ && (sim_post_ == n_ + 1);
         const bool host_gumbel = dev_gumbel_ && pending_; // the host runs this cycle's Gumbel step itself: state down, step, state up
+        // muzero_atari: the root's 96x96 representation is not part of the kernel; simulation 0 of a move runs as one lock-step cycle
+        // (select, host planes, stand-alone kernels) whose outputs the next phase1 expands on the host, the other n as one launch
+        const bool root_cycle = sim_root_host_ && (!pending_ || done);
         for (auto& L : lanes_) {
             int rc = MZ_OK;
             if (host_gumbel && (rc = syncGumbel(*L, false))) { return rc; }
-            if ((rc = phase1(*L, root_expansion, done, false))) { return rc; }
+            if ((rc = phase1(*L, root_expansion, done, root_cycle))) { return rc; }
             if (host_gumbel && (rc = syncGumbel(*L, true))) { return rc; }
             for (int j = 0; j < L->n; ++j) { L->h_rot.p[j] = static_cast<uint8_t>(games_[L->g0 + j].rot); }
         }
         if (pending_) { sims_done_ = done ? 0 : sim_post_; }
         const int sim0 = sims_done_;
+        if (root_cycle) {
+            for (auto& L : lanes_) {
+                int rc = phase2(*L);
+                if (rc) { return rc; }
+            }
+            flushDeferred();
+            root_host_pending_ = true;
+            pending_ = true;
+            stats_.cycles += 1;
+            stats_.leaf_evals += uint64_t(G_);
+            i += 1;
+            stats_.ms_total += nowMs() - t0;
+            continue;
+        }
         int batch = 1;
         // Cycles after this one join the launch while they need nothing from the host but RNG draws.  The cycle behind the root
         // expansion (sim index 1) needs the Dirichlet noise of the root children: its values only depend on the RNG stream and on
         // the NUMBER of root children = legal moves of the root position, which the host engine knows, so they are drawn here in the
         // reference's order ([noise][rotation] per actor, zero_actor.cpp:194-213 then :56) and applied by the kernel before simulation 1.
-        const bool device_noise = cfg_.actor_use_dirichlet_noise || (cfg_.actor_use_gumbel_noise && !sim_mz_); // the kernel applies either kind
+        const bool device_noise = cfg_.actor_use_dirichlet_noise || cfg_.actor_use_gumbel_noise; // the kernel applies either kind
         bool noise_in_batch = false;
         while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg && !device_noise)) {
             const bool noise_cycle = (sim0 + batch == 1) && noise_cfg;
@@ -1269,16 +1299,16 @@ int Worker::runCyclesSim(int n)
             if (noise_in_batch) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, L->stream)); }
             bool launched = false;
             MZ_HIP(hipEventRecord(L->ev0, L->stream));
+            GumbelView gv = gum_;
+            gv.state = L->d_gum.p;
+            const int noise_kind = cfg_.actor_use_dirichlet_noise ? 1 : 2;
             int rc = sim_mz_ ? L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
-                                                  games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, sim0, batch, &launched,
-                                                  noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon)
-                              : [&]() {
-                                    GumbelView gv = gum_;
-                                    gv.state = L->d_gum.p;
-                                    return L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched,
-                                                            noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon,
-                                                            cfg_.actor_use_dirichlet_noise ? 1 : 2, dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, host_gumbel);
-                                }();
+                                                  games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_reward.p, sim0, batch,
+                                                  &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
+                                                  dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, host_gumbel)
+                              : L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched,
+                                                 noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
+                                                 dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, host_gumbel);
             if (rc) { return rc; }
             if (!launched) { setError("worker: no simulation-kernel instance for this network"); return MZ_ERR_STATE; }
             MZ_HIP(hipEventRecord(L->ev1, L->stream));
@@ -1459,6 +1489,13 @@ int mz_env_feature_bits(const mz_env* e, int rotation, uint32_t* out)
 }
 
 int mz_sort_candidates(int device, const float* policy, int n, int* order_out) { return mz::sortCandidatesOnDevice(device, policy, n, order_out); }
+
+int mz_invert_values_device(int device, const float* values, int n, float* out)
+{
+    if (mz_device_count() < 1) { mz::setError("mz_invert_values_device: no GPU (libmzgpu has no CPU path)"); return MZ_ERR_DEVICE; }
+    if (!values || !out || n < 0) { mz::setError("mz_invert_values_device: bad arguments"); return MZ_ERR_ARG; }
+    return mz::invertValuesOnDevice(device, values, n, out);
+}
 
 int mz_godev_playout(int device, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots, uint32_t* feat_out,
                      uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out)

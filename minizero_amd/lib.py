@@ -139,6 +139,7 @@ def load():
         L.mz_env_feature_bits.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
         L.mz_godev_playout.argtypes = [C.c_int, C.c_int, C.c_float, ip, C.c_int, C.c_int, ip, C.POINTER(C.c_uint32), u8p, ip, fp, ip]
         L.mz_sort_candidates.argtypes = [C.c_int, fp, C.c_int, ip]
+        L.mz_invert_values_device.argtypes = [C.c_int, fp, C.c_int, fp]
     _LIB = L
     return L
 
@@ -438,6 +439,15 @@ def godev_playout(board_size, komi, actions, root_prefix, rots, device=0):
     _check(L, L.mz_godev_playout(device, board_size, komi, _i(acts), len(acts), root_prefix, _i(rots), feat.ctypes.data_as(C.POINTER(C.c_uint32)),
                                  legal.ctypes.data_as(C.POINTER(C.c_uint8)), _i(term), _f(ev), _i(pl)))
     return feat, legal, term, ev, pl
+
+
+def invert_values_device(values, device=0):
+    """invertValue (601-bin decode) of every element by the device function of the simulation kernel."""
+    L = load()
+    v = np.ascontiguousarray(values, np.float32)
+    out = np.zeros(len(v), np.float32)
+    _check(L, L.mz_invert_values_device(device, _f(v), len(v), _f(out)))
+    return out
 
 
 def sort_candidates(policy, device=0):

@@ -158,3 +158,17 @@ def test_muzero_atari_network(mz, oracle, name):
         assert same_bits(h2, oh2) and same_bits(l2, ol2) and same_bits(p2, op2) and same_bits(v2, ov2) and same_bits(r2, or2)
         assert np.abs(h2 - g[f"b{B}_rec_hidden_state"]).max() <= 1e-4 and np.abs(p2 - g[f"b{B}_rec_policy"]).max() <= 1e-4
         assert np.abs(v2 - onet.invert(g[f"b{B}_rec_value"])).max() <= 1e-3 and np.abs(r2 - onet.invert(g[f"b{B}_rec_reward"])).max() <= 1e-3
+
+
+def test_invert_value_on_device(mz):
+    """The device twin of invertValue (simulation kernel, muzero_atari) against the host function, which calls the same libm as the
+    reference (utils.h:102-108): bit-exact on a dense sweep of the 601-bin range and on random values."""
+    rng = np.random.default_rng(5)
+    v = np.concatenate([np.linspace(-300, 300, 200001, dtype=np.float32), rng.normal(0, 3, 200000).astype(np.float32),
+                        rng.uniform(-300, 300, 200000).astype(np.float32), np.array([0.0, -0.0, 1e-30, -1e-30, 300.0, -300.0], np.float32)])
+    dev = mz.invert_values_device(v)
+    L = mz.lib.load()
+    L.mz_invert_value.restype = __import__("ctypes").c_float
+    L.mz_invert_value.argtypes = [__import__("ctypes").c_float]
+    host = np.array([L.mz_invert_value(float(x)) for x in v[::7]], np.float32)
+    assert np.array_equal(dev[::7].view(np.uint32), host.view(np.uint32))

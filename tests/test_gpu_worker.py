@@ -243,3 +243,39 @@ def test_othello_full_games_to_the_end(mz, oracle):
     lines, olines, st = run_both(mz, oracle, conf, OTHELLO_ARGS, 5 * 62 * 3, threads=2, seed=11)
     check(lines, olines, 12)
     assert st["games"] >= 12
+
+
+ATARI_SMALL = ("env_game=atari:nn_type_name=muzero:actor_num_simulation=8:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+               "actor_use_gumbel_noise=true:actor_gumbel_sample_size=4:actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:"
+               "actor_mcts_reward_discount=0.997:atari_init_q=true:zero_actor_intermediate_sequence_length=6:learner_n_step_return=2:"
+               "learner_muzero_unrolling_step=1:env_atari_episode_length=20:zero_num_parallel_games=5")
+ATARI_ARGS = ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari")
+
+
+def test_atari_execution_modes_are_equivalent(mz):
+    """muzero_atari on the simulation kernel (root by a lock-step cycle with the stand-alone 96x96 representation kernels, simulations
+    1..n in one launch: dynamics trunk with 18 action planes, 601-bin value / reward heads + invertValue on the device, value-rescaled
+    PUCT, Gumbel root logic, serial backup with the value-bound multiset) against the lock-step kernels with host hops."""
+    total = 9 * 60
+    lockstep = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=false", ATARI_ARGS, [total], total)
+    sim_whole = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true", ATARI_ARGS, [total], total)
+    sim_chunks = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true", ATARI_ARGS, [1, 2, 5, 9, 3, 40, 10, 8], total)
+    assert len(lockstep) >= 10
+    assert lockstep == sim_whole
+    assert lockstep == sim_chunks
+
+
+def test_go_muzero_gumbel_execution_modes_are_equivalent(mz, oracle):
+    """MuZero board game with a Gumbel root: device Gumbel step + noise on the logits inside sim_kernel_mz vs lock-step vs oracle."""
+    conf = ("env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=12:zero_num_parallel_games=5:actor_use_dirichlet_noise=false:"
+            "actor_use_gumbel=true:actor_use_gumbel_noise=true:actor_gumbel_sample_size=8")
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "muzero")
+    total = 13 * 170
+    lockstep = _lines_of(mz, conf + ":mz_sim_kernel=false", args, [total], total)
+    sim_whole = _lines_of(mz, conf + ":mz_sim_kernel=true", args, [total], total)
+    sim_chunks = _lines_of(mz, conf + ":mz_sim_kernel=true", args, [1, 2, 5, 13, 3, 40, 12, 14], total)
+    assert len(lockstep) >= 5
+    assert lockstep == sim_whole
+    assert lockstep == sim_chunks
+    lines, olines, _ = run_both(mz, oracle, conf, args, 13 * 170, threads=2, seed=4)
+    check(lines, olines, 4)
