@@ -4,6 +4,10 @@
 #include "net_dev.h"
 #include "net_body.h"
 
+#ifndef MZ_HPROF
+#define MZ_HPROF(k) // experiment hook (sim.hip -DMZ_SIM_HPROF): time stamps inside the 601-bin heads
+#endif
+
 namespace mz {
 
 struct DiscreteParams { const float *conv_w, *conv_b, *fc1_wT, *fc1_b, *fc2_wT, *fc2_b; int hc, hidden, size; };
@@ -18,62 +22,124 @@ struct AtariHeadParams {
 // side by side on the two halves.  Both halves pass the same barriers; `active` = false: barriers only.  Every sum is the reference's
 // sequential f32 chain (dotChain: the weights of 16 steps are loaded ahead of the 16 dependent fmas); the 601 quotients of the
 // expectation are independent and computed by all threads, only the two index-ordered sums are serial.
+// s = ((x[0] + x[1]) + x[2]) + ... in index order, by ONE wave: lane l holds elements [l * VPL, (l + 1) * VPL) in registers and the running
+// sum is handed from lane to lane (v_readlane).  The same n - 1 dependent adds as a scalar loop, but without an LDS round trip per
+// element (one lane reading x[i] and adding, 601 times, cost 33 us per sum: the 601-bin heads have four such sums).
+__device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
+{
+    constexpr int VPL = 16;
+    if (n > 64 * VPL) { // not reached by the supported head sizes: plain loop
+        float s = 0.0f;
+        for (int i = 0; i < n; ++i) { s += x[i]; }
+        return s;
+    }
+    const int vpl = (n + 63) / 64;
+    float v[VPL]; // slots beyond the lane's elements hold +0: adding +0 never changes a sum that is not -0, and these sums never are
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) { const int i = lane * vpl + k; v[k] = (k < vpl && i < n) ? x[i] : 0.0f; }
+    float acc = 0.0f;
+    const int lanes = (n + vpl - 1) / vpl;
+    for (int l = 0; l < lanes; ++l) { // straight-line body: 16 dependent adds in every lane, lane l's result is the one that counts
+        float a = acc;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { a = a + v[k]; }
+        acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), l));
+    }
+    return acc;
+}
+
 template <int NT>
 __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool active, const float* xs, int C, int P, float* f, float* h1, float* lg, float* red,
                              float* out, int t)
 {
     const int lane = t & 63, wave = t >> 6;
+    constexpr int K = NT >= 512 ? 2 : 3; // outputs per thread and pass: 601 bins / 612 conv outputs in one pass of the half
     if (active) {
-        for (int i = t; i < d.hc * P; i += NT) {
-            const int j = i / P, p = i - j * P;
-            const float v = dotChain<16>(xs + p, P, d.conv_w + j * C, 1, C) + d.conv_b[j];
-            f[i] = v > 0.0f ? v : 0.0f;
+        const int n0 = d.hc * P;
+        for (int i0 = t; i0 < n0; i0 += NT * K) {
+            const float* xk[K];
+            const float* wk[K];
+            int idx[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                idx[k] = i0 + k * NT < n0 ? i0 + k * NT : n0 - 1; // lanes beyond the end redo the last output and drop it
+                const int j = idx[k] / P, p = idx[k] - j * P;
+                xk[k] = xs + p;
+                wk[k] = d.conv_w + j * C;
+            }
+            float acc[K];
+            dotChainK<32, K>(xk, P, wk, 1, C, acc);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (i0 + k * NT < n0) { const float v = acc[k] + d.conv_b[idx[k] / P]; f[idx[k]] = v > 0.0f ? v : 0.0f; }
+            }
         }
     }
     __syncthreads();
+    MZ_HPROF(1);
     if (active) {
         const int n1 = d.hc * P;
         for (int o = t; o < d.hidden; o += NT) {
-            const float v = dotChain<16>(f, 1, d.fc1_wT + o, d.hidden, n1) + d.fc1_b[o];
+            const float v = dotChain<128>(f, 1, d.fc1_wT + o, d.hidden, n1) + d.fc1_b[o]; // one output per thread: 128 weights in flight
             h1[o] = v > 0.0f ? v : 0.0f;
         }
     }
     __syncthreads();
+    MZ_HPROF(2);
     float m = -3.4e38f;
     if (active) {
-        for (int o = t; o < d.size; o += NT) {
-            const float v = dotChain<16>(h1, 1, d.fc2_wT + o, d.size, d.hidden) + d.fc2_b[o];
-            lg[o] = v;
-            m = v > m ? v : m;
+        for (int o0 = t; o0 < d.size; o0 += NT * K) {
+            const float* xk[K];
+            const float* wk[K];
+            int idx[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                idx[k] = o0 + k * NT < d.size ? o0 + k * NT : d.size - 1;
+                xk[k] = h1;
+                wk[k] = d.fc2_wT + idx[k];
+            }
+            float acc[K];
+            dotChainK<32, K>(xk, 1, wk, d.size, d.hidden, acc);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (o0 + k * NT < d.size) {
+                    const float v = acc[k] + d.fc2_b[idx[k]];
+                    lg[idx[k]] = v;
+                    m = v > m ? v : m;
+                }
+            }
         }
         for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
         if (lane == 0) { red[wave] = m; }
     }
     __syncthreads();
+    MZ_HPROF(3);
     if (active) {
         m = red[0];
         for (int w = 1; w < NT / 64; ++w) { m = red[w] > m ? red[w] : m; }
         for (int o = t; o < d.size; o += NT) { lg[o] = mz_expf(lg[o] - m); }
     }
     __syncthreads();
-    if (active && t == 0) { // index-ordered sum of the exponentials (ref muzero_network.h:157-162)
-        float s = 0.0f;
-        for (int i = 0; i < d.size; ++i) { s += lg[i]; }
-        red[8] = s;
+    MZ_HPROF(4);
+    if (active && wave == 0) { // index-ordered sum of the exponentials (ref muzero_network.h:157-162)
+        const float s = orderedSumWave(lg, d.size, lane);
+        if (lane == 0) { red[8] = s; }
     }
     __syncthreads();
+    MZ_HPROF(5);
     if (active) {
         const float s = red[8];
         const int start_value = -d.size / 2;
         for (int o = t; o < d.size; o += NT) { lg[o] = (lg[o] / s) * static_cast<float>(start_value + o); } // value * start_value++ (int -> float, exact)
     }
     __syncthreads();
-    if (active && t == 0) { // accumulate(sum + value * start_value++), in index order
-        float e = 0.0f;
-        for (int i = 0; i < d.size; ++i) { e = e + lg[i]; }
-        *out = e;
+    MZ_HPROF(6);
+    if (active && wave == 0) { // accumulate(sum + value * start_value++), in index order
+        const float e = orderedSumWave(lg, d.size, lane);
+        if (lane == 0) { *out = e; }
     }
     __syncthreads();
+    MZ_HPROF(7);
 }
 
 // invertValue (ref utils/utils.h:102-108) on the device: the reference evaluates the inner expression in double (C `fabs` / `sqrt` on a
@@ -150,6 +216,7 @@ __device__ __forceinline__ void atariHeadsBody(const float* __restrict__ xg, con
     }
     // half 0: reward head on the unscaled state (ref muzero_atari_network.py: dynamics -> reward before the rescale);
     // half 1: value head on the rescaled state
+    MZ_HPROF(0);
     float* out = half == 0 ? reward + b : value + b;
     discreteHead<NTH>(half == 0 ? hp.reward : hp.value, half == 0 ? do_reward != 0 : true, half == 0 ? xr : xs, C, P, f, h1, lg, red, out, t);
     if (invert && t == 0 && (half == 1 || do_reward)) { *out = invertValueDev(*out); }

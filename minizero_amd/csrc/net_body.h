@@ -341,10 +341,8 @@ struct HeadParams {
 // acc = fmaf(x[i * xs], w[i * ws], acc) for i = 0 .. n-1 IN ORDER (one f32 chain), with the weights of CH steps loaded
 // ahead of the CH dependent fmas: the chain is latency-bound, and with the load issued next to each fma every step paid an L2 trip
 template <int CH>
-__device__ __forceinline__ float dotChain(const float* __restrict__ x, int xs, const float* __restrict__ w, size_t ws, int n)
+__device__ __forceinline__ void dotChainPart(float& acc, int& i0, const float* __restrict__ x, int xs, const float* __restrict__ w, size_t ws, int n)
 {
-    float acc = 0.0f;
-    int i0 = 0;
     for (; i0 + CH <= n; i0 += CH) {
         float wv[CH];
 #pragma unroll
@@ -352,8 +350,44 @@ __device__ __forceinline__ float dotChain(const float* __restrict__ x, int xs, c
 #pragma unroll
         for (int k = 0; k < CH; ++k) { acc = __builtin_fmaf(x[(i0 + k) * xs], wv[k], acc); }
     }
+}
+template <int CH>
+__device__ __forceinline__ float dotChain(const float* __restrict__ x, int xs, const float* __restrict__ w, size_t ws, int n)
+{
+    float acc = 0.0f;
+    int i0 = 0;
+    dotChainPart<CH>(acc, i0, x, xs, w, ws, n);
+    if (CH > 16) { dotChainPart<16>(acc, i0, x, xs, w, ws, n); } // the tail of a deep prefetch in shallower groups, not one load at a time
+    if (CH > 4) { dotChainPart<4>(acc, i0, x, xs, w, ws, n); }
     for (; i0 < n; ++i0) { acc = __builtin_fmaf(x[i0 * xs], w[size_t(i0) * ws], acc); }
     return acc;
+}
+
+// K independent chains per thread (each one the same ordered f32 chain as dotChain): the weights of CH steps of all K chains are in flight
+// together and the K dependent fma sequences interleave, so a latency-bound thread with several outputs finishes them in the time of one
+template <int CH, int K>
+__device__ __forceinline__ void dotChainK(const float* const (&x)[K], int xs, const float* const (&w)[K], size_t ws, int n, float (&acc)[K])
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k) { acc[k] = 0.0f; }
+    int i0 = 0;
+    for (; i0 + CH <= n; i0 += CH) {
+        float wv[K][CH];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { wv[k][c] = w[k][size_t(i0 + c) * ws]; }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) { acc[k] = __builtin_fmaf(x[k][(i0 + c) * xs], wv[k][c], acc[k]); }
+        }
+    }
+    for (; i0 < n; ++i0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { acc[k] = __builtin_fmaf(x[k][i0 * xs], w[k][size_t(i0) * ws], acc[k]); }
+    }
 }
 
 // the body of heads_kernel for sample `b`, run by NT threads (a multiple of 64, >= 128); `sm` = (C*P + PC*P + P + VH + A + 16) floats of LDS

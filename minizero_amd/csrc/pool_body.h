@@ -437,21 +437,37 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
         }
         return;
     }
-    // with value rescaling the value-bound multiset is updated node by node: a serial chain, done by lane 0
-    if (lane != 0) { return; }
-    int bsize = 0;
-    float* bkey = lds;                                     // value-bound multiset, LDS copy (lane 0 only)
+    // with value rescaling the value-bound multiset (std::map<float,int> of the reference, kept as an unordered array) is updated node by
+    // node: a serial chain over the path, but every step is wave-cooperative — the two key searches are ballots over 64 entries at a
+    // time (a 50-simulation Atari search holds hundreds of distinct values), the copy in / out of LDS and the final min / max too
+    float* bkey = lds;                                     // value-bound multiset, LDS copy
     int* bcnt = reinterpret_cast<int*>(lds + v.bound_cap);
-    if (v.value_rescale) {
-        bsize = v.bound_size[g];
-        for (int j = 0; j < bsize; ++j) { bkey[j] = v.bound_key[size_t(g) * v.bound_cap + j]; bcnt[j] = v.bound_cnt[size_t(g) * v.bound_cap + j]; }
-    }
+    int bsize = v.bound_size[g];
+    for (int j = lane; j < bsize; j += 64) { bkey[j] = v.bound_key[size_t(g) * v.bound_cap + j]; bcnt[j] = v.bound_cnt[size_t(g) * v.bound_cap + j]; }
     const float val = value_in[g], rew = reward_in[g];
-    v.value[base + leaf] = val;
-    v.rec[base + leaf].reward = rew;
-    if (len >= 2 && v.rec[base + leaf].count == 0.0f && (static_cast<unsigned>(v.rec[base + path[len - 2]].players) >> 16) != 0xFFFFu) {
-        v.rec[base + path[len - 2]].players += 1 << 16;
+    if (lane == 0) {
+        v.value[base + leaf] = val;
+        v.rec[base + leaf].reward = rew;
+        if (len >= 2 && v.rec[base + leaf].count == 0.0f && (static_cast<unsigned>(v.rec[base + path[len - 2]].players) >> 16) != 0xFFFFu) {
+            v.rec[base + path[len - 2]].players += 1 << 16;
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    auto find = [&](float key) { // index of the entry with this key (f32 ==: -0 and +0 are one key), -1 if none; wave-uniform
+        for (int b0 = 0; b0 < bsize; b0 += 64) {
+            const int j = b0 + lane;
+            const unsigned long long m = __ballot(j < bsize && bkey[j] == key);
+            if (m) { return b0 + static_cast<int>(__builtin_ctzll(m)); }
+        }
+        return -1;
+    };
+    auto sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     float updated = val;
     for (int i = len - 1; i >= 0; --i) {
         NodeRec* n = v.rec + base + path[i];
@@ -461,33 +477,50 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
         // MCTSNode::add(value, 1.0f) (ref mcts.cpp:20-28); count + 1 <= 0 cannot happen for count >= 0
         cnt += 1.0f;
         mean += 1.0f * (updated - mean) / cnt;
-        n->mean = mean;
-        n->count = cnt;
-        if (v.value_rescale) { // updateTreeValueBound(old, new) (ref mcts.cpp:219-228): std::map<float,int> as an unordered array
+        if (lane == 0) {
+            n->mean = mean;
+            n->count = cnt;
+        }
+        { // updateTreeValueBound(old, new) (ref mcts.cpp:219-228)
             const float new_mean = r + v.gamma * mean;
-            for (int j = 0; j < bsize; ++j) {
-                if (bkey[j] == old_mean) {
-                    if (--bcnt[j] == 0) { --bsize; bkey[j] = bkey[bsize]; bcnt[j] = bcnt[bsize]; }
-                    break;
+            const int jo = find(old_mean);
+            if (jo >= 0) {
+                const int c = bcnt[jo] - 1;
+                if (c == 0) { --bsize; }
+                if (lane == 0) {
+                    if (c == 0) { bkey[jo] = bkey[bsize]; bcnt[jo] = bcnt[bsize]; } else { bcnt[jo] = c; }
                 }
+                sync();
             }
-            int j = 0;
-            for (; j < bsize; ++j) { if (bkey[j] == new_mean) { ++bcnt[j]; break; } }
-            if (j == bsize && bsize < v.bound_cap) { bkey[bsize] = new_mean; bcnt[bsize] = 1; ++bsize; }
+            const int jn = find(new_mean);
+            if (jn >= 0) {
+                if (lane == 0) { ++bcnt[jn]; }
+            } else if (bsize < v.bound_cap) {
+                if (lane == 0) { bkey[bsize] = new_mean; bcnt[bsize] = 1; }
+                ++bsize;
+            }
+            sync();
         }
         updated = r + v.gamma * updated;
     }
-    if (v.value_rescale) {
-        float lo = 0.0f, hi = 0.0f;
-        for (int j = 0; j < bsize; ++j) {
+    {
+        float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+        for (int j = lane; j < bsize; j += 64) {
             v.bound_key[size_t(g) * v.bound_cap + j] = bkey[j];
             v.bound_cnt[size_t(g) * v.bound_cap + j] = bcnt[j];
-            if (j == 0 || bkey[j] < lo) { lo = bkey[j]; }
-            if (j == 0 || bkey[j] > hi) { hi = bkey[j]; }
+            lo = bkey[j] < lo ? bkey[j] : lo;
+            hi = bkey[j] > hi ? bkey[j] : hi;
         }
-        v.bound_size[g] = bsize;
-        v.bound_lo[g] = lo;
-        v.bound_hi[g] = hi;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if (lane == 0) {
+            v.bound_size[g] = bsize;
+            v.bound_lo[g] = bsize > 0 ? lo : 0.0f;
+            v.bound_hi[g] = bsize > 0 ? hi : 0.0f;
+        }
     }
 }
 

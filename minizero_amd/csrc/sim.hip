@@ -20,6 +20,18 @@ __shared__ int s_tp_idx;
     } while (0)
 #endif
 #include "net_body.h"
+#ifdef MZ_SIM_HPROF // experiment: where the time of the in-kernel 601-bin heads goes (game 0)
+__device__ unsigned long long g_hp[16];
+__shared__ unsigned long long s_hp_prev;
+#define MZ_HPROF(k)                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                                    \
+            const unsigned long long t_ = wall_clock64();                                             \
+            if ((k) > 0) { g_hp[(k)] += t_ - s_hp_prev; } else { g_hp[15] += 1; }                     \
+            s_hp_prev = t_;                                                                           \
+        }                                                                                             \
+    } while (0)
+#endif
 #include "net_atari_body.h"
 #include "pool_body.h"
 #include "go_body.h"
@@ -352,10 +364,14 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
     float* head_scratch = reinterpret_cast<float*>(rcp_w + rcp_n);
     const PoolView v = ldc(&a->pv);
+    unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr; // MZ_SIM_PROF=1: [select, tower, heads, cand+expand] ticks + sims
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (prof) { t0 = wall_clock64(); }
         if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds); }
         __syncthreads();
+        if (prof) { t1 = wall_clock64(); }
         const float* xt;
         if (slot == 0) { // initial inference: representation trunk on the root planes (board games; muzero_atari roots never come here)
             xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
@@ -368,10 +384,16 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             xt = towerBody<H, W, CDYN_PAD, CPAD>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action, a->action_planes);
         }
         __syncthreads();
+        if (prof) { t2 = wall_clock64(); }
         simMzHeads(a, slot, g, tid, tiles, head_scratch, xt, planeStride(H, W), W + 2);
         __syncthreads();
+        if (prof) { t3 = wall_clock64(); }
         if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles); }
         __syncthreads();
+        if (prof && tid == 0) {
+            const unsigned long long t4 = wall_clock64();
+            prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
+        }
     }
 }
 
@@ -415,6 +437,16 @@ static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, in
 
 void Net::dumpSimProf()
 {
+#ifdef MZ_SIM_HPROF
+    {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hp), sizeof(h)) == hipSuccess && h[15]) {
+            fprintf(stderr, "[mz sim hprof] us per phase of discreteHead (game 0, avg over %llu calls):", h[15]);
+            for (int i = 1; i < 10; ++i) { fprintf(stderr, " %.2f", double(h[i]) / double(h[15]) * 0.01); }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 #ifdef MZ_SIM_TPROF
     {
         unsigned long long h[64];
@@ -581,6 +613,13 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.use_gumbel = gum ? 1 : 0;
     if (gum) { a.gum = *gum; }
     a.start = d_start;
+    if (getenv("MZ_SIM_PROF")) {
+        if (sim_prof_.n == 0) {
+            if (!sim_prof_.alloc(size_t(pool.v_.games) * 8)) { setError("hipMalloc of the profile buffer failed"); return MZ_ERR_DEVICE; }
+            MZ_HIP(hipMemset(sim_prof_.p, 0, sim_prof_.n * sizeof(unsigned long long)));
+        }
+        a.prof = sim_prof_.p;
+    }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
     const int cmax = std::max(std::max(c0, cd), C);
     const size_t tile_bytes = size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float);
