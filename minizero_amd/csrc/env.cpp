@@ -122,6 +122,19 @@ public:
             out[27 + p] = turn_ == 2 ? 1.0f : 0.0f;
         }
     }
+    bool hasDeviceTwin() const override { return true; }
+    int deviceKind() const override { return 2; }
+    void exportDeviceRoot(void* dst) const override // the fields of GoRootSnapshot the TicTacToe device engine reads (go_body.h tttLeafBody)
+    {
+        GoRootSnapshot& s = *static_cast<GoRootSnapshot*>(dst);
+        s.stones[0][0] = m_[0];
+        s.stones[1][0] = m_[1];
+        s.hash = 0;
+        s.hist_len = 0;
+        s.turn = turn_;
+        s.nmoves = static_cast<int32_t>(action_ids_.size());
+        s.passes = 0;
+    }
     int numInputChannels() const override { return 4; }
     int boardSize() const override { return 3; }
     int policySize() const override { return 9; }

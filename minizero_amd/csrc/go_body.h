@@ -474,6 +474,58 @@ __device__ __forceinline__ void othLeafBody(const GoDevView& v, const PoolView& 
     }
 }
 
+// ---- TicTacToe (ref environment/tictactoe/tictactoe.cpp:19-97): two 9-bit boards per slot; the planes are Othello's (own, opponent,
+// black to move, white to move); no pass, terminal = a complete line or a full board.
+__device__ __forceinline__ void tttLeafBody(const GoDevView& v, const PoolView& pv, int rot, int slot, int g, int lane)
+{
+    const int P = 9, MD = pv.max_depth;
+    const int len = pv.path_len[g];
+    const int* path = pv.path + size_t(g) * MD;
+    const int* pact = pv.path_action + size_t(g) * MD;
+    const int depth = len - 1;
+    const GoRootSnapshot& S = v.snap[g];
+    const int root_turn = S.turn;
+    const size_t sb = size_t(g) * v.slots;
+    const int* hs = pv.hslot + size_t(g) * pv.cap;
+    const int src = depth == 0 ? 0 : hs[path[len - 2]];
+    unsigned s[2] = {static_cast<unsigned>(v.stones[((sb + src) * 2 + 0) * v.W]), static_cast<unsigned>(v.stones[((sb + src) * 2 + 1) * v.W])};
+    const int t = (depth & 1) ? 3 - root_turn : root_turn; // the player to move at the leaf
+    if (depth >= 1) {
+        s[2 - t] |= 1u << pact[len - 1]; // moved by the other player
+        if (lane == 0) {
+            v.stones[((sb + slot) * 2 + 0) * v.W] = s[0];
+            v.stones[((sb + slot) * 2 + 1) * v.W] = s[1];
+        }
+    }
+    int winner = 0;
+    {
+        const unsigned lines[8] = {0007, 0070, 0700, 0111, 0222, 0444, 0421, 0124};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (winner == 0 && (s[0] & lines[i]) == lines[i]) { winner = 1; }
+            if (winner == 0 && (s[1] & lines[i]) == lines[i]) { winner = 2; }
+        }
+    }
+    const bool terminal = winner != 0 || (s[0] | s[1]) == 0777u;
+    if (lane == 0) { v.legal[size_t(g) * v.LW] = terminal ? 0ull : static_cast<unsigned long long>(~(s[0] | s[1]) & 0777u); }
+    {
+        const uint16_t* map = v.inv + size_t(rot) * P;
+        const int q = lane < P ? map[lane] : 0;
+        const unsigned own = static_cast<unsigned>(__ballot(lane < P && ((s[t - 1] >> q) & 1)));
+        const unsigned opp = static_cast<unsigned>(__ballot(lane < P && ((s[2 - t] >> q) & 1)));
+        uint32_t* out = v.feat + size_t(g) * 4 * v.W32;
+        if (lane == 0) { out[0] = own; }
+        if (lane == 1) { out[v.W32] = opp; }
+        if (lane == 2) { out[2 * v.W32] = t == 1 ? 0777u : 0u; }
+        if (lane == 3) { out[3 * v.W32] = t == 2 ? 0777u : 0u; }
+    }
+    if (lane == 0) {
+        v.leaf_player[g] = t;
+        v.terminal[g] = terminal ? 1 : 0;
+        v.eval[g] = winner == 1 ? 1.0f : (winner == 2 ? -1.0f : 0.0f);
+    }
+}
+
 // order `k` candidates in cs[] like the reference's std::sort(policy descending): result in out[]
 __device__ void orderCandidates(Cand* cs, Cand* out, int* stack, int k, int lane, int* err)
 {

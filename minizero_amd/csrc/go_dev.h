@@ -32,7 +32,7 @@ struct RotPack { uint32_t w[kRotPackGames / 10]; }; // per-game feature rotation
 inline void rotPackSet(RotPack& r, int g, int rot) { r.w[g / 10] = (r.w[g / 10] & ~(7u << (3 * (g % 10)))) | (uint32_t(rot) << (3 * (g % 10))); }
 
 struct GoDevView {
-    int kind;                  // 0: Go, 1: Othello (two bitboards + pass count per slot, no hash / group ids; same outputs)
+    int kind;                  // 0: Go, 1: Othello (two bitboards + pass count per slot, no hash / group ids; same outputs), 2: TicTacToe
     int channels;              // feature planes of the game (Go 18, Othello 4)
     int games, n, P, W, A, slots, Ppad, W32, LW;
     float komi;
@@ -53,7 +53,7 @@ struct GoDevView {
 
 class GoDevice {
 public:
-    // kind 0: Go (keys = Zobrist table [2][P]); kind 1: Othello (board_n <= 8, keys unused)
+    // kind 0: Go (keys = Zobrist table [2][P]); kind 1: Othello (board_n <= 8, keys unused); kind 2: TicTacToe (3x3, 9 actions)
     int init(int device, int games, int board_n, float komi, int action_size, int slots, int max_depth, hipStream_t stream, const int* const inv[8],
              const int* const fwd[8], const uint64_t* keys, int kind = 0);
     GoRootSnapshot* hostSnap(int g) { return h_snap_.p + g; }

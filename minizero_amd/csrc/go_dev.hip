@@ -32,6 +32,11 @@ __global__ __launch_bounds__(64) void go_leaf_kernel(GoDevView v, PoolView pv, R
     goLeafBody<CPL>(v, pv, rotOf(rp, blockIdx.x), slot, blockIdx.x, threadIdx.x, smem);
 }
 
+__global__ __launch_bounds__(64) void ttt_leaf_kernel(GoDevView v, PoolView pv, RotPack rp, int slot)
+{
+    tttLeafBody(v, pv, rotOf(rp, blockIdx.x), slot, blockIdx.x, threadIdx.x);
+}
+
 __global__ __launch_bounds__(64) void oth_leaf_kernel(GoDevView v, PoolView pv, RotPack rp, int slot)
 {
     othLeafBody(v, pv, rotOf(rp, blockIdx.x), slot, blockIdx.x, threadIdx.x);
@@ -68,7 +73,8 @@ int GoDevice::init(int device, int games, int board_n, float komi, int action_si
                    const int* const fwd[8], const uint64_t* keys, int kind)
 {
     if (kind == 1 && board_n > 8) { setError("GoDevice: Othello boards up to 8x8"); return MZ_ERR_ARG; }
-    if (board_n < 2 || board_n > kGoMaxN || games < 1 || games > kRotPackGames || action_size != board_n * board_n + 1) {
+    if (kind == 2 && (board_n != 3 || action_size != 9)) { setError("GoDevice: TicTacToe is 3x3 with 9 actions"); return MZ_ERR_ARG; }
+    if (board_n < 2 || board_n > kGoMaxN || games < 1 || games > kRotPackGames || action_size != board_n * board_n + (kind == 2 ? 0 : 1)) {
         setError("GoDevice: unsupported shape (board %d, %d games, %d actions)", board_n, games, action_size);
         return MZ_ERR_ARG;
     }
@@ -77,7 +83,7 @@ int GoDevice::init(int device, int games, int board_n, float komi, int action_si
     max_depth_ = max_depth;
     MZ_HIP(hipSetDevice(device));
     GoDevView& v = v_;
-    v.kind = kind; v.channels = kind == 1 ? 4 : 18;
+    v.kind = kind; v.channels = kind == 0 ? 18 : 4;
     v.games = games; v.n = board_n; v.P = board_n * board_n; v.W = (v.P + 63) / 64; v.A = action_size; v.slots = slots;
     v.Ppad = 64 * v.W; v.W32 = (v.P + 31) / 32; v.LW = (v.A + 63) / 64; v.komi = komi;
     const size_t GS = size_t(games) * slots;
@@ -113,6 +119,11 @@ int GoDevice::uploadRoots()
 int GoDevice::leafAsync(const PoolView& pv, const RotPack& rot, int slot)
 {
     if (slot < 0 || slot >= v_.slots) { setError("GoDevice::leafAsync: slot %d out of range", slot); return MZ_ERR_ARG; }
+    if (v_.kind == 2) {
+        hipLaunchKernelGGL(ttt_leaf_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, pv, rot, slot);
+        MZ_HIP(hipGetLastError());
+        return MZ_OK;
+    }
     if (v_.kind == 1) {
         hipLaunchKernelGGL(oth_leaf_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, pv, rot, slot);
         MZ_HIP(hipGetLastError());

@@ -122,7 +122,8 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
         a->prof[size_t(g) * 8 + 6] += pv.path_len[g];
     }
     const GoDevView gv = ldc(&a->gv);
-    if constexpr (CPL == 0) { othLeafBody(gv, pv, rot, slot, g, lane); } // CPL 0: Othello (go_body.h)
+    if constexpr (CPL == -1) { tttLeafBody(gv, pv, rot, slot, g, lane); } // CPL -1: TicTacToe, 0: Othello (go_body.h)
+    else if constexpr (CPL == 0) { othLeafBody(gv, pv, rot, slot, g, lane); }
     else { goLeafBody<CPL>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles)); }
 }
 
@@ -433,7 +434,8 @@ static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, in
     X(9, 9, 20, 64, 2)  /* 9x9 Go, 64 channels (BASELINE configs[1]) */ \
     X(9, 9, 20, 8, 2)   /* small 9x9 test nets */ \
     X(8, 8, 4, 64, 0)   /* 8x8 Othello, 64 channels (BASELINE configs[2]); CPL 0 = the Othello rules */ \
-    X(8, 8, 4, 8, 0)    /* small 8x8 Othello test nets */
+    X(8, 8, 4, 8, 0)    /* small 8x8 Othello test nets */ \
+    X(3, 3, 4, 16, -1)  /* TicTacToe, 16 channels (BASELINE configs[0]); CPL -1 = the TicTacToe rules */
 
 void Net::dumpSimProf()
 {
@@ -489,7 +491,7 @@ bool Net::hasSimKernel(int board_n, int env_kind) const
     if (!makeTowerArgs(repr_, true, true, &ta, &c0)) { return false; }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
 #define MZ_SIM_HAS(h, w, cin0, cpad, cpl) \
-    if (H == h && W == w && c0 == cin0 && C == cpad && board_n == h && (env_kind == 1 ? 0 : (h * w + 63) / 64) == cpl) { return true; }
+    if (H == h && W == w && c0 == cin0 && C == cpad && board_n == h && (env_kind == 2 ? -1 : env_kind == 1 ? 0 : (h * w + 63) / 64) == cpl) { return true; }
     MZ_SIM_CASES(MZ_SIM_HAS)
 #undef MZ_SIM_HAS
     return false;
@@ -549,7 +551,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
         sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
     }
 #define MZ_SIM_LAUNCH(h, w, cin0, cpad, cpl) \
-    if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && (gv.kind == 1 ? 0 : gv.W) == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
+    if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && (gv.kind == 2 ? -1 : gv.kind == 1 ? 0 : gv.W) == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
     MZ_SIM_CASES(MZ_SIM_LAUNCH)
 #undef MZ_SIM_LAUNCH
     return MZ_OK;

@@ -279,3 +279,17 @@ def test_go_muzero_gumbel_execution_modes_are_equivalent(mz, oracle):
     assert lockstep == sim_chunks
     lines, olines, _ = run_both(mz, oracle, conf, args, 13 * 170, threads=2, seed=4)
     check(lines, olines, 4)
+
+
+def test_tictactoe_execution_modes_are_equivalent(mz):
+    """TicTacToe's device rules (go_body.h tttLeafBody) in the lock-step kernels and in the simulation kernel against the host engine."""
+    conf = "env_game=tictactoe:actor_num_simulation=16:zero_num_parallel_games=5"
+    total = 17 * 60
+    host = _lines_of(mz, conf + ":mz_device_env=false", C1, [total], total)
+    resident = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=false", C1, [7, 1, 30], total)
+    sim_whole = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", C1, [total], total)
+    sim_chunks = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", C1, [1, 2, 5, 17, 3, 40, 16, 18], total)
+    assert len(host) >= 30
+    assert host == resident
+    assert host == sim_whole
+    assert host == sim_chunks
