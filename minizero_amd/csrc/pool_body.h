@@ -128,8 +128,28 @@ __device__ __forceinline__ LevelEval evalChild(const PoolView& v, const NodeRec&
 // num_children, count) through shuffles — a single dependent memory round trip per level.
 // rcp: the reciprocal table RN64(1/i) — v.rcp_tab (global) or an LDS copy of it (the simulation kernel: the table lookup is on the
 // per-level critical path, right behind the children records)
-template <class RcpPtr>
-__device__ __forceinline__ void selectBody(const PoolView& v, const int* __restrict__ start, int g, int lane, RcpPtr rcp)
+// Path speculation (simulation kernel only; `spec` = LDS words, nullptr: off).  A deep principal variation is walked again by almost every
+// simulation, one dependent level (~1 800 cycles of a single wave's instruction stream) after the other, and the launch lasts as long as
+// its deepest game.  The walk remembers, per level of the previous path, the node, its children block and its visit count after that
+// simulation's backup (nothing else can have changed it); while the new walk is on the previous path, 8 lanes per level evaluate the next
+// 8 predicted levels in ONE pass of the same arithmetic (per-lane parent parameters), and a scalar loop then accepts level after level as
+// long as the arg-max is the predicted node and the prediction checks out against the records just loaded.
+// Only immutable facts are remembered (a node's children block never moves once it is expanded), so an entry can never be wrong, only
+// useless; kSpecWays paths are kept (PUCT rotates through the better root children), the walk uses the one whose first move it repeats
+// and overwrites the oldest one otherwise.  The per-level tables (log / sqrt of the visit count) are LDS copies: their index is only known
+// once the records have arrived, and a second dependent trip to global memory would cost what the speculation saves.
+typedef __attribute__((address_space(3))) int LdsI32;
+typedef __attribute__((address_space(3))) const float LdsCFloat;
+typedef __attribute__((address_space(3))) const double LdsCDbl;
+constexpr int kSpecCap = 128;                                   // levels remembered per path
+constexpr int kSpecWay = 4 + 3 * kSpecCap;                      // words of one remembered path: [0] length, then node / first_child / num_children per level
+constexpr int kSpecWays = 16;                                   // remembered paths (one per recently walked root child)
+constexpr int kSpecWords = kSpecWays * kSpecWay + 8;            // the paths + [kSpecWays * kSpecWay] = the next one to replace; [+1] passes, [+3] walks that found their path, [+5] levels taken
+constexpr int kSpecNode = 4, kSpecFc = 4 + kSpecCap, kSpecNc = 4 + 2 * kSpecCap;
+struct SpecMem { LdsI32* w; LdsCFloat* bias; LdsCDbl* sqrt; }; // w == nullptr: no speculation
+
+template <bool SPEC = false, class RcpPtr>
+__device__ __forceinline__ void selectBody(const PoolView& v, const int* __restrict__ start, int g, int lane, RcpPtr rcp, SpecMem sm = SpecMem{nullptr, nullptr, nullptr})
 {
     GNodeRec* recs = (GNodeRec*)(v.rec + size_t(g) * v.cap);
     MZ_GLOBAL int* path = (MZ_GLOBAL int*)(v.path + size_t(g) * v.max_depth);
@@ -137,6 +157,30 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
     MZ_GLOBAL int* hact = v.host_path_action ? (MZ_GLOBAL int*)(v.host_path_action + size_t(g) * v.max_depth) : nullptr;
     MZ_GLOBAL const float* bias_tab = (MZ_GLOBAL const float*)v.bias_tab;
     MZ_GLOBAL const double* sqrt_tab = (MZ_GLOBAL const double*)v.sqrt_tab;
+    // remember level `d` of this walk for the next simulation: its count will be one higher after this simulation's backup
+    LdsI32* spec = nullptr; // the remembered path this walk follows / overwrites: chosen at its first step below the root
+    auto note = [&](int d, int n, const NodeRec& r) {
+        if (!SPEC || !sm.w) { return; }
+        if (d == 1) { // which remembered path starts with this move?  None: replace the oldest (round robin)
+            const int w = lane < kSpecWays ? lane : 0;
+            const int lw = sm.w[w * kSpecWay], nw = sm.w[w * kSpecWay + kSpecNode + 1];
+            const unsigned long long m = __ballot(lane < kSpecWays && lw > 1 && nw == n);
+            int way;
+            if (m != 0) {
+                way = static_cast<int>(__builtin_ctzll(m));
+                if (lane == 0) { sm.w[kSpecWays * kSpecWay + 3] += 1; }
+            } else {
+                way = __builtin_amdgcn_readfirstlane(sm.w[kSpecWays * kSpecWay]) & (kSpecWays - 1);
+                if (lane == 0) { sm.w[kSpecWays * kSpecWay] = way + 1; sm.w[way * kSpecWay] = 0; }
+            }
+            spec = sm.w + way * kSpecWay;
+        }
+        if (spec && lane == 0 && d < kSpecCap) {
+            spec[kSpecNode + d] = n;
+            spec[kSpecFc + d] = r.first_child;
+            spec[kSpecNc + d] = r.num_children;
+        }
+    };
     const int bsize = v.bound_size[g];
     const float lo = v.bound_lo[g], hi = v.bound_hi[g];
     // the node header travels down the walk in SCALAR registers: every lane loads the same record, readfirstlane tells the compiler so
@@ -161,6 +205,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
         node = st;
         cur = uniformRec(loadRec(recs + st));
         if (lane == 0) { path[1] = st; pact[1] = cur.action; if (hact) { hact[1] = cur.action; } }
+        note(1, st, cur);
         depth = 2;
     }
     const int max_depth = __builtin_amdgcn_readfirstlane(v.max_depth);
@@ -184,6 +229,115 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
             // of a node are a PREFIX of its children and the arg-max is among that prefix plus the first unvisited child.  The prefix
             // length is kept in the upper half of `players` (expandBackupBody).  Not at the root: the root noise re-orders its priors.
             const int ne = node == 0 ? nc : min(nc, static_cast<int>(static_cast<unsigned>(cur.players) >> 16) + 1); // children that need a look
+            if (SPEC && spec && node != 0 && !v.atari_init_q) {
+                const int L0 = depth - 1;
+                const int plen = __builtin_amdgcn_readfirstlane(spec[0]);
+                if (L0 + 1 < plen && L0 + 1 < kSpecCap && __builtin_amdgcn_readfirstlane(spec[kSpecNode + L0]) == node) {
+                    int K = plen - L0 < kSpecCap - L0 ? plen - L0 : kSpecCap - L0;
+                    K = K < 8 ? K : 8;
+                    const int k = lane >> 3, j = lane & 7, Lk = L0 + k, base8 = lane & ~7;
+                    const bool inrange = k < K;
+                    const int nk = inrange ? (k == 0 ? node : spec[kSpecNode + Lk]) : 0;
+                    const int fck = inrange ? (k == 0 ? fc : spec[kSpecFc + Lk]) : 0;
+                    const int nck = inrange ? (k == 0 ? nc : spec[kSpecNc + Lk]) : 0;
+                    const int pfc = (inrange && k >= 1) ? (k == 1 ? fc : spec[kSpecFc + Lk - 1]) : 0;   // the block the predicted node lives in
+                    const int pnc = (inrange && k >= 1) ? (k == 1 ? nc : spec[kSpecNc + Lk - 1]) : 0;
+                    const int nl = nck < 8 ? nck : 8;
+                    const bool ld = inrange && j < nl;
+                    const NodeRec c = loadRec(recs + (ld ? fck + j : 0));
+                    // the header of level k's node is one of the records level k - 1 loaded
+                    const int idx = nk - pfc;
+                    const bool idx_ok = idx >= 0 && idx < 8 && idx < pnc;
+                    const int srcl = idx_ok ? base8 - 8 + idx : lane;
+                    float hcount = __shfl(c.count, srcl);
+                    int hfc = __shfl(c.first_child, srcl), hnc = __shfl(c.num_children, srcl), hpl = __shfl(c.players, srcl);
+                    if (k == 0) { hcount = cur.count; hfc = fc; hnc = nc; hpl = cur.players; }
+                    bool okk = inrange && nck > 0 && (k == 0 || (idx_ok && hfc == fck && hnc == nck && hcount >= 1.0f));
+                    int Nk = static_cast<int>(hcount - 1);
+                    Nk = okk ? Nk : 0;
+                    const float biask = sm.bias ? sm.bias[Nk] : bias_tab[Nk];
+                    const double sqrtNk = sm.sqrt ? sm.sqrt[Nk] : sqrt_tab[Nk];
+                    const unsigned visn = static_cast<unsigned>(hpl) >> 16;
+                    const int nek = (visn == 0xFFFFu) ? nck : (nck < static_cast<int>(visn) + 1 ? nck : static_cast<int>(visn) + 1);
+                    okk = okk && nek <= 8;
+                    const int cplk = (hpl >> 8) & 0xFF;
+                    const bool has = okk && j < nek;
+                    const RcpPtr rp = rcp + (has ? static_cast<int>(c.count) : 0);
+                    bool tiny = false;
+                    const LevelEval e = evalChild(v, c, cplk, biask, sqrtNk, rp[0], rp[1], &tiny);
+                    const bool vis = has && c.count != 0.0f;
+                    if (__ballot(vis && tiny) == 0) { // (a subnormal quotient needs the reference's division: leave it to the plain walk)
+                        int mx = 0;
+#pragma unroll
+                        for (int t = 1; t <= 8; ++t) { if (__ballot(okk && nek >= t) != 0) { mx = t; } }
+                        // init Q: the ordered f32 sum over the visited children of the level's node (adding +0 for the others changes nothing)
+                        const float qm = vis ? e.q : 0.0f, vm1 = vis ? 1.0f : 0.0f;
+                        float sum_of_win = 0.0f, sum = 0.0f;
+                        if (mx <= 3) { // the usual case, straight-line: the six gathers are in flight together
+                            const float q0 = __shfl(qm, base8), q1 = __shfl(qm, base8 + 1), q2 = __shfl(qm, base8 + 2);
+                            const float v0 = __shfl(vm1, base8), v1 = __shfl(vm1, base8 + 1), v2 = __shfl(vm1, base8 + 2);
+                            sum_of_win = ((sum_of_win + q0) + q1) + q2;
+                            sum = ((sum + v0) + v1) + v2;
+                        } else {
+                            for (int i = 0; i < mx; ++i) {
+                                const float qi = __shfl(qm, base8 + i), vi = __shfl(vm1, base8 + i);
+                                sum_of_win = sum_of_win + qi;
+                                sum = sum + vi;
+                            }
+                        }
+                        const float init_q = (sum_of_win - 1) / (sum + 1);
+                        const float sc = e.score + (c.count == 0.0f ? init_q : e.q);
+                        float bs = 0.0f, bp = 0.0f;
+                        int bi = 0;
+                        if (mx <= 3) {
+                            const float s0 = __shfl(sc, base8), s1 = __shfl(sc, base8 + 1), s2 = __shfl(sc, base8 + 2);
+                            const float p0 = __shfl(c.policy, base8), p1 = __shfl(c.policy, base8 + 1), p2 = __shfl(c.policy, base8 + 2);
+                            bs = s0; bp = p0; bi = 0;
+                            if (1 < nek && better(s1, p1, 1, bs, bp, bi)) { bs = s1; bp = p1; bi = 1; }
+                            if (2 < nek && better(s2, p2, 2, bs, bp, bi)) { bs = s2; bp = p2; bi = 2; }
+                        } else {
+                            for (int i = 0; i < mx; ++i) {
+                                const float si = __shfl(sc, base8 + i), pi = __shfl(c.policy, base8 + i);
+                                if (i < nek && (i == 0 || better(si, pi, i, bs, bp, bi))) { bs = si; bp = pi; bi = i; }
+                            }
+                        }
+                        const int chl = base8 + bi; // the lane that holds the level's chosen child
+                        const float ch_count = __shfl(c.count, chl);
+                        const int ch_fc = __shfl(c.first_child, chl), ch_nc = __shfl(c.num_children, chl), ch_act = __shfl(c.action, chl),
+                                  ch_pl = __shfl(c.players, chl);
+                        // how many levels does the walk take?  Level k counts if levels 0 .. k - 1 did, its own data checked out (okk), the level
+                        // before it chose the node it was evaluated for, and that node was not the end of the walk
+                        const int chosen = fck + bi;
+                        const int prev_chosen = __shfl(chosen, lane >= 8 ? lane - 8 : lane), prev_nc = __shfl(ch_nc, lane >= 8 ? lane - 8 : lane);
+                        const bool link = okk && (k == 0 || (prev_chosen == nk && prev_nc != 0)) && depth + k < max_depth;
+                        const unsigned long long lm = __ballot(j == 0 && !link); // bit 8k set: level k breaks the chain
+                        const int adv_all = lm ? static_cast<int>(__builtin_ctzll(lm)) >> 3 : 8;
+                        const int adv = adv_all < K ? adv_all : K;
+                        if (adv > 0) {
+                            if (j == 0 && k < adv) { // every accepted level writes its own path entry and remembers itself
+                                path[depth + k] = chosen;
+                                pact[depth + k] = ch_act;
+                                if (hact) { hact[depth + k] = ch_act; }
+                                if (depth + k < kSpecCap) {
+                                    spec[kSpecNode + depth + k] = chosen;
+                                    spec[kSpecFc + depth + k] = ch_fc;
+                                    spec[kSpecNc + depth + k] = ch_nc;
+                                }
+                            }
+                            const int l = 8 * (adv - 1);
+                            cur.count = laneF(ch_count, l);
+                            cur.first_child = laneI(ch_fc, l);
+                            cur.num_children = laneI(ch_nc, l);
+                            cur.action = laneI(ch_act, l);
+                            cur.players = laneI(ch_pl, l);
+                            node = laneI(chosen, l);
+                            depth += adv;
+                        }
+                        if (lane == 0) { sm.w[kSpecWays * kSpecWay + 1] += 1; sm.w[kSpecWays * kSpecWay + 5] += adv; }
+                        if (adv > 0) { continue; }
+                    }
+                }
+            }
             if (node != 0 && ne <= 3) {
                 // 96 % of the levels of a 400-simulation search: one or two visited children plus the first unvisited one.  Same
                 // arithmetic, but the handful of values is compared through readlanes: no wave reductions, no loops.
@@ -212,6 +366,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
                 cur.action = laneI(c.action, ri);
                 cur.players = laneI(c.players, ri);
                 node = fc + ri;
+                note(depth, node, cur);
                 if (lane == 0) {
                     path[depth] = node;
                     pact[depth] = cur.action;
@@ -265,6 +420,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
             cur.action = laneI(best.action, owner);
             cur.players = laneI(best.players, owner);
             node = fc + ri;
+            note(depth, node, cur);
             if (lane == 0) {
                 path[depth] = node;
                 pact[depth] = cur.action;
@@ -343,6 +499,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
         cur.action = laneI(best.action, owner);
         cur.players = laneI(best.players, owner);
         node = fc + ri;
+        note(depth, node, cur);
         if (lane == 0) {
             path[depth] = node;
             pact[depth] = cur.action;
@@ -353,6 +510,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
     if (lane == 0) {
         v.path_len[g] = depth;
         if (v.host_path_len) { v.host_path_len[g] = depth; }
+        if (spec) { spec[0] = depth < kSpecCap ? depth : kSpecCap; }
     }
 }
 

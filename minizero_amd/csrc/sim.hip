@@ -73,7 +73,7 @@ struct SimArgs {
     int atari, action_planes;
     AtariHeadParams ahp;
     float* reward;                    // [games] reward head output (game scale)
-    unsigned* sink;                   // never-taken store target that keeps the prefetch loads alive
+    int no_spec;                      // MZ_NO_SPEC=1: path speculation of the walk off (experiments)
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
 
@@ -101,7 +101,7 @@ __device__ __forceinline__ T ldc(__attribute__((address_space(4))) const T* p) /
 typedef __attribute__((address_space(3))) const double LdsCDouble;
 
 template <int CPL, int WPE>
-__device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp)
+__device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -111,11 +111,11 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
     if (a->prof) { t0 = wall_clock64(); }
     const PoolView pv = ldc(&a->pv);
 #ifdef MZ_SELECT_TWICE // experiment: the walk again, now with its records in the caches -> the profile shows the arithmetic-only time
-    selectBody(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
+    selectBody<WPE == 2>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
     waveSync();
     if (a->prof) { t0 = wall_clock64(); }
 #endif
-    selectBody(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
+    selectBody<WPE == 2>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
     waveSync();
     if (a->prof && lane == 0) {
         a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
@@ -179,30 +179,6 @@ __device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, 
     waveSync();
 }
 
-// While wave 0 walks the tree, wave 1 pulls the children blocks along the PREVIOUS simulation's path into the L2: consecutive
-// simulations mostly share their upper path, the 32-B records of a level are a 2.6 KB block that the tower's traffic has evicted
-// (select: 26 % L2 hit rate), and the walk is one dependent memory round trip per level.  Pure hint: stale or torn path entries
-// are still node ids of this game.
-template <int WPE>
-__device__ __noinline__ void simPrefetchPath(CSimArgs* __restrict__ a, int g, int lane)
-{
-    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
-    g = __builtin_amdgcn_readfirstlane(g);
-    const PoolView v = ldc(&a->pv);
-    const int plen = v.path_len[g];
-    const int* path = v.path + size_t(g) * v.max_depth;
-    const NodeRec* recs = v.rec + size_t(g) * v.cap;
-    unsigned acc = 0;
-    for (int L = lane; L < plen; L += 64) {
-        const int node = path[L];
-        const int fc = recs[node].first_child, nc = recs[node].num_children;
-        if (nc <= 0) { continue; }
-        const char* base = reinterpret_cast<const char*>(recs + fc);
-        for (int off = 0; off < nc * int(sizeof(NodeRec)); off += 128) { acc ^= *reinterpret_cast<const unsigned*>(base + off); }
-    }
-    if (acc == 0x9e3779b9u && plen < 0) { *a->sink = acc; }
-}
-
 // the heads read the tower's last activations where they are (an LDS tile); tile 0 (the blocks' temporary) is free for their scratch
 template <int WPE>
 __device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
@@ -247,6 +223,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
     for (int i = tid; i < a->rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
     __syncthreads();
     LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
+    // path-speculation memory of the walk (pool_body.h) behind the reciprocal table: LDS copies of the sqrt / bias tables and the remembered
+    // paths — only in the one-game-per-CU kernels (9x9: deep principal variations); the 8x8 / 3x3 trees of BASELINE's configs are shallow
+    // and those kernels need their LDS to keep two games on a CU
+    SpecMem spec{nullptr, nullptr, nullptr};
+    int* spec_w = nullptr;
+    if constexpr (WPE == 2) {
+        const int tab_n = a->rcp_n - 2;
+        double* sqrt_w = rcp_w + a->rcp_n;
+        float* bias_w = reinterpret_cast<float*>(sqrt_w + tab_n);
+        spec_w = reinterpret_cast<int*>(bias_w + tab_n + (tab_n & 1));
+        for (int i = tid; i < tab_n; i += 512) { sqrt_w[i] = a->pv.sqrt_tab[i]; bias_w[i] = a->pv.bias_tab[i]; }
+        if (tid < kSpecWays) { spec_w[tid * kSpecWay] = 0; }
+        if (tid < 8) { spec_w[kSpecWays * kSpecWay + tid] = 0; }
+        __syncthreads();
+        spec = SpecMem{(a->no_spec & 1) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
+    }
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr;
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = position slot of its leaf
@@ -256,17 +248,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (wave == 0) {
             if (slot == 1 && a->root_noise) { simApplyRootNoise<WPE>(a, g, lane); }
             if (a->use_gumbel) { simGumbelStart<WPE>(a, slot, s == 0 && host_start != 0, g, lane, tiles); }
-            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds);
+            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec);
         }
-        else if (wave == 1 && s + slot > 0) { simPrefetchPath<WPE>(a, g, lane); }
         __syncthreads();
-        unsigned long long c1 = 0;
-        if (prof) { t1 = wall_clock64(); c1 = clock64(); }
+        if (prof) { t1 = wall_clock64(); }
         const float* xt;
         if constexpr (true) { xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles); } // its own function: its own register budget
         else { xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles); }
         __syncthreads();
-        if (prof) { t2 = wall_clock64(); if (tid == 0) { prof[7] += clock64() - c1; } }
+        if (prof) { t2 = wall_clock64(); }
         simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2);
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
@@ -277,6 +267,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
             prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
         }
     }
+    if (prof && tid == 0 && spec_w) { prof[7] += (static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 1]) << 40) | (static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 5]) << 20) | spec_w[kSpecWays * kSpecWay + 3]; }
 }
 
 // ---- MuZero (board games; ref muzero_network.h:97-178, zero_actor.cpp:215-245): no leaf environment.  The leaf is evaluated from
@@ -318,7 +309,7 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
     expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles);
 }
 
-__device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp)
+__device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     slot = __builtin_amdgcn_readfirstlane(slot);
@@ -326,7 +317,7 @@ __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, boo
     if (slot == 1 && a->root_noise) { simApplyRootNoise<2>(a, g, lane); }
     if (a->use_gumbel) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
     const PoolView pv = ldc(&a->pv);
-    selectBody(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp);
+    selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
 }
 
 __device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, float* scratch, const float* xtile, int xcs,
@@ -363,14 +354,24 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     for (int i = tid; i < rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
     __syncthreads();
     LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
-    float* head_scratch = reinterpret_cast<float*>(rcp_w + rcp_n);
+    // path-speculation memory of the walk (pool_body.h): LDS copies of the sqrt / bias tables + the remembered paths
+    const int tab_n = rcp_n - 2;
+    double* sqrt_w = rcp_w + rcp_n;
+    float* bias_w = reinterpret_cast<float*>(sqrt_w + tab_n);
+    int* spec_w = reinterpret_cast<int*>(bias_w + tab_n + (tab_n & 1));
+    for (int i = tid; i < tab_n; i += 512) { sqrt_w[i] = a->pv.sqrt_tab[i]; bias_w[i] = a->pv.bias_tab[i]; }
+    if (tid < kSpecWays) { spec_w[tid * kSpecWay] = 0; }
+    if (tid < 8) { spec_w[kSpecWays * kSpecWay + tid] = 0; }
+    __syncthreads();
+    SpecMem spec{((a->no_spec & 1) || a->atari) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
+    float* head_scratch = reinterpret_cast<float*>(spec_w + kSpecWords);
     const PoolView v = ldc(&a->pv);
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr; // MZ_SIM_PROF=1: [select, tower, heads, cand+expand] ticks + sims
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (prof) { t0 = wall_clock64(); }
-        if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds); }
+        if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds, spec); }
         __syncthreads();
         if (prof) { t1 = wall_clock64(); }
         const float* xt;
@@ -462,7 +463,7 @@ void Net::dumpSimProf()
     if (sim_prof_.n == 0) { return; }
     std::vector<unsigned long long> h(sim_prof_.n);
     if (hipMemcpy(h.data(), sim_prof_.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { return; }
-    { double cyc = 0, tk = 0; for (size_t g = 0; g < h.size() / 8; ++g) { cyc += double(h[g * 8 + 7]); tk += double(h[g * 8 + 1]); } fprintf(stderr, "[mz sim prof] shader clock during the tower: %.3f GHz (clock64 / wall_clock64)\n", cyc / std::max(1.0, tk) * 0.1); }
+    { double ps = 0, ac = 0, kk = 0; for (size_t g = 0; g < h.size() / 8; ++g) { ps += double(h[g * 8 + 7] >> 40); ac += double((h[g * 8 + 7] >> 20) & 0xFFFFF); kk += double(h[g * 8 + 7] & 0xFFFFF); } fprintf(stderr, "[mz sim prof] path speculation: %.0f passes, %.0f levels taken, %.0f walks that found a remembered path\n", ps, ac, kk); }
     const char* names[4] = {"select+leaf", "tower", "heads", "cand+expand"};
     const size_t G = h.size() / 8;
     double tot_all = 0, tot_max = 0;
@@ -524,8 +525,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     a.use_gumbel = gum ? 1 : 0;
     if (gum) { a.gum = *gum; }
     a.start = d_start;
-    if (!sim_sink_.ensure(4)) { setError("hipMalloc failed"); return MZ_ERR_DEVICE; }
-    a.sink = sim_sink_.p;
+    a.no_spec = getenv("MZ_NO_SPEC") ? atoi(getenv("MZ_NO_SPEC")) : 0;
     if (getenv("MZ_SIM_PROF")) {
         if (sim_prof_.n == 0) {
             if (!sim_prof_.alloc(size_t(gv.games) * 8)) { setError("hipMalloc of the profile buffer failed"); return MZ_ERR_DEVICE; }
@@ -541,7 +541,10 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     size_t scratch = std::max(std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A)), gumbelSmemBytes(gv.A));
     scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
     if (scratch > tile_bytes || heads > tile_bytes / kTowerTiles) { return MZ_OK; } // not launched: the caller falls back to the lock-step kernels
-    const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double);
+    // (+ the path-speculation memory of the one-game-per-CU kernels: same condition as simWavesPerEu() == 2)
+    const bool two_per_cu = H * W <= 64 && tile_bytes <= size_t(76) * 1024;
+    const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) +
+                       (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int));
     // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
     static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
@@ -615,6 +618,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.use_gumbel = gum ? 1 : 0;
     if (gum) { a.gum = *gum; }
     a.start = d_start;
+    a.no_spec = getenv("MZ_NO_SPEC") ? atoi(getenv("MZ_NO_SPEC")) : 0;
     if (getenv("MZ_SIM_PROF")) {
         if (sim_prof_.n == 0) {
             if (!sim_prof_.alloc(size_t(pool.v_.games) * 8)) { setError("hipMalloc of the profile buffer failed"); return MZ_ERR_DEVICE; }
@@ -628,7 +632,8 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     size_t scratch = std::max(azCandSmemBytes(a.A), gumbelSmemBytes(a.A));
     scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
     if (scratch > tile_bytes) { return MZ_OK; }
-    const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) + head_floats * sizeof(float);
+    const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) + size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int) +
+                       head_floats * sizeof(float);
     if (lds > 160 * 1024) { return MZ_OK; }
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
         if (!sim_args_.ensure(sizeof(SimArgs))) { setError("hipMalloc of the simulation arguments failed"); return MZ_ERR_DEVICE; }
