@@ -208,6 +208,9 @@ int mz_env_feature_bits(const mz_env* e, int rotation, uint32_t* out);
  * ------------------------------------------------------------------------------------------ */
 int mz_godev_playout(int device, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots,
                      uint32_t* feat_out, uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out);
+/* the same for any game with a device engine ("go", "othello", "tictactoe"): feat_out [steps][channels*ceil(P/32)], legal_out [steps][actions] */
+int mz_envdev_playout(int device, const char* game, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots,
+                      uint32_t* feat_out, uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out);
 int mz_sort_candidates(int device, const float* policy, int n, int* order_out);
 int mz_invert_values_device(int device, const float* values, int n, float* out);
 

@@ -1497,29 +1497,30 @@ int mz_invert_values_device(int device, const float* values, int n, float* out)
     return mz::invertValuesOnDevice(device, values, n, out);
 }
 
-int mz_godev_playout(int device, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots, uint32_t* feat_out,
-                     uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out)
+int mz_envdev_playout(int device, const char* game, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots,
+                      uint32_t* feat_out, uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out)
 {
     using namespace mz;
-    if (mz_device_count() < 1) { setError("mz_godev_playout: no GPU (libmzgpu has no CPU path)"); return MZ_ERR_DEVICE; }
-    if (!actions || !rots || count < 0 || root_prefix < 0 || root_prefix > count) { setError("mz_godev_playout: bad arguments"); return MZ_ERR_ARG; }
-    std::unique_ptr<GameEnv> env = createGameEnv("go", board_size, komi);
-    if (!env || !env->hasDeviceTwin()) { setError("mz_godev_playout: no device twin for this board"); return MZ_ERR_ARG; }
+    if (!game) { setError("mz_envdev_playout: NULL game"); return MZ_ERR_ARG; }
+    if (mz_device_count() < 1) { setError("mz_envdev_playout: no GPU (libmzgpu has no CPU path)"); return MZ_ERR_DEVICE; }
+    if (!actions || !rots || count < 0 || root_prefix < 0 || root_prefix > count) { setError("mz_envdev_playout: bad arguments"); return MZ_ERR_ARG; }
+    std::unique_ptr<GameEnv> env = createGameEnv(game, board_size, komi);
+    if (!env || !env->hasDeviceTwin()) { setError("mz_envdev_playout: no device twin for this board"); return MZ_ERR_ARG; }
     for (int i = 0; i < root_prefix; ++i) {
-        if (!env->act(actions[i], env->turn())) { setError("mz_godev_playout: illegal root action %d at move %d", actions[i], i); return MZ_ERR_ARG; }
+        if (!env->act(actions[i], env->turn())) { setError("mz_envdev_playout: illegal root action %d at move %d", actions[i], i); return MZ_ERR_ARG; }
     }
     const int steps = count - root_prefix + 1, A = env->policySize(), md = steps + 1;
     const int* inv[8];
     const int* fwd[8];
     for (int r = 0; r < 8; ++r) { inv[r] = env->rot()->inv[r].data(); fwd[r] = env->rot()->fwd[r].data(); }
     GoDevice gd;
-    int rc = gd.init(device, 1, env->boardSize(), komi, A, steps, md, nullptr, inv, fwd, env->zobristKeys());
+    int rc = gd.init(device, 1, env->boardSize(), komi, A, steps, md, nullptr, inv, fwd, env->zobristKeys(), env->deviceKind());
     if (rc) { return rc; }
     env->exportDeviceRoot(gd.hostSnap(0));
     if ((rc = gd.uploadRoots())) { return rc; }
     // a one-game "tree" that is a single chain: node d = the position after d device moves, kept in slot d
     DevBuf<int> d_i;
-    if (!d_i.alloc(size_t(1) + 3 * md)) { setError("mz_godev_playout: allocation failed"); return MZ_ERR_DEVICE; }
+    if (!d_i.alloc(size_t(1) + 3 * md)) { setError("mz_envdev_playout: allocation failed"); return MZ_ERR_DEVICE; }
     std::vector<int> h(size_t(1) + 3 * md, 0);
     for (int d = 0; d < md; ++d) {
         h[1 + d] = d;                                                                  // path
@@ -1536,9 +1537,15 @@ int mz_godev_playout(int device, int board_size, float komi, const int* actions,
         RotPack rp{};
         rotPackSet(rp, 0, rots[d] & 7);
         if ((rc = gd.leafAsync(pv, rp, d))) { return rc; }
-        if ((rc = gd.readLeaf(feat_out + size_t(d) * 18 * W32, legal_out + size_t(d) * A, terminal_out + d, eval_out + d, player_out + d))) { return rc; }
+        if ((rc = gd.readLeaf(feat_out + size_t(d) * env->numInputChannels() * W32, legal_out + size_t(d) * A, terminal_out + d, eval_out + d, player_out + d))) { return rc; }
     }
     return MZ_OK;
+}
+
+int mz_godev_playout(int device, int board_size, float komi, const int* actions, int count, int root_prefix, const int* rots, uint32_t* feat_out,
+                     uint8_t* legal_out, int* terminal_out, float* eval_out, int* player_out)
+{
+    return mz_envdev_playout(device, "go", board_size, komi, actions, count, root_prefix, rots, feat_out, legal_out, terminal_out, eval_out, player_out);
 }
 
 } // extern "C"

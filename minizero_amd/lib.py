@@ -138,6 +138,7 @@ def load():
         L.mz_env_features.argtypes = [vp, C.c_int, fp]
         L.mz_env_feature_bits.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
         L.mz_godev_playout.argtypes = [C.c_int, C.c_int, C.c_float, ip, C.c_int, C.c_int, ip, C.POINTER(C.c_uint32), u8p, ip, fp, ip]
+        L.mz_envdev_playout.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_float, ip, C.c_int, C.c_int, ip, C.POINTER(C.c_uint32), u8p, ip, fp, ip]
         L.mz_sort_candidates.argtypes = [C.c_int, fp, C.c_int, ip]
         L.mz_invert_values_device.argtypes = [C.c_int, fp, C.c_int, fp]
     _LIB = L
@@ -438,6 +439,26 @@ def godev_playout(board_size, komi, actions, root_prefix, rots, device=0):
     pl = np.zeros(steps, np.int32)
     _check(L, L.mz_godev_playout(device, board_size, komi, _i(acts), len(acts), root_prefix, _i(rots), feat.ctypes.data_as(C.POINTER(C.c_uint32)),
                                  legal.ctypes.data_as(C.POINTER(C.c_uint8)), _i(term), _f(ev), _i(pl)))
+    return feat, legal, term, ev, pl
+
+
+def envdev_playout(game, board_size, komi, actions, root_prefix, rots, channels, num_actions, device=0):
+    """Device rules engine of `game` ("go", "othello", "tictactoe"): root = actions[:root_prefix] on the host engine, then one device move per
+    remaining action.  Returns (feat_bits [steps][channels*W32], legal [steps][num_actions], terminal, eval, player)."""
+    L = load()
+    P = board_size * board_size
+    acts = np.ascontiguousarray(actions, np.int32)
+    steps = len(acts) - root_prefix + 1
+    rots = np.ascontiguousarray(rots, np.int32)
+    assert len(rots) >= steps
+    W32 = (P + 31) // 32
+    feat = np.zeros((steps, channels * W32), np.uint32)
+    legal = np.zeros((steps, num_actions), np.uint8)
+    term = np.zeros(steps, np.int32)
+    ev = np.zeros(steps, np.float32)
+    pl = np.zeros(steps, np.int32)
+    _check(L, L.mz_envdev_playout(device, game.encode(), board_size, komi, _i(acts), len(acts), root_prefix, _i(rots),
+                                  feat.ctypes.data_as(C.POINTER(C.c_uint32)), legal.ctypes.data_as(C.POINTER(C.c_uint8)), _i(term), _f(ev), _i(pl)))
     return feat, legal, term, ev, pl
 
 

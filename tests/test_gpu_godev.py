@@ -101,3 +101,51 @@ def test_device_candidate_sort_is_libstdcxx_sort(mz, ref_sort):
         assert np.array_equal(mz.sort_candidates(p), ref_sort(p)), f"case {it}: n={n} levels={levels}"
         cases += 1
     assert cases == 160
+
+
+def _play_and_compare_game(mz, game, conf, n, channels, num_actions, seed, max_moves, root_prefix_frac):
+    """Random legal playout on the host engine; the device engine replays the tail move by move: planes under random rotations, legal mask,
+    terminal flag, result and player to move must be identical after every move."""
+    rng = np.random.default_rng(seed)
+    env = mz.Env(conf)
+    actions = []
+    while not env.is_terminal() and len(actions) < max_moves:
+        legal = np.nonzero(env.legal_mask())[0]
+        a = int(rng.choice(legal))
+        assert env.act(a)
+        actions.append(a)
+    root_prefix = int(len(actions) * root_prefix_frac)
+    steps = len(actions) - root_prefix + 1
+    rots = rng.integers(0, 8, steps).astype(np.int32)
+    feat, legal, term, ev, pl = mz.envdev_playout(game, n, 0.0, actions, root_prefix, rots, channels, num_actions)
+    ref = mz.Env(conf)
+    for a in actions[:root_prefix]:
+        assert ref.act(a)
+    for d in range(steps):
+        where = f"{game} {n} seed {seed} step {d} (root_prefix {root_prefix}) actions {actions[:root_prefix + d]}"
+        assert pl[d] == ref.turn(), where
+        assert bool(term[d]) == ref.is_terminal(), where
+        if ref.is_terminal():
+            assert ev[d] == ref.eval_score(), where
+        else:
+            assert np.array_equal(legal[d], ref.legal_mask()), where
+        assert np.array_equal(feat[d], ref.feature_bits(int(rots[d]), channels, n * n)), where
+        if d + 1 < steps:
+            assert ref.act(actions[root_prefix + d]), where
+    return len(actions)
+
+
+@pytest.mark.parametrize("n", [8, 6, 4])
+def test_othello_device_engine_matches_host_engine(mz, n):
+    """othLeafBody: flips in all 8 directions, forced passes, the two-pass end, disc-count results — whole random games, several root depths."""
+    total = 0
+    for g in range(24):
+        total += _play_and_compare_game(mz, "othello", f"env_game=othello:env_board_size={n}", n, 4, n * n + 1, 100 * n + g, 200, (g % 4) / 4.0)
+    assert total > 24 * (n * n - 8) // 2
+
+
+def test_tictactoe_device_engine_matches_host_engine(mz):
+    total = 0
+    for g in range(60):
+        total += _play_and_compare_game(mz, "tictactoe", "env_game=tictactoe", 3, 4, 9, 7 + g, 9, (g % 3) / 3.0)
+    assert total >= 60 * 5
