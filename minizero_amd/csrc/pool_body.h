@@ -131,8 +131,8 @@ __device__ __forceinline__ LevelEval evalChild(const PoolView& v, const NodeRec&
 // Path speculation (simulation kernel only; `spec` = LDS words, nullptr: off).  A deep principal variation is walked again by almost every
 // simulation, one dependent level (~1 800 cycles of a single wave's instruction stream) after the other, and the launch lasts as long as
 // its deepest game.  The walk remembers, per level of the previous path, the node, its children block and its visit count after that
-// simulation's backup (nothing else can have changed it); while the new walk is on the previous path, 8 lanes per level evaluate the next
-// 8 predicted levels in ONE pass of the same arithmetic (per-lane parent parameters), and a scalar loop then accepts level after level as
+// simulation's backup (nothing else can have changed it); while the new walk is on the previous path, 4 lanes per level evaluate the next
+// 16 predicted levels in ONE pass of the same arithmetic (per-lane parent parameters), and a scalar loop then accepts level after level as
 // long as the arg-max is the predicted node and the prediction checks out against the records just loaded.
 // Only immutable facts are remembered (a node's children block never moves once it is expanded), so an entry can never be wrong, only
 // useless; kSpecWays paths are kept (PUCT rotates through the better root children), the walk uses the one whose first move it repeats
@@ -143,6 +143,7 @@ typedef __attribute__((address_space(3))) const float LdsCFloat;
 typedef __attribute__((address_space(3))) const double LdsCDbl;
 constexpr int kSpecCap = 128;                                   // levels remembered per path
 constexpr int kSpecWay = 4 + 3 * kSpecCap;                      // words of one remembered path: [0] length, then node / first_child / num_children per level
+constexpr int kGw = 4, kLv = 64 / kGw;                          // lanes per predicted level (its first children) and levels per pass
 constexpr int kSpecWays = 16;                                   // remembered paths (one per recently walked root child)
 constexpr int kSpecWords = kSpecWays * kSpecWay + 8;            // the paths + [kSpecWays * kSpecWay] = the next one to replace; [+1] passes, [+3] walks that found their path, [+5] levels taken
 constexpr int kSpecNode = 4, kSpecFc = 4 + kSpecCap, kSpecNc = 4 + 2 * kSpecCap;
@@ -234,21 +235,21 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
                 const int plen = __builtin_amdgcn_readfirstlane(spec[0]);
                 if (L0 + 1 < plen && L0 + 1 < kSpecCap && __builtin_amdgcn_readfirstlane(spec[kSpecNode + L0]) == node) {
                     int K = plen - L0 < kSpecCap - L0 ? plen - L0 : kSpecCap - L0;
-                    K = K < 8 ? K : 8;
-                    const int k = lane >> 3, j = lane & 7, Lk = L0 + k, base8 = lane & ~7;
+                    K = K < kLv ? K : kLv;
+                    const int k = lane / kGw, j = lane % kGw, Lk = L0 + k, base8 = lane - j;
                     const bool inrange = k < K;
                     const int nk = inrange ? (k == 0 ? node : spec[kSpecNode + Lk]) : 0;
                     const int fck = inrange ? (k == 0 ? fc : spec[kSpecFc + Lk]) : 0;
                     const int nck = inrange ? (k == 0 ? nc : spec[kSpecNc + Lk]) : 0;
                     const int pfc = (inrange && k >= 1) ? (k == 1 ? fc : spec[kSpecFc + Lk - 1]) : 0;   // the block the predicted node lives in
                     const int pnc = (inrange && k >= 1) ? (k == 1 ? nc : spec[kSpecNc + Lk - 1]) : 0;
-                    const int nl = nck < 8 ? nck : 8;
+                    const int nl = nck < kGw ? nck : kGw;
                     const bool ld = inrange && j < nl;
                     const NodeRec c = loadRec(recs + (ld ? fck + j : 0));
                     // the header of level k's node is one of the records level k - 1 loaded
                     const int idx = nk - pfc;
-                    const bool idx_ok = idx >= 0 && idx < 8 && idx < pnc;
-                    const int srcl = idx_ok ? base8 - 8 + idx : lane;
+                    const bool idx_ok = idx >= 0 && idx < kGw && idx < pnc;
+                    const int srcl = idx_ok ? base8 - kGw + idx : lane;
                     float hcount = __shfl(c.count, srcl);
                     int hfc = __shfl(c.first_child, srcl), hnc = __shfl(c.num_children, srcl), hpl = __shfl(c.players, srcl);
                     if (k == 0) { hcount = cur.count; hfc = fc; hnc = nc; hpl = cur.players; }
@@ -259,7 +260,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
                     const double sqrtNk = sm.sqrt ? sm.sqrt[Nk] : sqrt_tab[Nk];
                     const unsigned visn = static_cast<unsigned>(hpl) >> 16;
                     const int nek = (visn == 0xFFFFu) ? nck : (nck < static_cast<int>(visn) + 1 ? nck : static_cast<int>(visn) + 1);
-                    okk = okk && nek <= 8;
+                    okk = okk && nek <= kGw;
                     const int cplk = (hpl >> 8) & 0xFF;
                     const bool has = okk && j < nek;
                     const RcpPtr rp = rcp + (has ? static_cast<int>(c.count) : 0);
@@ -269,7 +270,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
                     if (__ballot(vis && tiny) == 0) { // (a subnormal quotient needs the reference's division: leave it to the plain walk)
                         int mx = 0;
 #pragma unroll
-                        for (int t = 1; t <= 8; ++t) { if (__ballot(okk && nek >= t) != 0) { mx = t; } }
+                        for (int t = 1; t <= kGw; ++t) { if (__ballot(okk && nek >= t) != 0) { mx = t; } }
                         // init Q: the ordered f32 sum over the visited children of the level's node (adding +0 for the others changes nothing)
                         const float qm = vis ? e.q : 0.0f, vm1 = vis ? 1.0f : 0.0f;
                         float sum_of_win = 0.0f, sum = 0.0f;
@@ -308,10 +309,10 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
                         // how many levels does the walk take?  Level k counts if levels 0 .. k - 1 did, its own data checked out (okk), the level
                         // before it chose the node it was evaluated for, and that node was not the end of the walk
                         const int chosen = fck + bi;
-                        const int prev_chosen = __shfl(chosen, lane >= 8 ? lane - 8 : lane), prev_nc = __shfl(ch_nc, lane >= 8 ? lane - 8 : lane);
+                        const int prev_chosen = __shfl(chosen, lane >= kGw ? lane - kGw : lane), prev_nc = __shfl(ch_nc, lane >= kGw ? lane - kGw : lane);
                         const bool link = okk && (k == 0 || (prev_chosen == nk && prev_nc != 0)) && depth + k < max_depth;
                         const unsigned long long lm = __ballot(j == 0 && !link); // bit 8k set: level k breaks the chain
-                        const int adv_all = lm ? static_cast<int>(__builtin_ctzll(lm)) >> 3 : 8;
+                        const int adv_all = lm ? static_cast<int>(__builtin_ctzll(lm)) / kGw : kLv;
                         const int adv = adv_all < K ? adv_all : K;
                         if (adv > 0) {
                             if (j == 0 && k < adv) { // every accepted level writes its own path entry and remembers itself
@@ -324,7 +325,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
                                     spec[kSpecNc + depth + k] = ch_nc;
                                 }
                             }
-                            const int l = 8 * (adv - 1);
+                            const int l = kGw * (adv - 1);
                             cur.count = laneF(ch_count, l);
                             cur.first_child = laneI(ch_fc, l);
                             cur.num_children = laneI(ch_nc, l);
