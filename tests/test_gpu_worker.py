@@ -293,3 +293,17 @@ def test_tictactoe_execution_modes_are_equivalent(mz):
     assert host == resident
     assert host == sim_whole
     assert host == sim_chunks
+
+
+def test_go_deep_search_modes_are_equivalent(mz):
+    """200-simulation searches: principal variations tens of levels deep, i.e. the walk's path speculation (pool_body.h: remembered paths, 16
+    predicted levels per pass) takes most levels — records must still equal those of the lock-step kernels with the host engine."""
+    conf = "env_game=go:env_board_size=9:actor_num_simulation=200:zero_num_parallel_games=5"
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    total = 201 * 168  # whole games (the synthetic nets play to the 2 * 81 move cap): the records only appear at the end
+    host = _lines_of(mz, conf + ":mz_device_env=false", args, [total], total)
+    sim_whole = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [total], total)
+    sim_chunks = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [1, 150, 5, 201, 3, 40, 777, 22], total)
+    assert len(host) >= 4
+    assert host == sim_whole
+    assert host == sim_chunks
