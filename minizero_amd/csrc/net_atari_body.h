@@ -79,32 +79,27 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
     MZ_HPROF(1);
     if (active) {
         const int n1 = d.hc * P;
-        for (int o = t; o < d.hidden; o += NT) {
-            const float v = dotChain<128>(f, 1, d.fc1_wT + o, d.hidden, n1) + d.fc1_b[o]; // one output per thread: 128 weights in flight
-            h1[o] = v > 0.0f ? v : 0.0f;
+        for (int o = 4 * t; o < d.hidden; o += 4 * NT) { // four adjacent hidden units per thread, 16-byte weight loads (dotChain4)
+            float acc[4];
+            dotChain4<32>(f, d.fc1_wT, d.hidden, o, d.hidden, n1, acc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (o + k < d.hidden) { const float v = acc[k] + d.fc1_b[o + k]; h1[o + k] = v > 0.0f ? v : 0.0f; }
+            }
         }
     }
     __syncthreads();
     MZ_HPROF(2);
     float m = -3.4e38f;
     if (active) {
-        for (int o0 = t; o0 < d.size; o0 += NT * K) {
-            const float* xk[K];
-            const float* wk[K];
-            int idx[K];
+        for (int o = 4 * t; o < d.size; o += 4 * NT) {
+            float acc[4];
+            dotChain4<32>(h1, d.fc2_wT, d.size, o, d.size, d.hidden, acc);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                idx[k] = o0 + k * NT < d.size ? o0 + k * NT : d.size - 1;
-                xk[k] = h1;
-                wk[k] = d.fc2_wT + idx[k];
-            }
-            float acc[K];
-            dotChainK<32, K>(xk, 1, wk, d.size, d.hidden, acc);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (o0 + k * NT < d.size) {
-                    const float v = acc[k] + d.fc2_b[idx[k]];
-                    lg[idx[k]] = v;
+            for (int k = 0; k < 4; ++k) {
+                if (o + k < d.size) {
+                    const float v = acc[k] + d.fc2_b[o + k];
+                    lg[o + k] = v;
                     m = v > m ? v : m;
                 }
             }

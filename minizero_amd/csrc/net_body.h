@@ -2,6 +2,7 @@
 // kernel (sim.hip): the fused residual tower and the fused heads.  gfx950, -ffp-contract=off; numerics contract in DESIGN.md §4.
 #pragma once
 #include "net_dev.h"
+#include <type_traits>
 
 namespace mz {
 
@@ -388,6 +389,42 @@ __device__ __forceinline__ void dotChainK(const float* const (&x)[K], int xs, co
 #pragma unroll
         for (int k = 0; k < K; ++k) { acc[k] = __builtin_fmaf(x[k][i0 * xs], w[k][size_t(i0) * ws], acc[k]); }
     }
+}
+
+// Four ADJACENT outputs o .. o + 3 of a fully connected layer with weights wT[i][o] (row stride `ws` floats): each of the four is its own
+// ordered f32 chain over i, and every step fetches the four weights with ONE 16-byte load — a wave has at most 63 loads in flight, so four
+// times the bytes per load is what a bandwidth-starved GEMV needs (one sample per CU: the weights of the 601-bin heads stream from L2).
+// nvalid < 4: the tail of the layer (outputs beyond it are computed from clamped addresses and dropped by the caller).
+template <int CH>
+__device__ __forceinline__ void dotChain4(const float* __restrict__ x, const float* __restrict__ wT, size_t ws, int o, int nout, int n, float (&acc)[4])
+{
+    typedef float vf4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int oc = o + 3 < nout ? o : (nout >= 4 ? nout - 4 : 0); // clamped so that the 16 bytes stay inside the row
+    const int sh = o - oc;                                         // outputs of this thread start at component `sh` of the clamped load
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int i0 = 0;
+    auto part = [&](auto chc) {
+        constexpr int C2 = decltype(chc)::value;
+        for (; i0 + C2 <= n; i0 += C2) {
+            vf4u wv[C2];
+#pragma unroll
+            for (int k = 0; k < C2; ++k) { wv[k] = *reinterpret_cast<const vf4u*>(wT + size_t(i0 + k) * ws + oc); }
+#pragma unroll
+            for (int k = 0; k < C2; ++k) {
+                const float xv = x[i0 + k];
+                a0 = __builtin_fmaf(xv, wv[k].x, a0);
+                a1 = __builtin_fmaf(xv, wv[k].y, a1);
+                a2 = __builtin_fmaf(xv, wv[k].z, a2);
+                a3 = __builtin_fmaf(xv, wv[k].w, a3);
+            }
+        }
+    };
+    part(std::integral_constant<int, CH>{});
+    part(std::integral_constant<int, 4>{});
+    part(std::integral_constant<int, 1>{});
+    const float r[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { acc[k] = (k + sh < 4) ? r[(k + sh) & 3] : 0.0f; } // component k + sh of the clamped load is output o + k
 }
 
 // the body of heads_kernel for sample `b`, run by NT threads (a multiple of 64, >= 128); `sm` = (C*P + PC*P + P + VH + A + 16) floats of LDS
