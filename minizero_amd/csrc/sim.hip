@@ -320,24 +320,58 @@ __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, boo
     selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
 }
 
-__device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, float* scratch, const float* xtile, int xcs,
-                                        int xpw)
+// scale_hidden_state (ref muzero_network.py:81-88) of the tower's output where it lies (padded planes in LDS), in place, and the rescaled state
+// to the slab slot `hd`: min / max are order-free, (h - min) / scale is one IEEE operation per element.  H, W compile-time: with run-time
+// geometry the three integer divisions per element and pass cost more than the arithmetic (heads 21.5 -> 13 us on BASELINE configs[3])
+template <int H, int W>
+__device__ __forceinline__ void rescaleTile(float* __restrict__ xt, int C, float* __restrict__ hd, int tid, float* __restrict__ red)
+{
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
+    const int lane = tid & 63, wave = tid >> 6;
+    float mn = 3.4e38f, mx = -3.4e38f;
+    for (int i = tid; i < C * P; i += 512) {
+        const int c = i / P, p = i - c * P;
+        const float v = xt[c * CS + (p / W + 1) * PW + p % W + 1];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
+        mn = m2 < mn ? m2 : mn;
+        mx = x2 > mx ? x2 : mx;
+    }
+    if (lane == 0) { red[wave] = mn; red[8 + wave] = mx; }
+    __syncthreads();
+    mn = red[0]; mx = red[8];
+    for (int w = 1; w < 8; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[8 + w] > mx ? red[8 + w] : mx; }
+    float scale = mx - mn;
+    if (scale < 1e-5f) { scale += 1e-5f; }
+    for (int i = tid; i < C * P; i += 512) {
+        const int c = i / P, p = i - c * P, k = c * CS + (p / W + 1) * PW + p % W + 1;
+        const float v = (xt[k] - mn) / scale;
+        xt[k] = v;
+        hd[i] = v;
+    }
+    __syncthreads();
+}
+
+template <int H, int W>
+__device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, float* scratch, float* xtile)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     slot = __builtin_amdgcn_readfirstlane(slot);
     g = __builtin_amdgcn_readfirstlane(g);
-    xcs = __builtin_amdgcn_readfirstlane(xcs);
-    xpw = __builtin_amdgcn_readfirstlane(xpw);
+    constexpr int xcs = planeStride(H, W), xpw = W + 2;
     if (a->atari) { // 601-bin value / reward heads, rescaled hidden state to the slab slot of this simulation, value and reward in game scale
         const AtariHeadParams hp = ldc(&a->ahp);
         float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
         atariHeadsBody<256>(nullptr, xtile, xcs, xpw, hp, a->policy, a->logit, a->value, a->reward, hd, 1, 1, g, tid, scratch);
         return;
     }
-    // hidden_dst + g * C * P must be the slab slot (g, slot): headsBody indexes its outputs with the sample index
-    float* hd = a->hidden + (size_t(g) * a->slots + slot - g) * size_t(a->hp.C) * a->hp.P;
     const HeadParams hp = ldc(&a->hp);
-    headsBody(nullptr, hp, a->policy, a->logit, a->value, hd, nullptr, 1, g, tid, 512, tiles, xtile, xcs, xpw);
+    float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
+    rescaleTile<H, W>(xtile, hp.C, hd, tid, tiles); // tile 0 (the blocks' temporary) is free: its first words hold the reduction scratch
+    headsBody(nullptr, hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
 }
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds, spec); }
         __syncthreads();
         if (prof) { t1 = wall_clock64(); }
-        const float* xt;
+        float* xt;
         if (slot == 0) { // initial inference: representation trunk on the root planes (board games; muzero_atari roots never come here)
             xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
         } else { // recurrent inference: dynamics trunk on (parent hidden state, move)
@@ -387,7 +421,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         }
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
-        simMzHeads(a, slot, g, tid, tiles, head_scratch, xt, planeStride(H, W), W + 2);
+        simMzHeads<H, W>(a, slot, g, tid, tiles, head_scratch, xt);
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
         if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles); }
