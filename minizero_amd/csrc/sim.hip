@@ -96,12 +96,42 @@ __device__ __forceinline__ T ldc(__attribute__((address_space(4))) const T* p) /
     return t;
 }
 
+// The heads' outputs and the candidate list of a simulation never leave the CU: they are handed from phase to phase through a small LDS
+// block instead of global memory (each hand-over was a store + a dependent load through L2).  The bodies index their arrays with the
+// game index, so they get generic pointers moved back by the game's offset.
+struct SimXchg { // word offsets inside the block for A actions
+    int A;
+    __device__ int policy() const { return 0; }
+    __device__ int logit() const { return A; }
+    __device__ int cpolicy() const { return 2 * A; }
+    __device__ int clogit() const { return 3 * A; }
+    __device__ int caction() const { return 4 * A; }
+    __device__ int scalars() const { return 5 * A; } // value, cand_count, cand_player, value_io, reward_io, leaf_player, terminal, eval
+    __device__ int legal() const { return 5 * A + 8; }   // 64-bit words of the leaf's legal mask (8-byte aligned: A is padded to even below)
+    __device__ int feat() const { return 5 * A + 8 + 16; } // the leaf's bit-packed planes (the tower's input)
+};
+inline size_t simXchgWords(int A, int channels, int W32) { return size_t(5) * (A + (A & 1)) + 8 + 16 + size_t(channels) * W32; }
+
+// the leaf's outputs (planes, legal mask, player, terminal flag, result) go to the next phases through the hand-over block too
+__device__ __forceinline__ GoDevView simLeafView(GoDevView gv, float* xchg, int g)
+{
+    const SimXchg x{gv.A + (gv.A & 1)};
+    float* sc = xchg + x.scalars();
+    gv.leaf_player = reinterpret_cast<int*>(sc + 5) - g;
+    gv.terminal = reinterpret_cast<int*>(sc + 6) - g;
+    gv.eval = sc + 7 - g;
+    gv.legal = reinterpret_cast<uint64_t*>(xchg + x.legal()) - size_t(g) * gv.LW;
+    gv.feat = reinterpret_cast<uint32_t*>(xchg + x.feat()) - size_t(g) * gv.channels * gv.W32;
+    return gv;
+}
+
 // The tree phases are separate (non-inlined) functions: inlined next to the tower they push the kernel to 256 VGPRs with spills in
 // the MFMA loop.  SimArgs lives in device memory (not in 1.3 KB of kernel arguments pinned in SGPRs for the whole kernel).
 typedef __attribute__((address_space(3))) const double LdsCDouble;
 
 template <int CPL, int WPE>
-__device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec)
+__device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
+                                           float* xchg)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -121,26 +151,32 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
         a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
         a->prof[size_t(g) * 8 + 6] += pv.path_len[g];
     }
-    const GoDevView gv = ldc(&a->gv);
+    const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
     if constexpr (CPL == -1) { tttLeafBody(gv, pv, rot, slot, g, lane); } // CPL -1: TicTacToe, 0: Othello (go_body.h)
     else if constexpr (CPL == 0) { othLeafBody(gv, pv, rot, slot, g, lane); }
     else { goLeafBody<CPL>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles)); }
 }
 
 template <int WPE>
-__device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles)
+__device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, float* xchg)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
     slot = __builtin_amdgcn_readfirstlane(slot);
     rot = __builtin_amdgcn_readfirstlane(rot);
-    const GoDevView gv = ldc(&a->gv);
+    const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
     const PoolView pv = ldc(&a->pv);
-    azCandBody(gv, a->policy, a->logit, a->value, rot, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io,
-               a->reward_io, a->err, g, lane, reinterpret_cast<uint64_t*>(tiles));
+    const SimXchg x{gv.A + (gv.A & 1)};
+    const size_t ga = size_t(g) * gv.A;
+    float* sc = xchg + x.scalars();
+    int* cand_count = reinterpret_cast<int*>(sc + 1) - g;
+    int* cand_player = reinterpret_cast<int*>(sc + 2) - g;
+    int* cand_action = reinterpret_cast<int*>(xchg + x.caction()) - ga;
+    azCandBody(gv, xchg + x.policy() - ga, xchg + x.logit() - ga, sc - g, rot, cand_count, cand_action, xchg + x.cpolicy() - ga, xchg + x.clogit() - ga,
+               cand_player, sc + 3 - g, sc + 4 - g, a->err, g, lane, reinterpret_cast<uint64_t*>(tiles));
     waveSync();
-    expandBackupBody(pv, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane,
-                     tiles);
+    expandBackupBody(pv, cand_count, cand_action, xchg + x.cpolicy() - ga, xchg + x.clogit() - ga, cand_player, sc + 3 - g, sc + 4 - g, slot, a->err, g,
+                     lane, tiles);
 }
 
 // Root exploration noise (ref zero_actor.cpp:194-213): policy = (1 - eps) * policy + eps * noise for the root's children, in storage
@@ -181,14 +217,16 @@ __device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, 
 
 // the heads read the tower's last activations where they are (an LDS tile); tile 0 (the blocks' temporary) is free for their scratch
 template <int WPE>
-__device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw)
+__device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw, float* xchg)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
     xcs = __builtin_amdgcn_readfirstlane(xcs);
     xpw = __builtin_amdgcn_readfirstlane(xpw);
     const HeadParams hp = ldc(&a->hp);
-    headsBody(nullptr, hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
+    const SimXchg x{hp.A + (hp.A & 1)};
+    const size_t ga = size_t(g) * hp.A;
+    headsBody(nullptr, hp, xchg + x.policy() - ga, xchg + x.logit() - ga, xchg + x.scalars() - g, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
 }
 
 // 8x8 boards: three tower tiles are 80 KB of LDS, so TWO games share a CU (16 waves) if the kernel stays within 128 VGPRs: one game's
@@ -199,14 +237,16 @@ template <int H, int W, int CIN0_PAD, int CPAD>
 constexpr int simWavesPerEu() { return (H * W <= 64 && kTowerTiles * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W) * 4 <= 76 * 1024) ? 4 : 2; }
 
 template <int H, int W, int CIN0_PAD, int CPAD>
-__device__ __noinline__ const float* simTower(CSimArgs* __restrict__ a, int g, int tid, float* tiles)
+__device__ __noinline__ const float* simTower(CSimArgs* __restrict__ a, int g, int tid, float* tiles, float* xchg)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
 #ifdef MZ_SIM_TPROF
     if (tid == 0 && g == 0) { s_tp_prev = clock64(); s_tp_idx = 0; g_tp[63] += 1; }
 #endif
-    return towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
+    g = __builtin_amdgcn_readfirstlane(g);
+    const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
+    return towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(gv.feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
 }
 
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
@@ -228,6 +268,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
     // and those kernels need their LDS to keep two games on a CU
     SpecMem spec{nullptr, nullptr, nullptr};
     int* spec_w = nullptr;
+    float* xchg = reinterpret_cast<float*>(rcp_w + a->rcp_n); // the phases' hand-over block (SimXchg), behind whatever the kernel keeps in LDS
     if constexpr (WPE == 2) {
         const int tab_n = a->rcp_n - 2;
         double* sqrt_w = rcp_w + a->rcp_n;
@@ -238,6 +279,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (tid < 8) { spec_w[kSpecWays * kSpecWay + tid] = 0; }
         __syncthreads();
         spec = SpecMem{(a->no_spec & 1) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
+        xchg = reinterpret_cast<float*>(spec_w + kSpecWords);
     }
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr;
     for (int s = 0; s < nsims; ++s) {
@@ -248,19 +290,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (wave == 0) {
             if (slot == 1 && a->root_noise) { simApplyRootNoise<WPE>(a, g, lane); }
             if (a->use_gumbel) { simGumbelStart<WPE>(a, slot, s == 0 && host_start != 0, g, lane, tiles); }
-            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec);
+            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec, xchg);
         }
         __syncthreads();
         if (prof) { t1 = wall_clock64(); }
         const float* xt;
-        if constexpr (true) { xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles); } // its own function: its own register budget
-        else { xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->gv.feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles); }
+        xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles, xchg); // its own function: its own register budget
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
-        simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2);
+        simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg);
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
-        if (wave == 0) { simCandExpand<WPE>(a, rot, slot, g, lane, tiles); }
+        if (wave == 0) { simCandExpand<WPE>(a, rot, slot, g, lane, tiles, xchg); }
         __syncthreads();
         if (prof && tid == 0) {
             t4 = wall_clock64();
@@ -578,7 +619,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     // (+ the path-speculation memory of the one-game-per-CU kernels: same condition as simWavesPerEu() == 2)
     const bool two_per_cu = H * W <= 64 && tile_bytes <= size_t(76) * 1024;
     const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) +
-                       (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int));
+                       (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int)) + simXchgWords(gv.A, gv.channels, gv.W32) * sizeof(float);
     // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
     static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
