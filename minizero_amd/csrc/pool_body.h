@@ -153,9 +153,10 @@ template <bool SPEC = false, class RcpPtr>
 __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restrict__ start, int g, int lane, RcpPtr rcp, SpecMem sm = SpecMem{nullptr, nullptr, nullptr})
 {
     GNodeRec* recs = (GNodeRec*)(v.rec + size_t(g) * v.cap);
-    MZ_GLOBAL int* path = (MZ_GLOBAL int*)(v.path + size_t(g) * v.max_depth);
-    MZ_GLOBAL int* pact = (MZ_GLOBAL int*)(v.path_action + size_t(g) * v.max_depth);
-    MZ_GLOBAL int* hact = v.host_path_action ? (MZ_GLOBAL int*)(v.host_path_action + size_t(g) * v.max_depth) : nullptr;
+    // (generic pointers: the simulation kernel keeps the path of its game in LDS and points the view there)
+    int* path = v.path + size_t(g) * v.max_depth;
+    int* pact = v.path_action + size_t(g) * v.max_depth;
+    int* hact = v.host_path_action ? v.host_path_action + size_t(g) * v.max_depth : nullptr;
     MZ_GLOBAL const float* bias_tab = (MZ_GLOBAL const float*)v.bias_tab;
     MZ_GLOBAL const double* sqrt_tab = (MZ_GLOBAL const double*)v.sqrt_tab;
     // remember level `d` of this walk for the next simulation: its count will be one higher after this simulation's backup

@@ -112,6 +112,18 @@ struct SimXchg { // word offsets inside the block for A actions
 };
 inline size_t simXchgWords(int A, int channels, int W32) { return size_t(5) * (A + (A & 1)) + 8 + 16 + size_t(channels) * W32; }
 
+// ... and so does the path of the simulation (node ids, moves, length): written by the walk, read by the leaf and by expand + backup
+__device__ __forceinline__ PoolView simPathView(PoolView pv, int* lds_path, int g)
+{
+    const size_t off = size_t(g) * pv.max_depth;
+    pv.path = lds_path - off;
+    pv.path_action = lds_path + pv.max_depth - off;
+    pv.path_len = lds_path + 2 * pv.max_depth - g;
+    pv.host_path_len = nullptr;
+    pv.host_path_action = nullptr;
+    return pv;
+}
+
 // the leaf's outputs (planes, legal mask, player, terminal flag, result) go to the next phases through the hand-over block too
 __device__ __forceinline__ GoDevView simLeafView(GoDevView gv, float* xchg, int g)
 {
@@ -139,7 +151,7 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
     rot = __builtin_amdgcn_readfirstlane(rot);
     unsigned long long t0 = 0;
     if (a->prof) { t0 = wall_clock64(); }
-    const PoolView pv = ldc(&a->pv);
+    const PoolView pv = simPathView(ldc(&a->pv), reinterpret_cast<int*>(xchg) - 2 * a->pv.max_depth - 2, g);
 #ifdef MZ_SELECT_TWICE // experiment: the walk again, now with its records in the caches -> the profile shows the arithmetic-only time
     selectBody<WPE == 2>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
     waveSync();
@@ -165,7 +177,7 @@ __device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, in
     slot = __builtin_amdgcn_readfirstlane(slot);
     rot = __builtin_amdgcn_readfirstlane(rot);
     const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
-    const PoolView pv = ldc(&a->pv);
+    const PoolView pv = simPathView(ldc(&a->pv), reinterpret_cast<int*>(xchg) - 2 * a->pv.max_depth - 2, g);
     const SimXchg x{gv.A + (gv.A & 1)};
     const size_t ga = size_t(g) * gv.A;
     float* sc = xchg + x.scalars();
@@ -268,7 +280,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
     // and those kernels need their LDS to keep two games on a CU
     SpecMem spec{nullptr, nullptr, nullptr};
     int* spec_w = nullptr;
-    float* xchg = reinterpret_cast<float*>(rcp_w + a->rcp_n); // the phases' hand-over block (SimXchg), behind whatever the kernel keeps in LDS
+    // the phases' hand-over block (SimXchg) behind whatever the kernel keeps in LDS, with the path of the simulation (2 * max_depth + 2 words) in front
+    const int path_words = 2 * a->pv.max_depth + 2;
+    float* xchg = reinterpret_cast<float*>(rcp_w + a->rcp_n) + path_words;
     if constexpr (WPE == 2) {
         const int tab_n = a->rcp_n - 2;
         double* sqrt_w = rcp_w + a->rcp_n;
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (tid < 8) { spec_w[kSpecWays * kSpecWay + tid] = 0; }
         __syncthreads();
         spec = SpecMem{(a->no_spec & 1) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
-        xchg = reinterpret_cast<float*>(spec_w + kSpecWords);
+        xchg = reinterpret_cast<float*>(spec_w + kSpecWords) + path_words;
     }
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr;
     for (int s = 0; s < nsims; ++s) {
@@ -619,7 +633,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     // (+ the path-speculation memory of the one-game-per-CU kernels: same condition as simWavesPerEu() == 2)
     const bool two_per_cu = H * W <= 64 && tile_bytes <= size_t(76) * 1024;
     const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) +
-                       (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int)) + simXchgWords(gv.A, gv.channels, gv.W32) * sizeof(float);
+                       (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int)) + (simXchgWords(gv.A, gv.channels, gv.W32) + 2 * size_t(pool.v_.max_depth) + 2) * sizeof(float);
     // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
     static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
