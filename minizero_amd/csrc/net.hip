@@ -217,6 +217,14 @@ int Net::launchConv(const ConvLayer& L, const float* in, const float* skip, floa
     MZ_CONV_CASE(8, 8, 68)
     MZ_CONV_CASE(8, 8, 8)
     MZ_CONV_CASE(8, 8, 12)
+    MZ_CONV_CASE(19, 19, 20) // 19x19 Go (per-layer kernels, lock-step modes)
+    MZ_CONV_CASE(19, 19, 64)
+    MZ_CONV_CASE(19, 19, 68)
+    MZ_CONV_CASE(19, 19, 8)
+    MZ_CONV_CASE(19, 19, 12)
+    MZ_CONV_CASE(6, 6, 4)   // 6x6 Othello
+    MZ_CONV_CASE(6, 6, 8)
+    MZ_CONV_CASE(6, 6, 64)
     MZ_CONV_CASE(3, 3, 4)   // TicTacToe stem
     MZ_CONV_CASE(3, 3, 16)
     MZ_CONV_CASE(3, 3, 20)

@@ -307,3 +307,11 @@ def test_go_deep_search_modes_are_equivalent(mz):
     assert len(host) >= 4
     assert host == sim_whole
     assert host == sim_chunks
+
+
+def test_go_19x19_lockstep_kernels_match_oracle(mz, oracle):
+    """19x19 Go has no fused-tower / simulation-kernel instance: per-layer MFMA convolutions + lock-step search kernels with the host engine."""
+    conf = "env_game=go:env_board_size=19:actor_num_simulation=4:zero_num_parallel_games=2"
+    args = ("go_19x19", 18, 19, 19, 8, 19, 19, 1, 1, 362, 16, 1, "alphazero")
+    lines, olines, _ = run_both(mz, oracle, conf, args, 5 * 800, threads=2, seed=2)
+    check(lines, olines, 2)
