@@ -79,14 +79,15 @@ public:
     int simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_logit, float* d_value, const uint8_t* d_rot, int sim0, int nsims,
                   bool* launched, const float* d_root_noise = nullptr, float noise_eps = 0.0f, int noise_kind = 1, const struct GumbelView* gum = nullptr,
                   int* d_start = nullptr, bool host_start = false);
-    bool hasSimKernel(int board_n, int env_kind = 0) const; // env_kind: GoDevView::kind
+    // num_simulation: the kernels keep per-search tables / the path in LDS; searches too long for 160 KB use the lock-step kernels
+    bool hasSimKernel(int board_n, int env_kind = 0, int num_simulation = 0) const; // env_kind: GoDevView::kind
     // MuZero (board games): the same for initial + recurrent inference; hidden states live in the caller's slab [games][slots][C * P]
     // nsims simulations (slots sim0 ..) of every game in one launch of sim_kernel_mz; muzero_atari: sim0 >= 1 (the root's 96x96 representation
     // runs as stand-alone kernels), value / reward come out of the kernel in game scale (d_reward: [games])
     int simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                     int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start);
-    bool hasSimKernelMz() const;
+    bool hasSimKernelMz(int num_simulation = 0) const;
     void makeAtariHeadParams(AtariHeadParams* out) const; // net_atari.hip
     int timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops);
     int timeTowerConv(int B, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch);

@@ -573,13 +573,26 @@ void Net::dumpSimProf()
     fprintf(stderr, "[mz sim prof] total        avg %8.2f us per simulation (slowest game %8.2f us)\n", tot_all, tot_max);
 }
 
-bool Net::hasSimKernel(int board_n, int env_kind) const
+// upper bound of the dynamic LDS a simulation kernel needs for searches of n simulations (the launch computes the exact figure)
+static size_t simLdsBound(size_t tile_bytes, int n, int A, size_t head_floats)
+{
+    const size_t rcp_n = size_t(n) + 5, max_depth = size_t(n) + 3;
+    return tile_bytes + rcp_n * (2 * sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int) + (size_t(5) * (A + 1) + 24 + 18 * 12 + 2 * max_depth + 2 + head_floats) * sizeof(float);
+}
+
+bool Net::hasSimKernel(int board_n, int env_kind, int num_simulation) const
 {
     if (desc_.type != 0 || !use_fused_) { return false; }
     TowerArgs ta;
     int c0 = 0;
     if (!makeTowerArgs(repr_, true, true, &ta, &c0)) { return false; }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+    {
+        const size_t tile_bytes = size_t(kTowerTiles) * std::max(c0, C) * planeStride(H, W) * sizeof(float);
+        if (simLdsBound(tile_bytes, num_simulation, desc_.action_size, 0) > size_t(160) * 1024) { return false; }
+        const size_t Wq = (size_t(board_n) * board_n + 63) / 64; // the Go leaf keeps the hashes of the path (max_depth words) in the tiles' scratch
+        if (sizeof(uint64_t) * (64 * Wq + size_t(num_simulation) + 3 + 18 * Wq) + 64 * Wq * 7 > tile_bytes) { return false; }
+    }
 #define MZ_SIM_HAS(h, w, cin0, cpad, cpl) \
     if (H == h && W == w && c0 == cin0 && C == cpad && board_n == h && (env_kind == 2 ? -1 : env_kind == 1 ? 0 : (h * w + 63) / 64) == cpl) { return true; }
     MZ_SIM_CASES(MZ_SIM_HAS)
@@ -629,7 +642,10 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     const size_t heads = (size_t(a.hp.PC) * a.hp.P + a.hp.P + a.hp.VH + a.hp.A + 16) * sizeof(float); // in tile 0 (the activations stay in tile 1)
     size_t scratch = std::max(std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A)), gumbelSmemBytes(gv.A));
     scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
-    if (scratch > tile_bytes || heads > tile_bytes / kTowerTiles) { return MZ_OK; } // not launched: the caller falls back to the lock-step kernels
+    if (scratch > tile_bytes || heads > tile_bytes / kTowerTiles) { // not launched
+        setError("simLaunch: the tree phases need %zu B / the heads %zu B of scratch, the tower tiles have %zu B", scratch, heads, tile_bytes);
+        return MZ_OK;
+    }
     // (+ the path-speculation memory of the one-game-per-CU kernels: same condition as simWavesPerEu() == 2)
     const bool two_per_cu = H * W <= 64 && tile_bytes <= size_t(76) * 1024;
     const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) +
@@ -649,7 +665,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     return MZ_OK;
 }
 
-bool Net::hasSimKernelMz() const
+bool Net::hasSimKernelMz(int num_simulation) const
 {
     if ((desc_.type != 1 && desc_.type != 2) || !use_fused_) { return false; }
     TowerArgs t1, t2;
@@ -658,6 +674,12 @@ bool Net::hasSimKernelMz() const
     else if (!makeTowerArgs(repr_, true, true, &t1, &c0)) { return false; }
     if (!makeTowerArgs(dyn_, false, true, &t2, &cd)) { return false; }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+    {
+        size_t head_floats = 0;
+        if (desc_.type == 2) { AtariHeadParams hp; makeAtariHeadParams(&hp); head_floats = atariHeadsSmemFloats(hp); }
+        const size_t tile_bytes = size_t(kTowerTiles) * std::max(std::max(c0, cd), C) * planeStride(H, W) * sizeof(float);
+        if (simLdsBound(tile_bytes, num_simulation, desc_.action_size, head_floats) > size_t(160) * 1024) { return false; }
+    }
 #define MZ_SIM_MZ_HAS(h, w, cin0, cdyn, cpad) \
     if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { return true; }
     MZ_SIM_MZ_CASES(MZ_SIM_MZ_HAS)

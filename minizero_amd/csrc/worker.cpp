@@ -464,7 +464,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             L->pool.v_.host_path_action = nullptr;
             if ((rc = uploadRoots(*L))) { return rc; }
         }
-        sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize(), e.deviceKind()) &&
+        sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize(), e.deviceKind(), cfg_.actor_num_simulation) &&
                       (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 1 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
         { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
         defer_info_ = sim_kernel_;
@@ -477,7 +477,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             }
         }
     }
-    sim_mz_ = !resident_ && cfg_.mz_sim_kernel && (desc.type == 1 || desc.type == 2) && net0().hasSimKernelMz() &&
+    sim_mz_ = !resident_ && cfg_.mz_sim_kernel && (desc.type == 1 || desc.type == 2) && net0().hasSimKernelMz(cfg_.actor_num_simulation) &&
               (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 1 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
     if (sim_mz_) {
         sim_kernel_ = true;
@@ -1310,7 +1310,7 @@ int Worker::runCyclesSim(int n)
                                                  noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
                                                  dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, host_gumbel);
             if (rc) { return rc; }
-            if (!launched) { setError("worker: no simulation-kernel instance for this network"); return MZ_ERR_STATE; }
+            if (!launched) { const std::string why = mz_last_error(); setError("worker: the simulation kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
             MZ_HIP(hipEventRecord(L->ev1, L->stream));
         }
         flushDeferred(); // the record strings of the move just decided: built while the launch runs
