@@ -68,6 +68,20 @@ __host__ __device__ constexpr bool cornerTapInside(int t) { return t == 3 || t =
 // a_first / have_first: this layer's tap-0 A-fragments if the previous layer already fetched them; next_wp / a_next: the NEXT layer's
 // weights (nullptr: none) whose tap-0 fragments are fetched during this layer's last tap, so that the layer boundary (epilogue,
 // barrier) does not end with an exposed L2 round trip; the bias values are fetched at the start of the layer for the same reason.
+// weights of a tower whose working set does not fit the L2 next to the heads' (muzero_atari: 2.1 MB + 2.5 MB per XCD of 4 MB) are streamed
+// with non-temporal loads so that they do not evict the heads' weights (heads 65 -> 58 us per simulation on BASELINE configs[4])
+template <bool NTW>
+__device__ __forceinline__ float4 loadW4(const float* p)
+{
+    if constexpr (NTW) {
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        const vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const float4*>(p);
+    }
+}
+
 #ifndef MZ_TPROF
 #define MZ_TPROF(slot) // tools/tower_prof.hip defines it: time stamps of wave phases inside a layer
 #endif
@@ -96,7 +110,7 @@ __device__ __forceinline__ PixSet<NT> makePixSet(int lane, int tile0)
     return px;
 }
 
-template <int H, int W, int CG, int NT, int CGN, bool CORNER>
+template <int H, int W, int CG, int NT, int CGN, bool CORNER, bool NTW = false>
 __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
                                             float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
                                             int lane, int ot, const PixSet<NT>& px, bool have_first, float (&a_first)[CG],
@@ -123,7 +137,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     auto loadFrom = [&](float* a, const float* base) { // base = first float of a (tap, oc-tile) block of CG * 64 floats
 #pragma unroll
         for (int c4 = 0; c4 < CG4; ++c4) {
-            const float4 w = *reinterpret_cast<const float4*>(base + c4 * 256 + lane * 4);
+            const float4 w = loadW4<NTW>(base + c4 * 256 + lane * 4);
             a[4 * c4] = w.x; a[4 * c4 + 1] = w.y; a[4 * c4 + 2] = w.z; a[4 * c4 + 3] = w.w;
         }
 #pragma unroll
@@ -180,7 +194,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
         const float* nb = next_wp + size_t(ot) * CGN * 64;
 #pragma unroll
         for (int c4 = 0; c4 < CGN4; ++c4) {
-            const float4 w = *reinterpret_cast<const float4*>(nb + c4 * 256 + lane * 4);
+            const float4 w = loadW4<NTW>(nb + c4 * 256 + lane * 4);
             a_next[4 * c4] = w.x; a_next[4 * c4 + 1] = w.y; a_next[4 * c4 + 2] = w.z; a_next[4 * c4 + 3] = w.w;
         }
 #pragma unroll
@@ -233,7 +247,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
 
 // the layer sequence of one wave: oc-tile `ot` x the NT pixel tiles from `tile0` (CORNER: the last of them is the corner tile); T0 = the
 // temporary (holds the stem's input on entry), T1 = x.  Every wave of the workgroup passes the same number of barriers (towerIdle).
-template <int H, int W, int CIN0_PAD, int CPAD, int NT, bool CORNER>
+template <int H, int W, int CIN0_PAD, int CPAD, int NT, bool CORNER, bool NTW = false>
 __device__ __forceinline__ void towerRun(const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ T0, float* __restrict__ T1,
                                          float* __restrict__ gout, int lane, int ot, int tile0)
 {
@@ -243,7 +257,7 @@ __device__ __forceinline__ void towerRun(const float* __restrict__ params, const
     bool have = false;
     if (ta.has_stem) { // stem: T0 -> T1
         const float* nw = ta.nlayers > 1 ? params + ta.w_off[1] : nullptr;
-        tower_layer<H, W, CIN0_PAD / 4, NT, CPAD / 4, CORNER>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0],
+        tower_layer<H, W, CIN0_PAD / 4, NT, CPAD / 4, CORNER, NTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0],
                                                              ta.C, ta.OT, lane, ot, px, false, aS, nw, aA);
         have = nw != nullptr;
         __syncthreads();
@@ -252,7 +266,7 @@ __device__ __forceinline__ void towerRun(const float* __restrict__ params, const
 #pragma unroll 1
     for (int l = ta.has_stem; l < ta.nlayers; ++l) { // residual blocks: tmp = relu(conv1(x)); x = relu(conv2(tmp) + x) — one code copy for both convs
         const bool second = ((l - ta.has_stem) & 1) != 0, last = l + 1 == ta.nlayers;
-        tower_layer<H, W, CPAD / 4, NT, CPAD / 4, CORNER>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, last ? gout : nullptr,
+        tower_layer<H, W, CPAD / 4, NT, CPAD / 4, CORNER, NTW>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, last ? gout : nullptr,
                                                          params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, ot, px, have, aA,
                                                          last ? nullptr : params + ta.w_off[l + 1], aB);
 #pragma unroll
@@ -271,7 +285,7 @@ __device__ __forceinline__ void towerIdle(const TowerArgs& ta)
 
 // the body of tower_fused for sample `b`, run by all 512 threads of a workgroup (tid 0..511); `tiles` = 3 x [CMAX][CS] floats of LDS
 // out == nullptr: the last layer's activations stay in LDS; the returned pointer is that tile ([C][CS] padded planes)
-template <int H, int W, int CIN0_PAD, int CPAD>
+template <int H, int W, int CIN0_PAD, int CPAD, bool NTW = false>
 // hidden_src != nullptr (MuZero dynamics, ref muzero_network.py:32): the input is cat(hidden_src[C][P], one-hot plane of `action`;
 // action_planes > 1: that many planes, plane `action` all ones)
 // instead of sample b of `in` (a pass / out-of-board action gives an all-zero plane, ref go.cpp:310-315)
@@ -320,9 +334,9 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     using TM = TileMap<H, W>;
     const int ot = wave & 3, half = wave >> 2;
     if (ot < ta.OT && half == 0) {
-        towerRun<H, W, CIN0_PAD, CPAD, TM::PT0, (TM::kCorner && TM::PT1 == 0)>(params, ta, T0, T1, gout, lane, ot, 0);
+        towerRun<H, W, CIN0_PAD, CPAD, TM::PT0, (TM::kCorner && TM::PT1 == 0), NTW>(params, ta, T0, T1, gout, lane, ot, 0);
     } else if (ot < ta.OT && TM::PT1 > 0) {
-        if constexpr (TM::PT1 > 0) { towerRun<H, W, CIN0_PAD, CPAD, TM::PT1, TM::kCorner>(params, ta, T0, T1, gout, lane, ot, TM::PT0); }
+        if constexpr (TM::PT1 > 0) { towerRun<H, W, CIN0_PAD, CPAD, TM::PT1, TM::kCorner, NTW>(params, ta, T0, T1, gout, lane, ot, TM::PT0); }
     } else {
         towerIdle(ta);
     }

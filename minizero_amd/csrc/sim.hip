@@ -472,7 +472,8 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             const int src = v.hslot[size_t(g) * v.cap + path[len - 2]];
             const int action = v.path_action[size_t(g) * v.max_depth + len - 1];
             const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;
-            xt = towerBody<H, W, CDYN_PAD, CPAD>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action, a->action_planes);
+            xt = towerBody<H, W, CDYN_PAD, CPAD, (H * W <= 36)>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action,
+                                                               a->action_planes); // 6x6 = muzero_atari: stream the tower's weights (net_body.h loadW4)
         }
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
