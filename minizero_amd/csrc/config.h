@@ -57,7 +57,8 @@ struct WorkerConfig {
     // not a reference key: wait for the GPU on a pinned completion word (spin) instead of hipStreamSynchronize
     bool mz_signal_wait = true;
     bool mz_sim_kernel = true; // with mz_device_env: whole runs of cycles as one launch of the per-game simulation kernel (sim.hip)
-    bool mz_device_env = true; // AlphaZero Go without Gumbel: rules, planes, legal mask and candidate sort on the device (go_dev.hip)
+    bool mz_raw_observations = true; // muzero_atari roots: ship the observation ring as bytes, expand the float planes on the device
+    bool mz_device_env = true; // AlphaZero Go / Othello / TicTacToe: rules, planes, legal mask and candidate sort on the device (go_dev.hip)
     int mz_zero_copy = 3; // bit 0: kernels read their inputs from pinned host memory; bit 1: kernels write their outputs there
 
     // returns false (and sets the library error string) on an unknown key or an unparsable value,

@@ -722,6 +722,19 @@ public:
             }
         }
     }
+    // raw form of features(): the 8 screens oldest first (3 x 96 x 96 bytes each), then 8 f32 action-plane values, then 8 valid bytes
+    int rawFeatureBytes() const override { return kHist * kFrame + kHist * 4 + kHist; }
+    void rawFeatures(uint8_t* dst) const override
+    {
+        float av[kHist];
+        for (int i = 0; i < kHist; ++i) {
+            const int slot = (head_ + i) % kHist;
+            memcpy(dst + size_t(i) * kFrame, frames_.data() + size_t(slot) * kFrame, kFrame);
+            av[i] = action_plane_[slot];
+            dst[size_t(kHist) * kFrame + kHist * 4 + i] = valid_[slot] ? 1 : 0;
+        }
+        memcpy(dst + size_t(kHist) * kFrame, av, sizeof(av));
+    }
     int numInputChannels() const override { return kHist * 4; }
     int boardSize() const override { return kRes; }
     int policySize() const override { return kActions; }

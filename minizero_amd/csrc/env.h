@@ -47,6 +47,10 @@ public:
     virtual std::string name() const = 0;
     virtual std::vector<std::pair<std::string, std::string>> loaderTags() const = 0;
     // engines with a device twin (go_dev.hip): the root position in the device's format, once per move
+    // observations that are cheaper to ship raw (bytes) and expand into float planes on the device (net_atari.hip atari_expand_features):
+    // rawFeatureBytes() > 0 = supported; layout documented at the implementation
+    virtual int rawFeatureBytes() const { return 0; }
+    virtual void rawFeatures(uint8_t* /*dst*/) const {}
     virtual bool hasDeviceTwin() const { return false; }
     virtual int deviceKind() const { return 0; } // GoDevView::kind (0 Go, 1 Othello)
     virtual void exportDeviceRoot(void* /*GoRootSnapshot*/) const {}

@@ -88,6 +88,7 @@ public:
                     int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start);
     bool hasSimKernelMz(int num_simulation = 0) const;
+    int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)
     void makeAtariHeadParams(AtariHeadParams* out) const; // net_atari.hip
     int timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops);
     int timeTowerConv(int B, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch);

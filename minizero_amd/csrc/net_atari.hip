@@ -272,4 +272,30 @@ int invertValuesOnDevice(int device, const float* values, int n, float* out)
     return MZ_OK;
 }
 
+// raw observations -> the network's float planes (ref atari.cpp:199-216 getFeatures: per history step one action plane, then R, G, B / 255):
+// `raw` per sample = hist screens oldest first (3 * res * res bytes each), hist f32 action-plane values, hist valid bytes (env.cpp rawFeatures).
+// Same values as the host's features() (one IEEE division per element); the point is the 4x smaller host-to-device copy per move.
+__global__ __launch_bounds__(256) void atari_expand_features(const uint8_t* __restrict__ raw, int raw_bytes, int hist, int res, float* __restrict__ out)
+{
+    const int b = blockIdx.y, i = blockIdx.x; // sample, history step
+    const int pix = res * res, frame = 3 * pix;
+    const uint8_t* r = raw + size_t(b) * raw_bytes;
+    float av;
+    memcpy(&av, r + size_t(hist) * frame + size_t(i) * 4, 4);
+    const bool valid = r[size_t(hist) * frame + size_t(hist) * 4 + i] != 0;
+    const uint8_t* f = r + size_t(i) * frame;
+    float* dst = out + (size_t(b) * hist + i) * 4 * pix;
+    for (int p = threadIdx.x; p < pix; p += 256) { dst[p] = av; }
+    for (int p = threadIdx.x; p < frame; p += 256) { dst[pix + p] = valid ? static_cast<float>(f[p]) / 255.0f : 0.0f; }
+}
+
+int Net::expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat)
+{
+    const int res = desc_.input_channel_height, hist = desc_.num_input_channels / 4;
+    if (desc_.input_channel_width != res || raw_bytes != hist * 3 * res * res + hist * 5) { setError("expandAtariFeatures: unexpected observation layout"); return MZ_ERR_ARG; }
+    hipLaunchKernelGGL(atari_expand_features, dim3(hist, B), dim3(256), 0, stream_, d_raw, raw_bytes, hist, res, d_feat);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
 } // namespace mz

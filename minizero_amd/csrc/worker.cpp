@@ -294,6 +294,8 @@ private:
         Pool pool;
         hipStream_t stream = nullptr;
         PinBuf<float> h_feat, h_out;
+        PinBuf<uint8_t> h_raw;   // raw root observations (muzero_atari: bytes up, planes expanded on the device)
+        DevBuf<uint8_t> d_raw;
         DevBuf<float> d_feat, d_out, d_hidden;
         Pool::View<float> h_policy, h_logit, h_value, h_reward, d_policy, d_logit, d_value, d_reward;
         DevBuf<int> d_src_idx, d_dst_idx, d_action_ids;
@@ -375,6 +377,7 @@ private:
     void flushDeferred();
     GumbelView gum_{};        // constants of the device-side Gumbel step (state pointer set per lane)
     bool dev_gumbel_ = false; // Gumbel root logic inside the simulation kernel
+    int raw_bytes_ = 0;             // > 0: root observations travel as bytes (GameEnv::rawFeatures) and are expanded on the device
     bool sim_root_host_ = false;    // muzero_atari on sim_kernel_mz: the root (96x96 representation) is evaluated by a lock-step cycle
     bool root_host_pending_ = false; // ... whose outputs the next phase1 still has to turn into the root's children (host candidate lists)
     int syncGumbel(Lane& L, bool to_device);
@@ -449,6 +452,12 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     int rcc = createActors();
     if (rcc) { return rcc; }
     feat_bits_ = (desc.type == 0) && net0().hasFusedTower();
+    raw_bytes_ = (desc.type == 2 && cfg_.mz_raw_observations) ? games_[0].env->rawFeatureBytes() : 0;
+    if (raw_bytes_ > 0) {
+        for (auto& L : lanes_) {
+            if (!L->h_raw.alloc(size_t(L->n) * raw_bytes_) || !L->d_raw.alloc(size_t(L->n) * raw_bytes_)) { setError("worker: allocation failed (raw observations)"); return MZ_ERR_DEVICE; }
+        }
+    }
     use_signal_ = cfg_.mz_signal_wait;
     resident_ = cfg_.mz_device_env && desc.type == 0 && feat_bits_ && games_[0].env->hasDeviceTwin() && lane_size_ <= kRotPackGames;
     if (resident_) {
@@ -674,7 +683,8 @@ void Worker::buildLeaf(int gi)
         if (feat_bits_) { g.leaf->featureBits(g.rot, reinterpret_cast<uint32_t*>(L.h_feat.p) + size_t(j) * g.env->featureWords()); }
         else { g.leaf->features(g.rot, feat); }
     } else if (sims_done_ == 0) {
-        g.env->features(0, feat);
+        if (raw_bytes_ > 0) { g.env->rawFeatures(L.h_raw.p + size_t(j) * raw_bytes_); }
+        else { g.env->features(0, feat); }
         g.env->legalMask(g.legal.data());
     }
 }
@@ -1154,7 +1164,12 @@ int Worker::phase2(Lane& L)
             return MZ_OK;
         }
     } else if (sims_done_ == 0) {
-        MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, size_t(L.n) * L.net.featSize() * sizeof(float), hipMemcpyHostToDevice, L.stream));
+        if (raw_bytes_ > 0) {
+            MZ_HIP(hipMemcpyAsync(L.d_raw.p, L.h_raw.p, size_t(L.n) * raw_bytes_, hipMemcpyHostToDevice, L.stream));
+            if ((rc = L.net.expandAtariFeatures(L.d_raw.p, raw_bytes_, L.n, L.d_feat.p))) { return rc; }
+        } else {
+            MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, size_t(L.n) * L.net.featSize() * sizeof(float), hipMemcpyHostToDevice, L.stream));
+        }
         if ((rc = L.pool.hiddenIndexAsync(n_ + 1, 0, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
         if ((rc = L.net.initial(L.d_feat.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_hidden.p, L.d_dst_idx.p))) { return rc; }
         MZ_HIP(hipMemsetAsync(L.d_reward.p, 0, L.n * sizeof(float), L.stream));

@@ -315,3 +315,14 @@ def test_go_19x19_lockstep_kernels_match_oracle(mz, oracle):
     args = ("go_19x19", 18, 19, 19, 8, 19, 19, 1, 1, 362, 16, 1, "alphazero")
     lines, olines, _ = run_both(mz, oracle, conf, args, 5 * 800, threads=2, seed=2)
     check(lines, olines, 2)
+
+
+def test_atari_raw_observation_path_is_equivalent(mz):
+    """Root observations as bytes + planes expanded on the device (default) vs float planes built on the host: identical records."""
+    total = 9 * 50
+    raw = _lines_of(mz, ATARI_SMALL + ":mz_raw_observations=true", ATARI_ARGS, [total], total)
+    host = _lines_of(mz, ATARI_SMALL + ":mz_raw_observations=false", ATARI_ARGS, [total], total)
+    lock = _lines_of(mz, ATARI_SMALL + ":mz_raw_observations=true:mz_sim_kernel=false", ATARI_ARGS, [total], total)
+    assert len(raw) >= 8
+    assert raw == host
+    assert raw == lock
