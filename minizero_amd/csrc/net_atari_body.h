@@ -25,27 +25,31 @@ struct AtariHeadParams {
 // s = ((x[0] + x[1]) + x[2]) + ... in index order, by ONE wave: lane l holds elements [l * VPL, (l + 1) * VPL) in registers and the running
 // sum is handed from lane to lane (v_readlane).  The same n - 1 dependent adds as a scalar loop, but without an LDS round trip per
 // element (one lane reading x[i] and adding, 601 times, cost 33 us per sum: the 601-bin heads have four such sums).
-__device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
+template <int VPL>
+__device__ __forceinline__ float orderedSumWaveT(const float* x, int n, int vpl, int lane)
 {
-    constexpr int VPL = 16;
-    if (n > 64 * VPL) { // not reached by the supported head sizes: plain loop
-        float s = 0.0f;
-        for (int i = 0; i < n; ++i) { s += x[i]; }
-        return s;
-    }
-    const int vpl = (n + 63) / 64;
     float v[VPL]; // slots beyond the lane's elements hold +0: adding +0 never changes a sum that is not -0, and these sums never are
 #pragma unroll
     for (int k = 0; k < VPL; ++k) { const int i = lane * vpl + k; v[k] = (k < vpl && i < n) ? x[i] : 0.0f; }
     float acc = 0.0f;
     const int lanes = (n + vpl - 1) / vpl;
-    for (int l = 0; l < lanes; ++l) { // straight-line body: 16 dependent adds in every lane, lane l's result is the one that counts
+    for (int l = 0; l < lanes; ++l) { // straight-line body: VPL dependent adds in every lane, lane l's result is the one that counts
         float a = acc;
 #pragma unroll
         for (int k = 0; k < VPL; ++k) { a = a + v[k]; }
         acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), l));
     }
     return acc;
+}
+__device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
+{
+    const int vpl = (n + 63) / 64;
+    if (vpl <= 4) { return orderedSumWaveT<4>(x, n, vpl, lane); }
+    if (vpl <= 10) { return orderedSumWaveT<10>(x, n, vpl, lane); } // 601 bins
+    if (vpl <= 16) { return orderedSumWaveT<16>(x, n, vpl, lane); }
+    float s = 0.0f; // not reached by the supported head sizes: plain loop
+    for (int i = 0; i < n; ++i) { s += x[i]; }
+    return s;
 }
 
 template <int NT>
