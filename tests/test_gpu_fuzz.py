@@ -1,0 +1,57 @@
+"""Randomised end-to-end parity: for seeded random search configurations (game, network type, PUCT / Gumbel root, noise, number of
+simulations and games, weights, program seed, chunking of run_cycles) the HIP worker in its default mode (per-game simulation kernels,
+device rules, path speculation) must emit exactly the `SelfPlay` lines of the CPU oracle.  Whole games, so every record is compared."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GAMES = {
+    "go": ("env_game=go:env_board_size=9", ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82), 170),
+    "othello": ("env_game=othello:env_board_size=8", ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65), 62),
+    "tictactoe": ("env_game=tictactoe", ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9), 10),
+}
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    game = str(rng.choice(list(GAMES)))
+    base, dargs, glen = GAMES[game]
+    typ = "muzero" if game != "othello" and rng.random() < 0.35 else "alphazero"
+    n = int(rng.choice([2, 5, 9, 16, 24]))
+    if game == "go":
+        n = min(n, 16)  # the oracle plays whole 9x9 games on the CPU
+    gumbel = bool(rng.random() < 0.4)
+    m = int(rng.choice([2, 4, 8]))
+    games = int(rng.integers(1, 5))
+    conf = (f"{base}:actor_num_simulation={n}:zero_num_parallel_games={games}:"
+            f"actor_use_gumbel={'true' if gumbel else 'false'}:actor_use_gumbel_noise={'true' if gumbel else 'false'}:actor_gumbel_sample_size={m}:"
+            f"actor_use_dirichlet_noise={'false' if gumbel or rng.random() < 0.3 else 'true'}:"
+            f"actor_select_action_by_count={'true' if rng.random() < 0.3 else 'false'}")
+    if typ == "muzero":
+        conf += ":nn_type_name=muzero"
+    cycles = (n + 1) * (glen + 4)
+    chunks = [int(x) for x in rng.integers(1, 3 * (n + 1), 5)]
+    return conf, dargs, typ, cycles, chunks, int(rng.integers(0, 50)), int(rng.integers(1, 1000))
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_configuration_matches_oracle(mz, oracle, seed):
+    conf, dargs, typ, cycles, chunks, wseed, pseed = _case(seed)
+    kw = dict(vh=16, dv=1, type_name=typ)
+    d, od = mz.make_desc(*dargs, **kw), oracle.make_desc(*dargs, **kw)
+    w = mz.generate_weights(d, wseed)
+    conf = f"{conf}:program_seed={pseed}:nn_file_name=/tmp/fuzz_{wseed}.pt"
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles(cycles)
+    wk = mz.Worker(conf + ":zero_num_threads=2", d, w)
+    wk.command("start")
+    done, k = 0, 0
+    while done < cycles:
+        c = min(chunks[k % len(chunks)], cycles - done)
+        assert wk.run_cycles(c) == c
+        done += c
+        k += 1
+    lines, olines = wk.pop_lines(), og.lines()
+    assert len(olines) >= 1, conf
+    assert lines == olines, conf
