@@ -15,7 +15,7 @@ __device__ __forceinline__ void waveSync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-inline size_t goLeafSmemBytes(const GoDevView& v, int max_depth) { return sizeof(uint64_t) * (size_t(v.Ppad) + max_depth + 18 * v.W) + size_t(v.Ppad) * (4 + 2 + 1); }
+inline size_t goLeafSmemBytes(const GoDevView& v, int max_depth) { return sizeof(uint64_t) * (size_t(v.Ppad) + max_depth + 4 + 18 * v.W) + size_t(v.Ppad) * (4 + 2 + 1); }
 
 struct Cand { int action; float policy, logit; };
 struct CandGreater { __host__ __device__ bool operator()(const Cand& l, const Cand& r) const { return l.policy > r.policy; } };
@@ -38,12 +38,15 @@ __device__ inline int rotOf(const RotPack& r, int g) { return (r.w[g / 10] >> (3
 
 // position + legal mask + feature planes of the leaf selected for game `g` (one wave64; `smem` as sized by goLeafSmemBytes)
 template <int CPL>
-__device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& pv, int rot, int slot, int g, int lane, uint64_t* __restrict__ smem)
+// seen_lds: optional LDS copy of the root's positional-superko table (GoRootSnapshot::seen; constant during a move) — the simulation kernel
+// makes one per launch so that the probes of every candidate point are LDS reads instead of dependent trips to L2
+__device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& pv, int rot, int slot, int g, int lane, uint64_t* __restrict__ smem,
+                                           const uint64_t* __restrict__ seen_lds = nullptr)
 {
     const int P = v.P, n = v.n, W = v.W, Ppad = v.Ppad, MD = pv.max_depth;
     uint64_t* gh = smem;                                   // [Ppad] XOR of the keys of a group, by group id
-    uint64_t* ph = gh + Ppad;                              // [MD]   (normalised) hashes of the positions along the path
-    uint64_t* hb = ph + MD;                                // [8][2][W] stones k moves before the leaf
+    uint64_t* ph = gh + Ppad;                              // [MD + 4] (normalised) hashes of the positions along the path, 0-padded to a multiple of 4
+    uint64_t* hb = ph + MD + 4;                            // [8][2][W] stones k moves before the leaf
     uint64_t* cur = hb + 16 * W;                           // [2][W] stones at the leaf
     int* libs = reinterpret_cast<int*>(cur + 2 * W);       // [Ppad] liberties of a group, by group id
     uint16_t* lab = reinterpret_cast<uint16_t*>(libs + Ppad); // [Ppad] group id per point
@@ -183,6 +186,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     const bool terminal = passes >= 2 || nmoves > 2 * P; // ref go.cpp:246-257
     // ---- hashes along the path (d = 1 .. depth; the root and everything before it is in the root's table) ----
     for (int d = 1 + lane; d <= depth; d += 64) { ph[d - 1] = normH(d == depth ? hash : v.hash[sb + hs[path[d]]]); }
+    if (lane < 4) { ph[depth + lane] = 0; } // normH never returns 0: the padding matches no candidate
     // ---- group liberties / key sums at the leaf ----
 #pragma unroll
     for (int i = 0; i < CPL; ++i) { libs[i * 64 + lane] = 0; gh[i * 64 + lane] = 0; }
@@ -236,12 +240,16 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
             if (ok) {
                 const uint64_t h = normH(nh);
                 bool rep = false;
+                const uint64_t* seen = seen_lds ? seen_lds : S.seen;
                 for (uint32_t s = static_cast<uint32_t>(h) & (kGoSeenCap - 1);; s = (s + 1) & (kGoSeenCap - 1)) {
-                    const uint64_t e = S.seen[s];
+                    const uint64_t e = seen[s];
                     if (e == 0) { break; }
                     if (e == h) { rep = true; break; }
                 }
-                for (int d = 0; d < depth && !rep; ++d) { rep = ph[d] == h; }
+                for (int d = 0; d < depth; d += 4) { // four hashes per step, no early exit: a deep path made this loop the longest part of the leaf
+                    const uint64_t a0 = ph[d], a1 = ph[d + 1], a2 = ph[d + 2], a3 = ph[d + 3];
+                    rep |= (a0 == h) | (a1 == h) | (a2 == h) | (a3 == h);
+                }
                 bit = !rep;
             }
         }

@@ -111,6 +111,7 @@ struct SimXchg { // word offsets inside the block for A actions
     __device__ int feat() const { return 5 * A + 8 + 16; } // the leaf's bit-packed planes (the tower's input)
 };
 inline size_t simXchgWords(int A, int channels, int W32) { return size_t(5) * (A + (A & 1)) + 8 + 16 + size_t(channels) * W32; }
+__device__ __forceinline__ int simXchgWordsDev(int A, int channels, int W32) { return 5 * (A + (A & 1)) + 8 + 16 + channels * W32; }
 
 // ... and so does the path of the simulation (node ids, moves, length): written by the walk, read by the leaf and by expand + backup
 __device__ __forceinline__ PoolView simPathView(PoolView pv, int* lds_path, int g)
@@ -143,7 +144,7 @@ typedef __attribute__((address_space(3))) const double LdsCDouble;
 
 template <int CPL, int WPE>
 __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
-                                           float* xchg)
+                                           float* xchg, const uint64_t* seen_lds)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -166,7 +167,7 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
     const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
     if constexpr (CPL == -1) { tttLeafBody(gv, pv, rot, slot, g, lane); } // CPL -1: TicTacToe, 0: Othello (go_body.h)
     else if constexpr (CPL == 0) { othLeafBody(gv, pv, rot, slot, g, lane); }
-    else { goLeafBody<CPL>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles)); }
+    else { goLeafBody<CPL>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles), seen_lds); }
 }
 
 template <int WPE>
@@ -295,6 +296,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         spec = SpecMem{(a->no_spec & 1) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
         xchg = reinterpret_cast<float*>(spec_w + kSpecWords) + path_words;
     }
+    // Go, one game per CU: the root's positional-superko table (8 KB, constant during the move) behind the hand-over block
+    const uint64_t* seen_lds = nullptr;
+    if constexpr (CPL > 0 && WPE == 2) {
+        uint64_t* sw = reinterpret_cast<uint64_t*>(xchg + ((simXchgWordsDev(a->gv.A, a->gv.channels, a->gv.W32) + 1) & ~1));
+        for (int i = tid; i < kGoSeenCap; i += 512) { sw[i] = a->gv.snap[g].seen[i]; }
+        __syncthreads();
+        seen_lds = sw;
+    }
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr;
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = position slot of its leaf
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (wave == 0) {
             if (slot == 1 && a->root_noise) { simApplyRootNoise<WPE>(a, g, lane); }
             if (a->use_gumbel) { simGumbelStart<WPE>(a, slot, s == 0 && host_start != 0, g, lane, tiles); }
-            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec, xchg);
+            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec, xchg, seen_lds);
         }
         __syncthreads();
         if (prof) { t1 = wall_clock64(); }
@@ -578,7 +587,8 @@ void Net::dumpSimProf()
 static size_t simLdsBound(size_t tile_bytes, int n, int A, size_t head_floats)
 {
     const size_t rcp_n = size_t(n) + 5, max_depth = size_t(n) + 3;
-    return tile_bytes + rcp_n * (2 * sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int) + (size_t(5) * (A + 1) + 24 + 18 * 12 + 2 * max_depth + 2 + head_floats) * sizeof(float);
+    return tile_bytes + rcp_n * (2 * sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int) + (size_t(5) * (A + 1) + 26 + 18 * 12 + 2 * max_depth + 2 + head_floats) * sizeof(float) +
+           size_t(kGoSeenCap) * sizeof(uint64_t);
 }
 
 bool Net::hasSimKernel(int board_n, int env_kind, int num_simulation) const
@@ -592,7 +602,7 @@ bool Net::hasSimKernel(int board_n, int env_kind, int num_simulation) const
         const size_t tile_bytes = size_t(kTowerTiles) * std::max(c0, C) * planeStride(H, W) * sizeof(float);
         if (simLdsBound(tile_bytes, num_simulation, desc_.action_size, 0) > size_t(160) * 1024) { return false; }
         const size_t Wq = (size_t(board_n) * board_n + 63) / 64; // the Go leaf keeps the hashes of the path (max_depth words) in the tiles' scratch
-        if (sizeof(uint64_t) * (64 * Wq + size_t(num_simulation) + 3 + 18 * Wq) + 64 * Wq * 7 > tile_bytes) { return false; }
+        if (sizeof(uint64_t) * (64 * Wq + size_t(num_simulation) + 3 + 4 + 18 * Wq) + 64 * Wq * 7 > tile_bytes) { return false; }
     }
 #define MZ_SIM_HAS(h, w, cin0, cpad, cpl) \
     if (H == h && W == w && c0 == cin0 && C == cpad && board_n == h && (env_kind == 2 ? -1 : env_kind == 1 ? 0 : (h * w + 63) / 64) == cpl) { return true; }
@@ -650,7 +660,8 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     // (+ the path-speculation memory of the one-game-per-CU kernels: same condition as simWavesPerEu() == 2)
     const bool two_per_cu = H * W <= 64 && tile_bytes <= size_t(76) * 1024;
     const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) +
-                       (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int)) + (simXchgWords(gv.A, gv.channels, gv.W32) + 2 * size_t(pool.v_.max_depth) + 2) * sizeof(float);
+                       (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int)) + (simXchgWords(gv.A, gv.channels, gv.W32) + 2 + 2 * size_t(pool.v_.max_depth) + 2) * sizeof(float) +
+                       ((gv.kind == 0 && !two_per_cu) ? size_t(kGoSeenCap) * sizeof(uint64_t) : 0);
     // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
     static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
