@@ -236,10 +236,12 @@ __device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, 
     g = __builtin_amdgcn_readfirstlane(g);
     xcs = __builtin_amdgcn_readfirstlane(xcs);
     xpw = __builtin_amdgcn_readfirstlane(xpw);
+    MZ_HPROF(0);
     const HeadParams hp = ldc(&a->hp);
     const SimXchg x{hp.A + (hp.A & 1)};
     const size_t ga = size_t(g) * hp.A;
     headsBody(nullptr, hp, xchg + x.policy() - ga, xchg + x.logit() - ga, xchg + x.scalars() - g, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
+    MZ_HPROF(1);
 }
 
 // 8x8 boards: three tower tiles are 80 KB of LDS, so TWO games share a CU (16 waves) if the kernel stays within 128 VGPRs: one game's
@@ -392,6 +394,7 @@ __device__ __forceinline__ void rescaleTile(float* __restrict__ xt, int C, float
 {
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
     const int lane = tid & 63, wave = tid >> 6;
+    MZ_HPROF(0);
     float mn = 3.4e38f, mx = -3.4e38f;
     for (int i = tid; i < C * P; i += 512) {
         const int c = i / P, p = i - c * P;
@@ -406,6 +409,7 @@ __device__ __forceinline__ void rescaleTile(float* __restrict__ xt, int C, float
     }
     if (lane == 0) { red[wave] = mn; red[8 + wave] = mx; }
     __syncthreads();
+    MZ_HPROF(1);
     mn = red[0]; mx = red[8];
     for (int w = 1; w < 8; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[8 + w] > mx ? red[8 + w] : mx; }
     float scale = mx - mn;
@@ -416,11 +420,13 @@ __device__ __forceinline__ void rescaleTile(float* __restrict__ xt, int C, float
         xt[k] = v;
         hd[i] = v;
     }
+    MZ_HPROF(2);
     __syncthreads();
+    MZ_HPROF(3);
 }
 
 template <int H, int W>
-__device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, float* scratch, float* xtile)
+__device__ __forceinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, float* scratch, float* xtile)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     slot = __builtin_amdgcn_readfirstlane(slot);
@@ -436,6 +442,7 @@ __device__ __noinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int 
     float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
     rescaleTile<H, W>(xtile, hp.C, hd, tid, tiles); // tile 0 (the blocks' temporary) is free: its first words hold the reduction scratch
     headsBody(nullptr, hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
+    MZ_HPROF(4);
 }
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
