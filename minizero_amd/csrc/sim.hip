@@ -230,7 +230,7 @@ __device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, 
 
 // the heads read the tower's last activations where they are (an LDS tile); tile 0 (the blocks' temporary) is free for their scratch
 template <int WPE>
-__device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw, float* xchg)
+__device__ __forceinline__ void simHeadsImpl(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw, float* xchg)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -242,6 +242,13 @@ __device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, 
     const size_t ga = size_t(g) * hp.A;
     headsBody(nullptr, hp, xchg + x.policy() - ga, xchg + x.logit() - ga, xchg + x.scalars() - g, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
     MZ_HPROF(1);
+}
+// a non-inlined device function saves the callee-saved VGPRs it uses on entry (scratch stores + loads by all 8 waves): worth it for the
+// 9x9 kernels (the heads keep their own register budget, and their version needs none saved), not for the 128-VGPR 8x8 / 3x3 kernels
+template <int WPE>
+__device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw, float* xchg)
+{
+    simHeadsImpl<WPE>(a, g, tid, tiles, xtile, xcs, xpw, xchg);
 }
 
 // 8x8 boards: three tower tiles are 80 KB of LDS, so TWO games share a CU (16 waves) if the kernel stays within 128 VGPRs: one game's
@@ -323,7 +330,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles, xchg); // its own function: its own register budget
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
-        simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg);
+        if constexpr (WPE == 4) { simHeadsImpl<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
+        else { simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
         if (wave == 0) { simCandExpand<WPE>(a, rot, slot, g, lane, tiles, xchg); }
