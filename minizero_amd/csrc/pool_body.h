@@ -225,13 +225,13 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
         const int N = static_cast<int>(cur.count - 1);
         const float bias = bias_tab[N];
         const double sqrtN = sqrt_tab[N];
-        if (nc <= 128 && !v.value_rescale) {
+        if (nc <= 128) { // (with value rescaling the normalised means come from normalizedMean() itself: the reciprocal trick covers the plain case)
             // Children are stored in descending prior order and an unvisited child can only be chosen while every child before it has
             // been visited (equal init-Q, u monotone in the prior, ties go to the higher prior / lower index), so the visited children
             // of a node are a PREFIX of its children and the arg-max is among that prefix plus the first unvisited child.  The prefix
             // length is kept in the upper half of `players` (expandBackupBody).  Not at the root: the root noise re-orders its priors.
             const int ne = node == 0 ? nc : min(nc, static_cast<int>(static_cast<unsigned>(cur.players) >> 16) + 1); // children that need a look
-            if (SPEC && spec && node != 0 && !v.atari_init_q) {
+            if (SPEC && spec && node != 0 && !v.atari_init_q && !v.value_rescale) {
                 const int L0 = depth - 1;
                 const int plen = __builtin_amdgcn_readfirstlane(spec[0]);
                 if (L0 + 1 < plen && L0 + 1 < kSpecCap && __builtin_amdgcn_readfirstlane(spec[kSpecNode + L0]) == node) {
@@ -350,7 +350,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
                 LevelEval e = evalChild(v, c, cplayer, bias, sqrtN, rp[0], rp[1], &tiny);
                 const bool vis = has && c.count != 0.0f;
                 const unsigned long long vm = __ballot(vis);
-                if (__ballot(vis && tiny) != 0) { e.q = normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi); }
+                if (v.value_rescale || __ballot(vis && tiny) != 0) { e.q = normalizedMean(v, c.reward, c.mean, c.count, cplayer, bsize, lo, hi); }
                 // ordered sum over the visited children (adding +0 for an unvisited one changes nothing: the sum is never -0)
                 float sum_of_win = 0.0f, sum = 0.0f;
                 sum_of_win += (vm & 1) ? laneF(e.q, 0) : 0.0f; sum += (vm & 1) ? 1.0f : 0.0f;
@@ -390,7 +390,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
             const bool vis0 = has0 && c0.count != 0.0f;
             bool vis1 = false;
             if (two) { e1 = evalChild(v, c1, cplayer, bias, sqrtN, r10, r11, &tiny1); vis1 = has1 && c1.count != 0.0f; }
-            if (__ballot((vis0 && tiny0) || (vis1 && tiny1)) != 0) { // subnormal quotient: the reference's division (never seen in practice)
+            if (v.value_rescale || __ballot((vis0 && tiny0) || (vis1 && tiny1)) != 0) { // value rescaling, or a subnormal quotient (never seen in practice): the reference's own formula
                 e0.q = normalizedMean(v, c0.reward, c0.mean, c0.count, cplayer, bsize, lo, hi);
                 e1.q = normalizedMean(v, c1.reward, c1.mean, c1.count, cplayer, bsize, lo, hi);
             }
