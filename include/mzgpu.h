@@ -163,9 +163,14 @@ int mz_worker_set_weights(mz_worker* w, const float* weights, size_t count);
 int mz_worker_run_cycles(mz_worker* w, int n);
 /* next pending stdout line ("SelfPlay ... #", ref actor_group.cpp:24-50); returns its length, 0 if none */
 int mz_worker_pop_line(mz_worker* w, char* buf, int cap);
+/* test / monitoring access: the record of game `game` as it stands, unfinished games included (BaseActor::getRecord with no extra
+ * tags, ref actor/base_actor.cpp:39-57); returns its length.  Does not disturb the search. */
+int mz_worker_peek_record(mz_worker* w, int game, char* buf, int cap);
 typedef struct mz_worker_stats {
     uint64_t cycles, leaf_evals, moves, games;
     double ms_select, ms_env, ms_forward, ms_expand, ms_move, ms_total;
+    uint64_t sim_launches; /* launches of the per-game simulation kernel (sim.hip); 0 = the lock-step kernels ran */
+    uint64_t sim_cycles;   /* cycles that ran inside those launches */
 } mz_worker_stats;
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out);
 mz_net* mz_worker_net(mz_worker* w);

@@ -279,6 +279,7 @@ public:
     }
     int runCycles(int n);
     int popLine(char* buf, int cap);
+    int peekRecord(int game, char* buf, int cap);
     mz_worker_stats stats_{};
     Net& net0() { return lanes_[0]->net; }
 
@@ -1327,7 +1328,9 @@ int Worker::runCyclesSim(int n)
             if (rc) { return rc; }
             if (!launched) { const std::string why = mz_last_error(); setError("worker: the simulation kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
             MZ_HIP(hipEventRecord(L->ev1, L->stream));
+            ++stats_.sim_launches;
         }
+        stats_.sim_cycles += batch;
         flushDeferred(); // the record strings of the move just decided: built while the launch runs
         sims_done_ = sim0 + batch - 1;
         pending_ = true;
@@ -1381,6 +1384,18 @@ int Worker::popLine(char* buf, int cap)
     memcpy(buf, s.data(), len);
     buf[len] = 0;
     lines_.pop_front();
+    return len;
+}
+
+int Worker::peekRecord(int game, char* buf, int cap)
+{
+    if (game < 0 || game >= G_) { setError("peek_record: game %d out of range", game); return MZ_ERR_ARG; }
+    flushDeferred();
+    const std::string s = record(games_[game], {});
+    const int len = static_cast<int>(s.size());
+    if (cap <= len) { setError("peek_record: buffer of %d bytes too small for a %d-byte record", cap, len); return MZ_ERR_ARG; }
+    memcpy(buf, s.data(), len);
+    buf[len] = 0;
     return len;
 }
 
@@ -1456,6 +1471,11 @@ int mz_worker_pop_line(mz_worker* w, char* buf, int cap)
 {
     if (!w || !buf) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
     return w->w.popLine(buf, cap);
+}
+int mz_worker_peek_record(mz_worker* w, int game, char* buf, int cap)
+{
+    if (!w || !buf) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
+    return w->w.peekRecord(game, buf, cap);
 }
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out)
 {

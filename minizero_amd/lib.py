@@ -34,7 +34,7 @@ class SearchCfg(C.Structure):
 class WorkerStats(C.Structure):
     _fields_ = [("cycles", C.c_uint64), ("leaf_evals", C.c_uint64), ("moves", C.c_uint64), ("games", C.c_uint64),
                 ("ms_select", C.c_double), ("ms_env", C.c_double), ("ms_forward", C.c_double), ("ms_expand", C.c_double),
-                ("ms_move", C.c_double), ("ms_total", C.c_double)]
+                ("ms_move", C.c_double), ("ms_total", C.c_double), ("sim_launches", C.c_uint64), ("sim_cycles", C.c_uint64)]
 
 
 NET_TYPES = {"alphazero": 0, "muzero": 1, "muzero_atari": 2}
@@ -120,6 +120,7 @@ def load():
         L.mz_worker_run_cycles.argtypes = [vp, C.c_int]
         L.mz_worker_pop_line.argtypes = [vp, C.c_char_p, C.c_int]
         L.mz_worker_get_stats.argtypes = [vp, C.POINTER(WorkerStats)]
+        L.mz_worker_peek_record.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         L.mz_worker_net.restype = vp
         L.mz_worker_net.argtypes = [vp]
         L.mz_env_create.restype = vp
@@ -369,6 +370,15 @@ class Worker:
             n = self.L.mz_worker_pop_line(self.h, buf, len(buf))
             if n <= 0:
                 break
+            out.append(buf.value.decode())
+        return out
+
+    def peek_records(self, games):
+        """Records of games 0..games-1 as they stand (unfinished ones included)."""
+        buf = C.create_string_buffer(1 << 22)
+        out = []
+        for g in range(games):
+            _check(self.L, self.L.mz_worker_peek_record(self.h, g, buf, len(buf)))
             out.append(buf.value.decode())
         return out
 

@@ -231,6 +231,8 @@ unsigned long long mzo_group_leaf_evals(void* g) { return static_cast<Group*>(g)
 unsigned long long mzo_group_games(void* g) { return static_cast<Group*>(g)->games_; }
 int mzo_group_num_lines(void* g) { return static_cast<int>(static_cast<Group*>(g)->lines_.size()); }
 int mzo_group_line(void* g, int i, char* buf, int cap) { return copyOut(static_cast<Group*>(g)->lines_[i], buf, cap); }
+// record of actor i's game as it stands (unfinished games included): lets a test compare move / visit distributions without playing to the end
+int mzo_group_peek_record(void* g, int i, char* buf, int cap) { return copyOut(static_cast<Group*>(g)->actors_[i]->getRecord({}), buf, cap); }
 int mzo_group_num_trace(void* g) { return static_cast<int>(static_cast<Group*>(g)->trace_lines_.size()); }
 int mzo_group_trace(void* g, int i, char* buf, int cap) { return copyOut(static_cast<Group*>(g)->trace_lines_[i], buf, cap); }
 

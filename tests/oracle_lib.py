@@ -111,6 +111,7 @@ def lib():
     L.mzo_group_games.argtypes = [C.c_void_p]
     L.mzo_group_num_lines.argtypes = [C.c_void_p]
     L.mzo_group_line.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L.mzo_group_peek_record.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     L.mzo_group_num_trace.argtypes = [C.c_void_p]
     L.mzo_group_trace.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     _lib = L
@@ -221,6 +222,10 @@ class OracleGroup:
 
     def trace(self):
         return self._strings(self.L.mzo_group_num_trace, self.L.mzo_group_trace)
+
+    def peek_records(self, games):
+        """Records of the games as they stand (unfinished ones included)."""
+        return self._strings(lambda h: games, self.L.mzo_group_peek_record)
 
 
 class OracleEnv:

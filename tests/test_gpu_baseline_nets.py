@@ -1,0 +1,79 @@
+"""Oracle parity of the worker on the BASELINE.json networks (6 blocks x 64 channels) — the very `sim_kernel` / `sim_kernel_mz`
+instantiations `bench.py` and `tools/run_configs.py` time (sim.hip: <9,9,20,64,2>, <8,8,4,64,0>, mz<9,9,20,68,64>, mz<6,6,64,84,64>).
+Fewer games than BASELINE so that the CPU oracle finishes in seconds; simulations per move, network, search options = BASELINE.
+Games that have not finished are compared through their records as they stand (`peek_record`: every move with its P[visit
+distribution] V[root value] R[reward] tags), finished ones through their `SelfPlay` lines.  Every test asserts that the per-game
+simulation kernel did run (worker stats: sim_launches / sim_cycles)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _games(conf, games):
+    head, tail = conf.split("zero_num_parallel_games=")
+    return head + f"zero_num_parallel_games={games}" + (":" + tail.split(":", 1)[1] if ":" in tail else "")
+
+
+def _run(mz, oracle, key, games, chunks, extra="", seed=1, wseed=0, threads=2):
+    d, od = mz.DESCS[key](), getattr(oracle, "desc_" + key)()
+    w = mz.generate_weights(d, wseed)
+    conf = _games(mz.CONFIGS[key], games) + extra + f":program_seed={seed}:nn_file_name=/tmp/w/baseline_{key}_seed{wseed}.pt"
+    total = sum(chunks)
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles(total)
+    wk = mz.Worker(conf + f":zero_num_threads={threads}", d, w)
+    wk.command("start")
+    for c in chunks:
+        assert wk.run_cycles(c) == c
+    st = wk.stats()
+    assert st["cycles"] == total and st["leaf_evals"] == og.leaf_evals() == total * games
+    assert st["sim_launches"] > 0 and st["sim_cycles"] >= total - 2 * (st["moves"] // games + 2), "the per-game simulation kernel did not run"
+    lines, olines = wk.pop_lines(), og.lines()
+    for i, (a, b) in enumerate(zip(lines, olines)):
+        assert a == b, f"line {i} differs:\n  hip   : {a[:400]}\n  oracle: {b[:400]}"
+    assert len(lines) == len(olines)
+    recs, orecs = wk.peek_records(games), og.peek_records(games)
+    for g, (a, b) in enumerate(zip(recs, orecs)):
+        assert a == b, f"game {g}: records as they stand differ:\n  hip   : {a[:600]}\n  oracle: {b[:600]}"
+    return lines, recs, st
+
+
+def test_c2_go_alphazero_6bx64_n400(mz, oracle):
+    """BASELINE configs[1] (sim_kernel<9,9,20,64,2>): 8 games, 2 complete moves + 37 simulations of the third, one run_cycles call cut
+    in the middle of a move (ref zero_actor.cpp:51-98)."""
+    lines, recs, st = _run(mz, oracle, "c2", 8, [150, 401 + 251, 37])
+    assert st["moves"] == 16
+    for r in recs:
+        assert r.count(";B[") + r.count(";W[") == 2 and r.count("P[") == 2
+
+
+def test_c2_go_alphazero_6bx64_no_noise_count_selection(mz, oracle):
+    """Same kernel, the deterministic move rule and no root noise; other weights / seed."""
+    extra = ":actor_use_dirichlet_noise=false:actor_select_action_by_count=true:actor_select_action_by_softmax_count=false"
+    _run(mz, oracle, "c2", 4, [401, 401, 5], extra=extra, seed=5, wseed=3)
+
+
+def test_c3_othello_gumbel_alphazero_6bx64_n16(mz, oracle):
+    """BASELINE configs[2] (sim_kernel<8,8,4,64,0>, two games per CU): 64 games x 12 moves."""
+    lines, recs, st = _run(mz, oracle, "c3", 64, [17 * 5 + 3, 17 * 7 - 3 + 1])
+    assert st["moves"] == 64 * 12
+
+
+def test_c3_othello_whole_games(mz, oracle):
+    """... and whole games (records with results) on the same kernel: 8 games to the end."""
+    lines, recs, st = _run(mz, oracle, "c3", 8, [17 * 70])
+    assert len(lines) >= 8
+
+
+def test_c4_go_muzero_6bx64_n50(mz, oracle):
+    """BASELINE configs[3] (sim_kernel_mz<9,9,20,68,64>): 8 games x 4 moves."""
+    lines, recs, st = _run(mz, oracle, "c4", 8, [51 * 2 + 20, 51 * 2 - 20 + 1])
+    assert st["moves"] == 32
+
+
+def test_c5_atari_gumbel_muzero_6bx64_n50(mz, oracle):
+    """BASELINE configs[4] per-GPU shard (sim_kernel_mz<6,6,64,84,64>, 601-bin heads, value rescale, discount, ATARI init-Q): 4 games x
+    8 moves with a short intermediate-sequence length, so that `SelfPlay false ... DLEN[a-b]` lines appear (ref actor_group.cpp:52-64)."""
+    extra = ":zero_actor_intermediate_sequence_length=4:learner_n_step_return=1:learner_muzero_unrolling_step=1:env_atari_episode_length=7"
+    lines, recs, st = _run(mz, oracle, "c5", 4, [51 * 3 + 9, 51 * 5 - 9 + 1], extra=extra, seed=2)
+    assert any(l.startswith("SelfPlay false") for l in lines) and any(l.startswith("SelfPlay true") for l in lines)
