@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — self-play hot path on N MI355X of one node.
 
-A "step" is one lock-step cycle of the worker: one MCTS simulation (select -> leaf environment + features ->
-network forward -> expand + backup) for every game of the batch, i.e. `games` leaf evaluations per GPU.
-Workload = BASELINE.json configs[1]: 9x9 Go AlphaZero, n=400, 6 blocks x 64 channels, 256 parallel games
-per GPU, synthetic fixed-weight network (deterministic generator, seed 0), games from the empty board.
-Games shard across GPUs with no data-path collective: weak scaling, rank r seeds program_seed + r.
+A "step" is one MOVE of every game of the batch: actor_num_simulation + 1 = 401 lock-step cycles of the reference
+(ref actor/actor_group.cpp:136-147: one MCTS simulation — select -> leaf environment + features -> network forward ->
+expand + backup — of every game per cycle), followed by the per-move host work (move decision, Dirichlet noise of the next
+root, record strings, root snapshot upload: ref actor_group.cpp:116-134, zero_actor.cpp:74-98).  One step = games x 401 leaf
+evaluations per GPU, so a driver call with `--steps 20 --warmup 5` times 20 whole moves after 5 warm-up moves.
+Workload = BASELINE.json configs[1]: 9x9 Go AlphaZero, n=400, 6 blocks x 64 channels, 256 parallel games per GPU, synthetic
+fixed-weight network (deterministic generator, seed 0), games from the empty board.  Games shard across GPUs with no data-path
+collective: weak scaling, rank r seeds program_seed + r.
+
+After the timed region (not part of `value`) the same worker keeps playing for --game-moves more moves (default 164 = one full
+game length: 9x9 games of the synthetic net run to the 163-move cap) and the line reports MEASURED games/s = finished
+`SelfPlay true` records / wall-clock of that leg.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -21,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak (== f32 vector peak)
-GO_GAME_LENGTH_CAP = 163       # 9x9 Go: terminal once #actions > 2*81 (ref go.cpp:253-254); synthetic nets neither pass twice nor resign
+N_SIM = 400
 
 
 def cpu_baseline(conf, seconds):
@@ -42,23 +49,41 @@ def cpu_baseline(conf, seconds):
         cycles += 1
     dt = time.time() - t0
     evals = cycles * 256
-    return {"value": evals / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
-            "sample": f"{cycles} lock-step cycles x 256 games of the same workload ({dt:.1f} s): tree+env phase on "
-                      f"{host_threads} threads, network forward (f32, same arithmetic as the GPU path) on {cores} threads"}
+    out = {"value": evals / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
+           "sample": f"{cycles} lock-step cycles x 256 games of the same workload ({dt:.1f} s): tree+env phase on "
+                     f"{host_threads} threads, network forward (f32, same arithmetic as the GPU path) on {cores} threads",
+           "moves_per_sec": evals / dt / (N_SIM + 1), "games_per_sec_at_163_moves": evals / dt / (N_SIM + 1) / 163.0}
+    del g
+    # BASELINE.json configs[0] as stated: TicTacToe AlphaZero n=16, 2 blocks x 16 channels, 8 parallel games, ONE actor thread
+    # (the reference's deterministic contract), whole games
+    d1 = O.desc_c1()
+    g1 = O.OracleGroup(mz.CONFIGS["c1"] + ":program_seed=1:nn_file_name=synthetic_ttt_2bx16_seed0.pt", d1, O.gen_weights(d1, 0))
+    g1.cycles(17)
+    t0 = time.time()
+    c1_cycles, e0, n0 = 0, g1.leaf_evals(), g1.games()
+    while time.time() - t0 < 2.0:
+        g1.cycles(17 * 8)
+        c1_cycles += 17 * 8
+    dt1 = time.time() - t0
+    out["c1_tictactoe"] = {"leaf_evals_per_sec": (g1.leaf_evals() - e0) / dt1, "games_per_sec": (g1.games() - n0) / dt1, "cores": 1,
+                           "sample": f"BASELINE configs[0]: TicTacToe AZ n=16, 2bx16, 8 games, {c1_cycles} cycles ({dt1:.1f} s), 1 actor thread"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=802)   # 2 full moves of every game (401 cycles per move)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20, help="timed moves of every game (401 cycles each)")
+    ap.add_argument("--warmup", type=int, default=3, help="untimed warm-up moves")
     ap.add_argument("--games", type=int, default=256)
-    ap.add_argument("--threads", type=int, default=0, help="host threads for env/feature/candidate work (0 = cores / ranks)")
-    ap.add_argument("--lanes", type=int, default=1, help="software-pipelined lanes the 256 games are split into")
+    ap.add_argument("--game-moves", type=int, default=164, help="moves of the games/s leg after the timed region (0 = skip)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for the per-move work (0 = cores / ranks)")
+    ap.add_argument("--lanes", type=int, default=1, help="software-pipelined lanes the games are split into")
     ap.add_argument("--zero-copy", type=int, default=3)
     ap.add_argument("--pin", type=int, default=1, help="pin the host threads of rank r to CPUs [r*threads, (r+1)*threads)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-conf", default="", help="extra k=v:k=v keys (profiling variants only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,45 +105,74 @@ def main():
     threads = args.threads or max(1, min(32, usable // max(1, world) - 1))  # spin-wait pool incl. the calling thread
     base_conf = mz.CONFIGS["c2"].replace("zero_num_parallel_games=256", f"zero_num_parallel_games={args.games}")
     conf = (f"{base_conf}:zero_num_threads={threads}:mz_pipeline_lanes={args.lanes}:mz_zero_copy={args.zero_copy}:mz_cpu_base={local_rank * threads if args.pin else -1}:program_seed={shard_seed(1, rank)}:"
-            "nn_file_name=synthetic_go_6bx64_seed0.pt")
+            "nn_file_name=synthetic_go_6bx64_seed0.pt" + (":" + args.extra_conf if args.extra_conf else ""))
     desc = mz.DESCS["c2"]()
     # the optional synchronous weight broadcast (load_model fan-out): rank 0's blob is the one every rank loads
     weights = grp.broadcast_weights(mz.generate_weights(desc, 0))
     worker = mz.Worker(conf, desc, weights, device=local_rank)
     worker.command("start")
 
-    assert worker.run_cycles(args.warmup) == args.warmup
+    cpm = N_SIM + 1  # cycles per move
+    if args.warmup > 0:
+        assert worker.run_cycles(args.warmup * cpm) == args.warmup * cpm
     s0 = worker.stats()
     grp.barrier()
     t0 = time.perf_counter()
-    assert worker.run_cycles(args.steps) == args.steps
+    for _ in range(args.steps):  # one call per move, like the `-mode sp` loop of the facade (commands are polled between moves)
+        assert worker.run_cycles(cpm) == cpm
     grp.barrier()
     dt = time.perf_counter() - t0
     s1 = worker.stats()
     dt = float(grp.reduce([dt], "max")[0])
     moves, games_done = grp.reduce([s1["moves"] - s0["moves"], s1["games"] - s0["games"]], "sum")
 
+    # ---- games/s leg: the same worker keeps playing (steady state: games at every stage of their 163 moves) ----
+    g_dt, g_games, g_moves, g_evals = 0.0, 0.0, 0.0, 0.0
+    if args.game_moves > 0:
+        worker.pop_lines()
+        grp.barrier()
+        tg = time.perf_counter()
+        for _ in range(args.game_moves):
+            assert worker.run_cycles(cpm) == cpm
+        grp.barrier()
+        g_dt = time.perf_counter() - tg
+        s2 = worker.stats()
+        lines = worker.pop_lines()
+        finished = sum(1 for l in lines if l.startswith("SelfPlay true "))
+        assert finished == s2["games"] - s1["games"]
+        g_dt = float(grp.reduce([g_dt], "max")[0])
+        g_games, g_moves, g_evals = grp.reduce([finished, s2["moves"] - s1["moves"], s2["leaf_evals"] - s1["leaf_evals"]], "sum")
+
     if rank == 0:
-        evals = args.games * args.steps * world
+        evals = args.games * cpm * args.steps * world
         value = evals / dt
         # dominant kernel: sim_kernel (sim.hip) — every game's whole simulations (select, Go leaf, residual tower on the f32 MFMA pipe,
-        # heads, candidates, expand + backup) in one launch per run of cycles.  Its GPU time inside the timed region comes from HIP
-        # events recorded on the worker's own stream around every launch (worker stats: ms_forward); the algorithmic work per step is
-        # 256 leaf evaluations x 73.3 MFLOP of 3x3 convolutions.
+        # heads, candidates, expand + backup), two launches per move (the root expansion, then the other 400 simulations).  Its GPU time
+        # inside the timed region comes from HIP events recorded on the worker's own stream around every launch (worker stats:
+        # ms_forward); the algorithmic work per leaf evaluation is 73.3 MFLOP of 3x3 convolutions.
         net = worker.net()
         ms_fwd, ms_tower, fl_tower = net.time_forward(args.games, 100)          # the stand-alone tower + heads kernels, for reference
         ms_layer, fl_layer, bytes_layer = net.time_tower_conv(args.games, 200)  # the stand-alone per-layer kernel, for reference
         gpu_ms = s1["ms_forward"] - s0["ms_forward"]
-        flops_per_step = fl_tower  # one step = one forward of args.games samples
-        resident = gpu_ms > 0.5 * dt * 1e3  # the simulation kernel ran (otherwise ms_forward is host wait time of the lock-step path)
-        achieved = (flops_per_step * args.steps) / (gpu_ms * 1e-3) / 1e12 if resident else fl_tower / (ms_tower * 1e-3) / 1e12
-        # HBM traffic per step from the rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; the x2 on
-        # gfx950 was re-calibrated on a known-size copy kernel with the same 4-B/lane access, see profiles/README.md)
-        traffic = None
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sim.json")))["bytes_per_step"]
-        except Exception:
-            pass
+        launches = s1["sim_launches"] - s0["sim_launches"]
+        flops_per_eval = fl_tower / args.games
+        flops_total = flops_per_eval * args.games * cpm * args.steps  # this rank's timed region
+        resident = launches > 0
+        if not resident:
+            raise SystemExit("bench.py: the simulation kernel did not run (sim_launches == 0)")
+        achieved = flops_total / (gpu_ms * 1e-3) / 1e12
+        # HBM traffic from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; the x2 on
+        # gfx950 per MI355X_MICROARCH.md, re-calibrated on a known-size copy kernel with the same 4-B/lane access, see profiles/README.md)
+        traffic, traffic_src = None, None
+        for name in ("r02_pmc_sim.json", "r01_pmc_sim.json"):
+            try:
+                j = json.load(open(os.path.join(ROOT, "profiles", name)))
+                per_cycle = j.get("bytes_per_cycle", j.get("bytes_per_step"))
+                traffic = per_cycle * cpm * args.steps / launches
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this bench; bytes per lock-step cycle x cycles per average launch)"
+                break
+            except Exception:
+                pass
         phase = {k: round((s1[k] - s0[k]) / args.steps, 4) for k in ("ms_select", "ms_env", "ms_forward", "ms_expand", "ms_move", "ms_total")}
         out = {
             "metric": "self-play leaf-evals/s (9x9 Go AlphaZero n=400)", "value": value, "unit": "leaf-evals/s",
@@ -126,25 +180,29 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 9x9 Go AlphaZero, n=400, 6 blocks x 64 ch, 256 parallel games per GPU, "
                                    "synthetic fixed-weight net (seed 0), Dirichlet noise + random rotation + softmax-count moves (reference defaults)",
-                       "games_per_gpu": args.games, "actor_num_simulation": 400, "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_cores": cores, "host_cpus_usable": usable,
+                       "step": "one move of every game = 401 lock-step cycles = games x 401 leaf evaluations per GPU, per-move host work included",
+                       "games_per_gpu": args.games, "actor_num_simulation": N_SIM, "leaf_evals_per_step": args.games * cpm * world,
+                       "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_cores": cores, "host_cpus_usable": usable,
                        "sharding": f"{world} x independent actor pools, no data-path collective"},
-            "moves_per_sec": moves / dt, "games_finished": games_done,
-            "games_per_sec": (games_done / dt) if games_done else None,
-            "games_per_sec_projected": moves / dt / GO_GAME_LENGTH_CAP,
-            "games_per_sec_note": f"projected = moves/s / {GO_GAME_LENGTH_CAP} (9x9 games of the synthetic net run to the move cap)",
+            "moves_per_sec": moves / dt, "games_finished_in_timed_region": games_done,
+            "games_per_sec": (g_games / g_dt) if g_dt > 0 else None,
+            "games_leg": {"moves_per_game_slot": args.game_moves, "seconds": g_dt, "games_finished": g_games, "moves": g_moves,
+                          "leaf_evals_per_sec": (g_evals / g_dt) if g_dt > 0 else None,
+                          "note": "measured after the timed region on the same workers: finished `SelfPlay true` records / wall-clock "
+                                  "(9x9 games of the synthetic net mostly run to the 163-move cap, ref go.cpp:253-254)"},
             "per_step_ms": phase,
             "forward": {"ms_per_forward": ms_fwd, "ms_tower_per_forward": ms_tower,
                         "per_layer_kernel": {"us_per_launch": ms_layer * 1e3, "tflops": fl_layer / (ms_layer * 1e-3) / 1e12}},
             "roofline": {"kernel": "sim_kernel<9,9,20,64,2> (per game: PUCT select, Go leaf position/planes/legal mask, stem + 12 x conv3x3 64->64 on "
-                                   "v_mfma_f32_16x16x4_f32 with activations in LDS, heads, candidate sort, expand + backup)" if resident else
-                                   "tower_fused<9,9,20,64>",
+                                   "v_mfma_f32_16x16x4_f32 with activations in LDS, heads, candidate sort, expand + backup)",
                          "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_sim.json (rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass of this bench, bytes per step)",
-                         "flops_per_step": flops_per_step, "gpu_us_per_step": gpu_ms / args.steps * 1e3,
-                         "timing": "HIP events on the worker's stream around every sim_kernel launch of the timed region",
-                         # per step, without the weights (1.9 MB: they stay in the XCDs' L2s between steps): a children block written + one read per game
-                         "compulsory_bytes_per_step": args.games * 2.0 * 2600,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "launches": launches, "avg_launch_ms": gpu_ms / launches, "flops_per_avg_launch": flops_total / launches,
+                         "flops_per_leaf_eval": flops_per_eval, "gpu_ms_per_step": gpu_ms / args.steps,
+                         "timing": "HIP events on the worker's stream around every sim_kernel launch of the timed region (2 launches per move: "
+                                   "1 root-expansion cycle + 400 cycles)",
+                         # per cycle, without the weights (1.9 MB: they stay in the XCDs' L2s): a children block written + one read per game
+                         "compulsory_bytes_per_avg_launch": args.games * 2.0 * 2600 * cpm * args.steps / launches,
                          "tower_alone": {"kernel": "tower_fused<9,9,20,64> (the same tower as a stand-alone launch of 256 samples)",
                                          "us_per_launch": ms_tower * 1e3, "achieved": fl_tower / (ms_tower * 1e-3) / 1e12,
                                          "frac": fl_tower / (ms_tower * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}},

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Throughput of all five BASELINE.json configs on one GPU (leaf-evals/s); C2 is what bench.py reports."""
+"""Throughput of the five BASELINE.json configs on one GPU (leaf-evals/s) with a roofline block per config; C2 is what bench.py reports.
+usage: run_configs.py [c1 .. c5] [--moves M] [--out file.json]
+The roofline numerator is the algorithmic work of the leaf evaluations (3x3 convolutions + linear layers of one forward, 2 x MAC),
+the denominator the HIP-event time of the simulation-kernel launches on the worker's stream (worker stats: ms_forward)."""
 import json
 import os
 import sys
@@ -8,24 +11,77 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import minizero_amd as mz  # noqa: E402
 
-PLAN = {"c1": (17 * 400, 17), "c2": (401 * 2, 40), "c3": (17 * 20, 17), "c4": (51 * 10, 51), "c5": (51 * 6, 51)}
-out = {}
-threads = min(32, os.cpu_count() or 1)
-for key in sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]:
-    d = mz.DESCS[key]()
-    conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_cpu_base=0"
-    wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
-    wk.command("start")
-    steps, warm = PLAN[key]
-    wk.run_cycles(warm)
-    s0 = wk.stats()
-    t0 = time.perf_counter()
-    wk.run_cycles(steps)
-    dt = time.perf_counter() - t0
-    s1 = wk.stats()
-    out[key] = {"leaf_evals_per_sec": (s1["leaf_evals"] - s0["leaf_evals"]) / dt, "ms_per_cycle": dt / steps * 1e3,
-                "moves_per_sec": (s1["moves"] - s0["moves"]) / dt, "games_per_sec": (s1["games"] - s0["games"]) / dt,
-                "games_in_pool": s1["leaf_evals"] // s1["cycles"], "config": mz.CONFIGS[key]}
-    print(key, json.dumps(out[key]), flush=True)
-    del wk
-json.dump(out, open(os.path.join("gpurun_out", "configs.json"), "w"), indent=1)
+F32_MFMA_PEAK_TFLOPS = 157.3
+MOVES = {"c1": 400, "c2": 4, "c3": 40, "c4": 20, "c5": 12}
+KERNEL = {"c1": "sim_kernel<3,3,4,16,-1>", "c2": "sim_kernel<9,9,20,64,2>", "c3": "sim_kernel<8,8,4,64,0>", "c4": "sim_kernel_mz<9,9,20,68,64>",
+          "c5": "sim_kernel_mz<6,6,64,84,64>"}
+
+
+def flops_per_leaf_eval(d):
+    """2 x MAC of the network evaluated at a (non-root) leaf: AlphaZero = the whole forward; MuZero = dynamics + prediction."""
+    P, C, A, nb = d.hidden_channel_height * d.hidden_channel_width, d.num_hidden_channels, d.action_size, d.num_blocks
+    cin0 = d.num_input_channels if d.type == 0 else C + d.num_action_feature_channels
+    conv = 2.0 * 9 * P * (cin0 * C + 2 * nb * C * C)
+    pc = -(-A // P)
+    heads = 2.0 * (P * C * pc + pc * P * A)  # policy conv1x1 + FC
+    if d.discrete_value_size > 1:
+        hc, hid, sz = 0, d.num_value_hidden_channels, d.discrete_value_size
+        # DiscreteValueNetwork (value and reward): conv1x1 C->C, FC C*P->hidden, FC hidden->601 (ref network_unit.py:67-87)
+        heads += 2 * 2.0 * (P * C * C + C * P * hid + hid * sz)
+    else:
+        heads += 2.0 * (P * C * 1 + P * d.num_value_hidden_channels + d.num_value_hidden_channels)
+    return conv, heads
+
+
+def main():
+    argv = sys.argv[1:]
+    out_path = os.path.join("gpurun_out", "configs.json")
+    moves_override = None
+    keys = []
+    i = 0
+    while i < len(argv):
+        if argv[i] == "--moves":
+            moves_override = int(argv[i + 1]); i += 2
+        elif argv[i] == "--out":
+            out_path = argv[i + 1]; i += 2
+        else:
+            keys.append(argv[i]); i += 1
+    out = {}
+    threads = max(1, mz.usable_cpus() - 1)
+    for key in keys or ["c1", "c2", "c3", "c4", "c5"]:
+        d = mz.DESCS[key]()
+        conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_cpu_base=0"
+        n = int(mz.CONFIGS[key].split("actor_num_simulation=")[1].split(":")[0])
+        games = int(mz.CONFIGS[key].split("zero_num_parallel_games=")[1].split(":")[0])
+        wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
+        wk.command("start")
+        moves = moves_override or MOVES[key]
+        wk.run_cycles(2 * (n + 1))
+        s0 = wk.stats()
+        t0 = time.perf_counter()
+        for _ in range(moves):
+            wk.run_cycles(n + 1)
+        dt = time.perf_counter() - t0
+        s1 = wk.stats()
+        evals = s1["leaf_evals"] - s0["leaf_evals"]
+        conv, heads = flops_per_leaf_eval(d)
+        gpu_ms = s1["ms_forward"] - s0["ms_forward"]
+        launches = s1["sim_launches"] - s0["sim_launches"]
+        sim_evals = (s1["sim_cycles"] - s0["sim_cycles"]) * games
+        ach = (conv + heads) * sim_evals / (gpu_ms * 1e-3) / 1e12 if launches else None
+        out[key] = {"leaf_evals_per_sec": evals / dt, "ms_per_move": dt / moves * 1e3, "moves_per_sec": (s1["moves"] - s0["moves"]) / dt,
+                    "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "config": mz.CONFIGS[key],
+                    "roofline": {"kernel": KERNEL[key], "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": (ach / F32_MFMA_PEAK_TFLOPS) if ach else None, "launches": launches,
+                                 "avg_launch_ms": gpu_ms / launches if launches else None, "flops_per_leaf_eval": conv + heads,
+                                 "conv3x3_flops_per_leaf_eval": conv, "leaf_evals_in_launches": sim_evals,
+                                 "wall_frac": (conv + heads) * evals / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                 "timing": "HIP events on the worker's stream around every simulation-kernel launch"}}
+        print(key, json.dumps(out[key]), flush=True)
+        del wk
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
