@@ -1,10 +1,19 @@
-// minizero::actor::ActorGroup facade over libmzgpu's worker — the `-mode sp` loop with the reference's
-// stdin/stdout protocol (ref actor/actor_group.cpp:136-252, actor_group.h:46-68): one command per stdin line
-// (start | stop | load_model <path> | update_config <k=v:..> | reset_actors | quit | anything else ignored),
-// one `SelfPlay <terminal> <data_len> <game_len> <return> <record> #` line per finished game on stdout,
-// logs on stderr.  Header-only; link with -lmzgpu -pthread.
+// minizero::actor::ActorGroup facade over libmzgpu's worker — the `-mode sp` loop with the reference's stdin/stdout protocol
+// (ref actor/actor_group.cpp:136-252, actor_group.h:46-68): one command per stdin line (start | stop | load_model <path> |
+// update_config <k=v:..> | reset_actors | quit | anything else ignored), one `SelfPlay <terminal> <data_len> <game_len> <return> <record> #`
+// line per finished game on stdout, logs on stderr.  Header-only; link with -lmzgpu -pthread.
+//
+// Like the reference, ONE process drives every visible GPU (ref actor_group.cpp:168-187: one Network per device, actor i on device
+// i % G; scripts/zero-worker.sh:159-162 hands one `-mode sp` process zero_num_parallel_games = batch x #GPUs and all CUDA_VISIBLE_DEVICES):
+// G = min(mz_device_count(), zero_num_parallel_games) workers, worker g owns the games {i : i % G == g} on device g, is driven by its own
+// host thread and seeds program_seed + g (the reference's slave thread g seeds program_seed + g, actor_group.cpp:66-70); stdout is written
+// under one mutex (actor_group.cpp:42-49).  The main thread reads stdin; every command is applied by each device thread between two moves
+// of its games (the reference applies commands between two cycles of the CPU phase, actor_group.cpp:200-219).
 #pragma once
+#include "mzgpu_config.h"
 #include "network.h"
+#include <atomic>
+#include <chrono>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -14,83 +23,130 @@ namespace minizero::actor {
 
 class ActorGroup {
 public:
-    // conf: the merged configuration string (conf_file lines joined with ':' then -conf_str), incl. nn_file_name and env_game
-    ActorGroup(const std::string& conf, int gpu_id = 0) : conf_(conf), gpu_id_(gpu_id) {}
-    ~ActorGroup() { if (worker_) { mz_worker_destroy(worker_); } }
+    // the reference's constructor (mode_handler.cpp:147): configuration from minizero::config (see mzgpu_config.h), all visible GPUs
+    ActorGroup() : conf_(config::mzgpuCollectConfiguration()), gpu_id_(-1) {}
+    // conf: the merged configuration string (conf_file lines joined with ':' then -conf_str), incl. nn_file_name and env_game;
+    // gpu_id >= 0: that device only; -1: every visible device
+    explicit ActorGroup(const std::string& conf, int gpu_id = -1) : conf_(conf), gpu_id_(gpu_id) {}
+    virtual ~ActorGroup()
+    {
+        for (auto& d : devices_) { if (d.worker) { mz_worker_destroy(d.worker); } }
+    }
 
     void run()
     {
         initialize();
-        while (true) {
-            if (!handleCommand()) { return; }
-            if (!running_) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
-            if (mz_worker_run_cycles(worker_, 1) < 0) { std::cerr << mz_last_error() << std::endl; exit(0); }
-            flushGames();
-        }
+        std::vector<std::thread> threads;
+        for (size_t g = 0; g < devices_.size(); ++g) { threads.emplace_back([this, g]() { deviceLoop(static_cast<int>(g)); }); }
+        handleIO(); // returns on quit / end of stdin
+        for (auto& t : threads) { t.join(); }
     }
 
+    inline int getNumDevices() const { return static_cast<int>(devices_.size()); }
+
 protected:
-    virtual void initialize()
+    struct Device {
+        int gpu = 0, games = 0;
+        mz_worker* worker = nullptr;
+        size_t next_command = 0;
+        bool running = false;
+    };
+
+    virtual void initialize() // createNeuralNetworks + createActors (ref actor_group.cpp:149-187)
     {
-        const std::string key = "nn_file_name=";
-        size_t p = conf_.rfind(key);
-        std::string nn_file = (p == std::string::npos) ? "" : conf_.substr(p + key.size(), conf_.find(':', p) == std::string::npos ? std::string::npos : conf_.find(':', p) - p - key.size());
-        mz_net_desc desc;
-        std::vector<float> w;
-        if (!network::readWeightFile(nn_file, desc, w)) { exit(0); }
-        worker_ = mz_worker_create(gpu_id_, conf_.c_str(), &desc, w.data(), w.size());
-        if (!worker_) { std::cerr << mz_last_error() << std::endl; exit(0); }
-        io_thread_ = std::thread([this]() { handleIO(); });
-        io_thread_.detach();
+        if (conf_.empty()) { std::cerr << "ActorGroup: empty configuration (set minizero::config::mzgpuConfigurationString() or build next to config/configuration.h)" << std::endl; exit(0); }
+        const int visible = mz_device_count();
+        if (visible < 1) { std::cerr << "ActorGroup: no GPU visible (libmzgpu has no CPU path)" << std::endl; exit(0); }
+        auto number = [&](const char* key, int def) { const std::string v = config::mzgpuConfValue(conf_, key); return v.empty() ? def : std::stoi(v); };
+        const int total_games = number("zero_num_parallel_games", 32), seed = number("program_seed", 0), threads = number("zero_num_threads", 4);
+        const int G = gpu_id_ >= 0 ? 1 : std::max(1, std::min(visible, total_games));
+        devices_.resize(G);
+        for (int g = 0; g < G; ++g) {
+            Device& d = devices_[g];
+            d.gpu = gpu_id_ >= 0 ? gpu_id_ : g;
+            d.games = (total_games - g + G - 1) / G; // |{i < total : i % G == g}| (ref actor_group.cpp:185)
+            const std::string conf = conf_ + ":zero_num_parallel_games=" + std::to_string(d.games) + ":program_seed=" + std::to_string(seed + g) +
+                                     ":zero_num_threads=" + std::to_string(std::max(1, threads / G));
+            d.worker = mz_worker_create(d.gpu, conf.c_str(), nullptr, nullptr, 0); // reads nn_file_name itself
+            if (!d.worker) { std::cerr << mz_last_error() << std::endl; exit(0); }
+        }
+        std::cerr << "[mzgpu] " << total_games << " games on " << G << " GPU(s)" << std::endl;
     }
-    virtual void handleIO() // ref actor_group.cpp:189-198
+
+    virtual void handleIO() // ref actor_group.cpp:189-198 (here on the calling thread; the device threads do the work)
     {
         std::string command;
-        while (getline(std::cin, command)) {
-            std::lock_guard<std::mutex> lock(mutex_);
-            commands_.push_back(command);
+        while (!quit_.load() && getline(std::cin, command)) {
+            const std::string prefix = command.substr(0, command.find(' '));
+            if (!isIgnored(prefix)) { std::cerr << "[command] " << command << std::endl; }
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                commands_.push_back(command);
+            }
+            if (prefix == "quit" && !isIgnored(prefix)) { return; }
         }
         std::lock_guard<std::mutex> lock(mutex_);
         commands_.push_back("quit"); // stdin closed == the server went away
     }
-    virtual bool handleCommand() // ref actor_group.cpp:200-252
+
+    bool isIgnored(const std::string& prefix) const // zero_actor_ignored_command (ref actor_group.cpp:204-212)
+    {
+        std::string ignored = config::mzgpuConfValue(conf_, "zero_actor_ignored_command");
+        if (ignored.empty() && conf_.find("zero_actor_ignored_command") == std::string::npos) { ignored = "reset_actors"; }
+        std::istringstream iss(ignored);
+        std::string tok;
+        while (iss >> tok) { if (tok == prefix) { return true; } }
+        return false;
+    }
+
+    // one device: apply pending commands, then one move of every game of this device (n + 1 cycles = ONE kernel launch in the worker)
+    void deviceLoop(int g)
+    {
+        Device& d = devices_[g];
+        const int chunk = std::max(1, mz_worker_cycles_per_move(d.worker));
+        while (true) {
+            if (!handleCommand(d)) { quit_.store(true); return; }
+            if (!d.running) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
+            if (mz_worker_run_cycles(d.worker, chunk) < 0) { std::cerr << mz_last_error() << std::endl; exit(0); }
+            flushGames(d);
+        }
+    }
+
+    virtual bool handleCommand(Device& d) // ref actor_group.cpp:200-252
     {
         std::deque<std::string> cmds;
         {
             std::lock_guard<std::mutex> lock(mutex_);
-            cmds.swap(commands_);
+            for (; d.next_command < commands_.size(); ++d.next_command) { cmds.push_back(commands_[d.next_command]); }
         }
         for (const std::string& command : cmds) {
             const std::string prefix = command.substr(0, command.find(' '));
-            if (prefix == "load_model" && command.find(' ') != std::string::npos) {
-                mz_net_desc desc;
-                std::vector<float> w;
-                if (!network::readWeightFile(command.substr(command.find(' ') + 1), desc, w)) { exit(0); }
-                mz_worker_set_weights(worker_, w.data(), w.size());
-            }
-            std::cerr << "[command] " << command << std::endl;
-            const int rc = mz_worker_command(worker_, command.c_str());
+            const int rc = mz_worker_command(d.worker, command.c_str()); // the worker applies zero_actor_ignored_command itself
             if (rc < 0) { std::cerr << mz_last_error() << std::endl; exit(0); }
             if (rc == 1) { return false; } // quit
-            if (prefix == "start") { running_ = true; }
-            if (prefix == "stop") { running_ = false; }
+            if (isIgnored(prefix)) { continue; }
+            if (prefix == "start") { d.running = true; }
+            if (prefix == "stop") { d.running = false; }
         }
         return true;
     }
-    void flushGames()
+
+    void flushGames(Device& d)
     {
         static thread_local std::vector<char> buf(1 << 22);
         int n;
-        while ((n = mz_worker_pop_line(worker_, buf.data(), static_cast<int>(buf.size()))) > 0) { std::cout << buf.data() << std::endl; }
+        while ((n = mz_worker_pop_line(d.worker, buf.data(), static_cast<int>(buf.size()))) > 0) {
+            std::lock_guard<std::mutex> lock(out_mutex_); // ref actor_group.cpp:42-49
+            std::cout << buf.data() << std::endl;
+        }
     }
 
     std::string conf_;
     int gpu_id_;
-    mz_worker* worker_ = nullptr;
-    bool running_ = false;
-    std::mutex mutex_;
+    std::vector<Device> devices_;
+    std::mutex mutex_, out_mutex_;
     std::deque<std::string> commands_;
-    std::thread io_thread_;
+    std::atomic<bool> quit_{false};
 };
 
 } // namespace minizero::actor

@@ -3,8 +3,8 @@
 // create_network.h:11-30), no LibTorch.  Header-only; link with -lmzgpu.
 //
 // Differences a maintainer must know:
-//   * loadModel("x.pt", gpu) reads the TorchScript archive the reference's trainer writes natively (mz_net_read_pt: zip + pickle,
-//     no LibTorch); if "x.pt" does not exist it opens the sibling "x.mzw" (flat blob of minizero_amd/export_weights.py: magic,
+//   * loadModel("x.pt", gpu) reads the TorchScript archive the reference's trainer writes natively (mz_net_read_weight_file: zip +
+//     pickle, no LibTorch); if "x.pt" does not exist it opens the sibling "x.mzw" (flat blob of minizero_amd/export_weights.py: magic,
 //     mz_net_desc, count, f32 data) and keeps "x.pt" as getNetworkFileName()
 //   * gpu_id == -1 (CPU) is not supported: loadModel prints the library error and aborts like the reference's
 //     c10::Error path (network.cpp:20-26)
@@ -29,31 +29,11 @@ public:
 
 inline bool readWeightFile(const std::string& nn_file_name, mz_net_desc& desc, std::vector<float>& weights)
 {
-    std::string path = nn_file_name;
-    if (path.size() > 3 && path.substr(path.size() - 3) == ".pt") {
-        if (FILE* pt = fopen(path.c_str(), "rb")) { // the reference's own file format
-            fclose(pt);
-            size_t count = 0;
-            if (mz_net_read_pt(path.c_str(), &desc, nullptr, 0, &count) != MZ_OK) { std::cerr << mz_last_error() << std::endl; return false; }
-            weights.resize(count);
-            if (mz_net_read_pt(path.c_str(), &desc, weights.data(), count, &count) != MZ_OK) { std::cerr << mz_last_error() << std::endl; return false; }
-            return true;
-        }
-        path = path.substr(0, path.size() - 3) + ".mzw";
-    }
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) { std::cerr << "cannot open " << path << std::endl; return false; }
-    char magic[4];
-    uint64_t count = 0;
-    bool ok = fread(magic, 1, 4, f) == 4 && magic[0] == 'M' && magic[1] == 'Z' && magic[2] == 'W' && magic[3] == '1' &&
-              fread(&desc, sizeof(desc), 1, f) == 1 && fread(&count, sizeof(count), 1, f) == 1;
-    if (ok) {
-        weights.resize(count);
-        ok = fread(weights.data(), sizeof(float), count, f) == count;
-    }
-    fclose(f);
-    if (!ok) { std::cerr << "bad weight file " << path << std::endl; }
-    return ok;
+    size_t count = 0;
+    if (mz_net_read_weight_file(nn_file_name.c_str(), &desc, nullptr, 0, &count) != MZ_OK) { std::cerr << mz_last_error() << std::endl; return false; }
+    weights.resize(count);
+    if (mz_net_read_weight_file(nn_file_name.c_str(), &desc, weights.data(), count, &count) != MZ_OK) { std::cerr << mz_last_error() << std::endl; return false; }
+    return true;
 }
 
 class Network {

@@ -64,6 +64,10 @@ int mz_net_generate_weights(const mz_net_desc* desc, uint64_t seed, float* out);
  * above.  Call with weights_out == NULL to get *count_out; capacity = floats available in weights_out. */
 int mz_net_read_pt(const char* path, mz_net_desc* desc_out, float* weights_out, size_t capacity, size_t* count_out);
 
+/* The same for `path` as Network::loadModel is given it (ref network/network.h:18-37): the TorchScript archive if it exists, else — for
+ * "x.pt" — the sibling flat blob "x.mzw" (magic "MZW1", mz_net_desc, uint64 count, f32 data: minizero_amd/export_weights.py). */
+int mz_net_read_weight_file(const char* path, mz_net_desc* desc_out, float* weights_out, size_t capacity, size_t* count_out);
+
 /* createNetwork(file, gpu_id) (ref network/create_network.h:11-30): here the caller hands the parsed
  * blob; device must be a valid GPU ordinal (gpu_id == -1 / CPU is NOT supported: MZ_ERR_DEVICE). */
 mz_net* mz_net_create(int device, const mz_net_desc* desc, const float* weights, size_t count);
@@ -152,20 +156,48 @@ typedef struct mz_worker mz_worker;
 /* conf: the reference's "k=v:k=v" configuration string (ref config/configure_loader.cpp:51-117) plus
  * env_game=tictactoe|go|othello (the reference picks the game at compile time).  The worker owns a
  * pool of zero_num_parallel_games trees and a network on `device`. */
+/* desc == NULL and weights == NULL: the network is read from the configuration's nn_file_name (mz_net_read_weight_file), as
+ * ActorGroup::createNeuralNetworks does (ref actor_group.cpp:168-177). */
 mz_worker* mz_worker_create(int device, const char* conf, const mz_net_desc* desc, const float* weights, size_t count);
 void mz_worker_destroy(mz_worker* w);
 /* one stdin line: start | stop | load_model <path> | update_config k=v:.. | reset_actors | quit | other (ignored)
- * (ref actor_group.cpp:200-252).  load_model with a path needs mz_worker_set_weights first. */
+ * (ref actor_group.cpp:200-252).  load_model <path> reads the file itself (mz_net_read_weight_file) and checks that its hyper-parameters
+ * are those of the running network; weights staged with mz_worker_set_weights (in-memory callers) take precedence and are consumed.
+ * update_config: keys that size device state at creation (actor_num_simulation, zero_num_parallel_games, the PUCT / Gumbel constants,
+ * env_*, nn_type_name, mz_*) cannot change on a live worker: MZ_ERR_ARG with the key named, nothing applied.
+ * Returns 1 for quit, 0, or a negative error. */
 int mz_worker_command(mz_worker* w, const char* line);
 int mz_worker_set_weights(mz_worker* w, const float* weights, size_t count);
 /* run n lock-step cycles (one simulation of every game per cycle, ref actor_group.cpp:139-147);
- * returns the number of cycles actually run (0 while stopped) or a negative error */
+ * returns the number of cycles actually run (0 while stopped) or a negative error.  Cycles of one call that need nothing from the host
+ * run as ONE kernel launch: call with mz_worker_cycles_per_move() (= actor_num_simulation + 1) and poll commands between calls. */
 int mz_worker_run_cycles(mz_worker* w, int n);
+int mz_worker_cycles_per_move(const mz_worker* w);
 /* next pending stdout line ("SelfPlay ... #", ref actor_group.cpp:24-50); returns its length, 0 if none */
 int mz_worker_pop_line(mz_worker* w, char* buf, int cap);
 /* test / monitoring access: the record of game `game` as it stands, unfinished games included (BaseActor::getRecord with no extra
  * tags, ref actor/base_actor.cpp:39-57); returns its length.  Does not disturb the search. */
 int mz_worker_peek_record(mz_worker* w, int game, char* buf, int cap);
+/* BaseActor::getRecord(tags) (ref base_actor.cpp:39-57): the same with extra tags (later tags of the same key win, like addTag) */
+int mz_worker_record(mz_worker* w, int game, const char* const* keys, const char* const* values, int ntags, char* buf, int cap);
+
+/* Per-actor stepping: the BaseActor / ZeroActor surface (ref actor/base_actor.h:16-55, zero_actor.h:24-70, create_actor.h:10-19) for callers
+ * that drive single games themselves (ZeroActor::think(), the console).  With mz_manual_step=true in the configuration the worker never plays
+ * on its own: mz_worker_run_cycles stops (returning the cycles it ran) when the searches are complete (isSearchDone) and holds the decision:
+ *   mz_worker_search_action   getSearchAction() / isResign(): action id, its player, resign flag (ref zero_actor.h:39-40)
+ *   mz_worker_act             BaseActor::act(Action): 1 = played (the P/V/R action info of the completed search is attached,
+ *                             base_actor.cpp:22-30), 0 = illegal
+ *   mz_worker_reset_search    ZeroActor::resetSearch() of every game (zero_actor.cpp:29-34): required before the next run_cycles
+ *   mz_worker_reset_game      ZeroActor::reset() without the search part: new game + resign coin (zero_actor.cpp:23-27)
+ *   mz_worker_emit_game       ThreadSharedData::outputGame(actor): queues the `SelfPlay ... #` line of game g (actor_group.cpp:24-50)
+ *   mz_worker_env_query       what = 0 isTerminal, 1 getTurn, 2 getEvalScore(false), 3 getEvalScore(true), 4 number of actions, 5 getReward */
+int mz_worker_search_done(const mz_worker* w);
+int mz_worker_search_action(const mz_worker* w, int game, int* action_id, int* player, int* is_resign);
+int mz_worker_act(mz_worker* w, int game, int action_id, int player);
+int mz_worker_reset_search(mz_worker* w);
+int mz_worker_reset_game(mz_worker* w, int game);
+int mz_worker_emit_game(mz_worker* w, int game);
+int mz_worker_env_query(const mz_worker* w, int game, int what, float* out);
 typedef struct mz_worker_stats {
     uint64_t cycles, leaf_evals, moves, games;
     double ms_select, ms_env, ms_forward, ms_expand, ms_move, ms_total;

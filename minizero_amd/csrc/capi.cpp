@@ -17,6 +17,44 @@ void setError(const char* fmt, ...)
     va_end(ap);
 }
 const char* lastError() { return g_err; }
+
+bool readWeightFile(const std::string& path_in, mz_net_desc* desc, std::vector<float>* weights)
+{
+    std::string path = path_in;
+    mz_net_desc d;
+    std::vector<float> w;
+    const bool is_pt = path.size() > 3 && path.compare(path.size() - 3, 3, ".pt") == 0;
+    FILE* probe = is_pt ? fopen(path.c_str(), "rb") : nullptr;
+    if (probe) {
+        fclose(probe);
+        std::string err;
+        if (!readTorchScript(path, &d, &w, &err)) { setError("%s", err.c_str()); return false; }
+    } else {
+        if (is_pt) { path = path.substr(0, path.size() - 3) + ".mzw"; }
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) { setError("cannot open %s%s", path_in.c_str(), is_pt ? (" (nor " + path + ")").c_str() : ""); return false; }
+        char magic[4];
+        uint64_t count = 0;
+        bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "MZW1", 4) == 0 && fread(&d, sizeof(d), 1, f) == 1 && fread(&count, sizeof(count), 1, f) == 1 &&
+                  count < (1ull << 32);
+        if (ok) {
+            w.resize(count);
+            ok = fread(w.data(), sizeof(float), count, f) == count;
+        }
+        fclose(f);
+        if (!ok) { setError("bad weight file %s", path.c_str()); return false; }
+        d.game_name[sizeof(d.game_name) - 1] = 0;
+    }
+    if (!netValidateDesc(d)) { return false; }
+    if (static_cast<long>(w.size()) != netParamCount(d)) {
+        setError("%s: %zu floating-point values in the file, the %d-block network of its hyper-parameters has %ld", path.c_str(), w.size(), d.num_blocks,
+                 netParamCount(d));
+        return false;
+    }
+    if (desc) { *desc = d; }
+    if (weights) { weights->swap(w); }
+    return true;
+}
 } // namespace mz
 
 struct mz_net { mz::Net net; };
@@ -62,6 +100,21 @@ int mz_net_read_pt(const char* path, mz_net_desc* desc_out, float* weights_out, 
     if (count_out) { *count_out = w.size(); }
     if (weights_out) {
         if (capacity < w.size()) { mz::setError("mz_net_read_pt: buffer of %zu floats, %zu needed", capacity, w.size()); return MZ_ERR_ARG; }
+        memcpy(weights_out, w.data(), w.size() * sizeof(float));
+    }
+    return MZ_OK;
+}
+
+int mz_net_read_weight_file(const char* path, mz_net_desc* desc_out, float* weights_out, size_t capacity, size_t* count_out)
+{
+    if (!path) { mz::setError("mz_net_read_weight_file: NULL path"); return MZ_ERR_ARG; }
+    mz_net_desc d;
+    std::vector<float> w;
+    if (!mz::readWeightFile(path, &d, &w)) { return MZ_ERR_ARG; }
+    if (desc_out) { *desc_out = d; }
+    if (count_out) { *count_out = w.size(); }
+    if (weights_out) {
+        if (capacity < w.size()) { mz::setError("mz_net_read_weight_file: buffer of %zu floats, %zu needed", capacity, w.size()); return MZ_ERR_ARG; }
         memcpy(weights_out, w.data(), w.size() * sizeof(float));
     }
     return MZ_OK;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,33 @@ const char* lastError();
             mz::setError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);          \
             return MZ_ERR_DEVICE;                                                                             \
         }                                                                                                     \
+    } while (0)
+
+// Kernels with more than 48 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize once PER DEVICE (one process may
+// drive several GPUs from several host threads: one worker per device, ref actor/actor_group.cpp:168-187)
+struct PerDeviceOnce {
+    std::mutex mu;
+    unsigned long long done = 0;
+    template <class F>
+    hipError_t run(F&& f)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) { return e; }
+        std::lock_guard<std::mutex> l(mu);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done & bit) { return hipSuccess; }
+        e = f();
+        if (e == hipSuccess) { done |= bit; }
+        return e;
+    }
+};
+#define MZ_LDS_ATTR(kernel, lds)                                                                                              \
+    do {                                                                                                                      \
+        static mz::PerDeviceOnce once_;                                                                                       \
+        if ((lds) > 48 * 1024) {                                                                                              \
+            MZ_HIP(once_.run([&]() { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); })); \
+        }                                                                                                                     \
     } while (0)
 
 // device buffer with size bookkeeping (no exceptions across the ABI: alloc returns false on failure)

@@ -23,7 +23,7 @@ const Key kKeys[] = {
     K(actor_resign_threshold, T_FLOAT), K(zero_num_threads, T_INT), K(zero_num_parallel_games, T_INT),
     K(zero_disable_resign_ratio, T_FLOAT), K(zero_actor_intermediate_sequence_length, T_INT), K(zero_actor_ignored_command, T_STRING),
     K(learner_muzero_unrolling_step, T_INT), K(learner_n_step_return, T_INT), K(nn_file_name, T_STRING), K(nn_type_name, T_STRING),
-    K(env_board_size, T_INT), K(env_go_komi, T_FLOAT), K(env_go_ko_rule, T_STRING), K(env_game, T_STRING), K(atari_init_q, T_BOOL), K(mz_pipeline_lanes, T_INT), K(mz_zero_copy, T_INT), K(mz_cpu_base, T_INT), K(mz_signal_wait, T_BOOL), K(mz_device_env, T_BOOL), K(mz_raw_observations, T_BOOL), K(mz_sim_kernel, T_BOOL), K(env_atari_name, T_STRING), K(env_atari_episode_length, T_INT),
+    K(env_board_size, T_INT), K(env_go_komi, T_FLOAT), K(env_go_ko_rule, T_STRING), K(env_game, T_STRING), K(atari_init_q, T_BOOL), K(mz_pipeline_lanes, T_INT), K(mz_zero_copy, T_INT), K(mz_cpu_base, T_INT), K(mz_signal_wait, T_BOOL), K(mz_device_env, T_BOOL), K(mz_raw_observations, T_BOOL), K(mz_sim_kernel, T_BOOL), K(mz_manual_step, T_BOOL), K(env_atari_name, T_STRING), K(env_atari_episode_length, T_INT),
 };
 #undef K
 

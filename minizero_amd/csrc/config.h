@@ -59,6 +59,9 @@ struct WorkerConfig {
     bool mz_sim_kernel = true; // with mz_device_env: whole runs of cycles as one launch of the per-game simulation kernel (sim.hip)
     bool mz_raw_observations = true; // muzero_atari roots: ship the observation ring as bytes, expand the float planes on the device
     bool mz_device_env = true; // AlphaZero Go / Othello / TicTacToe: rules, planes, legal mask and candidate sort on the device (go_dev.hip)
+    // not a reference key: the worker never plays on its own — run_cycles stops when the searches are complete and the caller decides
+    // (mz_worker_search_action / mz_worker_act / mz_worker_reset_search): the per-actor stepping of BaseActor / ZeroActor::think()
+    bool mz_manual_step = false;
     int mz_zero_copy = 3; // bit 0: kernels read their inputs from pinned host memory; bit 1: kernels write their outputs there
 
     // returns false (and sets the library error string) on an unknown key or an unparsable value,

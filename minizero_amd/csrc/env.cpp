@@ -333,7 +333,9 @@ const GoStatic* goStatic(int n)
 class Go final : public GameEnv {
     static constexpr int kHashCap = 1024; // > 2 * (2*361 + 1) positions of the longest legal game at 19x19
 public:
-    Go(int n, float komi) : n_(n), P_(n * n), komi_(komi), st_(goStatic(n))
+    // situational: env_go_ko_rule=situational — a position repeats only with the same player to move: the hash of every position also
+    // carries a turn key on odd move counts (ref go.cpp:45-49,141,222); positional (the default): key 0
+    Go(int n, float komi, bool situational = false) : n_(n), P_(n * n), komi_(komi), st_(goStatic(n)), turn_key_(situational ? 0x9e3779b97f4a7c15ULL : 0)
     {
         rot_ = rotationTables(n, n * n + 1);
         reset();
@@ -409,7 +411,7 @@ public:
         if (a == P_) { return true; }
         if (a < 0 || a > P_ || board_[a] != 0) { return false; }
         bool ok = false;
-        uint64_t nh = hash_ ^ st_->key[player - 1][a];
+        uint64_t nh = hash_ ^ turn_key_ ^ st_->key[player - 1][a];
         int16_t grp[kMaxP];
         int16_t seen_rep[4];
         int nrep = 0;
@@ -458,7 +460,7 @@ public:
         for (int a = 0; a < P_; ++a) {
             if (board_[a] != 0) { out[a] = 0; continue; }
             bool ok = false;
-            uint64_t nh = hash_ ^ st_->key[player - 1][a];
+            uint64_t nh = hash_ ^ turn_key_ ^ st_->key[player - 1][a];
             int16_t cap[4];
             int ncap = 0;
             for (int k = 0; k < st_->nnbr[a]; ++k) {
@@ -490,6 +492,7 @@ public:
         action_ids_.push_back(static_cast<int16_t>(a));
         action_players_.push_back(static_cast<uint8_t>(player));
         turn_ = 3 - player;
+        hash_ ^= turn_key_;
         if (a != P_) {
             board_[a] = static_cast<uint8_t>(player);
             stones_[player - 1].set(a);
@@ -592,6 +595,7 @@ public:
         for (int p = 0; p < P_; ++p) { t[p >> 5] |= 1u << (p & 31); }
     }
     bool hasDeviceTwin() const override { return true; }
+    uint64_t turnKey() const override { return turn_key_; }
     const uint64_t* zobristKeys() const override
     {
         // [2][P_] contiguous copy of the [2][kMaxP] table
@@ -643,6 +647,7 @@ private:
     int n_, P_;
     float komi_;
     const GoStatic* st_;
+    uint64_t turn_key_;
     uint8_t board_[kMaxP];
     uint64_t hash_;
     uint64_t seen_[kHashCap];
@@ -765,7 +770,8 @@ private:
     float action_plane_[kHist] = {};
 };
 
-std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi, const std::string& atari_name, int atari_episode_length)
+std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi, const std::string& atari_name, int atari_episode_length,
+                                       const std::string& go_ko_rule)
 {
     if (game == "atari") { return std::make_unique<AtariSynth>(atari_name, atari_episode_length); }
     if (game == "tictactoe") { return std::make_unique<TicTacToe>(); }
@@ -777,7 +783,8 @@ std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, 
     if (game == "go") {
         const int n = board_size > 0 ? board_size : 9;
         if (n < 2 || n > kMaxN) { setError("go board size %d not supported (2..19)", n); return nullptr; }
-        return std::make_unique<Go>(n, go_komi);
+        if (go_ko_rule != "positional" && go_ko_rule != "situational") { setError("env_go_ko_rule '%s' not supported (positional | situational, ref go.cpp:47)", go_ko_rule.c_str()); return nullptr; }
+        return std::make_unique<Go>(n, go_komi, go_ko_rule == "situational");
     }
     setError("unknown env_game '%s' (tictactoe | go | othello | atari)", game.c_str());
     return nullptr;

@@ -55,6 +55,7 @@ public:
     virtual int deviceKind() const { return 0; } // GoDevView::kind (0 Go, 1 Othello)
     virtual void exportDeviceRoot(void* /*GoRootSnapshot*/) const {}
     virtual const uint64_t* zobristKeys() const { return nullptr; } // [2][points]
+    virtual uint64_t turnKey() const { return 0; }                  // Go, situational superko: XORed into the hash on every move
     int turn() const { return turn_; }
     int featureSize() const { return numInputChannels() * boardSize() * boardSize(); }
     const std::vector<int16_t>& actionIds() const { return action_ids_; }
@@ -71,6 +72,6 @@ protected:
 // game: "tictactoe" | "go" | "othello"; board_size 0 = the game's default (3 / 9 / 8)
 // game "atari": the synthetic Atari-shaped environment (18 actions, 32 x 96 x 96 features, 1 player)
 std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi, const std::string& atari_name = "ms_pacman",
-                                       int atari_episode_length = 1000);
+                                       int atari_episode_length = 1000, const std::string& go_ko_rule = "positional");
 
 } // namespace mz

@@ -93,6 +93,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     if (depth >= 1) { // leaf = parent + one move (ref go.cpp:132-190, observable effects only)
         const int a = pact[len - 1], m = 3 - t;
         ++nmoves;
+        hash ^= v.turn_key; // situational superko: every move, pass included (ref go.cpp:141); 0 with the positional rule
         if (a >= P) {
             passes = passes + 1 > 2 ? 2 : passes + 1;
         } else {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         if (c[i] == 0 && !terminal) {
             const int p = i * 64 + lane;
             bool ok = false;
-            uint64_t nh = hash ^ v.key[size_t(t - 1) * P + p];
+            uint64_t nh = hash ^ v.turn_key ^ v.key[size_t(t - 1) * P + p];
             int capl[4], ncap = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

@@ -42,6 +42,7 @@ struct GoDevView {
     uint16_t* lab;             // [games][slots][Ppad]
     const GoRootSnapshot* snap; // [games]
     const uint64_t* key;       // [2][P]
+    uint64_t turn_key;         // situational superko (env_go_ko_rule): XORed into the hash on every move, pass included; 0 = positional
     const uint16_t* inv;       // [8][P]  feature rotation: plane bit p <- position inv[r][p]
     const uint16_t* fwd;       // [8][A]  policy index of action a under rotation r
     uint32_t* feat;            // [games][18 * W32] bit-packed planes (the tower's input format)
@@ -55,7 +56,7 @@ class GoDevice {
 public:
     // kind 0: Go (keys = Zobrist table [2][P]); kind 1: Othello (board_n <= 8, keys unused); kind 2: TicTacToe (3x3, 9 actions)
     int init(int device, int games, int board_n, float komi, int action_size, int slots, int max_depth, hipStream_t stream, const int* const inv[8],
-             const int* const fwd[8], const uint64_t* keys, int kind = 0);
+             const int* const fwd[8], const uint64_t* keys, int kind = 0, uint64_t turn_key = 0);
     GoRootSnapshot* hostSnap(int g) { return h_snap_.p + g; }
     int uploadRoots();                                                   // snapshots H2D + slot 0 of every game
     int leafAsync(const PoolView& pv, const RotPack& rot, int slot);      // position + planes + legal mask of the selected leaves

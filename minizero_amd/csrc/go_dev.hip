@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void sort_test_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 int GoDevice::init(int device, int games, int board_n, float komi, int action_size, int slots, int max_depth, hipStream_t stream, const int* const inv[8],
-                   const int* const fwd[8], const uint64_t* keys, int kind)
+                   const int* const fwd[8], const uint64_t* keys, int kind, uint64_t turn_key)
 {
     if (kind == 1 && board_n > 8) { setError("GoDevice: Othello boards up to 8x8"); return MZ_ERR_ARG; }
     if (kind == 2 && (board_n != 3 || action_size != 9)) { setError("GoDevice: TicTacToe is 3x3 with 9 actions"); return MZ_ERR_ARG; }
@@ -103,6 +103,7 @@ int GoDevice::init(int device, int games, int board_n, float komi, int action_si
     MZ_HIP(hipMemcpy(fwd_.p, t.data(), size_t(8) * v.A * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (keys) { MZ_HIP(hipMemcpy(key_.p, keys, size_t(2) * v.P * sizeof(uint64_t), hipMemcpyHostToDevice)); }
     v.stones = stones_.p; v.hash = hash_.p; v.meta = meta_.p; v.lab = lab_.p; v.snap = d_snap_.p; v.key = key_.p; v.inv = inv_.p; v.fwd = fwd_.p;
+    v.turn_key = turn_key;
     v.feat = feat_.p; v.legal = legal_.p; v.leaf_player = misc_i_.p; v.terminal = misc_i_.p + games; v.eval = eval_.p;
     return MZ_OK;
 }

@@ -70,9 +70,9 @@ __device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelVie
             bool all = true;
             for (int i = 0; i < ncand; ++i) { if (!(cnt[cand[i]] >= static_cast<float>(budget))) { all = false; break; } }
             if (all) {
-                int lg2 = 0;
-                while ((1 << (lg2 + 1)) <= sample) { ++lg2; }
-                const int next_budget = gv.next_budget[lg2 < 8 ? lg2 : 7];
+                // int / (double * int / int): three IEEE double operations, no contraction (the reference's promotions)
+                const double nb = __builtin_floor(static_cast<double>(gv.num_simulation) / (gv.log2_m * static_cast<double>(sample) / 2.0));
+                const int next_budget = nb >= 2147483647.0 ? 2147483647 : static_cast<int>(nb);
                 if (next_budget > 0 && sample > 2) {
                     sample /= 2;
                     for (int i = 0; i < nc; ++i) {

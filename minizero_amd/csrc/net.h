@@ -39,6 +39,9 @@ bool packWeights(const mz_net_desc& d, const float* raw, size_t n, std::vector<f
                  HeadOffsets& h, AtariLayers& at);
 
 bool readTorchScript(const std::string& path, mz_net_desc* desc, std::vector<float>* weights, std::string* err); // ptfile.cpp
+// Network::loadModel's file access (ref network/network.h:18-37): `path` as the reference's TorchScript archive; if "x.pt" does not exist,
+// the sibling flat blob "x.mzw" (minizero_amd/export_weights.py); validated against the hyper-parameters.  Sets the error string on failure.
+bool readWeightFile(const std::string& path, mz_net_desc* desc, std::vector<float>* weights); // capi.cpp
 
 float invertValueHost(float value); // 601-bin decode helper (ref utils/utils.h:102-108)
 int invertValuesOnDevice(int device, const float* values, int n, float* out); // the device twin (net_atari_body.h), test access

@@ -190,11 +190,7 @@ template <int H, int W, int CIN_PAD>
 static int launchConvT(const ConvLayer& L, const float* params, const float* in, const float* skip, float* out, int B, hipStream_t s)
 {
     constexpr size_t lds = size_t(CIN_PAD) * planeStride(H, W) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma<H, W, CIN_PAD>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_set = true;
-    }
+    MZ_LDS_ATTR((conv3x3_mfma<H, W, CIN_PAD>), lds);
     hipLaunchKernelGGL((conv3x3_mfma<H, W, CIN_PAD>), dim3(B), dim3(256), lds, s, in, L.cin, params + L.w_off, params + L.b_off, skip, out, L.cout,
                        L.cout_pad / 16);
     MZ_HIP(hipGetLastError());
@@ -238,11 +234,7 @@ static int launchTowerT(const TowerArgs& ta, const float* params, const float* i
 {
     constexpr int CMAX = CIN0_PAD > CPAD ? CIN0_PAD : CPAD;
     constexpr size_t lds = size_t(kTowerTiles) * CMAX * planeStride(H, W) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fused<H, W, CIN0_PAD, CPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_set = true;
-    }
+    MZ_LDS_ATTR((tower_fused<H, W, CIN0_PAD, CPAD>), lds);
     hipLaunchKernelGGL((tower_fused<H, W, CIN0_PAD, CPAD>), dim3(B), dim3(512), lds, s, in, params, ta, out);
     MZ_HIP(hipGetLastError());
     return MZ_OK;

@@ -116,11 +116,7 @@ static int launchTiledT(const ConvLayer& L, const float* params, const float* in
 {
     constexpr int PR = 7 * STRIDE + 3, PC = 15 * STRIDE + 3;
     constexpr size_t lds = size_t(CIN_PAD) * PR * PC * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tiled<STRIDE, CIN_PAD, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_set = true;
-    }
+    MZ_LDS_ATTR((conv3x3_tiled<STRIDE, CIN_PAD, OT>), lds);
     const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
     const dim3 grid(((Wo + 15) / 16) * ((Ho + 7) / 8), B);
     hipLaunchKernelGGL((conv3x3_tiled<STRIDE, CIN_PAD, OT>), grid, dim3(256), lds, s, in, L.cin, H, W, params + L.w_off, params + L.b_off, skip, out, L.cout);
@@ -167,11 +163,7 @@ static int launchAtariHeads(const Net& net, const float* params, const HeadOffse
     AtariHeadParams hp;
     net.makeAtariHeadParams(&hp);
     const size_t lds = atariHeadsSmemFloats(hp) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_atari_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_set = true;
-    }
+    MZ_LDS_ATTR((heads_atari_kernel), lds);
     hipLaunchKernelGGL(heads_atari_kernel, dim3(B), dim3(1024), lds, s, x, hp, policy, logit, value, reward, hidden_dst, dst_idx, do_reward ? 1 : 0);
     MZ_HIP(hipGetLastError());
     return MZ_OK;

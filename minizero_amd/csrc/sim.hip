@@ -516,11 +516,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
 static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_set = true;
-    }
+    MZ_LDS_ATTR((sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), lds);
     hipLaunchKernelGGL((sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), dim3(games), dim3(512), lds, s, d_args, sim0, nsims, host_start);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
@@ -535,11 +531,7 @@ static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, i
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
 static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_set = true;
-    }
+    MZ_LDS_ATTR((sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), lds);
     hipLaunchKernelGGL((sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), dim3(games), dim3(512), lds, s, d_args, d_rot, sim0, nsims, host_start);
     MZ_HIP(hipGetLastError());
     return MZ_OK;

@@ -278,8 +278,17 @@ public:
         return MZ_OK;
     }
     int runCycles(int n);
+    int cyclesPerMove() const { return n_ + 1; }
     int popLine(char* buf, int cap);
-    int peekRecord(int game, char* buf, int cap);
+    int peekRecord(int game, char* buf, int cap, const char* const* keys = nullptr, const char* const* values = nullptr, int ntags = 0);
+    // per-actor stepping (mz_manual_step=true): BaseActor / ZeroActor surface (ref actor/base_actor.h:16-55, zero_actor.h:24-70)
+    bool searchDone() const { return search_done_; }
+    int searchAction(int g, int* action_id, int* player, int* resign) const;
+    int actGame(int g, int action_id, int player);
+    int resetSearchAll();
+    int resetGameAt(int g);
+    int emitGame(int g);
+    int envQuery(int g, int what, float* out) const;
     mz_worker_stats stats_{};
     Net& net0() { return lanes_[0]->net; }
 
@@ -376,6 +385,9 @@ private:
     std::vector<DeferredInfo> deferred_; // record strings of the last move, built while the next launch runs
     bool defer_info_ = false;
     void flushDeferred();
+    struct Held { int action = -1, player = 0; bool resign = false; ActionInfo info; };
+    std::vector<Held> held_;  // mz_manual_step: the decision of the completed search of every game
+    bool search_done_ = false, stop_now_ = false;
     GumbelView gum_{};        // constants of the device-side Gumbel step (state pointer set per lane)
     bool dev_gumbel_ = false; // Gumbel root logic inside the simulation kernel
     int raw_bytes_ = 0;             // > 0: root observations travel as bytes (GameEnv::rawFeatures) and are expanded on the device
@@ -449,6 +461,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     for (auto* v : {&rr_count_, &rr_mean_, &rr_policy_, &rr_logit_, &rr_noise_, &rr_value_, &rr_reward_}) { v->resize(GA); }
     for (auto* v : {&rr_root_count_, &rr_root_mean_, &rr_root_value_, &rr_lo_, &rr_hi_}) { v->resize(G_); }
     noise_mask_.assign(G_, 1);
+    held_.assign(G_, Held());
     noise_policy_.resize(GA); noise_logit_.resize(GA); noise_noise_.resize(GA);
     int rcc = createActors();
     if (rcc) { return rcc; }
@@ -468,16 +481,16 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         for (int r = 0; r < 8; ++r) { inv[r] = e.rot()->inv[r].data(); fwd[r] = e.rot()->fwd[r].data(); }
         for (auto& L : lanes_) {
             int rc = L->godev.init(device, L->n, e.boardSize(), cfg_.env_go_komi, A_, n_ + 1, L->pool.v_.max_depth, L->stream, inv, fwd, e.zobristKeys(),
-                                   e.deviceKind());
+                                   e.deviceKind(), e.turnKey());
             if (rc) { return rc; }
             L->pool.v_.host_path_len = nullptr; // nobody on the host reads the paths any more
             L->pool.v_.host_path_action = nullptr;
             if ((rc = uploadRoots(*L))) { return rc; }
         }
         sim_kernel_ = cfg_.mz_sim_kernel && net0().hasSimKernel(e.boardSize(), e.deviceKind(), cfg_.actor_num_simulation) &&
-                      (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 1 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
+                      (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 2 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
         { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
-        defer_info_ = sim_kernel_;
+        defer_info_ = sim_kernel_ && !cfg_.mz_manual_step;
         if (sim_kernel_) {
             for (auto& L : lanes_) {
                 if (!L->h_rot.alloc(size_t(n_ + 1) * L->n) || !L->d_rot.alloc(size_t(n_ + 1) * L->n)) { setError("worker: allocation failed (rot table)"); return MZ_ERR_DEVICE; }
@@ -488,10 +501,10 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         }
     }
     sim_mz_ = !resident_ && cfg_.mz_sim_kernel && (desc.type == 1 || desc.type == 2) && net0().hasSimKernelMz(cfg_.actor_num_simulation) &&
-              (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 1 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
+              (!cfg_.actor_use_gumbel || (cfg_.actor_gumbel_sample_size >= 2 && cfg_.actor_gumbel_sample_size <= kGumbelMaxSample));
     if (sim_mz_) {
         sim_kernel_ = true;
-        defer_info_ = true;
+        defer_info_ = !cfg_.mz_manual_step;
         sim_root_host_ = desc.type == 2;
         { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
         const int fw = sim_root_host_ ? 1 : games_[0].env->featureWords(), LW = (A_ + 63) / 64;
@@ -521,7 +534,8 @@ int Worker::setupDeviceGumbel() // the constants of the device-side Gumbel step 
         gum_.sigma_visit_c = cfg_.actor_gumbel_sigma_visit_c;
         gum_.sigma_scale_c = cfg_.actor_gumbel_sigma_scale_c;
         gum_.budget0 = static_cast<int>(std::max(1.0, std::floor(cfg_.actor_num_simulation / (std::log2(m) * m))));
-        for (int k = 0; k < 8; ++k) { gum_.next_budget[k] = static_cast<int>(std::floor(cfg_.actor_num_simulation / (std::log2(m) * (1 << k) / 2))); }
+        gum_.num_simulation = cfg_.actor_num_simulation;
+        gum_.log2_m = std::log2(m);
         for (auto& L : lanes_) {
             const size_t n = size_t(L->n) * (3 + kGumbelMaxSample);
             if (!L->h_gum.alloc(n) || !L->d_gum.alloc(n)) { setError("worker: allocation failed (gumbel state)"); return MZ_ERR_DEVICE; }
@@ -563,7 +577,7 @@ int Worker::createActors()
     games_.clear();
     games_.resize(G_);
     for (auto& g : games_) {
-        g.env = createGameEnv(cfg_.env_game, cfg_.env_board_size, cfg_.env_go_komi, cfg_.env_atari_name, cfg_.env_atari_episode_length);
+        g.env = createGameEnv(cfg_.env_game, cfg_.env_board_size, cfg_.env_go_komi, cfg_.env_atari_name, cfg_.env_atari_episode_length, cfg_.env_go_ko_rule);
         if (!g.env) { return MZ_ERR_ARG; }
         if (g.env->policySize() != A_ || g.env->featureSize() != net0().featSize()) {
             setError("network (A=%d, features=%d) does not fit env %s (A=%d, features=%d)", A_, net0().featSize(), g.env->name().c_str(),
@@ -944,6 +958,14 @@ void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor
     Game& gm = games_[g];
     const size_t off = size_t(g) * A_;
     const bool resign = isResign(g);
+    if (cfg_.mz_manual_step) { // the caller plays: keep what ZeroActor::handleSearchDone leaves behind (zero_actor.cpp:128-176)
+        Held& h = held_[g];
+        h.action = rr_action_[off + gm.selected];
+        h.player = gm.env->turn();
+        h.resign = resign;
+        h.info = rr_root_count_[g] > 0 ? actionInfo(g, h.player) : ActionInfo(); // ZeroActor::getActionInfo (zero_actor.cpp:114-119)
+        return;
+    }
     bool acted = false;
     int mover = 0;
     if (!resign) {
@@ -1051,7 +1073,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
             if (done) { gm.selected = decideAction(g); }                  // zero_actor.cpp:96 handleSearchDone()
             if (cfg_.actor_use_gumbel) { gumbelSequentialHalving(g); }     // zero_actor.cpp:97
             if (done) { handleSearchDone(g); }                             // actor_group.cpp:92
-            if (az) { // beforeNNEvaluation: the rotation draw (zero_actor.cpp:56)
+            if (az && !(done && cfg_.mz_manual_step)) { // beforeNNEvaluation: the rotation draw (zero_actor.cpp:56)
                 gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
             }
         }
@@ -1061,12 +1083,13 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
             const size_t o = size_t(g0) * A_;
             if ((rc = L.pool.rootSetNoise(noise_mask_.data() + g0, noise_policy_.data() + o, noise_logit_.data() + o, noise_noise_.data() + o))) { return rc; }
         }
-        if (done) {
+        if (done && !cfg_.mz_manual_step) {
             std::vector<int> rp(L.n);
             for (int j = 0; j < L.n; ++j) { rp[j] = rootPlayerFor(games_[g0 + j]); }
             if ((rc = L.pool.resetSearch(nullptr, rp.data()))) { return rc; }
             if ((resident_ || sim_mz_) && (rc = uploadRoots(L))) { return rc; }
         }
+        if (done && cfg_.mz_manual_step) { return MZ_OK; } // no next selection: the caller acts and resets the search first
         t0 = nowMs();
         stats_.ms_move += t0 - t2;
         trace_.add(5, t0 - ts);
@@ -1201,6 +1224,7 @@ int Worker::cycle()
         int rc = phase1(*L, root_expansion, done);
         if (rc) { return rc; }
     }
+    if (done && cfg_.mz_manual_step) { search_done_ = true; stop_now_ = true; pending_ = false; sims_done_ = 0; return MZ_OK; }
     if (pending_) { sims_done_ = done ? 0 : sim_post_; }
     for (auto& L : lanes_) {
         int rc = phase2(*L);
@@ -1265,6 +1289,7 @@ int Worker::runCyclesSim(int n)
             if (host_gumbel && (rc = syncGumbel(*L, true))) { return rc; }
             for (int j = 0; j < L->n; ++j) { L->h_rot.p[j] = static_cast<uint8_t>(games_[L->g0 + j].rot); }
         }
+        if (done && cfg_.mz_manual_step) { search_done_ = true; pending_ = false; sims_done_ = 0; stats_.ms_total += nowMs() - t0; return i; }
         if (pending_) { sims_done_ = done ? 0 : sim_post_; }
         const int sim0 = sims_done_;
         if (root_cycle) {
@@ -1357,11 +1382,13 @@ int Worker::runCyclesSim(int n)
 
 int Worker::runCycles(int n)
 {
-    if (!running_) { return 0; }
+    if (!running_ || search_done_) { return 0; }
     if (sim_kernel_) { return runCyclesSim(n); }
+    stop_now_ = false;
     for (int i = 0; i < n; ++i) {
         int rc = cycle();
         if (rc) { return rc; }
+        if (stop_now_) { n = i; break; }
     }
     if (resident_) { // the cycles above were only queued: the call returns when they have run
         const double t0 = nowMs();
@@ -1387,11 +1414,78 @@ int Worker::popLine(char* buf, int cap)
     return len;
 }
 
-int Worker::peekRecord(int game, char* buf, int cap)
+int Worker::searchAction(int g, int* action_id, int* player, int* resign) const
+{
+    if (g < 0 || g >= G_) { setError("search_action: game %d out of range", g); return MZ_ERR_ARG; }
+    if (!search_done_) { setError("search_action: the search is not complete"); return MZ_ERR_STATE; }
+    if (action_id) { *action_id = held_[g].action; }
+    if (player) { *player = held_[g].player; }
+    if (resign) { *resign = held_[g].resign ? 1 : 0; }
+    return MZ_OK;
+}
+
+int Worker::actGame(int g, int action_id, int player) // BaseActor::act (ref base_actor.cpp:22-30)
+{
+    if (g < 0 || g >= G_) { setError("act: game %d out of range", g); return MZ_ERR_ARG; }
+    if (!cfg_.mz_manual_step) { setError("act: the worker plays on its own (mz_manual_step=false)"); return MZ_ERR_STATE; }
+    Game& gm = games_[g];
+    if (!gm.env->act(action_id, player)) { return 0; }
+    gm.action_info_history.resize(gm.env->actionIds().size());
+    gm.action_info_history.back() = search_done_ ? held_[g].info : ActionInfo();
+    ++stats_.moves;
+    return 1;
+}
+
+int Worker::resetSearchAll() // ZeroActor::resetSearch (ref zero_actor.cpp:29-34) of every game
+{
+    MZ_HIP(hipSetDevice(device_));
+    for (auto& L : lanes_) { MZ_HIP(hipStreamSynchronize(L->stream)); }
+    sims_done_ = 0;
+    pending_ = false;
+    search_done_ = false;
+    root_host_pending_ = false;
+    for (auto& h : held_) { h = Held(); }
+    return resetAllSearches();
+}
+
+int Worker::resetGameAt(int g) // ZeroActor::reset without the search part (ref zero_actor.cpp:23-27, base_actor.cpp:8-13)
+{
+    if (g < 0 || g >= G_) { setError("reset_game: game %d out of range", g); return MZ_ERR_ARG; }
+    resetGame(games_[g], rng_);
+    return MZ_OK;
+}
+
+int Worker::emitGame(int g) // ThreadSharedData::outputGame (ref actor_group.cpp:24-50)
+{
+    if (g < 0 || g >= G_) { setError("emit_game: game %d out of range", g); return MZ_ERR_ARG; }
+    flushDeferred();
+    outputGame(games_[g]);
+    return MZ_OK;
+}
+
+int Worker::envQuery(int g, int what, float* out) const
+{
+    if (g < 0 || g >= G_ || !out) { setError("env_query: bad arguments"); return MZ_ERR_ARG; }
+    const GameEnv& e = *games_[g].env;
+    switch (what) {
+        case 0: *out = e.isTerminal() ? 1.0f : 0.0f; break;
+        case 1: *out = static_cast<float>(e.turn()); break;
+        case 2: *out = e.evalScore(false); break;
+        case 3: *out = e.evalScore(true); break;
+        case 4: *out = static_cast<float>(e.actionIds().size()); break;
+        case 5: *out = e.reward(); break;
+        default: setError("env_query: unknown query %d", what); return MZ_ERR_ARG;
+    }
+    return MZ_OK;
+}
+
+int Worker::peekRecord(int game, char* buf, int cap, const char* const* keys, const char* const* values, int ntags)
 {
     if (game < 0 || game >= G_) { setError("peek_record: game %d out of range", game); return MZ_ERR_ARG; }
     flushDeferred();
-    const std::string s = record(games_[game], {});
+    ActionInfo extra;
+    for (int i = 0; i < ntags; ++i) { extra.push_back({keys[i], values[i]}); }
+    const std::string s = record(games_[game], extra);
     const int len = static_cast<int>(s.size());
     if (cap <= len) { setError("peek_record: buffer of %d bytes too small for a %d-byte record", cap, len); return MZ_ERR_ARG; }
     memcpy(buf, s.data(), len);
@@ -1405,6 +1499,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
     std::istringstream ign(cfg_.zero_actor_ignored_command);
     std::string tok;
     while (ign >> tok) { if (tok == prefix) { return MZ_OK; } }
+    MZ_HIP(hipSetDevice(device_));
     if (prefix == "start") { running_ = true; }
     else if (prefix == "stop") { running_ = false; }
     else if (prefix == "reset_actors") {
@@ -1415,17 +1510,45 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         return resetAllSearches();
     } else if (prefix == "load_model") {
         if (line.find(' ') == std::string::npos) { setError("load_model needs a path"); return MZ_ERR_ARG; }
-        cfg_.nn_file_name = line.substr(line.find(' ') + 1);
-        if (!pending_weights_.empty()) {
-            for (auto& L : lanes_) {
-                MZ_HIP(hipStreamSynchronize(L->stream));
-                int rc = L->net.reload(pending_weights_.data(), pending_weights_.size());
-                if (rc) { return rc; }
+        const std::string path = line.substr(line.find(' ') + 1);
+        if (pending_weights_.empty()) { // the reference's path: every network re-reads the file (actor_group.cpp:227-232)
+            mz_net_desc nd;
+            if (!readWeightFile(path, &nd, &pending_weights_)) { pending_weights_.clear(); return MZ_ERR_ARG; }
+            nd.game_name[sizeof(nd.game_name) - 1] = 0;
+            mz_net_desc a = nd, b = desc_;
+            memset(a.game_name, 0, sizeof(a.game_name));
+            memset(b.game_name, 0, sizeof(b.game_name));
+            if (memcmp(&a, &b, sizeof(a)) != 0) {
+                pending_weights_.clear();
+                setError("load_model %s: the file's hyper-parameters are not those of the running network (%s, %d blocks x %d channels)", path.c_str(),
+                         desc_.game_name, desc_.num_blocks, desc_.num_hidden_channels);
+                return MZ_ERR_ARG;
             }
-            pending_weights_.clear();
         }
+        for (auto& L : lanes_) {
+            MZ_HIP(hipStreamSynchronize(L->stream));
+            int rc = L->net.reload(pending_weights_.data(), pending_weights_.size());
+            if (rc) { pending_weights_.clear(); return rc; }
+        }
+        pending_weights_.clear();
+        cfg_.nn_file_name = path;
     } else if (prefix == "update_config") {
-        if (line.find(' ') == std::string::npos || !cfg_.loadFromString(line.substr(line.find(' ') + 1))) { return MZ_ERR_ARG; }
+        if (line.find(' ') == std::string::npos) { setError("update_config needs a configuration string"); return MZ_ERR_ARG; }
+        WorkerConfig nc = cfg_;
+        if (!nc.loadFromString(line.substr(line.find(' ') + 1))) { return MZ_ERR_ARG; }
+        // keys whose values were turned into device state when the worker was created (pool and slab sizes, PUCT tables, Gumbel constants,
+        // kernels, engines): a live change would leave host and device disagreeing, so it is refused by name
+        const char* fixed = nullptr;
+#define MZ_FIXED(k) if (!fixed && !(nc.k == cfg_.k)) { fixed = #k; }
+        MZ_FIXED(actor_num_simulation) MZ_FIXED(actor_mcts_puct_base) MZ_FIXED(actor_mcts_puct_init) MZ_FIXED(actor_mcts_reward_discount)
+        MZ_FIXED(actor_mcts_value_rescale) MZ_FIXED(actor_mcts_value_flipping_player) MZ_FIXED(actor_use_gumbel) MZ_FIXED(actor_gumbel_sample_size)
+        MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
+        MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
+        MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
+        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+#undef MZ_FIXED
+        if (fixed) { setError("update_config: %s is fixed when the worker is created (restart the worker to change it)", fixed); return MZ_ERR_ARG; }
+        cfg_ = nc;
     } else if (prefix == "quit") {
         running_ = false;
         return 1;
@@ -1446,11 +1569,23 @@ int mz_usable_cpus(void) { return mz::usableCpus(); }
 
 mz_worker* mz_worker_create(int device, const char* conf, const mz_net_desc* desc, const float* weights, size_t count)
 {
-    if (!conf || !desc || !weights) { mz::setError("mz_worker_create: NULL argument"); return nullptr; }
+    if (!conf || (!desc != !weights)) { mz::setError("mz_worker_create: NULL argument"); return nullptr; }
     std::unique_ptr<mz_worker> w(new mz_worker());
+    mz_net_desc file_desc;
+    std::vector<float> file_weights;
+    if (!desc) { // the network comes from the configuration's nn_file_name (ref actor_group.cpp:168-177)
+        mz::WorkerConfig c;
+        if (!c.loadFromString(conf)) { return nullptr; }
+        if (c.nn_file_name.empty()) { mz::setError("mz_worker_create: no network given and nn_file_name is empty"); return nullptr; }
+        if (!mz::readWeightFile(c.nn_file_name, &file_desc, &file_weights)) { return nullptr; }
+        desc = &file_desc;
+        weights = file_weights.data();
+        count = file_weights.size();
+    }
     if (w->w.init(device, conf, *desc, weights, count) != MZ_OK) { return nullptr; }
     return w.release();
 }
+int mz_worker_cycles_per_move(const mz_worker* w) { return w ? w->w.cyclesPerMove() : MZ_ERR_ARG; }
 void mz_worker_destroy(mz_worker* w) { delete w; }
 int mz_worker_command(mz_worker* w, const char* line)
 {
@@ -1477,6 +1612,42 @@ int mz_worker_peek_record(mz_worker* w, int game, char* buf, int cap)
     if (!w || !buf) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
     return w->w.peekRecord(game, buf, cap);
 }
+int mz_worker_record(mz_worker* w, int game, const char* const* keys, const char* const* values, int ntags, char* buf, int cap)
+{
+    if (!w || !buf || ntags < 0 || (ntags > 0 && (!keys || !values))) { mz::setError("mz_worker_record: bad arguments"); return MZ_ERR_ARG; }
+    return w->w.peekRecord(game, buf, cap, keys, values, ntags);
+}
+int mz_worker_search_done(const mz_worker* w) { return w ? (w->w.searchDone() ? 1 : 0) : MZ_ERR_ARG; }
+int mz_worker_search_action(const mz_worker* w, int game, int* action_id, int* player, int* is_resign)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.searchAction(game, action_id, player, is_resign);
+}
+int mz_worker_act(mz_worker* w, int game, int action_id, int player)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.actGame(game, action_id, player);
+}
+int mz_worker_reset_search(mz_worker* w)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.resetSearchAll();
+}
+int mz_worker_reset_game(mz_worker* w, int game)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.resetGameAt(game);
+}
+int mz_worker_emit_game(mz_worker* w, int game)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.emitGame(game);
+}
+int mz_worker_env_query(const mz_worker* w, int game, int what, float* out)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.envQuery(game, what, out);
+}
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out)
 {
     if (!w || !out) { return MZ_ERR_ARG; }
@@ -1490,7 +1661,7 @@ mz_env* mz_env_create(const char* conf)
     mz::WorkerConfig c;
     if (!conf || !c.loadFromString(conf)) { return nullptr; }
     std::unique_ptr<mz_env> e(new mz_env());
-    e->e = mz::createGameEnv(c.env_game, c.env_board_size, c.env_go_komi, c.env_atari_name, c.env_atari_episode_length);
+    e->e = mz::createGameEnv(c.env_game, c.env_board_size, c.env_go_komi, c.env_atari_name, c.env_atari_episode_length, c.env_go_ko_rule);
     if (!e->e) { return nullptr; }
     return e.release();
 }
@@ -1539,7 +1710,8 @@ int mz_envdev_playout(int device, const char* game, int board_size, float komi, 
     if (!game) { setError("mz_envdev_playout: NULL game"); return MZ_ERR_ARG; }
     if (mz_device_count() < 1) { setError("mz_envdev_playout: no GPU (libmzgpu has no CPU path)"); return MZ_ERR_DEVICE; }
     if (!actions || !rots || count < 0 || root_prefix < 0 || root_prefix > count) { setError("mz_envdev_playout: bad arguments"); return MZ_ERR_ARG; }
-    std::unique_ptr<GameEnv> env = createGameEnv(game, board_size, komi);
+    const bool situational = std::string(game) == "go_situational"; // test access to env_go_ko_rule=situational
+    std::unique_ptr<GameEnv> env = createGameEnv(situational ? "go" : game, board_size, komi, "ms_pacman", 1000, situational ? "situational" : "positional");
     if (!env || !env->hasDeviceTwin()) { setError("mz_envdev_playout: no device twin for this board"); return MZ_ERR_ARG; }
     for (int i = 0; i < root_prefix; ++i) {
         if (!env->act(actions[i], env->turn())) { setError("mz_envdev_playout: illegal root action %d at move %d", actions[i], i); return MZ_ERR_ARG; }
@@ -1549,7 +1721,7 @@ int mz_envdev_playout(int device, const char* game, int board_size, float komi, 
     const int* fwd[8];
     for (int r = 0; r < 8; ++r) { inv[r] = env->rot()->inv[r].data(); fwd[r] = env->rot()->fwd[r].data(); }
     GoDevice gd;
-    int rc = gd.init(device, 1, env->boardSize(), komi, A, steps, md, nullptr, inv, fwd, env->zobristKeys(), env->deviceKind());
+    int rc = gd.init(device, 1, env->boardSize(), komi, A, steps, md, nullptr, inv, fwd, env->zobristKeys(), env->deviceKind(), env->turnKey());
     if (rc) { return rc; }
     env->exportDeviceRoot(gd.hostSnap(0));
     if ((rc = gd.uploadRoots())) { return rc; }

@@ -118,6 +118,8 @@ def load():
         L.mz_worker_command.argtypes = [vp, C.c_char_p]
         L.mz_worker_set_weights.argtypes = [vp, fp, C.c_size_t]
         L.mz_worker_run_cycles.argtypes = [vp, C.c_int]
+        L.mz_worker_cycles_per_move.argtypes = [vp]
+        L.mz_net_read_weight_file.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mz_worker_pop_line.argtypes = [vp, C.c_char_p, C.c_int]
         L.mz_worker_get_stats.argtypes = [vp, C.POINTER(WorkerStats)]
         L.mz_worker_peek_record.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
@@ -180,6 +182,17 @@ def read_pt(path):
     _check(L, L.mz_net_read_pt(path.encode(), C.byref(d), None, 0, C.byref(n)))
     w = np.empty(n.value, np.float32)
     _check(L, L.mz_net_read_pt(path.encode(), C.byref(d), _f(w), n.value, C.byref(n)))
+    return d, w
+
+
+def read_weight_file(path):
+    """(desc, weights) of `path` as Network::loadModel is given it: the TorchScript archive, or for a missing x.pt its sibling x.mzw."""
+    L = load()
+    d = NetDesc()
+    n = C.c_size_t(0)
+    _check(L, L.mz_net_read_weight_file(path.encode(), C.byref(d), None, 0, C.byref(n)))
+    w = np.empty(n.value, np.float32)
+    _check(L, L.mz_net_read_weight_file(path.encode(), C.byref(d), _f(w), n.value, C.byref(n)))
     return d, w
 
 
@@ -338,12 +351,19 @@ class Pool:
 class Worker:
     """Mirror of minizero::actor::ActorGroup (`-mode sp`, ref actor/actor_group.cpp:136-252)."""
 
-    def __init__(self, conf, desc, weights, device=0):
+    def __init__(self, conf, desc=None, weights=None, device=0):
+        """desc / weights None: the network is read from the configuration's nn_file_name (.pt, or its .mzw sibling)"""
         self.L = load()
-        w = np.ascontiguousarray(weights, np.float32)
-        self.h = self.L.mz_worker_create(device, conf.encode(), C.byref(desc), _f(w), w.size)
+        if desc is None:
+            self.h = self.L.mz_worker_create(device, conf.encode(), None, None, 0)
+        else:
+            w = np.ascontiguousarray(weights, np.float32)
+            self.h = self.L.mz_worker_create(device, conf.encode(), C.byref(desc), _f(w), w.size)
         if not self.h:
             raise MzError("mz_worker_create failed: " + _err(self.L))
+        if desc is None:
+            desc = NetDesc()
+            _check(self.L, self.L.mz_net_get_desc(self.L.mz_worker_net(self.h), C.byref(desc)))
         self.desc = desc
 
     def close(self):
@@ -362,6 +382,9 @@ class Worker:
 
     def run_cycles(self, n):
         return _check(self.L, self.L.mz_worker_run_cycles(self.h, n))
+
+    def cycles_per_move(self):
+        return _check(self.L, self.L.mz_worker_cycles_per_move(self.h))
 
     def pop_lines(self):
         out = []

@@ -269,12 +269,13 @@ private:
 typedef std::bitset<361> GoBB;
 typedef uint64_t GoHashKey;
 static std::vector<GoHashKey> g_grid_key[2];
+static GoHashKey g_turn_key = 0;
 static void goInitialize() // ref go.cpp:19-43: mt19937_64(0): turn key, then per position (empty, black, white)
 {
     if (!g_grid_key[0].empty()) { return; }
     std::mt19937_64 generator;
     generator.seed(0);
-    (void)generator(); // turn_hash_key (unused with positional superko, go.cpp:45-49)
+    g_turn_key = generator(); // turn_hash_key: only enters the hashes with env_go_ko_rule=situational (go.cpp:45-49)
     g_grid_key[0].resize(361);
     g_grid_key[1].resize(361);
     for (int pos = 0; pos < 361; ++pos) {
@@ -295,9 +296,10 @@ class GoEnv : public Env {
         void removeLiberty(int pos) { if (!liberty_bb.test(pos)) { return; } liberty_bb.reset(pos); --num_liberty; }
     };
 public:
-    GoEnv(int board_size, float komi) : board_size_(board_size), cfg_komi_(komi)
+    GoEnv(int board_size, float komi, bool situational = false) : board_size_(board_size), cfg_komi_(komi)
     {
         goInitialize();
+        turn_key_ = situational ? g_turn_key : 0; // getGoTurnHashKey() (go.cpp:45-49)
         int n = board_size_ * board_size_;
         grid_player_.resize(n); grid_block_.resize(n); blocks_.resize(n); neighbors_.resize(n);
         for (int pos = 0; pos < n; ++pos) { // ref go_grid.h:43-54: up(+y), right(+x), down(-y), left(-x)
@@ -341,6 +343,7 @@ public:
         const int position = action.getActionID();
         const Player player = action.getPlayer();
         turn_ = getNextPlayer(player, 2);
+        hash_key_ ^= turn_key_; // go.cpp:141
         actions_.push_back(action);
         if (isPass(action)) {
             stone_history_.push_back({stone_bb_[0], stone_bb_[1]});
@@ -381,7 +384,7 @@ public:
         if (grid_player_[position] != kPlayerNone) { return false; }
         bool is_legal = false;
         GoBB checked;
-        GoHashKey new_hash_key = hash_key_ ^ key(position, player);
+        GoHashKey new_hash_key = hash_key_ ^ turn_key_ ^ key(position, player); // go.cpp:222
         for (int neighbor_pos : neighbors_[position]) {
             if (grid_player_[neighbor_pos] == kPlayerNone) {
                 is_legal = true;
@@ -537,7 +540,7 @@ private:
     }
     int board_size_;
     float cfg_komi_, komi_ = 7.5f;
-    GoHashKey hash_key_ = 0;
+    GoHashKey hash_key_ = 0, turn_key_ = 0;
     GoBB board_mask_, left_boundary_, right_boundary_, free_block_id_;
     GoBB stone_bb_[2];
     std::vector<Player> grid_player_;
@@ -645,7 +648,7 @@ std::unique_ptr<Env> createEnv(const Config& cfg, Random* rng)
     if (cfg.env_game == "atari") { return std::make_unique<AtariSynthEnv>(cfg, rng); }
     if (cfg.env_game == "tictactoe") { return std::make_unique<TicTacToeEnv>(); }
     if (cfg.env_game == "othello") { return std::make_unique<OthelloEnv>(cfg.env_board_size); }
-    if (cfg.env_game == "go") { return std::make_unique<GoEnv>(cfg.env_board_size, cfg.env_go_komi); }
+    if (cfg.env_game == "go") { return std::make_unique<GoEnv>(cfg.env_board_size, cfg.env_go_komi, cfg.env_go_ko_rule == "situational"); }
     return nullptr;
 }
 

@@ -1,0 +1,117 @@
+// Test driver of the C++ facades (include/minizero/{network,actor,actor_group}.h): built by __graft_entry__.build() into tests/_bin/,
+// run on the GPU by tests/test_gpu_facade.py, which compares what it prints / writes with the ctypes path and with the oracle.
+//   facade_check net <weight file> <out.bin> <batch>     createNetwork -> pushBack* -> forward / initialInference / recurrentInference
+//   facade_check actor <conf> <moves>                     createNetwork + createActor + think()/act() loop, SelfPlay lines on stdout
+#include "minizero/actor.h"
+#include "minizero/actor_group.h"
+#include <cstdio>
+#include <cstring>
+
+using namespace minizero;
+
+static float pattern(uint64_t i) // deterministic 0 / 1 planes (the test regenerates them in numpy)
+{
+    uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (z >> 40) % 10 < 3 ? 1.0f : 0.0f;
+}
+
+static void put(FILE* f, const std::vector<float>& v) { fwrite(v.data(), sizeof(float), v.size(), f); }
+
+static int runNet(const char* file, const char* out, int B)
+{
+    std::shared_ptr<network::Network> net = network::createNetwork(file, 0);
+    std::cerr << net->toString();
+    FILE* f = fopen(out, "wb");
+    if (!f) { return 2; }
+    const size_t fs = size_t(net->getNumInputChannels()) * net->getInputChannelHeight() * net->getInputChannelWidth();
+    if (net->getNetworkTypeName() == "alphazero") {
+        auto az = std::static_pointer_cast<network::AlphaZeroNetwork>(net);
+        for (int b = 0; b < B; ++b) {
+            std::vector<float> x(fs);
+            for (size_t i = 0; i < fs; ++i) { x[i] = pattern(b * fs + i); }
+            if (az->pushBack(x) != b) { return 3; }
+        }
+        if (az->getBatchSize() != B) { return 4; }
+        auto outs = az->forward();
+        if (static_cast<int>(outs.size()) != B || az->getBatchSize() != 0) { return 5; }
+        for (auto& o : outs) {
+            auto a = std::static_pointer_cast<network::AlphaZeroNetworkOutput>(o);
+            put(f, a->policy_); put(f, a->policy_logits_); put(f, {a->value_});
+        }
+    } else {
+        auto mzn = std::static_pointer_cast<network::MuZeroNetwork>(net);
+        for (int b = 0; b < B; ++b) {
+            std::vector<float> x(fs);
+            for (size_t i = 0; i < fs; ++i) { x[i] = pattern(b * fs + i); }
+            if (mzn->pushBackInitialData(x) != b) { return 3; }
+        }
+        if (mzn->getInitialInputBatchSize() != B) { return 4; }
+        auto outs = mzn->initialInference();
+        if (static_cast<int>(outs.size()) != B || mzn->getInitialInputBatchSize() != 0) { return 5; }
+        const size_t P = size_t(net->getHiddenChannelHeight()) * net->getHiddenChannelWidth(), as = size_t(mzn->getNumActionFeatureChannels()) * P;
+        for (int b = 0; b < B; ++b) {
+            auto m = std::static_pointer_cast<network::MuZeroNetworkOutput>(outs[b]);
+            put(f, m->policy_); put(f, m->policy_logits_); put(f, {m->value_}); put(f, m->hidden_state_);
+            // action planes of action (b % action_size): board games one plane with a single 1 (pass: all 0), Atari-style nets one plane per action
+            std::vector<float> act(as, 0.0f);
+            const int a = b % net->getActionSize();
+            if (mzn->getNumActionFeatureChannels() == 1) { if (a < static_cast<int>(P)) { act[a] = 1.0f; } }
+            else { for (size_t p = 0; p < P; ++p) { act[size_t(a % mzn->getNumActionFeatureChannels()) * P + p] = 1.0f; } }
+            if (mzn->pushBackRecurrentData(m->hidden_state_, act) != b) { return 6; }
+        }
+        if (mzn->getRecurrentInputBatchSize() != B) { return 7; }
+        auto rec = mzn->recurrentInference();
+        if (static_cast<int>(rec.size()) != B) { return 8; }
+        for (auto& o : rec) {
+            auto m = std::static_pointer_cast<network::MuZeroNetworkOutput>(o);
+            put(f, m->policy_); put(f, m->policy_logits_); put(f, {m->value_}); put(f, {m->reward_}); put(f, m->hidden_state_);
+        }
+    }
+    fclose(f);
+    return 0;
+}
+
+// ActorGroup's handleSearchDone (ref actor_group.cpp:116-134) written against the per-actor surface, one actor
+static int runActor(const std::string& conf, int moves)
+{
+    config::mzgpuConfigurationString() = conf;
+    const std::string file = config::mzgpuConfValue(conf, "nn_file_name");
+    std::shared_ptr<network::Network> net = network::createNetwork(file, 0);
+    const int n = std::stoi(config::mzgpuConfValue(conf, "actor_num_simulation"));
+    std::shared_ptr<actor::BaseActor> a = actor::createActor(uint64_t(n + 1) * net->getActionSize(), net); // ref actor_group.cpp:183
+    std::vector<char> buf(1 << 22);
+    for (int m = 0; m < moves; ++m) {
+        if (m % 2 == 0) {
+            a->think(false, false);
+        } else { // the stepping surface: one beforeNNEvaluation / afterNNEvaluation pair per simulation (ref actor_group.cpp:81-114)
+            a->resetSearch();
+            int pairs = 0;
+            while (!a->isSearchDone()) {
+                a->beforeNNEvaluation();
+                if (a->getNNEvaluationBatchIndex() != 0) { return 3; }
+                a->afterNNEvaluation(nullptr);
+                ++pairs;
+            }
+            if (pairs != n + 1) { std::cerr << "search took " << pairs << " evaluations, expected " << n + 1 << std::endl; return 4; }
+        }
+        if (!a->isResign()) { if (!a->act(a->getSearchAction())) { return 5; } }
+        if (a->isResign() || a->isEnvTerminal()) {
+            if (mz_worker_emit_game(a->handle(), 0) != MZ_OK) { return 6; }
+            while (mz_worker_pop_line(a->handle(), buf.data(), static_cast<int>(buf.size())) > 0) { std::cout << buf.data() << std::endl; }
+            a->reset();
+        }
+    }
+    std::cout << "RECORD " << a->getRecord({{"XX", "tag"}}) << std::endl;
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc >= 5 && !strcmp(argv[1], "net")) { return runNet(argv[2], argv[3], atoi(argv[4])); }
+    if (argc >= 4 && !strcmp(argv[1], "actor")) { return runActor(argv[2], atoi(argv[3])); }
+    std::cerr << "usage: facade_check net <file> <out> <batch> | actor <conf> <moves>" << std::endl;
+    return 1;
+}

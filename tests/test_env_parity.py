@@ -6,7 +6,9 @@ import numpy as np
 import pytest
 
 GAMES = [("env_game=tictactoe", 60), ("env_game=othello:env_board_size=8", 25), ("env_game=go:env_board_size=9", 12),
-         ("env_game=go:env_board_size=5", 25), ("env_game=othello:env_board_size=6", 20), ("env_game=go:env_board_size=13", 3)]
+         ("env_game=go:env_board_size=5", 25), ("env_game=othello:env_board_size=6", 20), ("env_game=go:env_board_size=13", 3),
+         ("env_game=go:env_board_size=5:env_go_ko_rule=situational", 25), ("env_game=go:env_board_size=4:env_go_ko_rule=situational", 40),
+         ("env_game=go:env_board_size=9:env_go_ko_rule=situational", 8)]
 
 
 @pytest.mark.parametrize("conf,playouts", GAMES)
@@ -70,6 +72,32 @@ def test_go_superko_and_capture_cases(mz, oracle):
     assert e.legal_mask()[0] == 1 and e.turn() == 1  # own eye: legal for black
     e.act(22, 1)
     assert e.legal_mask()[0] == 0  # suicide for white
+
+
+def test_situational_superko_differs_from_positional(mz, oracle):
+    """env_go_ko_rule=situational (ref go.cpp:45-49,141,222): a position only repeats with the same player to move.  Same random 3x3
+    playouts under both rules on the host engine and on the oracle: the engines agree under each rule, and the rules do differ."""
+    rng = np.random.default_rng(5)
+    differ = 0
+    for game in range(120):
+        envs = {r: (mz.Env(f"env_game=go:env_board_size=3:env_go_ko_rule={r}"), oracle.OracleEnv(f"env_game=go:env_board_size=3:env_go_ko_rule={r}"))
+                for r in ("positional", "situational")}
+        for ply in range(60):
+            masks = {}
+            for r, (a, b) in envs.items():
+                masks[r] = a.legal_mask()
+                assert np.array_equal(masks[r], b.legal_mask()), (r, game, ply)
+            differ += int(not np.array_equal(masks["positional"], masks["situational"]))
+            both = np.nonzero(masks["positional"] & masks["situational"])[0]
+            board = both[both != 9]
+            act = 9 if len(board) == 0 or rng.random() < 0.2 else int(rng.choice(board))
+            for a, b in envs.values():
+                assert a.act(act) and b.act(act)
+            if envs["positional"][0].is_terminal():
+                break
+    assert differ > 0, "the playouts never reached a position where the two rules differ"
+    with pytest.raises(mz.MzError):
+        mz.Env("env_game=go:env_go_ko_rule=natural")
 
 
 def test_tromp_taylor_empty_board_goes_to_black(mz, oracle):

@@ -1,0 +1,122 @@
+"""GPU tests of the C++ facades (include/minizero/{network,actor,actor_group}.h) through tests/csrc/facade_check.cpp (built by
+__graft_entry__.build() into tests/_bin/): the reference's class / method names executed for real —
+  * createNetwork -> pushBack -> forward and pushBackInitialData / pushBackRecurrentData -> initial / recurrentInference
+    (ref network/alphazero_network.h:48-104, muzero_network.h:65-178, create_network.h:11-30): bit-equal to the ctypes path;
+  * createActor -> think() / beforeNNEvaluation() + afterNNEvaluation() / isSearchDone() / getSearchAction() / isResign() / act() /
+    reset() / getRecord(tags) (ref base_actor.h:16-55, zero_actor.h:24-70, create_actor.h:10-19) in ActorGroup's handleSearchDone
+    loop (actor_group.cpp:116-134): `SelfPlay` lines identical to the oracle's one-actor group."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "_bin", "facade_check")
+
+
+def _pattern(n):
+    with np.errstate(over="ignore"):
+        z = (np.arange(1, n + 1, dtype=np.uint64)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (((z >> np.uint64(40)) % np.uint64(10)) < 3).astype(np.float32)
+
+
+def _write(mz, tmp_path, d, w, name="weight_iter_7.pt"):
+    from minizero_amd.export_weights import write_mzw
+    pt = str(tmp_path / name)
+    write_mzw(pt[:-3] + ".mzw", d, w)  # the facade is given the .pt name and opens the sibling .mzw
+    return pt
+
+
+def _run(args, timeout=300):
+    assert os.path.exists(EXE), "run __graft_entry__.build() first"
+    p = subprocess.run([EXE] + args, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, f"facade_check {args[:1]} failed ({p.returncode}): {p.stderr[-2000:]}"
+    return p
+
+
+@pytest.mark.parametrize("key", ["c2", "c3"])
+def test_alphazero_network_facade(mz, tmp_path, key):
+    d = mz.DESCS[key]()
+    w = mz.generate_weights(d, 2)
+    pt = _write(mz, tmp_path, d, w)
+    B, A = 5, d.action_size
+    out = str(tmp_path / "out.bin")
+    p = _run(["net", pt, out, str(B)])
+    assert f"Number of blocks: {d.num_blocks}" in p.stderr and "Network type name: alphazero" in p.stderr and "weight_iter_7.pt" in p.stderr
+    fs = d.num_input_channels * d.input_channel_height * d.input_channel_width
+    x = _pattern(B * fs).reshape(B, fs)
+    pol, lg, v = mz.Net(d, w).forward(x)
+    got = np.fromfile(out, np.float32).reshape(B, 2 * A + 1)
+    assert np.array_equal(got[:, :A].view(np.uint32), pol.view(np.uint32))
+    assert np.array_equal(got[:, A:2 * A].view(np.uint32), lg.view(np.uint32))
+    assert np.array_equal(got[:, 2 * A].view(np.uint32), v.view(np.uint32))
+
+
+@pytest.mark.parametrize("key", ["c4", "small_atari"])
+def test_muzero_network_facade(mz, tmp_path, key):
+    d = mz.DESCS[key]() if key in mz.DESCS else mz.make_desc("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari")
+    w = mz.generate_weights(d, 3)
+    pt = _write(mz, tmp_path, d, w)
+    B, A = 3, d.action_size
+    out = str(tmp_path / "out.bin")
+    p = _run(["net", pt, out, str(B)])
+    assert "Number of action feature channels" in p.stderr
+    fs = d.num_input_channels * d.input_channel_height * d.input_channel_width
+    P = d.hidden_channel_height * d.hidden_channel_width
+    HS = d.num_hidden_channels * P
+    x = _pattern(B * fs).reshape(B, fs)
+    net = mz.Net(d, w)
+    pol, lg, v, h = net.initial_inference(x)
+    ac = d.num_action_feature_channels
+    act = np.zeros((B, ac * P), np.float32)
+    for b in range(B):
+        a = b % A
+        if ac == 1:
+            if a < P:
+                act[b, a] = 1.0
+        else:
+            act[b, (a % ac) * P:(a % ac + 1) * P] = 1.0
+    rp, rl, rv, rr, rh = net.recurrent_inference(h, act)
+    got = np.fromfile(out, np.float32)
+    n_init = B * (2 * A + 1 + HS)
+    gi = got[:n_init].reshape(B, 2 * A + 1 + HS)
+    gr = got[n_init:].reshape(B, 2 * A + 2 + HS)
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)  # noqa: E731
+    assert np.array_equal(bits(gi[:, :A]), bits(pol)) and np.array_equal(bits(gi[:, A:2 * A]), bits(lg)) and np.array_equal(bits(gi[:, 2 * A]), bits(v))
+    assert np.array_equal(bits(gi[:, 2 * A + 1:]), bits(h))
+    assert np.array_equal(bits(gr[:, :A]), bits(rp)) and np.array_equal(bits(gr[:, A:2 * A]), bits(rl))
+    assert np.array_equal(bits(gr[:, 2 * A]), bits(rv)) and np.array_equal(bits(gr[:, 2 * A + 1]), bits(rr)) and np.array_equal(bits(gr[:, 2 * A + 2:]), bits(rh))
+
+
+CASES = [
+    ("c1 tictactoe", "env_game=tictactoe:actor_num_simulation=16", ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9, 256, 1, "alphazero"), 70, 8),
+    ("go 9x9 (simulation kernel)", "env_game=go:env_board_size=9:actor_num_simulation=10", ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero"), 24, 0),
+    ("othello gumbel", "env_game=othello:env_board_size=8:actor_num_simulation=16:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+     "actor_use_gumbel_noise=true:actor_gumbel_sample_size=8", ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65, 16, 1, "alphazero"), 130, 2),
+    ("go muzero", "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=9", ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "muzero"), 12, 0),
+]
+
+
+@pytest.mark.parametrize("name,conf,dargs,moves,min_lines", CASES)
+def test_actor_facade_against_the_oracle(mz, oracle, tmp_path, name, conf, dargs, moves, min_lines):
+    kw = dict(vh=dargs[10], dv=dargs[11], type_name=dargs[12])
+    d, od = mz.make_desc(*dargs[:10], **kw), oracle.make_desc(*dargs[:10], **kw)
+    w = mz.generate_weights(d, 1)
+    pt = _write(mz, tmp_path, d, w)
+    conf = f"{conf}:zero_num_parallel_games=1:program_seed=3:nn_file_name={pt}"
+    p = _run(["actor", conf, str(moves)])
+    out = p.stdout.strip().split("\n")
+    lines, rec = [l for l in out if l.startswith("SelfPlay ")], [l for l in out if l.startswith("RECORD ")]
+    n = int(conf.split("actor_num_simulation=")[1].split(":")[0])
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles(moves * (n + 1) + 1)
+    olines = og.lines()
+    assert len(olines) >= min_lines
+    assert lines == olines
+    assert len(rec) == 1 and "XX[tag]" in rec[0]
+    assert rec[0][len("RECORD "):].replace("XX[tag]", "") == og.peek_records(1)[0]

@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _play_and_compare(mz, n, komi, seed, max_moves, pass_prob, root_prefix_frac):
+def _play_and_compare(mz, n, komi, seed, max_moves, pass_prob, root_prefix_frac, ko="positional", oracle=None):
+    """oracle=None: the device engine against the product's host engine (itself tested against the oracle on the CPU, tests/test_env_parity.py);
+    oracle=<oracle_lib>: the device engine DIRECTLY against the oracle's restatement of the reference's GoEnv."""
     rng = np.random.default_rng(seed)
-    conf = f"env_game=go:env_board_size={n}:env_go_komi={komi}"
+    conf = f"env_game=go:env_board_size={n}:env_go_komi={komi}:env_go_ko_rule={ko}"
     P = n * n
     env = mz.Env(conf)
     actions = []
@@ -35,8 +37,19 @@ def _play_and_compare(mz, n, komi, seed, max_moves, pass_prob, root_prefix_frac)
     root_prefix = int(len(actions) * root_prefix_frac)
     steps = len(actions) - root_prefix + 1
     rots = rng.integers(0, 8, steps).astype(np.int32)
-    feat, legal, term, ev, pl = mz.godev_playout(n, komi, actions, root_prefix, rots)
-    ref = mz.Env(conf)
+    feat, legal, term, ev, pl = mz.envdev_playout("go" if ko == "positional" else "go_situational", n, komi, actions, root_prefix, rots, 18, P + 1)
+    ref = mz.Env(conf) if oracle is None else oracle.OracleEnv(conf)
+    W32 = (P + 31) // 32
+
+    def ref_bits(rot):
+        if oracle is None:
+            return ref.feature_bits(rot, 18, P)
+        planes = ref.features(rot).reshape(18, P)
+        assert set(np.unique(planes)) <= {0.0, 1.0}
+        out = np.zeros((18, W32), np.uint32)
+        for p in range(P):
+            out[:, p >> 5] |= (planes[:, p] != 0).astype(np.uint32) << np.uint32(p & 31)
+        return out.reshape(-1)
     for a in actions[:root_prefix]:
         assert ref.act(a)
     captures = 0
@@ -48,7 +61,7 @@ def _play_and_compare(mz, n, komi, seed, max_moves, pass_prob, root_prefix_frac)
             assert ev[d] == ref.eval_score(), where
         else:
             assert np.array_equal(legal[d], ref.legal_mask()), where
-        assert np.array_equal(feat[d], ref.feature_bits(int(rots[d]), 18, P)), where
+        assert np.array_equal(feat[d], ref_bits(int(rots[d]))), where
         if d + 1 < steps:
             assert ref.act(actions[root_prefix + d]), where
     return len(actions), captures
@@ -62,6 +75,26 @@ def test_device_engine_matches_host_engine(mz, n, games, max_moves):
                                      root_prefix_frac=[0.0, 0.3, 0.7][g % 3])
         total += moves
     assert total > games * 5
+
+
+@pytest.mark.parametrize("n,games,max_moves,ko", [(9, 6, 170, "positional"), (5, 20, 120, "positional"), (3, 30, 60, "situational"), (9, 4, 170, "situational"),
+                                                  (19, 1, 400, "positional")])
+def test_device_engine_matches_the_oracle_directly(mz, oracle, n, games, max_moves, ko):
+    """No product code on the reference side: legal masks, planes under random rotations, terminal flags and Tromp-Taylor results of the
+    device engine against the oracle's GoEnv (ref environment/go/go.cpp:132-308,703-723), both ko rules."""
+    total = 0
+    for g in range(games):
+        moves, _ = _play_and_compare(mz, n, 7.5 if g % 2 == 0 else 6.5, 7000 * n + g, max_moves, pass_prob=0.05 if g % 3 else 0.2,
+                                     root_prefix_frac=[0.0, 0.5][g % 2], ko=ko, oracle=oracle)
+        total += moves
+    assert total > games * 4
+
+
+@pytest.mark.parametrize("n,games,max_moves", [(3, 40, 60), (5, 20, 120), (9, 4, 170)])
+def test_device_engine_situational_superko(mz, n, games, max_moves):
+    """env_go_ko_rule=situational on the device (a turn key XORed into the hash on every move, ref go.cpp:45-49,141,222) against the host engine"""
+    for g in range(games):
+        _play_and_compare(mz, n, 7.0, 31000 * n + g, max_moves, pass_prob=0.2, root_prefix_frac=[0.0, 0.3, 0.7][g % 3], ko="situational")
 
 
 def test_device_engine_long_9x9_game_to_the_move_cap(mz):

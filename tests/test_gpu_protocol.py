@@ -40,3 +40,41 @@ def test_sp_executable_protocol(mz, oracle, tmp_path):
     for l in lines:
         assert l.startswith("SelfPlay true ") and l.endswith(" #") and "EV[weight_iter_0.pt]" in l
     assert "[command] start" in p.stderr.read()
+
+
+def test_one_process_drives_every_visible_gpu(mz, oracle, tmp_path):
+    """ref actor_group.cpp:168-187 + scripts/zero-worker.sh:159-162: ONE `-mode sp` process, zero_num_parallel_games = batch x #GPUs, actor i on
+    device i % G.  Here: worker g = games {i % G == g} on device g, seed program_seed + g, one stdout mutex."""
+    G = mz.device_count()
+    if G < 2:
+        pytest.skip("needs at least 2 GPUs in one node")
+    from minizero_amd.export_weights import write_mzw
+    exe = os.path.join(ROOT, "apps", "mzgpu_sp")
+    d = mz.DESCS["c1"]()
+    w = mz.generate_weights(d, 0)
+    pt = str(tmp_path / "weight_iter_0.pt")
+    write_mzw(pt[:-3] + ".mzw", d, w)
+    games = 4 * G + 1
+    conf_str = f"nn_file_name={pt}:program_seed=5:actor_num_simulation=16:zero_num_parallel_games={games}:zero_num_threads={G}"
+    p = subprocess.Popen([exe, "-conf_str", conf_str, "-mode", "sp", "-game", "tictactoe"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    p.stdin.write("start\n")
+    p.stdin.flush()
+    lines = [p.stdout.readline().rstrip("\n") for _ in range(30 * G)]
+    p.stdin.write("quit\n")
+    p.stdin.flush()
+    p.wait(timeout=60)
+    assert f"{games} games on {G} GPU(s)" in p.stderr.read()
+    expected = {}
+    for g in range(G):
+        n_g = len(range(g, games, G))
+        og = oracle.OracleGroup(f"env_game=tictactoe:actor_num_simulation=16:zero_num_parallel_games={n_g}:program_seed={5 + g}:nn_file_name={pt}", oracle.desc_c1(), w)
+        og.cycles(17 * 200)
+        expected[g] = og.lines()
+    # every printed line is the next unseen line of exactly one device's stream (per-device order is kept, devices interleave freely)
+    cursor = {g: 0 for g in range(G)}
+    for l in lines:
+        owners = [g for g in range(G) if cursor[g] < len(expected[g]) and expected[g][cursor[g]] == l]
+        assert owners, "a line that is not the next record of any device: " + l[:120]
+        cursor[owners[0]] += 1
+    assert all(c > 0 for c in cursor.values()), "a device printed nothing"

@@ -64,6 +64,23 @@ def test_go_resign_and_count_selection(mz, oracle):
     check(lines, olines, 4)
 
 
+def test_go_situational_superko(mz, oracle):
+    """env_go_ko_rule=situational through the whole worker: per-game simulation kernel with the device rules, and the lock-step mode with the
+    host engine (the rule itself is exercised on small boards by tests/test_env_parity.py and tests/test_gpu_godev.py)"""
+    conf9 = "env_game=go:env_board_size=9:env_go_ko_rule=situational:actor_num_simulation=8:zero_num_parallel_games=5"
+    args9 = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    lines9, olines9, st9 = run_both(mz, oracle, conf9, args9, 9 * 380, threads=2, seed=6)
+    check(lines9, olines9, 5)
+    assert st9["sim_launches"] > 0
+    d9 = mz.make_desc(*args9[:10], vh=16, dv=1)
+    wk = mz.Worker(conf9 + ":mz_device_env=false:mz_sim_kernel=false:program_seed=6:nn_file_name=/tmp/weights/synthetic_0.pt:zero_num_threads=2", d9, mz.generate_weights(d9, 0))
+    wk.command("start")
+    assert wk.run_cycles(9 * 380) == 9 * 380
+    assert wk.stats()["sim_launches"] == 0 and wk.pop_lines() == lines9
+    with pytest.raises(mz.MzError):
+        mz.Worker(conf9.replace("situational", "natural") + ":program_seed=1", d9, mz.generate_weights(d9, 0))
+
+
 def test_small_othello_gumbel_alphazero(mz, oracle):
     conf = ("env_game=othello:env_board_size=8:actor_num_simulation=16:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
             "actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:actor_gumbel_sigma_visit_c=50:actor_gumbel_sigma_scale_c=1:"
@@ -79,6 +96,28 @@ def test_gumbel_sequential_halving_n50(mz, oracle):
     args = ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65, 16, 1, "alphazero")
     lines, olines, _ = run_both(mz, oracle, conf, args, 51 * 140)
     check(lines, olines, 4)
+
+
+@pytest.mark.parametrize("m,n,chunks", [(12, 50, [51 * 140]), (6, 50, [7, 30, 51 * 140 - 37]), (3, 24, [25 * 140]), (12, 120, [13, 121 * 70 - 13]), (5, 16, [17 * 150])])
+def test_gumbel_sample_size_not_a_power_of_two(mz, oracle, m, n, chunks):
+    """Sequential halving with m = 12 -> 6 -> 3 ...: the next budget floor(n / (log2(m) * size / 2)) depends on the CURRENT size
+    (ref gumbel_zero.cpp:110); the device step evaluates it in the reference's double operations, whatever the run_cycles chunking."""
+    conf = (f"env_game=othello:env_board_size=8:actor_num_simulation={n}:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+            f"actor_use_gumbel_noise=true:actor_gumbel_sample_size={m}:zero_num_parallel_games=3")
+    args = ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65, 16, 1, "alphazero")
+    kw = dict(vh=16, dv=1, type_name="alphazero")
+    d, od = mz.make_desc(*args[:10], **kw), oracle.make_desc(*args[:10], **kw)
+    w = mz.generate_weights(d, 4)
+    conf += ":program_seed=9:nn_file_name=g.pt"
+    total = sum(chunks)
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles(total)
+    wk = mz.Worker(conf, d, w)
+    wk.command("start")
+    for c in chunks:
+        assert wk.run_cycles(c) == c
+    assert wk.stats()["sim_launches"] > 0
+    check(wk.pop_lines(), og.lines(), 3)
 
 
 def test_small_go_muzero(mz, oracle):
