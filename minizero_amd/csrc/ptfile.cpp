@@ -43,10 +43,10 @@ bool readZipDirectory(const std::vector<uint8_t>& f, std::map<std::string, ZipEn
     if (count == 0xFFFF || cd_off == 0xFFFFFFFFu || cd_size == 0xFFFFFFFFu) { // ZIP64: locator right before the EOCD
         if (eocd < 20 || rd32(&f[eocd - 20]) != 0x07064b50u) { err = "zip64 locator missing"; return false; }
         const uint64_t e64 = rd64(&f[eocd - 20 + 8]);
-        if (e64 + 56 > f.size() || rd32(&f[e64]) != 0x06064b50u) { err = "zip64 end record missing"; return false; }
+        if (e64 > f.size() || f.size() - e64 < 56 || rd32(&f[e64]) != 0x06064b50u) { err = "zip64 end record missing"; return false; }
         count = rd64(&f[e64 + 32]); cd_size = rd64(&f[e64 + 40]); cd_off = rd64(&f[e64 + 48]);
     }
-    if (cd_off + cd_size > f.size()) { err = "zip central directory out of range"; return false; }
+    if (cd_off > f.size() || cd_size > f.size() - cd_off) { err = "zip central directory out of range"; return false; }
     size_t p = cd_off;
     for (uint64_t i = 0; i < count; ++i) {
         if (p + 46 > f.size() || rd32(&f[p]) != 0x02014b50u) { err = "bad central directory entry"; return false; }
@@ -67,12 +67,14 @@ bool readZipDirectory(const std::vector<uint8_t>& f, std::map<std::string, ZipEn
             }
             x += 4 + sz;
         }
-        if (lho + 30 > f.size() || rd32(&f[lho]) != 0x04034b50u) { err = "bad local header for " + name; return false; }
+        // offsets and sizes come from the file: compare without additions that could wrap (crafted ZIP64 values)
+        if (lho > f.size() || f.size() - lho < 30 || rd32(&f[lho]) != 0x04034b50u) { err = "bad local header for " + name; return false; }
         ZipEntry e;
         e.data_off = lho + 30 + rd16(&f[lho + 26]) + rd16(&f[lho + 28]);
         e.size = usize;
         e.method = method;
-        if (e.data_off + (method == 0 ? usize : csize) > f.size()) { err = "member out of range: " + name; return false; }
+        const uint64_t stored = method == 0 ? usize : csize;
+        if (e.data_off > f.size() || stored > f.size() - e.data_off) { err = "member out of range: " + name; return false; }
         out[name] = e;
         p += 46 + nlen + xlen + clen;
     }
@@ -301,8 +303,13 @@ bool collect(const PV& v, const std::vector<uint8_t>& file, const std::map<std::
         if (it == zip.end() || it->second.method != 0) { err = "storage " + v.s + " missing or compressed"; return false; }
         const float* base = reinterpret_cast<const float*>(&file[it->second.data_off]);
         const int64_t avail = static_cast<int64_t>(it->second.size / 4);
+        if (v.strides.size() != v.sizes.size()) { err = "tensor with " + std::to_string(v.sizes.size()) + " sizes but " + std::to_string(v.strides.size()) + " strides"; return false; }
         int64_t numel = 1;
-        for (int64_t d : v.sizes) { numel *= d; }
+        for (int64_t d : v.sizes) {
+            if (d < 0 || (d > 0 && numel > avail / d)) { err = "tensor larger than its storage"; return false; } // also bounds stride-0 views
+            numel *= d;
+        }
+        if (numel > avail || out.size() + static_cast<size_t>(numel) > (size_t(1) << 31)) { err = "tensor larger than its storage"; return false; }
         std::vector<int64_t> idx(v.sizes.size(), 0);
         for (int64_t k = 0; k < numel; ++k) {
             int64_t off = v.offset;

@@ -149,7 +149,7 @@ def load():
 
 
 def _err(L):
-    return (L.mz_last_error() or b"").decode()
+    return (L.mz_last_error() or b"").decode(errors="replace")
 
 
 def _check(L, rc):

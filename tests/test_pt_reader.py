@@ -50,3 +50,38 @@ def test_reader_rejects_garbage(mz, tmp_path):
         mz.read_pt(str(p))
     with pytest.raises(mz.MzError):
         mz.read_pt(str(tmp_path / "missing.pt"))
+
+
+def test_reader_survives_corrupted_archives(mz, tmp_path):
+    """Crafted / damaged files must come back as MzError, never as an out-of-bounds read: truncations, flipped bytes in the zip directory and
+    in the pickle (sizes / strides / offsets), 0xFF-filled ZIP64-style fields."""
+    import torch
+    sys.path.insert(0, REF)
+    from minizero.network.py.create_network import create_network
+    net = create_network(*CASES["small_go_az"])
+    net.eval()
+    path = str(tmp_path / "good.pt")
+    torch.jit.script(net).save(path)
+    good = open(path, "rb").read()
+    desc, w = mz.read_pt(path)
+    rng = np.random.default_rng(0)
+    bad = tmp_path / "bad.pt"
+    pkl = good.find(b"data.pkl")
+    outcomes = {"ok": 0, "rejected": 0}
+    variants = [good[:n] for n in (10, 100, len(good) // 2, len(good) - 30, len(good) - 5)]
+    for _ in range(300):
+        b = bytearray(good)
+        region = rng.integers(0, 3)
+        lo, hi = [(max(0, len(b) - 400), len(b)), (pkl, pkl + 4000), (0, len(b))][region]
+        for _k in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(lo, min(hi, len(b))))] = int(rng.choice([0, 0xFF, rng.integers(0, 256)]))
+        variants.append(bytes(b))
+    for v in variants:
+        bad.write_bytes(v)
+        try:
+            d2, w2 = mz.read_pt(str(bad))
+            outcomes["ok"] += 1
+            assert len(w2) == mz.param_count(d2)
+        except mz.MzError:
+            outcomes["rejected"] += 1
+    assert outcomes["rejected"] > 20
