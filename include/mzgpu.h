@@ -207,6 +207,11 @@ typedef struct mz_worker_stats {
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out);
 mz_net* mz_worker_net(mz_worker* w);
 
+/* utils::compressString (ref utils/utils.h:35-91): what the `OBS[...]` tag of an Atari record holds — the gzip member
+ * (boost::iostreams::gzip_compressor defaults) of n bytes as lower-case hex, NUL-terminated; "" for n == 0.  Returns the hex length
+ * (out == NULL: length only) or a negative error. */
+long mz_compress_string(const void* data, size_t n, char* out, size_t capacity);
+
 /* ------------------------------------------------------------------------------------------
  * Host-side environment access (rules engines the worker uses for AlphaZero leaves; exposed so the
  * parity tests can run the reference's env_test-style playout/replay check, ref

@@ -11,6 +11,7 @@
 namespace mz {
 
 void setError(const char* fmt, ...);
+bool compressToHex(const uint8_t* data, size_t n, std::string* hex); // gzhex.cpp: utils::compressString (ref utils/utils.h:35-91)
 const char* lastError();
 
 #define MZ_HIP(expr)                                                                                          \

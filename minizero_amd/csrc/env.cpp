@@ -672,7 +672,8 @@ class AtariSynth final : public GameEnv {
         return z ^ (z >> 31);
     }
 public:
-    AtariSynth(const std::string& name, int episode_length) : name_(name), episode_length_(episode_length), frames_(size_t(kHist) * kFrame, 0) { resetSeed(0); }
+    AtariSynth(const std::string& name, int episode_length, size_t recent_observations)
+        : name_(name), episode_length_(episode_length), recent_(recent_observations), frames_(size_t(kHist) * kFrame, 0) { resetSeed(0); }
     std::unique_ptr<GameEnv> clone() const override { return std::make_unique<AtariSynth>(*this); }
     void copyFrom(const GameEnv& o) override { *this = static_cast<const AtariSynth&>(o); }
     bool needsSeed() const override { return true; }
@@ -688,6 +689,10 @@ public:
         for (auto& v : valid_) { v = false; }
         for (auto& a : action_plane_) { a = 0.0f; }
         head_ = 0;
+        lives_.clear();
+        lives_.push_back(livesAt(0)); // ref atari.cpp:61-62
+        lost_ = 0;
+        observations_.clear();
         pushFrame(0, 0.0f, false);
     }
     bool isLegal(int a, int) const override { return a >= 0 && a < kActions; }
@@ -703,6 +708,8 @@ public:
         const uint64_t h = mix(static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0x9E3779B97F4A7C15ULL + 0x5157ULL * step);
         reward_ = ((h >> 40) < uint64_t(0.05 * (1 << 24))) ? 1.0f : 0.0f;
         total_reward_ += reward_;
+        lost_ += (mix(static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0xA24BAED4963EE407ULL + 0x11F3ULL * step) % 23) == 0;
+        lives_.push_back(lost_ >= 3 ? 0 : 3 - lost_); // ref atari.cpp:83: the synthetic ale_.lives()
         action_ids_.push_back(static_cast<int16_t>(a));
         action_players_.push_back(static_cast<uint8_t>(player));
         pushFrame(step, a * 1.0f / kActions, true);
@@ -746,34 +753,54 @@ public:
     int numPlayers() const override { return 1; }
     std::string name() const override { return "atari_" + name_; }
     std::vector<std::pair<std::string, std::string>> loaderTags() const override { return {{"SD", std::to_string(seed_)}}; }
+    bool hasObservations() const override { return true; }
+    void appendObservations(std::string* out) const override { for (const auto& o : observations_) { out->append(o); } }
+    const std::vector<int>* livesHistory() const override { return &lives_; }
 
 private:
+    int livesAt(int) const { return 3; }
     void pushFrame(int step, float action_value, bool with_action)
     {
         // ring of the last 8 (action, screen) pairs: overwrite the oldest slot, which then becomes the newest
         const int slot = head_;
         uint8_t* f = frames_.data() + size_t(slot) * kFrame;
+        // the synthetic screen of (seed, step): one hash byte per 8x8 block of every colour plane — piecewise constant like a real frame
         const uint64_t base = static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0xD1B54A32D192ED03ULL + static_cast<uint64_t>(step) * 0x100000001B3ULL;
-        for (int i = 0; i < kFrame; i += 8) {
-            const uint64_t z = mix(base + static_cast<uint64_t>(i >> 3) * 0x9E3779B97F4A7C15ULL);
-            memcpy(f + i, &z, 8); // little-endian: byte k = (z >> 8k) & 0xFF
+        constexpr int kB = kRes / 8;
+        for (int cy = 0; cy < 3 * kB; ++cy) { // (plane, block row)
+            uint8_t row[kRes];
+            for (int bx = 0; bx < kB; ++bx) {
+                const uint8_t v = static_cast<uint8_t>(mix(base + static_cast<uint64_t>(cy * kB + bx) * 0x9E3779B97F4A7C15ULL) >> 56);
+                memset(row + bx * 8, v, 8);
+            }
+            for (int y = 0; y < 8; ++y) { memcpy(f + (size_t(cy) * 8 + y) * kRes, row, kRes); }
+        }
+        // ref atari.cpp:85-91: the observation string of the step, older ones dropped beyond the configured window
+        observations_.emplace_back(reinterpret_cast<const char*>(f), size_t(kFrame));
+        if (observations_.size() > recent_) {
+            std::string& old = observations_[observations_.size() - recent_];
+            old.clear();
+            old.shrink_to_fit();
         }
         valid_[slot] = true;
         action_plane_[slot] = with_action ? action_value : 0.0f;
         head_ = (head_ + 1) % kHist;
     }
     std::string name_;
-    int episode_length_, seed_ = 0, head_ = 0;
+    int episode_length_, seed_ = 0, head_ = 0, lost_ = 0;
+    size_t recent_;
     float reward_ = 0, total_reward_ = 0;
+    std::vector<int> lives_;
+    std::vector<std::string> observations_;
     std::vector<uint8_t> frames_;
     bool valid_[kHist] = {};
     float action_plane_[kHist] = {};
 };
 
 std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi, const std::string& atari_name, int atari_episode_length,
-                                       const std::string& go_ko_rule)
+                                       const std::string& go_ko_rule, size_t atari_recent_observations)
 {
-    if (game == "atari") { return std::make_unique<AtariSynth>(atari_name, atari_episode_length); }
+    if (game == "atari") { return std::make_unique<AtariSynth>(atari_name, atari_episode_length, std::max<size_t>(1, atari_recent_observations)); }
     if (game == "tictactoe") { return std::make_unique<TicTacToe>(); }
     if (game == "othello") {
         const int n = board_size > 0 ? board_size : 8;

@@ -46,6 +46,11 @@ public:
     virtual int numPlayers() const { return 2; }
     virtual std::string name() const = 0;
     virtual std::vector<std::pair<std::string, std::string>> loaderTags() const = 0;
+    // ref base_env.h:216-220 (OBS tag) and atari.cpp:187-197 (L tags): only the Atari-shaped environment has either.
+    // appendObservations: all kept observation strings (chw bytes per step, the initial one first) concatenated onto *out
+    virtual bool hasObservations() const { return false; }
+    virtual void appendObservations(std::string* /*out*/) const {}
+    virtual const std::vector<int>* livesHistory() const { return nullptr; } // [i] = lives before action i
     // engines with a device twin (go_dev.hip): the root position in the device's format, once per move
     // observations that are cheaper to ship raw (bytes) and expand into float planes on the device (net_atari.hip atari_expand_features):
     // rawFeatureBytes() > 0 = supported; layout documented at the implementation
@@ -71,7 +76,10 @@ protected:
 
 // game: "tictactoe" | "go" | "othello"; board_size 0 = the game's default (3 / 9 / 8)
 // game "atari": the synthetic Atari-shaped environment (18 actions, 32 x 96 x 96 features, 1 player)
+// atari_recent_observations: observation strings kept for the OBS tag (ref atari.cpp:87: intermediate sequence length + 8 + n-step +
+// unrolling + 1, or everything when sequences are off)
 std::unique_ptr<GameEnv> createGameEnv(const std::string& game, int board_size, float go_komi, const std::string& atari_name = "ms_pacman",
-                                       int atari_episode_length = 1000, const std::string& go_ko_rule = "positional");
+                                       int atari_episode_length = 1000, const std::string& go_ko_rule = "positional",
+                                       size_t atari_recent_observations = 108001);
 
 } // namespace mz

@@ -353,7 +353,11 @@ private:
     void handleSearchDone(int g);
     void outputGame(Game& gm);
     std::pair<int, int> trainingDataRange(const Game& gm) const;
-    std::string record(const Game& gm, const ActionInfo& extra) const;
+    // obs_raw != nullptr: the OBS tag is left as a one-byte placeholder and the observation bytes are returned for finishObservations()
+    std::string record(const Game& gm, const ActionInfo& extra, std::string* obs_raw = nullptr) const;
+    struct ObsJob { std::string* line; std::string raw; };
+    std::vector<ObsJob> obs_jobs_; // records waiting for their OBS tag (gzip + hex of megabytes: done on all host threads after the serial section)
+    int finishObservations();
     ActionInfo actionInfo(int g, int child_player) const;
 
     WorkerConfig cfg_;
@@ -577,7 +581,12 @@ int Worker::createActors()
     games_.clear();
     games_.resize(G_);
     for (auto& g : games_) {
-        g.env = createGameEnv(cfg_.env_game, cfg_.env_board_size, cfg_.env_go_komi, cfg_.env_atari_name, cfg_.env_atari_episode_length, cfg_.env_go_ko_rule);
+        // ref atari.cpp:87: observations kept for the OBS tag of the next record
+        const size_t recent_obs = static_cast<size_t>(cfg_.zero_actor_intermediate_sequence_length == 0
+                                                          ? 108000
+                                                          : cfg_.zero_actor_intermediate_sequence_length + 8 + cfg_.learner_n_step_return + cfg_.learner_muzero_unrolling_step) + 1;
+        g.env = createGameEnv(cfg_.env_game, cfg_.env_board_size, cfg_.env_go_komi, cfg_.env_atari_name, cfg_.env_atari_episode_length, cfg_.env_go_ko_rule,
+                              recent_obs);
         if (!g.env) { return MZ_ERR_ARG; }
         if (g.env->policySize() != A_ || g.env->featureSize() != net0().featSize()) {
             setError("network (A=%d, features=%d) does not fit env %s (A=%d, features=%d)", A_, net0().featSize(), g.env->name().c_str(),
@@ -888,7 +897,9 @@ ActionInfo Worker::actionInfo(int g, int child_player) const // ref base_actor.c
     return info;
 }
 
-std::string Worker::record(const Game& gm, const ActionInfo& extra) const // ref base_actor.cpp:39-57, base_env.h:207-233
+static const char kObsPlaceholder[] = "\x01OBS\x01";
+
+std::string Worker::record(const Game& gm, const ActionInfo& extra, std::string* obs_raw) const // ref base_actor.cpp:39-57, base_env.h:207-233
 {
     ActionInfo tags;
     auto addTag = [&](const std::string& k, const std::string& v) {
@@ -897,7 +908,18 @@ std::string Worker::record(const Game& gm, const ActionInfo& extra) const // ref
     };
     addTag("GM", gm.env->name());
     addTag("RE", std::to_string(gm.env->evalScore(false)));
-    addTag("OBS", "");
+    if (!gm.env->hasObservations()) {
+        addTag("OBS", ""); // compressString("") == "" (utils.h:37): board games keep no observations
+    } else if (obs_raw) {
+        obs_raw->clear();
+        gm.env->appendObservations(obs_raw);
+        addTag("OBS", kObsPlaceholder);
+    } else { // ref base_env.h:216-220
+        std::string raw, hex;
+        gm.env->appendObservations(&raw);
+        (void)compressToHex(reinterpret_cast<const uint8_t*>(raw.data()), raw.size(), &hex);
+        addTag("OBS", hex);
+    }
     for (auto& t : gm.env->loaderTags()) { addTag(t.first, t.second); }
     addTag("EV", cfg_.nn_file_name.substr(cfg_.nn_file_name.find_last_of('/') + 1));
     if (!gm.env->isTerminal()) { // unfinished game = resigned: the player to move loses (base_actor.cpp:49-54)
@@ -911,14 +933,41 @@ std::string Worker::record(const Game& gm, const ActionInfo& extra) const // ref
     for (const auto& t : tags) { oss << t.first << "[" << escapeSGF(t.second) << "]"; }
     const auto& ids = gm.env->actionIds();
     const auto& pls = gm.env->actionPlayers();
+    const std::vector<int>* lives = gm.env->livesHistory(); // ref atari.cpp:187-197: L[lives] on the action before which a life was lost
+    int previous_lives = lives && !lives->empty() ? (*lives)[0] : 0;
     for (size_t i = 0; i < ids.size(); ++i) {
         oss << ";" << (pls[i] == 1 ? 'B' : 'W') << "[" << ids[i] << "]";
+        bool lost = false;
+        int now = previous_lives;
+        if (lives && i < lives->size()) { now = (*lives)[i]; lost = now < previous_lives; previous_lives = now; }
         if (gm.action_info_history.size() > i) {
-            for (const auto& info : gm.action_info_history[i]) { oss << info.first << "[" << escapeSGF(info.second) << "]"; }
+            for (const auto& info : gm.action_info_history[i]) {
+                const bool is_l = lost && info.first == "L"; // VectorMap: an existing key keeps its place and takes the new value
+                oss << info.first << "[" << escapeSGF(is_l ? std::to_string(now) : info.second) << "]";
+                if (is_l) { lost = false; }
+            }
         }
+        if (lost) { oss << "L[" << now << "]"; }
     }
     oss << ")";
     return oss.str();
+}
+
+int Worker::finishObservations()
+{
+    if (obs_jobs_.empty()) { return MZ_OK; }
+    std::atomic<int> bad{0};
+    threads_->parallelFor(static_cast<int>(obs_jobs_.size()), [this, &bad](int k) {
+        ObsJob& j = obs_jobs_[k];
+        std::string hex;
+        if (!compressToHex(reinterpret_cast<const uint8_t*>(j.raw.data()), j.raw.size(), &hex)) { bad.fetch_add(1); return; }
+        const size_t at = j.line->find(kObsPlaceholder);
+        if (at == std::string::npos) { bad.fetch_add(1); return; }
+        j.line->replace(at, sizeof(kObsPlaceholder) - 1, hex);
+    });
+    obs_jobs_.clear();
+    if (bad.load()) { setError("worker: building the OBS tag of %d record(s) failed", bad.load()); return MZ_ERR_STATE; }
+    return MZ_OK;
 }
 
 std::pair<int, int> Worker::trainingDataRange(const Game& gm) const // ref actor_group.cpp:52-64
@@ -942,14 +991,16 @@ void Worker::outputGame(Game& gm) // ref actor_group.cpp:24-50
     const std::pair<int, int> range = trainingDataRange(gm);
     const bool is_terminal = (cfg_.zero_actor_intermediate_sequence_length == 0 || gm.env->isTerminal());
     std::ostringstream oss;
+    std::string obs_raw;
     oss << "SelfPlay " << (is_terminal ? "true" : "false") << " " << (range.second - range.first + 1) << " " << game_length << " "
         << gm.env->evalScore(!gm.env->isTerminal()) << " "
-        << record(gm, {{"DLEN", std::to_string(range.first) + "-" + std::to_string(range.second)}}) << " "
+        << record(gm, {{"DLEN", std::to_string(range.first) + "-" + std::to_string(range.second)}}, &obs_raw) << " "
         << "#";
     if (!is_terminal) {
         for (int i = range.first; i <= range.second; ++i) { gm.action_info_history[i].clear(); gm.action_info_history[i].shrink_to_fit(); }
     }
     lines_.push_back(oss.str());
+    if (gm.env->hasObservations()) { obs_jobs_.push_back(ObsJob{&lines_.back(), std::move(obs_raw)}); } // deque: references stay valid
     if (is_terminal) { ++stats_.games; }
 }
 
@@ -1077,6 +1128,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
                 gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
             }
         }
+        if ((rc = finishObservations())) { return rc; }
         const double ts = nowMs();
         trace_.add(4, ts - t2);
         if (want_noise) {
@@ -1460,7 +1512,7 @@ int Worker::emitGame(int g) // ThreadSharedData::outputGame (ref actor_group.cpp
     if (g < 0 || g >= G_) { setError("emit_game: game %d out of range", g); return MZ_ERR_ARG; }
     flushDeferred();
     outputGame(games_[g]);
-    return MZ_OK;
+    return finishObservations();
 }
 
 int Worker::envQuery(int g, int what, float* out) const

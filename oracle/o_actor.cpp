@@ -78,8 +78,25 @@ std::string ZeroActor::getRecord(const std::vector<std::pair<std::string, std::s
     addTag("GM", env_->name());
     addTag("RE", "0");
     addTag("RE", std::to_string(env_->getEvalScore()));
-    addTag("OBS", ""); // compressString("") == "" (utils.h:37); board games have no observations
+    { // ref base_env.h:216-220: OBS = compressString(all observation strings concatenated); board games have none -> ""
+        std::string observations;
+        for (const auto& obs : env_->getObservationHistory()) { observations += obs; }
+        addTag("OBS", compressString(observations));
+    }
     for (auto& t : env_->loaderTags()) { addTag(t.first, t.second); }
+    // ref atari.cpp:187-197 AtariEnvLoader::loadFromEnvironment: action i gets L[lives] when the lives before it are fewer than before action i-1
+    std::vector<std::pair<size_t, std::string>> lives_tags;
+    {
+        const std::vector<int> lives_history = env_->getLivesHistory();
+        if (!lives_history.empty()) {
+            int previous_lives = lives_history[0];
+            for (size_t i = 0; i < env_->getActionHistory().size(); ++i) {
+                const int lives = lives_history[i];
+                if (lives < previous_lives) { lives_tags.push_back({i, std::to_string(lives)}); }
+                previous_lives = lives;
+            }
+        }
+    }
     addTag("EV", cfg_->nn_file_name.substr(cfg_->nn_file_name.find_last_of('/') + 1));
     if (!isEnvTerminal()) {
         float result = env_->getEvalScore(true);
@@ -95,9 +112,17 @@ std::string ZeroActor::getRecord(const std::vector<std::pair<std::string, std::s
     const auto& actions = env_->getActionHistory();
     for (size_t i = 0; i < actions.size(); ++i) {
         oss << ";" << playerToChar(actions[i].getPlayer()) << "[" << actions[i].getActionID() << "]";
+        bool has_l = false; // VectorMap semantics: an existing "L" key keeps its place and takes the new value
+        std::string l_value;
+        for (const auto& lt : lives_tags) { if (lt.first == i) { has_l = true; l_value = lt.second; } }
         if (action_info_history_.size() > i) {
-            for (const auto& info : action_info_history_[i]) { oss << info.first << "[" << escapeSGFString(info.second) << "]"; }
+            for (const auto& info : action_info_history_[i]) {
+                const bool is_l = has_l && info.first == "L";
+                oss << info.first << "[" << escapeSGFString(is_l ? l_value : info.second) << "]";
+                if (is_l) { has_l = false; }
+            }
         }
+        if (has_l) { oss << "L[" << escapeSGFString(l_value) << "]"; }
     }
     oss << ")";
     return oss.str();

@@ -214,6 +214,9 @@ int mzo_tree_value_bound(void* tp, float* lo, float* hi)
     return static_cast<int>(m.size());
 }
 
+// compressString (utils.h:35-91) of n bytes: returns the hex length (the string itself when cap is large enough)
+int mzo_compress_string(const char* data, int n, char* buf, int cap) { return copyOut(compressString(std::string(data, static_cast<size_t>(n))), buf, cap); }
+
 // ---- self-play group ----
 void* mzo_group_create(const char* conf, const NetDesc* d, const float* raw, long n)
 {

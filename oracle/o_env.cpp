@@ -569,6 +569,10 @@ public:
     static constexpr int kRes = 96, kHist = 8, kActions = 18;
     AtariSynthEnv(const Config& cfg, Random* rng) : name_(cfg.env_atari_name), episode_length_(cfg.env_atari_episode_length)
     {
+        // ref atari.cpp:87: observations older than this are dropped (kAtariMaxNumFramesPerEpisode = 108000 when no intermediate sequences)
+        recent_observation_length_ = static_cast<size_t>(cfg.zero_actor_intermediate_sequence_length == 0
+                                                              ? 108000
+                                                              : cfg.zero_actor_intermediate_sequence_length + kHist + cfg.learner_n_step_return + cfg.learner_muzero_unrolling_step) + 1;
         rng_ = rng;
         reset(); // ref atari.h:47-50: the constructor resets (and draws a seed)
     }
@@ -581,6 +585,10 @@ public:
         reward_ = 0;
         total_reward_ = 0;
         actions_.clear();
+        lives_history_.clear();
+        lives_history_.push_back(livesAt(0));            // ref atari.cpp:61-62
+        observations_.clear();
+        observations_.push_back(observationString(0));   // ref atari.cpp:64-66: the initial observation
         feature_history_.assign(kHist, std::vector<float>(3 * kRes * kRes, 0.0f));
         feature_history_.push_back(observation(0));
         feature_history_.erase(feature_history_.begin());
@@ -591,7 +599,13 @@ public:
         const int step = static_cast<int>(actions_.size()) + 1;
         reward_ = ((amix(static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0x9E3779B97F4A7C15ULL + 0x5157ULL * step) >> 40) < uint64_t(0.05 * (1 << 24))) ? 1.0f : 0.0f;
         total_reward_ += reward_;
+        lives_history_.push_back(livesAt(step));          // ref atari.cpp:83
         actions_.push_back(action);
+        observations_.push_back(observationString(step)); // ref atari.cpp:85-91
+        if (observations_.size() > recent_observation_length_) {
+            observations_[observations_.size() - recent_observation_length_].clear();
+            observations_[observations_.size() - recent_observation_length_].shrink_to_fit();
+        }
         action_feature_history_.push_back(action.getActionID() * 1.0f / kActions);
         action_feature_history_.erase(action_feature_history_.begin());
         feature_history_.push_back(observation(step));
@@ -624,18 +638,39 @@ public:
     int getNumPlayer() const override { return 1; }
     std::string name() const override { return "atari_" + name_; }
     std::vector<std::pair<std::string, std::string>> loaderTags() const override { return {{"SD", std::to_string(seed_)}}; } // ref atari.cpp:190
+    const std::vector<std::string>& getObservationHistory() const override { return observations_; }
+    std::vector<int> getLivesHistory() const override { return lives_history_; }
 
 private:
+    // The synthetic screen of (seed, step): every 8x8 block of every colour plane is one byte of a counter hash — piecewise-constant like
+    // a real Atari frame (which gzip shrinks ~50x), not noise.
+    uint8_t screenByte(int step, int c, int y, int x) const
+    {
+        const uint64_t base = static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0xD1B54A32D192ED03ULL + static_cast<uint64_t>(step) * 0x100000001B3ULL;
+        const uint64_t block = static_cast<uint64_t>((c * (kRes / 8) + y / 8) * (kRes / 8) + x / 8);
+        return static_cast<uint8_t>(amix(base + block * 0x9E3779B97F4A7C15ULL) >> 56);
+    }
     std::vector<float> observation(int step) const // bytes / 255 (ref atari.cpp:142-158 getObservation(scale_01))
     {
         std::vector<float> o(size_t(3) * kRes * kRes);
-        const uint64_t base = static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0xD1B54A32D192ED03ULL + static_cast<uint64_t>(step) * 0x100000001B3ULL;
-        for (size_t i = 0; i < o.size(); i += 8) { // 8 bytes per hash
-            uint64_t z = amix(base + (i >> 3) * 0x9E3779B97F4A7C15ULL);
-            for (int k = 0; k < 8; ++k) { o[i + k] = static_cast<float>((z >> (8 * k)) & 0xFF) / 255.0f; }
-        }
+        for (int c = 0; c < 3; ++c) { for (int y = 0; y < kRes; ++y) { for (int x = 0; x < kRes; ++x) { o[(size_t(c) * kRes + y) * kRes + x] = static_cast<float>(screenByte(step, c, y, x)) / 255.0f; } } }
         return o;
     }
+    std::string observationString(int step) const // ref atari.cpp:160-169: the same screen as chw bytes
+    {
+        std::string s(size_t(3) * kRes * kRes, '\0');
+        for (int c = 0; c < 3; ++c) { for (int y = 0; y < kRes; ++y) { for (int x = 0; x < kRes; ++x) { s[(size_t(c) * kRes + y) * kRes + x] = static_cast<char>(screenByte(step, c, y, x)); } } }
+        return s;
+    }
+    int livesAt(int step) const // synthetic ale_.lives(): 3 lives, one lost at every step whose counter hash hits 1 in 23
+    {
+        int lost = 0;
+        for (int s = 1; s <= step; ++s) { lost += (amix(static_cast<uint64_t>(static_cast<uint32_t>(seed_)) * 0xA24BAED4963EE407ULL + 0x11F3ULL * s) % 23) == 0; }
+        return lost >= 3 ? 0 : 3 - lost;
+    }
+    size_t recent_observation_length_ = 108001;
+    std::vector<int> lives_history_;
+    std::vector<std::string> observations_;
     std::string name_;
     int episode_length_, seed_ = 0;
     float reward_ = 0, total_reward_ = 0;

@@ -145,6 +145,9 @@ public:
     virtual std::string name() const = 0;
     virtual int getNumPlayer() const { return 2; }
     virtual std::vector<std::pair<std::string, std::string>> loaderTags() const = 0; // SZ / KM after OBS
+    // ref base_env.h:105-106: observation strings of the game so far (only Atari keeps any); atari.h:84: lives before action i (index i)
+    virtual const std::vector<std::string>& getObservationHistory() const { static const std::vector<std::string> none; return none; }
+    virtual std::vector<int> getLivesHistory() const { return {}; }
     int getRotateAction(int action_id, Rotation rotation) const { return getPositionByRotating(rotation, action_id, getBoardSize()); }
     Player getTurn() const { return turn_; }
     const std::vector<Action>& getActionHistory() const { return actions_; }
@@ -159,6 +162,8 @@ public:
     Random* rng_ = nullptr; // only the Atari-shaped env draws from it (ref atari.h:54: reset(Random::randInt()))
 };
 std::unique_ptr<Env> createEnv(const Config& cfg, Random* rng = nullptr);
+// ref utils/utils.h:35-91: gzip member (boost::iostreams::gzip_compressor defaults) of `s`, then two lower-case hex digits per byte; "" -> ""
+std::string compressString(const std::string& s);
 
 // ----------------------------------------------------------------------------
 // network (the math of network/py/*.py with BN folded; see o_nn.cpp)

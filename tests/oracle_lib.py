@@ -100,6 +100,7 @@ def lib():
     L.mzo_tree_num_nodes.argtypes = [C.c_void_p]
     L.mzo_tree_dump.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, ip, fp, fp, fp, fp, fp, fp, fp]
     L.mzo_tree_value_bound.argtypes = [C.c_void_p, fp, fp]
+    L.mzo_compress_string.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.mzo_group_create.restype = C.c_void_p
     L.mzo_group_create.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_long]
     L.mzo_group_destroy.argtypes = [C.c_void_p]
@@ -179,6 +180,16 @@ class OracleNet:
         r, h = np.zeros(B, np.float32), np.empty((B, self._hs()), np.float32)
         self.L.mzo_net_recurrent(self.h, fptr(hidden), fptr(action), B, fptr(p), fptr(l), fptr(v), fptr(r), fptr(h))
         return p, l, v, r, h
+
+
+def compress_string(data):
+    """compressString (ref utils/utils.h:35-91) of the oracle: gzip member, lower-case hex"""
+    L = lib()
+    data = bytes(data)
+    n = L.mzo_compress_string(data, len(data), None, 0)
+    buf = C.create_string_buffer(n + 1)
+    L.mzo_compress_string(data, len(data), buf, n + 1)
+    return buf.value.decode()
 
 
 class OracleGroup:
