@@ -51,6 +51,7 @@ bool Config::loadFromString(const std::string& conf)
     P_(actor_gumbel_sample_size); P_(actor_gumbel_sigma_visit_c); P_(actor_gumbel_sigma_scale_c); P_(actor_resign_threshold);
     P_(zero_num_threads); P_(zero_num_parallel_games); P_(zero_disable_resign_ratio); P_(zero_actor_intermediate_sequence_length);
     PS(zero_actor_ignored_command); P_(learner_muzero_unrolling_step); P_(learner_n_step_return);
+    P_(zero_num_games_per_iteration); P_(zero_replay_buffer); PB(learner_use_per); P_(learner_per_alpha); P_(learner_per_init_beta); P_(learner_batch_size);
     PS(nn_file_name); PS(nn_type_name); P_(env_board_size); P_(env_go_komi); PS(env_go_ko_rule);
     PS(env_game); PB(atari_init_q); P_(oracle_throughput_threads); PS(env_atari_name); P_(env_atari_episode_length);
 #undef P_

@@ -217,6 +217,70 @@ int mzo_tree_value_bound(void* tp, float* lo, float* hi)
 // compressString (utils.h:35-91) of n bytes: returns the hex length (the string itself when cap is large enough)
 int mzo_compress_string(const char* data, int n, char* buf, int cap) { return copyOut(compressString(std::string(data, static_cast<size_t>(n))), buf, cap); }
 
+// ---- learner-side sampler ----
+void* mzo_loader_create(const char* conf)
+{
+    Config c;
+    if (!c.loadFromString(conf)) { return nullptr; }
+    return new DataLoaderOracle(c);
+}
+void mzo_loader_destroy(void* l) { delete static_cast<DataLoaderOracle*>(l); }
+int mzo_loader_add(void* l, const char* line) { return static_cast<DataLoaderOracle*>(l)->addEnvString(line) ? 1 : 0; }
+void mzo_loader_finish(void* l) { static_cast<DataLoaderOracle*>(l)->finishLoading(); }
+void mzo_loader_load_file(void* l, const char* path) { static_cast<DataLoaderOracle*>(l)->loadDataFromFile(path); }
+int mzo_loader_num_data(void* l) { return static_cast<DataLoaderOracle*>(l)->num_data_; }
+int mzo_loader_num_games(void* l) { return static_cast<int>(static_cast<DataLoaderOracle*>(l)->env_loaders_.size()); }
+void mzo_loader_sample(void* l, float* features, float* action_features, float* policy, float* value, float* reward, float* loss_scale, int* sampled_index)
+{
+    DataLoaderOracle::Batch b{features, action_features, policy, value, reward, loss_scale, sampled_index};
+    static_cast<DataLoaderOracle*>(l)->sampleData(b);
+}
+void mzo_loader_update_priority(void* l, const int* sampled_index, const float* batch_values) { static_cast<DataLoaderOracle*>(l)->updatePriority(sampled_index, batch_values); }
+// the record state machine alone (pinned to the reference's SGFLoader): renders tags and actions of `content` parsed with SGF move values
+int mzo_sgf_parse(const char* content, char* buf, int cap)
+{
+    RecordLoader r;
+    std::ostringstream o;
+    const bool ok = r.loadFromString(content, -1, true);
+    o << (ok ? "ok" : "fail") << "|";
+    for (auto& t : r.tags_.items) { o << t.first << "=" << t.second << ";"; }
+    o << "|";
+    for (size_t i = 0; i < r.sgf_moves_.size(); ++i) {
+        o << r.sgf_moves_[i].first << ":" << r.sgf_moves_[i].second << "{";
+        for (auto& t : r.actions_[i].info.items) { o << t.first << "=" << t.second << ";"; }
+        o << "}";
+    }
+    return copyOut(o.str(), buf, cap);
+}
+// VectorMap semantics: ops = lines "set k v" | "insert k v" | "erase k"; renders k[v]...
+int mzo_tagmap_apply(const char* ops, char* buf, int cap)
+{
+    TagMap m;
+    std::istringstream iss(ops);
+    std::string line;
+    while (std::getline(iss, line)) {
+        std::istringstream ls(line);
+        std::string op, k, v;
+        ls >> op >> k >> v;
+        if (op == "set") { m[k] = v; }
+        else if (op == "insert") { m.insert(k, v); }
+        else if (op == "erase") { m.erase(k); }
+    }
+    std::ostringstream o;
+    for (auto& t : m.items) { o << t.first << "[" << t.second << "]"; }
+    return copyOut(o.str(), buf, cap);
+}
+int mzo_sgf_coords(int action_id, int board_size, const char* coord, const char* sgf, int* out)
+{
+    out[0] = boardCoordinateStringToActionID(coord, board_size);
+    out[1] = sgfStringToActionID(sgf, board_size);
+    return 0;
+}
+int mzo_sgf_strings(int action_id, int board_size, char* buf, int cap)
+{
+    return copyOut(actionIDToBoardCoordinateString(action_id, board_size) + "|" + actionIDToSGFString(action_id, board_size), buf, cap);
+}
+
 // ---- self-play group ----
 void* mzo_group_create(const char* conf, const NetDesc* d, const float* raw, long n)
 {

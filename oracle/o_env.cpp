@@ -578,6 +578,7 @@ public:
     }
     std::unique_ptr<Env> clone() const override { return std::make_unique<AtariSynthEnv>(*this); }
     void reset() override { resetSeed(rng_ ? rng_->randInt() : 0); } // ref atari.h:54
+    void resetWithSeed(int seed) override { resetSeed(seed); }
     void resetSeed(int seed) // ref atari.cpp:48-72
     {
         turn_ = kPlayer1;

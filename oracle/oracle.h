@@ -27,6 +27,7 @@
 #include <map>
 #include <memory>
 #include <random>
+#include <deque>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -70,6 +71,13 @@ struct Config {
     std::string zero_actor_ignored_command = "reset_actors";
     int learner_muzero_unrolling_step = 5;
     int learner_n_step_return = 0;
+    // learner-side sampler (ref configuration.cpp:40-67): replay buffer size and prioritised replay
+    int zero_num_games_per_iteration = 2000;
+    int zero_replay_buffer = 20;
+    bool learner_use_per = false;
+    float learner_per_alpha = 1.0f;
+    float learner_per_init_beta = 1.0f;
+    int learner_batch_size = 1024;
     std::string nn_file_name = "";
     std::string nn_type_name = "alphazero";
     int env_board_size = 0;
@@ -148,6 +156,7 @@ public:
     // ref base_env.h:105-106: observation strings of the game so far (only Atari keeps any); atari.h:84: lives before action i (index i)
     virtual const std::vector<std::string>& getObservationHistory() const { static const std::vector<std::string> none; return none; }
     virtual std::vector<int> getLivesHistory() const { return {}; }
+    virtual void resetWithSeed(int) { reset(); } // atari.h:53: reset(seed)
     int getRotateAction(int action_id, Rotation rotation) const { return getPositionByRotating(rotation, action_id, getBoardSize()); }
     Player getTurn() const { return turn_; }
     const std::vector<Action>& getActionHistory() const { return actions_; }
@@ -164,6 +173,83 @@ public:
 std::unique_ptr<Env> createEnv(const Config& cfg, Random* rng = nullptr);
 // ref utils/utils.h:35-91: gzip member (boost::iostreams::gzip_compressor defaults) of `s`, then two lower-case hex digits per byte; "" -> ""
 std::string compressString(const std::string& s);
+
+// ----------------------------------------------------------------------------
+// learner-side sampler (o_loader.cpp): record loaders + replay buffer + DataLoader, one slave thread
+// ----------------------------------------------------------------------------
+struct TagMap { // utils/vector_map.h
+    std::vector<std::pair<std::string, std::string>> items;
+    std::string& operator[](const std::string& key);
+    const std::string& get(const std::string& key) const;
+    bool count(const std::string& key) const;
+    bool insert(const std::string& key, const std::string& value);
+    void erase(const std::string& key);
+};
+int sgfStringToActionID(const std::string& sgf_string, int board_size);
+std::string actionIDToSGFString(int action_id, int board_size);
+int boardCoordinateStringToActionID(const std::string& s, int board_size);
+std::string actionIDToBoardCoordinateString(int action_id, int board_size);
+
+class RecordLoader { // the record state machine shared by utils/sgf_loader.cpp and base_env.h
+public:
+    struct Pair { Action action; TagMap info; };
+    // sgf_moves: move values are SGF coordinates kept as strings (SGFLoader); else "digits = action id" (BaseEnvLoader)
+    bool loadFromString(const std::string& content, int default_board_size, bool sgf_moves);
+    TagMap tags_;
+    std::vector<Pair> actions_;
+    std::vector<std::pair<std::string, std::string>> sgf_moves_; // SGFLoader::SGFAction (player key, board coordinate)
+    int board_size_ = 0;
+};
+
+class GameLoader : public RecordLoader { // EnvironmentLoader of the configured game
+public:
+    explicit GameLoader(const Config* cfg);
+    bool load(const std::string& content);
+    std::pair<int, int> getDataRange() const;
+    std::vector<float> getFeatures(int pos, Rotation rotation, Random* rng) const;
+    std::vector<float> getActionFeatures(int pos, Rotation rotation, Random* rng) const;
+    std::vector<float> getPolicy(int pos, Rotation rotation) const;
+    std::vector<float> getValue(int pos) const;
+    std::vector<float> getReward(int pos) const;
+    float getPriority(int pos) const;
+    bool setActionPairInfo(int pos, const std::string& tag, const std::string& value);
+    int policySize() const;
+
+private:
+    std::unique_ptr<Env> newEnv() const;
+    int rotateAction(int action_id, Rotation rotation) const;
+    std::vector<float> getFeaturesByReplay(int pos) const;
+    void addObservations(const std::string& compressed_obs);
+    float baseValue(int pos) const;
+    float baseReward(int pos) const;
+    float calculateNStepValue(int pos) const;
+    const Config* cfg_;
+    std::vector<std::string> observations_;
+};
+
+class DataLoaderOracle {
+public:
+    struct Batch { float *features, *action_features, *policy, *value, *reward, *loss_scale; int* sampled_index; };
+    explicit DataLoaderOracle(const Config& cfg);
+    bool addEnvString(const std::string& env_string);
+    void finishLoading();
+    void loadDataFromFile(const std::string& file_name);
+    void sampleData(Batch& b);
+    void updatePriority(const int* sampled_index, const float* batch_values);
+    int num_data_ = 0;
+    float game_priority_sum_ = 0.0f;
+    std::deque<float> game_priorities_;
+    std::deque<std::deque<float>> position_priorities_;
+    std::deque<GameLoader> env_loaders_;
+    Config cfg_;
+
+private:
+    void addData(const GameLoader& env_loader);
+    int sampleIndex(const std::deque<float>& weight);
+    float getLossScale(const std::pair<int, int>& p);
+    void sampleOne(int batch_index, Batch& b);
+    Random rng_;
+};
 
 // ----------------------------------------------------------------------------
 // network (the math of network/py/*.py with BN folded; see o_nn.cpp)

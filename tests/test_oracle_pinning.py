@@ -166,3 +166,37 @@ def test_live_reference_build_agrees(oracle):
         for r in range(8):
             for p in range(n * n + 1):
                 assert R.mzref_rotate(r, p, n) == L.mzo_rotate(r, p, n)
+
+
+def _sgf_fixture():
+    with open(os.path.join(HERE, "golden", "ref_sgf_vectormap.json")) as f:
+        return json.load(f)
+
+
+def test_record_state_machine_matches_reference_sgf_loader(oracle):
+    """oracle RecordLoader (the state machine base_env.h:150-205 shares with utils/sgf_loader.cpp:26-83) against the reference's own SGFLoader"""
+    L = oracle.lib()
+    fx = _sgf_fixture()
+    assert len(fx["sgf"]) >= 40
+    buf = C.create_string_buffer(1 << 16)
+    for e in fx["sgf"]:
+        L.mzo_sgf_parse(e["in"].encode(), buf, len(buf))
+        assert buf.value.decode(errors="replace") == e["out"], e["in"]
+    for e in fx["coords"]:
+        o = (C.c_int * 2)()
+        L.mzo_sgf_coords(0, e["n"], e["coord"].encode(), e["sgf"].encode(), o)
+        assert [o[0], o[1]] == e["out"], e
+    for e in fx["strings"]:
+        L.mzo_sgf_strings(e["action"], e["n"], buf, len(buf))
+        assert buf.value.decode() == e["out"], e
+
+
+def test_tag_map_matches_reference_vector_map(oracle):
+    """oracle TagMap against the reference's utils/vector_map.h: operator[] finds-or-appends, insert keeps an existing value, order = insertion"""
+    L = oracle.lib()
+    fx = _sgf_fixture()
+    buf = C.create_string_buffer(1 << 16)
+    for e in fx["tagmap"]:
+        L.mzo_tagmap_apply(e["ops"].encode(), buf, len(buf))
+        assert buf.value.decode() == e["out"], e["ops"]
+    assert fx["go_unit"] == {"kMaxGoBoardSize": 19, "kGoNumPlayer": 2, "sizeof_GoHashKey": 8, "GoBitboard_bits": 361, "kGoName_len": 2}
