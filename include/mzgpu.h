@@ -207,6 +207,30 @@ typedef struct mz_worker_stats {
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out);
 mz_net* mz_worker_net(mz_worker* w);
 
+/* ------------------------------------------------------------------------------------------
+ * Learner-side sampler.  Replaces learner::DataLoader and its pybind surface (ref learner/data_loader.h:75-93, data_loader.cpp:200-255,
+ * learner/pybind.cpp:62-84): load_data_from_file / sample_data / update_priority, with ONE slave thread (thread 0 seeds program_seed + 0).
+ * conf: the reference's configuration string (+ env_game).  The feature planes of a batch are produced on the GPU (a replay of every sampled
+ * game on the device rules engine, or the stored Atari screens expanded), the targets on the host.
+ * sample_data: buffers for learner_batch_size samples, laid out like the numpy arrays learner/train.py hands the reference
+ *   features [B][C*H*W], action_features [B][U][a*h*w] (muzero), policy [B][(U+1)][A] ([B][A] alphazero), value [B][(U+1)][V] ([B][V]),
+ *   reward [B][U][V] (muzero), loss_scale [B], sampled_index [B][2] = (game, position); U = learner_muzero_unrolling_step, V = 601 for the
+ *   Atari-shaped game, else 1.  where = MZ_HOST or MZ_DEVICE (all seven buffers on that side; alphazero: action_features / reward may be NULL).
+ * mz_loader_shape(what): 0 batch size, 1..5 floats per sample of features / action_features / policy / value / reward.
+ * add_record returns 1 (loaded), 0 (the record does not load: skipped like data_loader.cpp:120-127) or a negative error.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mz_loader mz_loader;
+mz_loader* mz_loader_create(int device, const char* conf);
+void mz_loader_destroy(mz_loader* l);
+int mz_loader_load_data_from_file(mz_loader* l, const char* file_name); /* returns the number of records loaded */
+int mz_loader_add_record(mz_loader* l, const char* line);
+int mz_loader_sample_data(mz_loader* l, float* features, float* action_features, float* policy, float* value, float* reward, float* loss_scale,
+                          int* sampled_index, int where);
+int mz_loader_update_priority(mz_loader* l, const int* sampled_index, const float* batch_values);
+int mz_loader_num_data(const mz_loader* l);
+int mz_loader_num_games(const mz_loader* l);
+int mz_loader_shape(const mz_loader* l, int what);
+
 /* utils::compressString (ref utils/utils.h:35-91): what the `OBS[...]` tag of an Atari record holds — the gzip member
  * (boost::iostreams::gzip_compressor defaults) of n bytes as lower-case hex, NUL-terminated; "" for n == 0.  Returns the hex length
  * (out == NULL: length only) or a negative error. */

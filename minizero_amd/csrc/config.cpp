@@ -22,17 +22,18 @@ const Key kKeys[] = {
     K(actor_gumbel_sample_size, T_INT), K(actor_gumbel_sigma_visit_c, T_FLOAT), K(actor_gumbel_sigma_scale_c, T_FLOAT),
     K(actor_resign_threshold, T_FLOAT), K(zero_num_threads, T_INT), K(zero_num_parallel_games, T_INT),
     K(zero_disable_resign_ratio, T_FLOAT), K(zero_actor_intermediate_sequence_length, T_INT), K(zero_actor_ignored_command, T_STRING),
-    K(learner_muzero_unrolling_step, T_INT), K(learner_n_step_return, T_INT), K(nn_file_name, T_STRING), K(nn_type_name, T_STRING),
+    K(learner_muzero_unrolling_step, T_INT), K(learner_n_step_return, T_INT), K(zero_num_games_per_iteration, T_INT), K(zero_replay_buffer, T_INT),
+    K(learner_use_per, T_BOOL), K(learner_per_alpha, T_FLOAT), K(learner_per_init_beta, T_FLOAT), K(learner_batch_size, T_INT), K(nn_file_name, T_STRING), K(nn_type_name, T_STRING),
     K(env_board_size, T_INT), K(env_go_komi, T_FLOAT), K(env_go_ko_rule, T_STRING), K(env_game, T_STRING), K(atari_init_q, T_BOOL), K(mz_pipeline_lanes, T_INT), K(mz_zero_copy, T_INT), K(mz_cpu_base, T_INT), K(mz_signal_wait, T_BOOL), K(mz_device_env, T_BOOL), K(mz_raw_observations, T_BOOL), K(mz_sim_kernel, T_BOOL), K(mz_manual_step, T_BOOL), K(env_atari_name, T_STRING), K(env_atari_episode_length, T_INT),
 };
 #undef K
 
 // ref config/configuration.cpp:92-205: every other registered key
 const char* const kPassiveKeys[] = {
-    "program_use_color_message", "zero_server_port", "zero_training_directory", "zero_num_games_per_iteration", "zero_start_iteration",
-    "zero_end_iteration", "zero_replay_buffer", "zero_server_accept_different_model_games", "zero_display_latest_games", "learner_use_per",
-    "learner_per_alpha", "learner_per_init_beta", "learner_per_beta_anneal", "learner_training_step", "learner_training_display_step",
-    "learner_batch_size", "learner_optimizer", "learner_learning_rate", "learner_momentum", "learner_weight_decay", "learner_value_loss_scale",
+    "program_use_color_message", "zero_server_port", "zero_training_directory", "zero_start_iteration",
+    "zero_end_iteration", "zero_server_accept_different_model_games", "zero_display_latest_games", 
+    "learner_per_beta_anneal", "learner_training_step", "learner_training_display_step",
+    "learner_optimizer", "learner_learning_rate", "learner_momentum", "learner_weight_decay", "learner_value_loss_scale",
     "learner_num_thread", "nn_num_blocks", "nn_num_hidden_channels", "nn_num_value_hidden_channels", "env_atari_rom_dir",
     "env_conhex_use_swap_rule", "env_gomoku_rule", "env_gomoku_exactly_five_stones", "env_havannah_use_swap_rule", "env_hex_use_swap_rule",
     "env_killallgo_ko_rule", "env_killallgo_use_seki", "env_rubiks_scramble_rotate", "env_surakarta_no_capture_plies",

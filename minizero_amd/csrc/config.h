@@ -39,6 +39,13 @@ struct WorkerConfig {
     std::string zero_actor_ignored_command = "reset_actors";
     int learner_muzero_unrolling_step = 5;
     int learner_n_step_return = 0;
+    // learner-side sampler (loader.cpp; ref configuration.cpp:40-67)
+    int zero_num_games_per_iteration = 2000;
+    int zero_replay_buffer = 20;
+    bool learner_use_per = false;
+    float learner_per_alpha = 1.0f;
+    float learner_per_init_beta = 1.0f;
+    int learner_batch_size = 1024;
     std::string nn_file_name = "";
     std::string nn_type_name = "alphazero";
     int env_board_size = 0;

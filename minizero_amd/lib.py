@@ -144,6 +144,16 @@ def load():
         L.mz_envdev_playout.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_float, ip, C.c_int, C.c_int, ip, C.POINTER(C.c_uint32), u8p, ip, fp, ip]
         L.mz_sort_candidates.argtypes = [C.c_int, fp, C.c_int, ip]
         L.mz_invert_values_device.argtypes = [C.c_int, fp, C.c_int, fp]
+    L.mz_loader_create.restype = vp
+    L.mz_loader_create.argtypes = [C.c_int, C.c_char_p]
+    L.mz_loader_destroy.argtypes = [vp]
+    L.mz_loader_load_data_from_file.argtypes = [vp, C.c_char_p]
+    L.mz_loader_add_record.argtypes = [vp, C.c_char_p]
+    L.mz_loader_sample_data.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.mz_loader_update_priority.argtypes = [vp, vp, vp]
+    for n in ("mz_loader_num_data", "mz_loader_num_games"):
+        getattr(L, n).argtypes = [vp]
+    L.mz_loader_shape.argtypes = [vp, C.c_int]
     _LIB = L
     return L
 
@@ -412,6 +422,63 @@ class Worker:
 
     def net(self):
         return Net(self.desc, None, handle=self.L.mz_worker_net(self.h))
+
+
+class DataLoader:
+    """Mirror of the reference's learner-side `minizero_py.DataLoader` (ref learner/pybind.cpp:62-84, learner/data_loader.h:75-93): same
+    method names and argument order.  `conf` is the configuration STRING (the reference takes a .cfg file name; pass its lines joined with
+    ':' plus env_game).  Arrays may be numpy arrays (host) or torch CUDA tensors (the batch is then written in place on the device)."""
+
+    def __init__(self, conf, device=0):
+        self.L = load()
+        self.h = self.L.mz_loader_create(device, conf.encode())
+        if not self.h:
+            raise MzError("mz_loader_create failed: " + _err(self.L))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mz_loader_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def initialize(self):  # ref data_loader.cpp:194-198: thread creation; nothing to do here
+        pass
+
+    def load_data_from_file(self, file_name):
+        return _check(self.L, self.L.mz_loader_load_data_from_file(self.h, file_name.encode()))
+
+    def add_record(self, line):
+        return _check(self.L, self.L.mz_loader_add_record(self.h, line.encode()))
+
+    def num_data(self): return _check(self.L, self.L.mz_loader_num_data(self.h))
+    def num_games(self): return _check(self.L, self.L.mz_loader_num_games(self.h))
+
+    def shapes(self):
+        """(batch, floats per sample of features, action_features, policy, value, reward)"""
+        return tuple(_check(self.L, self.L.mz_loader_shape(self.h, k)) for k in range(6))
+
+    @staticmethod
+    def _ptr(a):
+        if a is None:
+            return None, None
+        if hasattr(a, "data_ptr"):  # torch tensor
+            assert a.is_contiguous()
+            return a.data_ptr(), bool(a.is_cuda)
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data, False
+
+    def sample_data(self, features, action_features, policy, value, reward, loss_scale, sampled_index):
+        ptrs = [self._ptr(a) for a in (features, action_features, policy, value, reward, loss_scale, sampled_index)]
+        sides = {d for p, d in ptrs if p is not None}
+        if len(sides) != 1:
+            raise MzError("sample_data: all buffers must be on the same side (host numpy arrays or CUDA tensors)")
+        _check(self.L, self.L.mz_loader_sample_data(self.h, *[p for p, _ in ptrs], MZ_DEVICE if sides.pop() else MZ_HOST))
+
+    def update_priority(self, sampled_index, batch_values):
+        si = np.ascontiguousarray(sampled_index, np.int32)
+        bv = np.ascontiguousarray(batch_values, np.float32)
+        _check(self.L, self.L.mz_loader_update_priority(self.h, si.ctypes.data, bv.ctypes.data))
 
 
 class Env:

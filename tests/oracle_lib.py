@@ -101,6 +101,20 @@ def lib():
     L.mzo_tree_dump.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, ip, fp, fp, fp, fp, fp, fp, fp]
     L.mzo_tree_value_bound.argtypes = [C.c_void_p, fp, fp]
     L.mzo_compress_string.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.mzo_sgf_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.mzo_tagmap_apply.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.mzo_sgf_coords.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+    L.mzo_sgf_strings.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.mzo_loader_create.restype = C.c_void_p
+    L.mzo_loader_create.argtypes = [C.c_char_p]
+    L.mzo_loader_destroy.argtypes = [C.c_void_p]
+    L.mzo_loader_add.argtypes = [C.c_void_p, C.c_char_p]
+    L.mzo_loader_finish.argtypes = [C.c_void_p]
+    L.mzo_loader_load_file.argtypes = [C.c_void_p, C.c_char_p]
+    L.mzo_loader_num_data.argtypes = [C.c_void_p]
+    L.mzo_loader_num_games.argtypes = [C.c_void_p]
+    L.mzo_loader_sample.argtypes = [C.c_void_p, fp, fp, fp, fp, fp, fp, ip]
+    L.mzo_loader_update_priority.argtypes = [C.c_void_p, ip, fp]
     L.mzo_group_create.restype = C.c_void_p
     L.mzo_group_create.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_long]
     L.mzo_group_destroy.argtypes = [C.c_void_p]
@@ -190,6 +204,30 @@ def compress_string(data):
     buf = C.create_string_buffer(n + 1)
     L.mzo_compress_string(data, len(data), buf, n + 1)
     return buf.value.decode()
+
+
+class OracleLoader:
+    """The oracle's learner-side sampler (ref learner/data_loader.cpp), one slave thread."""
+
+    def __init__(self, conf):
+        self.L = lib()
+        self.h = self.L.mzo_loader_create(conf.encode())
+        assert self.h, "oracle loader create failed: " + conf
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.mzo_loader_destroy(self.h)
+            self.h = None
+
+    def load_data_from_file(self, path): self.L.mzo_loader_load_file(self.h, path.encode())
+    def num_data(self): return self.L.mzo_loader_num_data(self.h)
+    def num_games(self): return self.L.mzo_loader_num_games(self.h)
+
+    def sample_data(self, features, action_features, policy, value, reward, loss_scale, sampled_index):
+        self.L.mzo_loader_sample(self.h, fptr(features), fptr(action_features), fptr(policy), fptr(value), fptr(reward), fptr(loss_scale), iptr(sampled_index))
+
+    def update_priority(self, sampled_index, batch_values):
+        self.L.mzo_loader_update_priority(self.h, iptr(np.ascontiguousarray(sampled_index, np.int32)), fptr(np.ascontiguousarray(batch_values, np.float32)))
 
 
 class OracleGroup:
