@@ -4,6 +4,10 @@
 #include "go_dev.h"
 #include "sort_emul.h"
 
+#ifndef MZ_LPROF
+#define MZ_LPROF(k) // experiment hook (sim.hip -DMZ_SIM_LPROF): time stamps inside the single-wave tree phases
+#endif
+
 namespace mz {
 
 // single-wave phases: make the wave's LDS / global writes visible to its other lanes (no s_barrier: the other waves of a
@@ -37,7 +41,8 @@ __device__ inline uint64_t normH(uint64_t h) { return h ? h : 1; }
 __device__ inline int rotOf(const RotPack& r, int g) { return (r.w[g / 10] >> (3 * (g % 10))) & 7; }
 
 // position + legal mask + feature planes of the leaf selected for game `g` (one wave64; `smem` as sized by goLeafSmemBytes)
-template <int CPL>
+template <int CPL, bool EXT_PLANES = false>
+// EXT_PLANES: the caller builds the feature planes itself from the history block this body leaves in `smem` (goPlanesPart, all waves)
 // seen_lds: optional LDS copy of the root's positional-superko table (GoRootSnapshot::seen; constant during a move) — the simulation kernel
 // makes one per launch so that the probes of every candidate point are LDS reads instead of dependent trips to L2
 __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& pv, int rot, int slot, int g, int lane, uint64_t* __restrict__ smem,
@@ -88,6 +93,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     uint64_t hash = v.hash[sb + src];
     int nmoves = v.meta[(sb + src) * 2], passes = v.meta[(sb + src) * 2 + 1];
     waveSync();
+    MZ_LPROF(1); // parent slot loaded
     const int t = (depth & 1) ? 3 - root_turn : root_turn; // the player to move at the leaf
 
     if (depth >= 1) { // leaf = parent + one move (ref go.cpp:132-190, observable effects only)
@@ -184,6 +190,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     for (int i = 0; i < CPL; ++i) {
         if (lane == 0) { cur[i] = sbw[i]; cur[W + i] = sww[i]; }
     }
+    MZ_LPROF(2); // move applied, slot stored
     const bool terminal = passes >= 2 || nmoves > 2 * P; // ref go.cpp:246-257
     // ---- hashes along the path (d = 1 .. depth; the root and everything before it is in the root's table) ----
     for (int d = 1 + lane; d <= depth; d += 64) { ph[d - 1] = normH(d == depth ? hash : v.hash[sb + hs[path[d]]]); }
@@ -213,6 +220,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         if (c[i] == 3 - t && libs[l[i]] == 1) { atomicXor(reinterpret_cast<unsigned long long*>(&gh[l[i]]), static_cast<unsigned long long>(v.key[size_t(2 - t) * P + p])); }
     }
     waveSync();
+    MZ_LPROF(3); // path hashes, liberties, key sums
     // ---- legal mask for the player to move (ref go.cpp:208-244): not occupied, not suicide, not a positional-superko repeat ----
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -259,6 +267,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         if (lane == 0) { v.legal[size_t(g) * v.LW + i] = w; }
     }
     if (v.LW > CPL && lane == 0) { v.legal[size_t(g) * v.LW + CPL] = (P >> 6) == CPL ? 1ull << (P & 63) : 0; } // P a multiple of 64
+    MZ_LPROF(4); // legal mask
     // ---- feature planes (ref go.cpp:280-308): planes 2k / 2k+1 = own / opponent stones k moves ago, 16 / 17 = black / white to move ----
     const int avail = root_hist_len + depth;
     for (int idx = lane; idx < 16 * W; idx += 64) {
@@ -272,7 +281,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         hb[idx] = val;
     }
     waveSync();
-    {
+    if constexpr (!EXT_PLANES) {
         const uint16_t* map = v.inv + size_t(rot) * P;
         uint32_t* out = v.feat + size_t(g) * 18 * v.W32;
 #pragma unroll
@@ -295,6 +304,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
             }
         }
     }
+    MZ_LPROF(5); // planes
     // ---- terminal: Tromp-Taylor area score + komi (ref go.cpp:259-278,703-723) ----
     float eval = 0.0f;
     if (terminal) {
@@ -361,6 +371,37 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         v.leaf_player[g] = t;
         v.terminal[g] = terminal ? 1 : 0;
         v.eval[g] = eval;
+    }
+}
+
+// The planes of goLeafBody<CPL, true>, shared by `nw` waves (the per-game simulation kernel: every wave takes the planes ch = w, w + nw, ...):
+// planes 2k / 2k+1 = own / opponent stones k moves ago under the rotation, 16 / 17 = black / white to move (ref go.cpp:280-308).
+// `smem` is the leaf's scratch block (its history words were filled by the leaf body), the player to move is read from v.leaf_player.
+template <int CPL>
+__device__ __forceinline__ void goPlanesPart(const GoDevView& v, int max_depth, int rot, int g, int w, int nw, int lane, const uint64_t* __restrict__ smem)
+{
+    const int P = v.P, W = v.W;
+    const uint64_t* hb = smem + v.Ppad + max_depth + 4;
+    const int t = v.leaf_player[g];
+    const uint16_t* map = v.inv + size_t(rot) * P;
+    uint32_t* out = v.feat + size_t(g) * 18 * v.W32;
+    for (int ch = w; ch < 18; ch += nw) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int p = i * 64 + lane;
+            uint64_t word;
+            if (ch < 16) {
+                const int q = p < P ? map[p] : 0;
+                const int k = ch >> 1, color = (ch & 1) == 0 ? t - 1 : 2 - t;
+                word = __ballot(p < P && ((hb[(k * 2 + color) * W + (q >> 6)] >> (q & 63)) & 1));
+            } else {
+                word = (ch == 16 ? t == 1 : t == 2) ? __ballot(p < P) : 0;
+            }
+            if (lane == 0) {
+                if (2 * i < v.W32) { out[ch * v.W32 + 2 * i] = static_cast<uint32_t>(word); }
+                if (2 * i + 1 < v.W32) { out[ch * v.W32 + 2 * i + 1] = static_cast<uint32_t>(word >> 32); }
+            }
+        }
     }
 }
 
@@ -561,8 +602,100 @@ __device__ void orderCandidates(Cand* cs, Cand* out, int* stack, int k, int lane
     }
 }
 
+// The same order computed by ALL waves of a workgroup (the per-game simulation kernel: 7 of its 8 waves idle while wave 0 runs the tree
+// phases, and the rank sort is VALU-bound: k^2 comparisons — 3.7 of the 8.5 us of candidates + expand + backup at 82 candidates).
+//   candDense   (one wave)   policies of cs[0..k) into a dense float array `dense` [128], padding below every softmax output
+//   candRankPart(every wave) wave w of nw counts, for each candidate i, the candidates j of ITS share of j that rank before i / tie with i
+//   candScatter (one wave)   sums the partial counts, writes out[rank] = cs[i]; ties among > 16 candidates -> the exact introsort replay
+// Workgroup barriers between the three steps are the caller's.  k <= 128.
+constexpr int kCandCoopMax = 128;
+__device__ __forceinline__ void candDense(const Cand* cs, int k, int lane, float* dense)
+{
+    dense[lane] = lane < k ? cs[lane].policy : -3.402823466e+38f;
+    dense[64 + lane] = 64 + lane < k ? cs[64 + lane].policy : -3.402823466e+38f;
+}
+__device__ __forceinline__ void candRankPart(const float* dense, int k, int w, int nw, int lane, int* part /* [nw][4][64] */)
+{
+    const float p0 = dense[lane], p1 = dense[64 + lane];
+    const int groups = (k + 3) >> 2, per = (32 + nw - 1) / nw;
+    int r0 = 0, r1 = 0, e0 = 0, e1 = 0;
+    for (int q = w * per; q < (w + 1) * per && q < groups; ++q) {
+        const float4 d = reinterpret_cast<const float4*>(dense)[q];
+        const float dj[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * q + e;
+            r0 += (dj[e] > p0) || (dj[e] == p0 && j < lane);
+            r1 += (dj[e] > p1) || (dj[e] == p1 && j < 64 + lane);
+            e0 += (dj[e] == p0);
+            e1 += (dj[e] == p1);
+        }
+    }
+    int* mine = part + w * 256;
+    mine[lane] = r0; mine[64 + lane] = r1; mine[128 + lane] = e0; mine[192 + lane] = e1;
+}
+__device__ __forceinline__ void candScatter(Cand* cs, Cand* out, int* stack, int k, int nw, int lane, const int* part, int* err)
+{
+    int r0 = 0, r1 = 0, e0 = 0, e1 = 0;
+    for (int w = 0; w < nw; ++w) { const int* p = part + w * 256; r0 += p[lane]; r1 += p[64 + lane]; e0 += p[128 + lane]; e1 += p[192 + lane]; }
+    const bool has0 = lane < k, has1 = 64 + lane < k;
+    const bool tie = (has0 && e0 > 1) || (has1 && e1 > 1); // every candidate equals itself once
+    if (has0) { out[r0] = cs[lane]; }
+    if (has1) { out[r1] = cs[64 + lane]; }
+    waveSync();
+    if (k > 16 && __ballot(tie) != 0) { // ties among > 16 elements: only the exact introsort gives the reference's order
+        if (lane == 0) {
+            StdSortEmul<Cand, CandGreater> s{cs, CandGreater()};
+            if (!s.sort(k, stack) && err) { atomicExch(err, MZ_ERR_CAPACITY); }
+        }
+        waveSync();
+        for (int i = lane; i < k; i += 64) { out[i] = cs[i]; }
+        waveSync();
+    }
+}
+
 // AlphaZero candidates of a leaf (ref zero_actor.cpp:215-245): legal actions in action order, policy / logit looked up through
 // the rotation, sorted by policy; a terminal leaf has no children and its value is the game result (zero_actor.cpp:85)
+// step 1: the legal actions of the leaf, in action order, into cs[]; returns their number (0 at a terminal leaf)
+__device__ __forceinline__ int azCandGather(const GoDevView& v, const float* __restrict__ policy, const float* __restrict__ logit, int rot, int g, int lane,
+                                            Cand* __restrict__ cs)
+{
+    const int A = v.A;
+    int k = 0;
+    if (v.terminal[g] != 0) { return 0; }
+    const uint16_t* fwd = v.fwd + size_t(rot) * A;
+    for (int base = 0; base < A; base += 64) {
+        const int a = base + lane;
+        const bool leg = a < A && ((v.legal[size_t(g) * v.LW + (a >> 6)] >> (a & 63)) & 1);
+        const uint64_t m = __ballot(leg);
+        if (leg) {
+            const int pos = k + __popcll(m & ((1ull << lane) - 1));
+            const int f = fwd[a];
+            cs[pos] = Cand{a, policy[size_t(g) * A + f], logit[size_t(g) * A + f]};
+        }
+        k += __popcll(m);
+    }
+    return k;
+}
+// step 3: the sorted candidates and the leaf's scalars where expand + backup read them
+__device__ __forceinline__ void azCandStore(const GoDevView& v, const float* __restrict__ value, const Cand* __restrict__ out, int k, int* __restrict__ cand_count,
+                                            int* __restrict__ cand_action, float* __restrict__ cand_policy, float* __restrict__ cand_logit,
+                                            int* __restrict__ cand_player, float* __restrict__ value_out, float* __restrict__ reward_out, int g, int lane)
+{
+    const int A = v.A;
+    for (int i = lane; i < k; i += 64) {
+        cand_action[size_t(g) * A + i] = out[i].action;
+        cand_policy[size_t(g) * A + i] = out[i].policy;
+        cand_logit[size_t(g) * A + i] = out[i].logit;
+    }
+    if (lane == 0) {
+        const bool terminal = v.terminal[g] != 0;
+        cand_count[g] = k;
+        cand_player[g] = v.leaf_player[g];
+        value_out[g] = terminal ? v.eval[g] : value[g];
+        reward_out[g] = 0.0f;
+    }
+}
 __device__ __forceinline__ void azCandBody(const GoDevView& v, const float* __restrict__ policy, const float* __restrict__ logit,
                                            const float* __restrict__ value, int rot, int* __restrict__ cand_count, int* __restrict__ cand_action,
                                            float* __restrict__ cand_policy, float* __restrict__ cand_logit, int* __restrict__ cand_player,
@@ -572,36 +705,16 @@ __device__ __forceinline__ void azCandBody(const GoDevView& v, const float* __re
     Cand* cs = reinterpret_cast<Cand*>(smem);
     Cand* out = cs + v.A;
     int* stack = reinterpret_cast<int*>(out + v.A);
-    const int A = v.A;
-    const bool terminal = v.terminal[g] != 0;
-    int k = 0;
-    if (!terminal) {
-        const uint16_t* fwd = v.fwd + size_t(rot) * A;
-        for (int base = 0; base < A; base += 64) {
-            const int a = base + lane;
-            const bool leg = a < A && ((v.legal[size_t(g) * v.LW + (a >> 6)] >> (a & 63)) & 1);
-            const uint64_t m = __ballot(leg);
-            if (leg) {
-                const int pos = k + __popcll(m & ((1ull << lane) - 1));
-                const int f = fwd[a];
-                cs[pos] = Cand{a, policy[size_t(g) * A + f], logit[size_t(g) * A + f]};
-            }
-            k += __popcll(m);
-        }
+    const int k = azCandGather(v, policy, logit, rot, g, lane, cs);
+    if (k > 0) {
         waveSync();
         orderCandidates(cs, out, stack, k, lane, err);
-        for (int i = lane; i < k; i += 64) {
-            cand_action[size_t(g) * A + i] = out[i].action;
-            cand_policy[size_t(g) * A + i] = out[i].policy;
-            cand_logit[size_t(g) * A + i] = out[i].logit;
-        }
     }
-    if (lane == 0) {
-        cand_count[g] = k;
-        cand_player[g] = v.leaf_player[g];
-        value_out[g] = terminal ? v.eval[g] : value[g];
-        reward_out[g] = 0.0f;
-    }
+    azCandStore(v, value, out, k, cand_count, cand_action, cand_policy, cand_logit, cand_player, value_out, reward_out, g, lane);
 }
+
+// scratch of the cooperative variant behind the cs / out / stack block: dense[128] floats + nw x 256 partial counts
+inline size_t candCoopOffsetBytes(int A) { return (azCandSmemBytes(A) + 15) & ~size_t(15); }
+inline size_t candCoopSmemBytes(int A, int nw) { return candCoopOffsetBytes(A) + kCandCoopMax * sizeof(float) + size_t(nw) * 256 * sizeof(int); }
 
 } // namespace mz

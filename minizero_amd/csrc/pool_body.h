@@ -5,6 +5,10 @@
 #include <cfloat>
 #include <climits>
 
+#ifndef MZ_LPROF
+#define MZ_LPROF(k)
+#endif
+
 namespace mz {
 
 // normalized mean of a visited child (ref mcts.cpp:40-53 with virtual_loss == 0, which ActorGroup never uses)
@@ -560,6 +564,7 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
         }
     }
     if (lane == 0 && hslot >= 0) { v.hslot[base + leaf] = hslot; }
+    MZ_LPROF(10);
     // ---- backup (ref mcts.cpp:166-179) ----
     if (!v.value_rescale) {
         // The only leaf -> root dependence is `updated = r + gamma * updated`, which needs the rewards but not the means: the
@@ -595,6 +600,7 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
                 n->count = cnt;
             }
         }
+        MZ_LPROF(11);
         return;
     }
     // with value rescaling the value-bound multiset (std::map<float,int> of the reference, kept as an unordered array) is updated node by

@@ -33,6 +33,18 @@ __shared__ unsigned long long s_hp_prev;
     } while (0)
 #endif
 #include "net_atari_body.h"
+#ifdef MZ_SIM_LPROF // experiment: where the time of the single-wave tree phases goes (game 0)
+__device__ unsigned long long g_lp[32];
+__shared__ unsigned long long s_lp_prev;
+#define MZ_LPROF(k)                                                                                   \
+    do {                                                                                              \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) {                                             \
+            const unsigned long long t_ = wall_clock64();                                             \
+            if ((k) > 0) { g_lp[(k)] += t_ - s_lp_prev; } else { g_lp[31] += 1; }                     \
+            s_lp_prev = t_;                                                                           \
+        }                                                                                             \
+    } while (0)
+#endif
 #include "pool_body.h"
 #include "go_body.h"
 #include "gumbel_body.h"
@@ -74,6 +86,7 @@ struct SimArgs {
     AtariHeadParams ahp;
     float* reward;                    // [games] reward head output (game scale)
     int no_spec;                      // MZ_NO_SPEC=1: path speculation of the walk off (experiments)
+    int cand_coop;                    // the candidate rank sort is shared by the 8 waves (its scratch fits the tower tiles)
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
 
@@ -164,10 +177,52 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
         a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
         a->prof[size_t(g) * 8 + 6] += pv.path_len[g];
     }
+    MZ_LPROF(0);
     const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
     if constexpr (CPL == -1) { tttLeafBody(gv, pv, rot, slot, g, lane); } // CPL -1: TicTacToe, 0: Othello (go_body.h)
     else if constexpr (CPL == 0) { othLeafBody(gv, pv, rot, slot, g, lane); }
-    else { goLeafBody<CPL>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles), seen_lds); }
+    else { goLeafBody<CPL, true>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles), seen_lds); } // planes: simLeafPlanes, all waves
+}
+
+// Go: the 18 feature planes of the leaf, two or three per wave (32 ballots over LDS words: 3.3 us on one wave)
+template <int CPL>
+__device__ __forceinline__ void simLeafPlanes(CSimArgs* __restrict__ a, int rot, int g, int wave, int lane, float* tiles, float* xchg)
+{
+    if constexpr (CPL > 0) {
+        const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
+        goPlanesPart<CPL>(gv, a->pv.max_depth, rot, g, wave, 8, lane, reinterpret_cast<const uint64_t*>(tiles));
+    }
+}
+
+// Candidates + expand + backup in three steps: wave 0 gathers the legal actions, ALL waves count ranks (the sort is VALU-bound and the other
+// seven waves would be idle), wave 0 scatters, expands and backs up.  A > 128 actions: wave 0 sorts alone in the first step.
+__device__ __forceinline__ float* simCandDense(float* tiles, int A) { return reinterpret_cast<float*>(reinterpret_cast<char*>(tiles) + ((2 * size_t(A) * sizeof(Cand) + kSortStackBytes + 16 + 15) & ~size_t(15))); }
+
+template <int WPE>
+__device__ __noinline__ void simCandGather(CSimArgs* __restrict__ a, int rot, int g, int lane, float* tiles, float* xchg)
+{
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    rot = __builtin_amdgcn_readfirstlane(rot);
+    const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
+    const SimXchg x{gv.A + (gv.A & 1)};
+    const size_t ga = size_t(g) * gv.A;
+    float* sc = xchg + x.scalars();
+    MZ_LPROF(6);
+    Cand* cs = reinterpret_cast<Cand*>(tiles);
+    const int k = azCandGather(gv, xchg + x.policy() - ga, xchg + x.logit() - ga, rot, g, lane, cs);
+    waveSync();
+    if (k > kCandCoopMax || !a->cand_coop) { if (k > 0) { orderCandidates(cs, cs + gv.A, reinterpret_cast<int*>(cs + 2 * gv.A), k, lane, a->err); } }
+    else { candDense(cs, k, lane, simCandDense(tiles, gv.A)); }
+    if (lane == 0) { reinterpret_cast<int*>(sc)[1] = k; } // cand_count: read by every wave after the barrier
+    MZ_LPROF(7);
+}
+
+__device__ __forceinline__ void simCandRank(int A, int k, int wave, int lane, float* tiles)
+{
+    if (k <= 0 || k > kCandCoopMax) { return; }
+    float* dense = simCandDense(tiles, A);
+    candRankPart(dense, k, wave, 8, lane, reinterpret_cast<int*>(dense + kCandCoopMax));
 }
 
 template <int WPE>
@@ -185,11 +240,20 @@ __device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, in
     int* cand_count = reinterpret_cast<int*>(sc + 1) - g;
     int* cand_player = reinterpret_cast<int*>(sc + 2) - g;
     int* cand_action = reinterpret_cast<int*>(xchg + x.caction()) - ga;
-    azCandBody(gv, xchg + x.policy() - ga, xchg + x.logit() - ga, sc - g, rot, cand_count, cand_action, xchg + x.cpolicy() - ga, xchg + x.clogit() - ga,
-               cand_player, sc + 3 - g, sc + 4 - g, a->err, g, lane, reinterpret_cast<uint64_t*>(tiles));
+    Cand* cs = reinterpret_cast<Cand*>(tiles);
+    Cand* out = cs + gv.A;
+    const int k = reinterpret_cast<const int*>(sc)[1];
+    if (k > 0 && k <= kCandCoopMax && a->cand_coop) {
+        float* dense = simCandDense(tiles, gv.A);
+        candScatter(cs, out, reinterpret_cast<int*>(out + gv.A), k, 8, lane, reinterpret_cast<const int*>(dense + kCandCoopMax), a->err);
+    }
+    MZ_LPROF(8);
+    azCandStore(gv, sc - g, out, k, cand_count, cand_action, xchg + x.cpolicy() - ga, xchg + x.clogit() - ga, cand_player, sc + 3 - g, sc + 4 - g, g, lane);
     waveSync();
+    MZ_LPROF(9);
     expandBackupBody(pv, cand_count, cand_action, xchg + x.cpolicy() - ga, xchg + x.clogit() - ga, cand_player, sc + 3 - g, sc + 4 - g, slot, a->err, g,
                      lane, tiles);
+    MZ_LPROF(12);
 }
 
 // Root exploration noise (ref zero_actor.cpp:194-213): policy = (1 - eps) * policy + eps * noise for the root's children, in storage
@@ -325,6 +389,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
             simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec, xchg, seen_lds);
         }
         __syncthreads();
+        if constexpr (CPL > 0) {
+            simLeafPlanes<CPL>(a, rot, g, wave, lane, tiles, xchg);
+            __syncthreads();
+        }
         if (prof) { t1 = wall_clock64(); }
         const float* xt;
         xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles, xchg); // its own function: its own register budget
@@ -334,6 +402,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         else { simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
+        if (wave == 0) { simCandGather<WPE>(a, rot, g, lane, tiles, xchg); }
+        __syncthreads();
+        {
+            const int A = a->gv.A;
+            const SimXchg x{A + (A & 1)};
+            if (a->cand_coop) { simCandRank(A, reinterpret_cast<const int*>(xchg + x.scalars())[1], wave, lane, tiles); }
+        }
+        __syncthreads();
         if (wave == 0) { simCandExpand<WPE>(a, rot, slot, g, lane, tiles, xchg); }
         __syncthreads();
         if (prof && tid == 0) {
@@ -556,6 +632,19 @@ void Net::dumpSimProf()
         }
     }
 #endif
+#ifdef MZ_SIM_LPROF
+    {
+        unsigned long long h[32];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lp), sizeof(h)) == hipSuccess && h[31]) {
+            fprintf(stderr, "[mz sim lprof] rank part %.2f us, introsort entered (x0.01 us as count proxy) %.4f, introsort+copy %.2f\n", double(h[13]) / double(h[31]) * 0.01, double(h[14]) / double(h[31]), double(h[8]) / double(h[31]) * 0.01);
+            const char* nm[13] = {"", "leaf.load_parent", "leaf.apply_move+store", "leaf.hashes+liberties", "leaf.legal_mask", "leaf.planes", "(tower+heads)", "cand.gather", "cand.sort",
+                                  "cand.store", "expand", "backup", "expand+backup"};
+            fprintf(stderr, "[mz sim lprof] us per section of the tree phases (game 0, avg over %llu simulations):", h[31]);
+            for (int i = 1; i < 13; ++i) { if (h[i]) { fprintf(stderr, " %s %.2f", nm[i], double(h[i]) / double(h[31]) * 0.01); } }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 #ifdef MZ_SIM_TPROF
     {
         unsigned long long h[64];
@@ -660,6 +749,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     const size_t heads = (size_t(a.hp.PC) * a.hp.P + a.hp.P + a.hp.VH + a.hp.A + 16) * sizeof(float); // in tile 0 (the activations stay in tile 1)
     size_t scratch = std::max(std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A)), gumbelSmemBytes(gv.A));
     scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
+    a.cand_coop = candCoopSmemBytes(gv.A, 8) <= tile_bytes ? 1 : 0;
     if (scratch > tile_bytes || heads > tile_bytes / kTowerTiles) { // not launched
         setError("simLaunch: the tree phases need %zu B / the heads %zu B of scratch, the tower tiles have %zu B", scratch, heads, tile_bytes);
         return MZ_OK;
