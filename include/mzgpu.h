@@ -74,6 +74,11 @@ mz_net* mz_net_create(int device, const mz_net_desc* desc, const float* weights,
 /* load_model on a live network (ref actor/actor_group.cpp:227-232) */
 int mz_net_reload(mz_net* net, const float* weights, size_t count);
 void mz_net_destroy(mz_net* net);
+/* opt-in arithmetic of the residual tower: 0 = f32 MFMA (default; bit-exact against the CPU oracle, records identical to the reference),
+ * 1 = "bf16x3": split-bf16 operands on the 16-bit MFMA with f32 accumulation — network outputs within 1e-3 of the f32 path (the north star's
+ * tolerance), about 2x the leaf evaluations per second, records NOT bit-identical.  AlphaZero networks with 64 hidden channels on 9x9 / 8x8
+ * boards; MZ_ERR_ARG otherwise.  The worker takes the same switch as the configuration key mz_nn_precision=f32|bf16x3. */
+int mz_net_set_precision(mz_net* net, int mode);
 int mz_net_get_desc(const mz_net* net, mz_net_desc* out);
 
 /* AlphaZeroNetwork::forward() (ref network/alphazero_network.h:63-104): features [B][C_in][H][W] f32

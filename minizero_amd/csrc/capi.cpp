@@ -133,6 +133,11 @@ int mz_net_reload(mz_net* net, const float* weights, size_t count)
     return net->net.reload(weights, count);
 }
 void mz_net_destroy(mz_net* net) { delete net; }
+int mz_net_set_precision(mz_net* net, int mode)
+{
+    if (!net) { mz::setError("NULL network"); return MZ_ERR_ARG; }
+    return net->net.setPrecision(mode);
+}
 int mz_net_get_desc(const mz_net* net, mz_net_desc* out)
 {
     if (!net || !out) { return MZ_ERR_ARG; }

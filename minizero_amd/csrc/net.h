@@ -47,6 +47,7 @@ float invertValueHost(float value); // 601-bin decode helper (ref utils/utils.h:
 int invertValuesOnDevice(int device, const float* values, int n, float* out); // the device twin (net_atari_body.h), test access
 
 struct TowerArgs;
+struct TowerArgsBf16;
 struct HeadParams;
 struct AtariHeadParams;
 struct PoolView;
@@ -93,6 +94,11 @@ public:
     bool hasSimKernelMz(int num_simulation = 0) const;
     int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)
     void makeAtariHeadParams(AtariHeadParams* out) const; // net_atari.hip
+    // opt-in 16-bit-input tower (net_bf16_body.h): 0 = f32 (default, bit-exact against the oracle), 1 = bf16x3 (split bf16 operands on
+    // v_mfma_f32_16x16x32_bf16, f32 accumulation; outputs within 1e-3 of the f32 path, records not bit-identical to the reference)
+    int setPrecision(int mode);
+    int precision() const { return precision_; }
+    bool bf16Supported() const;
     int timeForward(int B, int iters, float* ms_total, float* ms_conv, double* conv_flops);
     int timeTowerConv(int B, int iters, float* ms_per_launch, double* flops_per_launch, double* bytes_per_launch);
 
@@ -111,6 +117,13 @@ private:
     int launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits, bool has_stem = true);
     int launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden);
     bool makeTowerArgs(const std::vector<ConvLayer>& t, bool in_bits, bool has_stem, TowerArgs* out, int* c0) const;
+    bool makeTowerArgsBf16(TowerArgsBf16* out) const;
+    int packBf16(const std::vector<float>& packed);
+    int launchTowerBf16(const float* d_feat, float* out, int B, bool in_bits);
+    int precision_ = 0;
+    DevBuf<uint4> wfrag_;                 // bf16 hi / lo A-fragments of the representation trunk (built at load when the shape is supported)
+    std::vector<unsigned> wfrag_off_;     // per layer, in 16-byte units
+    DevBuf<unsigned> bits_in_;            // bf16 path: f32 0/1 planes packed to bits
     void makeHeadParams(HeadParams* out) const;
 
     DevBuf<float> params_;

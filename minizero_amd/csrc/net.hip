@@ -15,6 +15,7 @@
 //                 the hidden state (ref muzero_network.py:154-164) and its scatter into the HBM slab.
 #include "net.h"
 #include "net_body.h"
+#include "net_bf16_body.h"
 #include <cmath>
 #include <cstring>
 
@@ -105,6 +106,27 @@ __global__ __launch_bounds__(512) void tower_fused(const float* __restrict__ in,
     towerBody<H, W, CIN0_PAD, CPAD>(in, params, ta, out, blockIdx.x, threadIdx.x, tiles);
 }
 
+// the opt-in bf16x3 tower as a stand-alone launch (net_bf16_body.h): bit-packed planes in, f32 NCHW out
+template <int H, int W>
+__global__ __launch_bounds__(512) void tower_fused_bf16(const unsigned* __restrict__ in_bits, const uint4* __restrict__ wfrag, const float* __restrict__ params,
+                                                        TowerArgsBf16 ta, float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char bufs[];
+    towerBodyBf16<H, W>(in_bits, wfrag, params, ta, out, blockIdx.x, threadIdx.x, bufs);
+}
+
+// f32 planes that hold 0 / 1 (every board-game plane) -> one bit per point, the input format of the fused towers
+__global__ __launch_bounds__(256) void pack_bits_kernel(const float* __restrict__ feat, int C, int P, unsigned* __restrict__ bits)
+{
+    const int b = blockIdx.x, W32 = (P + 31) / 32;
+    for (int i = threadIdx.x; i < C * W32; i += 256) {
+        const int c = i / W32, w = i - c * W32;
+        unsigned v = 0;
+        for (int k = 0; k < 32 && w * 32 + k < P; ++k) { v |= (feat[(size_t(b) * C + c) * P + w * 32 + k] != 0.0f ? 1u : 0u) << k; }
+        bits[size_t(b) * C * W32 + i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // dynamics input: cat(hidden[src], action plane) on the channel axis (ref muzero_network.py:32)
 // action_mode 1: board games, one-hot position plane (all zero for pass; ref go.cpp:310-315)
@@ -168,7 +190,109 @@ int Net::reload(const float* raw, size_t n)
     MZ_HIP(hipStreamSynchronize(stream_));
     if (!params_.ensure(packed.size())) { setError("hipMalloc of %zu parameter floats failed", packed.size()); return MZ_ERR_DEVICE; }
     MZ_HIP(hipMemcpy(params_.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    return packBf16(packed);
+}
+
+// ---- opt-in bf16x3 tower: fragments, launch, switch ----
+bool Net::bf16Supported() const
+{
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width;
+    return desc_.type == 0 && desc_.num_hidden_channels == 64 && !repr_.empty() && repr_.size() >= 3 && repr_.size() <= 48 && (repr_.size() % 2) == 1 &&
+           repr_[0].cin <= 32 && ((H == 9 && W == 9) || (H == 8 && W == 8));
+}
+
+static uint16_t bf16Rne(float v)
+{
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) { return static_cast<uint16_t>(u >> 16); } // inf / nan: truncate
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return static_cast<uint16_t>(u >> 16);
+}
+static float bf16ToFloat(uint16_t h)
+{
+    const uint32_t u = static_cast<uint32_t>(h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int Net::packBf16(const std::vector<float>& packed)
+{
+    wfrag_off_.clear();
+    if (!bf16Supported()) { return MZ_OK; }
+    // per layer [tap][oc-tile][k-block][hi, lo][lane][8]: lane = 16 * kg + m holds W'[oc = 16 * ot + m][c = 32 * kb + 8 * kg + j][tap]
+    std::vector<uint16_t> frag;
+    for (const ConvLayer& L : repr_) {
+        const int CG = L.cin_pad / 4, OT = L.cout_pad / 16, KB = (L.cin + 31) / 32;
+        wfrag_off_.push_back(static_cast<unsigned>(frag.size() / 8));
+        for (int t = 0; t < 9; ++t)
+            for (int ot = 0; ot < OT; ++ot)
+                for (int kb = 0; kb < KB; ++kb)
+                    for (int hl = 0; hl < 2; ++hl)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int oc = 16 * ot + (l & 15), c = 32 * kb + 8 * (l >> 4) + j;
+                                float w = 0.0f;
+                                if (oc < L.cout && c < L.cin) { w = packed[L.w_off + ((size_t(t) * CG + c / 4) * OT + oc / 16) * 64 + 16 * (c % 4) + oc % 16]; }
+                                const uint16_t hi = bf16Rne(w);
+                                frag.push_back(hl == 0 ? hi : bf16Rne(w - bf16ToFloat(hi)));
+                            }
+    }
+    if (!wfrag_.ensure(frag.size() / 8)) { setError("hipMalloc of the bf16 fragments failed"); return MZ_ERR_DEVICE; }
+    MZ_HIP(hipMemcpy(wfrag_.p, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return MZ_OK;
+}
+
+bool Net::makeTowerArgsBf16(TowerArgsBf16* out) const
+{
+    if (!bf16Supported() || wfrag_off_.size() != repr_.size()) { return false; }
+    TowerArgsBf16& ta = *out;
+    memset(&ta, 0, sizeof(ta));
+    ta.nlayers = static_cast<int>(repr_.size());
+    ta.cin0 = repr_[0].cin;
+    ta.C = desc_.num_hidden_channels;
+    ta.OT = repr_[0].cout_pad / 16;
+    for (size_t i = 0; i < repr_.size(); ++i) { ta.w_off[i] = wfrag_off_[i]; ta.b_off[i] = static_cast<unsigned>(repr_[i].b_off); }
+    return true;
+}
+
+int Net::setPrecision(int mode)
+{
+    if (mode != 0 && mode != 1) { setError("precision %d unknown (0 = f32, 1 = bf16x3)", mode); return MZ_ERR_ARG; }
+    if (mode == 1 && !bf16Supported()) {
+        setError("mz_nn_precision=bf16x3 is built for AlphaZero networks with 64 hidden channels on 9x9 / 8x8 boards; this network keeps the f32 tower");
+        return MZ_ERR_ARG;
+    }
+    precision_ = mode;
+    return MZ_OK;
+}
+
+template <int H, int W>
+static int launchTowerBf16T(const TowerArgsBf16& ta, const uint4* wfrag, const float* params, const unsigned* bits, float* out, int B, hipStream_t s)
+{
+    constexpr size_t lds = towerBf16LdsBytes<H, W>(false);
+    MZ_LDS_ATTR((tower_fused_bf16<H, W>), lds);
+    hipLaunchKernelGGL((tower_fused_bf16<H, W>), dim3(B), dim3(512), lds, s, bits, wfrag, params, ta, out);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int Net::launchTowerBf16(const float* d_feat, float* out, int B, bool in_bits)
+{
+    TowerArgsBf16 ta;
+    if (!makeTowerArgsBf16(&ta)) { setError("bf16x3 tower: unsupported network"); return MZ_ERR_STATE; }
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width;
+    const unsigned* bits = reinterpret_cast<const unsigned*>(d_feat);
+    if (!in_bits) {
+        const int W32 = (P() + 31) / 32;
+        if (!bits_in_.ensure(size_t(B) * ta.cin0 * W32)) { setError("hipMalloc of the packed planes failed"); return MZ_ERR_DEVICE; }
+        hipLaunchKernelGGL(pack_bits_kernel, dim3(B), dim3(256), 0, stream_, d_feat, ta.cin0, P(), bits_in_.p);
+        MZ_HIP(hipGetLastError());
+        bits = bits_in_.p;
+    }
+    if (H == 9 && W == 9) { return launchTowerBf16T<9, 9>(ta, wfrag_.p, params_.p, bits, out, B, stream_); }
+    return launchTowerBf16T<8, 8>(ta, wfrag_.p, params_.p, bits, out, B, stream_);
 }
 
 int Net::ensureBatch(int B)
@@ -289,6 +413,12 @@ int Net::launchTower(const std::vector<ConvLayer>& t, const float* in, float* ou
 
 int Net::runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, float** d_out, bool in_bits)
 {
+    if (precision_ == 1 && &t == &repr_) {
+        int rc = launchTowerBf16(d_in, act_[0].p, B, in_bits);
+        if (rc) { return rc; }
+        *d_out = act_[0].p;
+        return MZ_OK;
+    }
     bool launched = false;
     int frc = launchTower(t, d_in, act_[0].p, B, &launched, in_bits);
     if (frc) { return frc; }

@@ -423,16 +423,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
 // ---- MuZero (board games; ref muzero_network.h:97-178, zero_actor.cpp:215-245): no leaf environment.  The leaf is evaluated from
 // its parent's hidden state (slab slot `hslot[parent]`) and the move; its children are ALL actions (the root: the legal ones) in
 // the reference's sort order; the new hidden state is rescaled to [0, 1] per sample and written to the slab slot of this simulation.
-__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles)
+__device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, int lane, float* tiles, int* kshare)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
-    slot = __builtin_amdgcn_readfirstlane(slot);
     const PoolView v = ldc(&a->pv);
     const int A = a->A, len = v.path_len[g], depth = len - 1;
     Cand* cs = reinterpret_cast<Cand*>(tiles);
-    Cand* out = cs + A;
-    int* stack = reinterpret_cast<int*>(out + A);
     int k = 0;
     for (int base = 0; base < A; base += 64) {
         const int ac = base + lane;
@@ -442,7 +439,25 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
         k += __popcll(m);
     }
     waveSync();
-    orderCandidates(cs, out, stack, k, lane, a->err);
+    if (k > kCandCoopMax || !a->cand_coop) { orderCandidates(cs, cs + A, reinterpret_cast<int*>(cs + 2 * A), k, lane, a->err); }
+    else { candDense(cs, k, lane, simCandDense(tiles, A)); }
+    if (lane == 0) { *kshare = k; }
+}
+
+__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k)
+{
+    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    k = __builtin_amdgcn_readfirstlane(k);
+    const PoolView v = ldc(&a->pv);
+    const int A = a->A, len = v.path_len[g], depth = len - 1;
+    Cand* cs = reinterpret_cast<Cand*>(tiles);
+    Cand* out = cs + A;
+    if (k > 0 && k <= kCandCoopMax && a->cand_coop) {
+        float* dense = simCandDense(tiles, A);
+        candScatter(cs, out, reinterpret_cast<int*>(out + A), k, 8, lane, reinterpret_cast<const int*>(dense + kCandCoopMax), a->err);
+    }
     for (int i = lane; i < k; i += 64) {
         a->cand_action[size_t(g) * A + i] = out[i].action;
         a->cand_policy[size_t(g) * A + i] = out[i].policy;
@@ -580,7 +595,13 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         simMzHeads<H, W>(a, slot, g, tid, tiles, head_scratch, xt);
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
-        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles); }
+        __shared__ int s_cand_k;
+        if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
+        __syncthreads();
+        const int cand_k = s_cand_k;
+        if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
+        __syncthreads();
+        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k); }
         __syncthreads();
         if (prof && tid == 0) {
             const unsigned long long t4 = wall_clock64();
@@ -852,6 +873,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     size_t scratch = std::max(azCandSmemBytes(a.A), gumbelSmemBytes(a.A));
     scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
     if (scratch > tile_bytes) { return MZ_OK; }
+    a.cand_coop = candCoopSmemBytes(a.A, 8) <= tile_bytes ? 1 : 0;
     const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) + size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int) +
                        head_floats * sizeof(float);
     if (lds > 160 * 1024) { return MZ_OK; }

@@ -95,6 +95,7 @@ def load():
     L.mz_net_reload.argtypes = [vp, fp, C.c_size_t]
     L.mz_net_destroy.argtypes = [vp]
     L.mz_net_get_desc.argtypes = [vp, C.POINTER(NetDesc)]
+    L.mz_net_set_precision.argtypes = [vp, C.c_int]
     L.mz_net_forward_az.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int]
     L.mz_net_initial.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int]
     L.mz_net_recurrent.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
@@ -241,6 +242,10 @@ class Net:
     def reload(self, weights):
         w = np.ascontiguousarray(weights, np.float32)
         _check(self.L, self.L.mz_net_reload(self.h, _f(w), w.size))
+
+    def set_precision(self, name):
+        """'f32' (default) or 'bf16x3' (opt-in split-bf16 tower, outputs within 1e-3 of f32)"""
+        _check(self.L, self.L.mz_net_set_precision(self.h, {"f32": 0, "bf16x3": 1}[name]))
 
     def hidden_size(self):
         d = self.desc
