@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-conf", default="", help="extra k=v:k=v keys (profiling variants only)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="arithmetic of the residual tower: f32 (default, the headline: bit-exact against the oracle) or the opt-in bf16x3 "
+                         "(split-bf16 operands on the 16-bit MFMA, outputs within 1e-3, records not bit-identical) — reported as its own line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +108,8 @@ def main():
     threads = args.threads or max(1, min(32, usable // max(1, world) - 1))  # spin-wait pool incl. the calling thread
     base_conf = mz.CONFIGS["c2"].replace("zero_num_parallel_games=256", f"zero_num_parallel_games={args.games}")
     conf = (f"{base_conf}:zero_num_threads={threads}:mz_pipeline_lanes={args.lanes}:mz_zero_copy={args.zero_copy}:mz_cpu_base={local_rank * threads if args.pin else -1}:program_seed={shard_seed(1, rank)}:"
-            "nn_file_name=synthetic_go_6bx64_seed0.pt" + (":" + args.extra_conf if args.extra_conf else ""))
+            "nn_file_name=synthetic_go_6bx64_seed0.pt" + (":" + args.extra_conf if args.extra_conf else "") +
+            (":mz_nn_precision=bf16x3" if args.precision == "bf16x3" else ""))
     desc = mz.DESCS["c2"]()
     # the optional synchronous weight broadcast (load_model fan-out): rank 0's blob is the one every rank loads
     weights = grp.broadcast_weights(mz.generate_weights(desc, 0))
@@ -161,6 +165,11 @@ def main():
         if not resident:
             raise SystemExit("bench.py: the simulation kernel did not run (sim_launches == 0)")
         achieved = flops_total / (gpu_ms * 1e-3) / 1e12
+        bf = args.precision == "bf16x3"
+        # bf16x3: every product is three MFMAs (hi*hi, hi*lo, lo*hi) at the 16-bit rate: the roofline is the dense bf16 peak against the
+        # MFMA work actually issued (3 x the f32-equivalent FLOPs)
+        peak = 2500.0 if bf else F32_MFMA_PEAK_TFLOPS
+        issued = achieved * (3.0 if bf else 1.0)
         # HBM traffic from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; the x2 on
         # gfx950 per MI355X_MICROARCH.md, re-calibrated on a known-size copy kernel with the same 4-B/lane access, see profiles/README.md)
         traffic, traffic_src = None, None
@@ -175,9 +184,9 @@ def main():
                 pass
         phase = {k: round((s1[k] - s0[k]) / args.steps, 4) for k in ("ms_select", "ms_env", "ms_forward", "ms_expand", "ms_move", "ms_total")}
         out = {
-            "metric": "self-play leaf-evals/s (9x9 Go AlphaZero n=400)", "value": value, "unit": "leaf-evals/s",
+            "metric": "self-play leaf-evals/s (9x9 Go AlphaZero n=400)" + (" — OPT-IN bf16x3 tower, not the headline" if bf else ""), "value": value, "unit": "leaf-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (split-bf16 MFMA inputs, f32 accumulate; outputs within 1e-3 of f32)" if bf else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 9x9 Go AlphaZero, n=400, 6 blocks x 64 ch, 256 parallel games per GPU, "
                                    "synthetic fixed-weight net (seed 0), Dirichlet noise + random rotation + softmax-count moves (reference defaults)",
                        "step": "one move of every game = 401 lock-step cycles = games x 401 leaf evaluations per GPU, per-move host work included",
@@ -193,10 +202,12 @@ def main():
             "per_step_ms": phase,
             "forward": {"ms_per_forward": ms_fwd, "ms_tower_per_forward": ms_tower,
                         "per_layer_kernel": {"us_per_launch": ms_layer * 1e3, "tflops": fl_layer / (ms_layer * 1e-3) / 1e12}},
-            "roofline": {"kernel": "sim_kernel<9,9,20,64,2> (per game: PUCT select, Go leaf position/planes/legal mask, stem + 12 x conv3x3 64->64 on "
-                                   "v_mfma_f32_16x16x4_f32 with activations in LDS, heads, candidate sort, expand + backup)",
-                         "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"kernel": ("sim_kernel<9,9,20,64,2,BF=true> (per game: PUCT select, Go leaf position/planes/legal mask, stem + 12 x conv3x3 64->64 as three "
+                                    "split-bf16 products on v_mfma_f32_16x16x32_bf16 with activations in LDS, heads, candidate sort, expand + backup)") if bf else
+                                   ("sim_kernel<9,9,20,64,2> (per game: PUCT select, Go leaf position/planes/legal mask, stem + 12 x conv3x3 64->64 on "
+                                    "v_mfma_f32_16x16x4_f32 with activations in LDS, heads, candidate sort, expand + backup)"),
+                         "bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s",
+                         "frac": issued / peak, "f32_equivalent_tflops": achieved, "traffic": None if bf else traffic, "traffic_source": None if bf else traffic_src,
                          "launches": launches, "avg_launch_ms": gpu_ms / launches, "flops_per_avg_launch": flops_total / launches,
                          "flops_per_leaf_eval": flops_per_eval, "gpu_ms_per_step": gpu_ms / args.steps,
                          "timing": "HIP events on the worker's stream around every sim_kernel launch of the timed region (2 launches per move: "

@@ -69,6 +69,9 @@ struct WorkerConfig {
     // not a reference key: the worker never plays on its own — run_cycles stops when the searches are complete and the caller decides
     // (mz_worker_search_action / mz_worker_act / mz_worker_reset_search): the per-actor stepping of BaseActor / ZeroActor::think()
     bool mz_manual_step = false;
+    // not a reference key: arithmetic of the residual tower — "f32" (default: bit-exact against the oracle, records identical to the reference)
+    // or "bf16x3" (opt-in: split-bf16 operands on the 16-bit MFMA, outputs within 1e-3, records not bit-identical; net_bf16_body.h)
+    std::string mz_nn_precision = "f32";
     int mz_zero_copy = 3; // bit 0: kernels read their inputs from pinned host memory; bit 1: kernels write their outputs there
 
     // returns false (and sets the library error string) on an unknown key or an unparsable value,

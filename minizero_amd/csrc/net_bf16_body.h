@@ -40,55 +40,92 @@ struct PixSetBf16 {
 
 // One conv3x3 layer (64 -> 64, or the stem with KB = 1 and no lo input) for oc-tile `ot` and NT pixel tiles.
 // out_f32 != nullptr: last layer, f32 padded planes [C][CS] for the heads instead of the bf16 pair.
-template <int H, int W, int KB, int NT, bool CORNER, bool HAS_LO>
+// A fragments travel kAhead steps ahead of their MFMAs in a register ring (a (tap, k-block) step is ~150 cycles of MFMA issue, an L2 round trip
+// several times that); the first kAhead steps of the NEXT layer (next_wf, NKB k-blocks per tap) are fetched before this layer's epilogue and
+// handed over in registers (ring_hi / ring_lo), so that a layer does not start with an exposed round trip.
+constexpr int kBf16Ahead = 4;
+template <int H, int W, int KB, int NT, bool CORNER, bool HAS_LO, int NKB>
 __device__ __forceinline__ void tower_layer_bf16(const char* __restrict__ in_hi, const char* __restrict__ in_lo, const char* __restrict__ skip_hi,
                                                  const char* __restrict__ skip_lo, char* __restrict__ out_hi, char* __restrict__ out_lo,
                                                  float* __restrict__ out_f32, float* __restrict__ gout, const uint4* __restrict__ wf, const float* __restrict__ bias,
-                                                 int OT, int lane, int ot, const PixSetBf16<NT>& px)
+                                                 int OT, int lane, int ot, const PixSetBf16<NT>& px, bool have_first, uint4 (&ring_hi)[kBf16Ahead],
+                                                 uint4 (&ring_lo)[kBf16Ahead], const uint4* __restrict__ next_wf)
 {
     using G = Bf16Geom<H, W>;
-    constexpr int PW = G::PW, CS = planeStride(H, W), P = H * W;
+    constexpr int PW = G::PW, CS = planeStride(H, W), P = H * W, STEPS = 9 * KB, D = kBf16Ahead;
     const int kg = lane >> 4;
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
     const float4 bias4 = *reinterpret_cast<const float4*>(bias + 16 * ot + 4 * kg);
     const float biasv[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
-    auto loadA = [&](int t, int kb, uint4& hi, uint4& lo) {
-        const uint4* p = wf + ((size_t(t) * OT + ot) * KB + kb) * 128 + lane;
+    const uint4* wme = wf + size_t(ot) * KB * 128 + lane;   // step s = (tap, kb): wme[(tap * OT * KB + kb) * 128]
+    auto loadStep = [&](int s, uint4& hi, uint4& lo) {
+        const uint4* p = wme + (size_t(s / KB) * OT * KB + (s % KB)) * 128;
         hi = p[0];
         lo = p[64];
     };
-    uint4 a_hi, a_lo, n_hi, n_lo;
-    loadA(0, 0, a_hi, a_lo);
+    if (!have_first) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+        for (int s = 0; s < D; ++s) { loadStep(s, ring_hi[s], ring_lo[s]); }
+    }
+    // B fragments one step ahead of their MFMAs (the order is pinned: left alone the scheduler puts every LDS read right in front of its
+    // MFMA, and two waves per SIMD then stall on the LDS together)
+    auto bload = [&](int s, uint4 (&bh)[NT], uint4 (&bl)[NT]) {
+        const int t = s / KB, kb = s % KB;
         const int tapoff = (t / 3) * PW + (t % 3);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            // the next step's A fragments are in flight during this step's MFMAs
-            const int nt = kb + 1 < KB ? t : t + 1, nkb = kb + 1 < KB ? kb + 1 : 0;
-            if (nt < 9) { loadA(nt, nkb, n_hi, n_lo); }
-            uint4 b_hi[NT], b_lo[NT];
+        for (int j = 0; j < NT; ++j) {
+            if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; }
+            const int off = actByte(px.src[j] + tapoff, kb * 4 + kg);
+            bh[j] = *reinterpret_cast<const uint4*>(in_hi + off);
+            if constexpr (HAS_LO) { bl[j] = *reinterpret_cast<const uint4*>(in_lo + off); }
+        }
+    };
+    uint4 b_hi[NT], b_lo[NT];
+    bload(0, b_hi, b_lo);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; }
-                const int off = actByte(px.src[j] + tapoff, kb * 4 + kg);
-                b_hi[j] = *reinterpret_cast<const uint4*>(in_hi + off);
-                if constexpr (HAS_LO) { b_lo[j] = *reinterpret_cast<const uint4*>(in_lo + off); }
-            }
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi), al = __builtin_bit_cast(bf16x8, a_lo);
+    for (int s = 0; s < STEPS; ++s) {
+        const int t = s / KB;
+        uint4 n_hi[NT], n_lo[NT];
+        if (s + 1 < STEPS) { bload(s + 1, n_hi, n_lo); }
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, ring_hi[s % D]), al = __builtin_bit_cast(bf16x8, ring_lo[s % D]);
+        if (s + D < STEPS) { loadStep(s + D, ring_hi[s % D], ring_lo[s % D]); } // this slot's fragments are in `ah` / `al` now
+        else if (next_wf) { // the next layer's step s + D - STEPS
+            const int ns = s + D - STEPS;
+            const uint4* p = next_wf + size_t(ot) * NKB * 128 + lane + (size_t(ns / NKB) * OT * NKB + (ns % NKB)) * 128;
+            ring_hi[s % D] = p[0];
+            ring_lo[s % D] = p[64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // product-major: consecutive MFMAs write different accumulators (three on one accumulator back to back wait for each other)
+        if constexpr (HAS_LO) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; } // all-zero B operand: nothing to add
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, b_hi[j]);
-                if constexpr (HAS_LO) { acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, b_lo[j]), acc[j], 0, 0, 0); }
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, b_lo[j]), acc[j], 0, 0, 0);
             }
-            a_hi = n_hi;
-            a_lo = n_lo;
         }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; }
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, b_hi[j]), acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (CORNER && j == NT - 1 && !cornerTapInside(t)) { continue; }
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, b_hi[j]), acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { b_hi[j] = n_hi[j]; if constexpr (HAS_LO) { b_lo[j] = n_lo[j]; } }
+    }
+    if (next_wf) { // the ring now holds the next layer's steps in slot order (STEPS + i) % D for step i: rotate to slot i
+        uint4 th[D], tl[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { th[i] = ring_hi[(STEPS + i) % D]; tl[i] = ring_lo[(STEPS + i) % D]; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) { ring_hi[i] = th[i]; ring_lo[i] = tl[i]; }
     }
     // epilogue: + bias (+ skip), ReLU; D layout of the 16x16 MFMA: lane (n = lane & 15, kg) holds output channels 16 * ot + 4 * kg + r at pixel n
     const int ocb = 16 * ot + 4 * kg;
@@ -150,15 +187,18 @@ __device__ __forceinline__ void towerRunBf16(const uint4* __restrict__ wfrag, co
     char* xl = bufs + G::kBufBytes;
     char* th = bufs + 2 * G::kBufBytes;   // the temporary; holds the stem's input planes (hi only: they are 0 / 1) on entry
     char* tl = bufs + 3 * G::kBufBytes;
+    uint4 ring_hi[kBf16Ahead], ring_lo[kBf16Ahead];
     // stem: t -> x
-    tower_layer_bf16<H, W, 1, NT, CORNER, false>(th, nullptr, nullptr, nullptr, xh, xl, nullptr, nullptr, wfrag + ta.w_off[0], params + ta.b_off[0], ta.OT, lane, ot, px);
+    tower_layer_bf16<H, W, 1, NT, CORNER, false, 2>(th, nullptr, nullptr, nullptr, xh, xl, nullptr, nullptr, wfrag + ta.w_off[0], params + ta.b_off[0], ta.OT, lane,
+                                                   ot, px, false, ring_hi, ring_lo, wfrag + ta.w_off[1]);
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l < ta.nlayers; ++l) { // residual blocks: t = relu(conv1(x)); x = relu(conv2(t) + x)
         const bool second = ((l - 1) & 1) != 0, last = l + 1 == ta.nlayers;
-        tower_layer_bf16<H, W, 2, NT, CORNER, true>(second ? th : xh, second ? tl : xl, second ? xh : nullptr, second ? xl : nullptr, second ? xh : th,
-                                                    second ? xl : tl, last ? out_f32 : nullptr, last ? gout : nullptr, wfrag + ta.w_off[l],
-                                                    params + ta.b_off[l], ta.OT, lane, ot, px);
+        tower_layer_bf16<H, W, 2, NT, CORNER, true, 2>(second ? th : xh, second ? tl : xl, second ? xh : nullptr, second ? xl : nullptr, second ? xh : th,
+                                                       second ? xl : tl, last ? out_f32 : nullptr, last ? gout : nullptr, wfrag + ta.w_off[l],
+                                                       params + ta.b_off[l], ta.OT, lane, ot, px, true, ring_hi, ring_lo,
+                                                       last ? nullptr : wfrag + ta.w_off[l + 1]);
         __syncthreads();
     }
 }

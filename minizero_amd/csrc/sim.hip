@@ -20,6 +20,7 @@ __shared__ int s_tp_idx;
     } while (0)
 #endif
 #include "net_body.h"
+#include "net_bf16_body.h"
 #ifdef MZ_SIM_HPROF // experiment: where the time of the in-kernel 601-bin heads goes (game 0)
 __device__ unsigned long long g_hp[16];
 __shared__ unsigned long long s_hp_prev;
@@ -87,6 +88,9 @@ struct SimArgs {
     float* reward;                    // [games] reward head output (game scale)
     int no_spec;                      // MZ_NO_SPEC=1: path speculation of the walk off (experiments)
     int cand_coop;                    // the candidate rank sort is shared by the 8 waves (its scratch fits the tower tiles)
+    // opt-in bf16x3 tower (net_bf16_body.h): fragments + layer table; used by the BF instantiations of sim_kernel
+    const uint4* wfrag;
+    TowerArgsBf16 tb;
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
 
@@ -319,8 +323,11 @@ __device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, 
 // tree phases and barrier bubbles are filled by the other's tower
 // waves per SIMD the kernel is compiled for: 4 (= two resident workgroups per CU, 128 VGPRs) for boards up to 64 points, whose tower
 // fits that register budget; 9x9 Go keeps 2 (its 6 pixel tiles per wave pair need ~166 VGPRs, and BASELINE's 256 games are one per CU)
-template <int H, int W, int CIN0_PAD, int CPAD>
-constexpr int simWavesPerEu() { return (H * W <= 64 && kTowerTiles * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W) * 4 <= 76 * 1024) ? 4 : 2; }
+template <int H, int W, int CIN0_PAD, int CPAD, bool BF = false>
+constexpr int simWavesPerEu() { return (!BF && H * W <= 64 && kTowerTiles * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W) * 4 <= 76 * 1024) ? 4 : 2; }
+// floats of the LDS region the tower works in (the tree phases and the heads take their scratch from its start)
+template <int H, int W, int CIN0_PAD, int CPAD, bool BF>
+constexpr int simTileFloats() { return BF ? towerBf16LdsBytes<H, W>(true) / 4 : kTowerTiles * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W); }
 
 template <int H, int W, int CIN0_PAD, int CPAD>
 __device__ __noinline__ const float* simTower(CSimArgs* __restrict__ a, int g, int tid, float* tiles, float* xchg)
@@ -335,16 +342,26 @@ __device__ __noinline__ const float* simTower(CSimArgs* __restrict__ a, int g, i
     return towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(gv.feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
 }
 
-template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPerEu<H, W, CIN0_PAD, CPAD>(), 4))) void sim_kernel(const SimArgs* __restrict__ a_, const uint8_t* __restrict__ rot_tab, int sim0, int nsims, int host_start)
+// the opt-in bf16x3 tower inside the simulation kernel: same hand-over (bit-packed planes in, f32 padded planes out) as simTower
+template <int H, int W>
+__device__ __noinline__ const float* simTowerBf16(CSimArgs* __restrict__ a, int g, int tid, float* tiles, float* xchg)
+{
+    g = __builtin_amdgcn_readfirstlane(g);
+    const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
+    return towerBodyBf16<H, W>(reinterpret_cast<const unsigned*>(gv.feat), a->wfrag, a->params, *(const TowerArgsBf16*)&a->tb, nullptr, g, tid,
+                               reinterpret_cast<char*>(tiles));
+}
+
+template <int H, int W, int CIN0_PAD, int CPAD, int CPL, bool BF = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPerEu<H, W, CIN0_PAD, CPAD, BF>(), 4))) void sim_kernel(const SimArgs* __restrict__ a_, const uint8_t* __restrict__ rot_tab, int sim0, int nsims, int host_start)
 {
     CSimArgs* a = (CSimArgs*)a_;
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int games = gridDim.x;
-    constexpr int WPE = simWavesPerEu<H, W, CIN0_PAD, CPAD>();
-    // the reciprocal table of the PUCT divisions lives in LDS above the three tower tiles for the whole launch
-    constexpr int kTileFloats = kTowerTiles * (CIN0_PAD > CPAD ? CIN0_PAD : CPAD) * planeStride(H, W);
+    constexpr int WPE = simWavesPerEu<H, W, CIN0_PAD, CPAD, BF>();
+    // the reciprocal table of the PUCT divisions lives in LDS above the tower's tiles for the whole launch
+    constexpr int kTileFloats = simTileFloats<H, W, CIN0_PAD, CPAD, BF>();
     double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
     for (int i = tid; i < a->rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
     __syncthreads();
@@ -395,7 +412,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         }
         if (prof) { t1 = wall_clock64(); }
         const float* xt;
-        xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles, xchg); // its own function: its own register budget
+        if constexpr (BF) { xt = simTowerBf16<H, W>(a, g, tid, tiles, xchg); }
+        else { xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles, xchg); } // its own function: its own register budget
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
         if constexpr (WPE == 4) { simHeadsImpl<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
@@ -625,11 +643,11 @@ static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, i
     X(6, 6, 64, 84, 64)  /* muzero_atari dynamics, 64 channels + 18 action planes (BASELINE configs[4]); the representation runs stand-alone */ \
     X(6, 6, 32, 52, 32)  /* small muzero_atari test nets */
 
-template <int H, int W, int CIN0_PAD, int CPAD, int CPL>
+template <int H, int W, int CIN0_PAD, int CPAD, int CPL, bool BF = false>
 static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
 {
-    MZ_LDS_ATTR((sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), lds);
-    hipLaunchKernelGGL((sim_kernel<H, W, CIN0_PAD, CPAD, CPL>), dim3(games), dim3(512), lds, s, d_args, d_rot, sim0, nsims, host_start);
+    MZ_LDS_ATTR((sim_kernel<H, W, CIN0_PAD, CPAD, CPL, BF>), lds);
+    hipLaunchKernelGGL((sim_kernel<H, W, CIN0_PAD, CPAD, CPL, BF>), dim3(games), dim3(512), lds, s, d_args, d_rot, sim0, nsims, host_start);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
@@ -765,8 +783,14 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
     const int cmax = c0 > C ? c0 : C;
+    const bool bf = precision_ == 1;
+    if (bf) {
+        if (!makeTowerArgsBf16(&a.tb)) { setError("simLaunch: bf16x3 tower not available for this network"); return MZ_OK; }
+        a.wfrag = wfrag_.p;
+    }
     // LDS: the tower tiles, and above them the reciprocal table; the heads and wave 0's tree phases take their scratch from the tiles
-    const size_t tile_bytes = size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float);
+    const size_t tile_bytes = bf ? size_t(4) * ((((H + 2) * (W + 2) + 16) / 16) * 16) * 128 + size_t(64) * planeStride(H, W) * 4
+                                 : size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float);
     const size_t heads = (size_t(a.hp.PC) * a.hp.P + a.hp.P + a.hp.VH + a.hp.A + 16) * sizeof(float); // in tile 0 (the activations stay in tile 1)
     size_t scratch = std::max(std::max(goLeafSmemBytes(gv, pool.v_.max_depth), azCandSmemBytes(gv.A)), gumbelSmemBytes(gv.A));
     scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
@@ -776,7 +800,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
         return MZ_OK;
     }
     // (+ the path-speculation memory of the one-game-per-CU kernels: same condition as simWavesPerEu() == 2)
-    const bool two_per_cu = H * W <= 64 && tile_bytes <= size_t(76) * 1024;
+    const bool two_per_cu = !bf && H * W <= 64 && tile_bytes <= size_t(76) * 1024;
     const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) +
                        (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int)) + (simXchgWords(gv.A, gv.channels, gv.W32) + 2 + 2 * size_t(pool.v_.max_depth) + 2) * sizeof(float) +
                        ((gv.kind == 0 && !two_per_cu) ? size_t(kGoSeenCap) * sizeof(uint64_t) : 0);
@@ -787,6 +811,12 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
         MZ_HIP(hipStreamSynchronize(stream_));
         MZ_HIP(hipMemcpy(sim_args_.p, &a, sizeof(SimArgs), hipMemcpyHostToDevice));
         sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
+    }
+    if (lds > size_t(160) * 1024) { setError("simLaunch: %zu bytes of LDS needed", lds); return MZ_OK; }
+    if (bf) { // the two BASELINE shapes the bf16x3 tower is built for
+        if (H == 9 && W == 9 && c0 == 20 && C == 64 && gv.n == 9 && gv.kind == 0 && gv.W == 2) { *launched = true; return launchSimT<9, 9, 20, 64, 2, true>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
+        if (H == 8 && W == 8 && c0 == 4 && C == 64 && gv.n == 8 && gv.kind == 1) { *launched = true; return launchSimT<8, 8, 4, 64, 0, true>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
+        return MZ_OK;
     }
 #define MZ_SIM_LAUNCH(h, w, cin0, cpad, cpl) \
     if (H == h && W == w && c0 == cin0 && C == cpad && gv.n == h && (gv.kind == 2 ? -1 : gv.kind == 1 ? 0 : gv.W) == cpl) { *launched = true; return launchSimT<h, w, cin0, cpad, cpl>(reinterpret_cast<const SimArgs*>(sim_args_.p), gv.games, d_rot, sim0, nsims, host_start ? 1 : 0, lds, stream_); }

@@ -38,3 +38,46 @@ def test_bf16x3_is_refused_where_it_is_not_built(mz):
         net = mz.Net(d, mz.generate_weights(d, 0))
         with pytest.raises(mz.MzError):
             net.set_precision("bf16x3")
+
+
+def _records(mz, key, games, cycles, prec, seed=1):
+    d = mz.DESCS[key]()
+    conf = mz.CONFIGS[key].replace(mz.CONFIGS[key].split("zero_num_parallel_games=")[1].split(":")[0], str(games))
+    wk = mz.Worker(f"{conf}:program_seed={seed}:nn_file_name=s.pt:zero_num_threads=2:mz_nn_precision={prec}", d, mz.generate_weights(d, 0))
+    wk.command("start")
+    assert wk.run_cycles(cycles) == cycles
+    st = wk.stats()
+    assert st["sim_launches"] > 0
+    return wk.peek_records(games), wk.pop_lines()
+
+
+@pytest.mark.parametrize("key,games,cycles", [("c2", 16, 401 * 3 + 1), ("c3", 64, 17 * 20 + 1)])
+def test_bf16x3_search_in_the_simulation_kernel(mz, key, games, cycles):
+    """The opt-in tower inside sim_kernel<..., BF = true>: the search code is the f32 kernel's (template), only the leaf evaluation differs by
+    ~1e-6, so the visit distributions of the first moves are the f32 mode's in (nearly) every game; records stay well-formed."""
+    import re
+    r32, _ = _records(mz, key, games, cycles, "f32")
+    r16, _ = _records(mz, key, games, cycles, "bf16x3")
+    same = total = 0
+    for a, b in zip(r32, r16):
+        pa, pb = re.findall(r";[BW]\[(\d+)\]P\[([^\]]*)\]", a), re.findall(r";[BW]\[(\d+)\]P\[([^\]]*)\]", b)
+        assert len(pa) == len(pb) >= 1
+        total += 1
+        # the first move: identical RNG stream, identical position — only the network arithmetic differs.  PUCT roots print integer visit
+        # counts (compared exactly), Gumbel roots print the improved policy as 6-digit floats (compared to 1e-3)
+        da, db = (dict((x.split(":")[0], float(x.split(":")[1])) for x in pp[0][1].split(",")) for pp in (pa, pb))
+        same += pa[0][0] == pb[0][0] and da.keys() == db.keys() and all(abs(da[k] - db[k]) <= (1e-3 if "." in pa[0][1] else 0) for k in da)
+        for mv, p in pb:
+            counts = [float(x.split(":")[1]) for x in p.split(",")]
+            assert all(c > 0 for c in counts)
+    assert same >= 0.9 * total, f"{key}: only {same} of {total} first-move visit distributions equal those of the f32 mode"
+    print(f"{key}: first-move visit distributions identical to the f32 mode in {same} of {total} games")
+
+
+def test_bf16x3_worker_refuses_unsupported_networks(mz):
+    d = mz.DESCS["c4"]()
+    with pytest.raises(mz.MzError):
+        mz.Worker(mz.CONFIGS["c4"] + ":program_seed=1:mz_nn_precision=bf16x3", d, mz.generate_weights(d, 0))
+    d2 = mz.DESCS["c2"]()
+    with pytest.raises(mz.MzError):
+        mz.Worker(mz.CONFIGS["c2"] + ":program_seed=1:mz_nn_precision=fp8", d2, mz.generate_weights(d2, 0))
