@@ -4,6 +4,10 @@
 #include "net_dev.h"
 #include <type_traits>
 
+#ifndef MZ_HPROF
+#define MZ_HPROF(k) // experiment hook (sim.hip -DMZ_SIM_HPROF): time stamps inside the heads
+#endif
+
 namespace mz {
 
 // ---------------------------------------------------------------------------------------------
@@ -495,6 +499,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
         __syncthreads();
     }
 
+    MZ_HPROF(5);
     // conv1x1 + folded BN + ReLU: PC policy planes and 1 value plane, one output element per thread
     for (int i = tid; i < (PC + 1) * P; i += NT) {
         const int j = i / P, p = i - j * P;
@@ -506,6 +511,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
         if (j < PC) { pf[i] = v; } else { vf[p] = v; }
     }
     __syncthreads();
+    MZ_HPROF(6);
 
     // policy FC (one logit per thread, waves 0..) and value FC1 (one hidden unit per thread, on other waves when there are enough)
     for (int a = tid; a < A; a += NT) {
@@ -521,6 +527,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
         }
     }
     __syncthreads();
+    MZ_HPROF(7);
 
     // value FC2 + tanh: one sequential chain (wave 1, lane 0) while wave 0 does the softmax
     if (tid == 64) {
@@ -537,6 +544,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
         float s = 0.0f;
         for (int a = 0; a < A; ++a) { s += lg[a]; } // index-order sum, every lane redundantly (LDS broadcast)
         for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lg[a] / s; }
+        MZ_HPROF(8);
     }
 }
 

@@ -525,14 +525,17 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
                                                  const float* __restrict__ cand_policy, const float* __restrict__ cand_logit,
                                                  const int* __restrict__ cand_player, const float* __restrict__ value_in,
                                                  const float* __restrict__ reward_in, int hslot, int* __restrict__ err, int g, int lane,
-                                                 float* __restrict__ lds)
+                                                 float* __restrict__ lds, int part = 0)
 {
+    // part 0: expand, then backup (one wave).  The two touch different words of the tree (expand: the new children, the leaf's child block and
+    // slot; backup: mean / count of the path's nodes and the parent's visited-prefix counter), so without value rescaling two waves can run
+    // them side by side: part 1 = expand only, part 2 = backup only (cand_count is not read).
     const size_t base = size_t(g) * v.cap;
     const int len = v.path_len[g];
     if (len <= 0) { return; }
     const int* path = v.path + size_t(g) * v.max_depth;
     const int leaf = path[len - 1];
-    const int k = cand_count[g];
+    const int k = part == 2 ? 0 : cand_count[g];
     // ---- expand (ref mcts.cpp:151-164, tree.h:71-77) ----
     if (k > 0) {
         const int fc = v.num_nodes[g];
@@ -563,8 +566,9 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
             v.num_nodes[g] = fc + k;
         }
     }
-    if (lane == 0 && hslot >= 0) { v.hslot[base + leaf] = hslot; }
+    if (part != 2 && lane == 0 && hslot >= 0) { v.hslot[base + leaf] = hslot; }
     MZ_LPROF(10);
+    if (part == 1) { return; }
     // ---- backup (ref mcts.cpp:166-179) ----
     if (!v.value_rescale) {
         // The only leaf -> root dependence is `updated = r + gamma * updated`, which needs the rewards but not the means: the

@@ -19,8 +19,6 @@ __shared__ int s_tp_idx;
         }                                                                                      \
     } while (0)
 #endif
-#include "net_body.h"
-#include "net_bf16_body.h"
 #ifdef MZ_SIM_HPROF // experiment: where the time of the in-kernel 601-bin heads goes (game 0)
 __device__ unsigned long long g_hp[16];
 __shared__ unsigned long long s_hp_prev;
@@ -33,6 +31,8 @@ __shared__ unsigned long long s_hp_prev;
         }                                                                                             \
     } while (0)
 #endif
+#include "net_body.h"
+#include "net_bf16_body.h"
 #include "net_atari_body.h"
 #ifdef MZ_SIM_LPROF // experiment: where the time of the single-wave tree phases goes (game 0)
 __device__ unsigned long long g_lp[32];
@@ -123,12 +123,12 @@ struct SimXchg { // word offsets inside the block for A actions
     __device__ int cpolicy() const { return 2 * A; }
     __device__ int clogit() const { return 3 * A; }
     __device__ int caction() const { return 4 * A; }
-    __device__ int scalars() const { return 5 * A; } // value, cand_count, cand_player, value_io, reward_io, leaf_player, terminal, eval
-    __device__ int legal() const { return 5 * A + 8; }   // 64-bit words of the leaf's legal mask (8-byte aligned: A is padded to even below)
-    __device__ int feat() const { return 5 * A + 8 + 16; } // the leaf's bit-packed planes (the tower's input)
+    __device__ int scalars() const { return 5 * A; } // value, cand_count, cand_player, value_io, reward_io, leaf_player, terminal, eval, + the backup wave's value / reward
+    __device__ int legal() const { return 5 * A + 12; }   // 64-bit words of the leaf's legal mask (8-byte aligned: A is padded to even below)
+    __device__ int feat() const { return 5 * A + 12 + 16; } // the leaf's bit-packed planes (the tower's input)
 };
-inline size_t simXchgWords(int A, int channels, int W32) { return size_t(5) * (A + (A & 1)) + 8 + 16 + size_t(channels) * W32; }
-__device__ __forceinline__ int simXchgWordsDev(int A, int channels, int W32) { return 5 * (A + (A & 1)) + 8 + 16 + channels * W32; }
+inline size_t simXchgWords(int A, int channels, int W32) { return size_t(5) * (A + (A & 1)) + 12 + 16 + size_t(channels) * W32; }
+__device__ __forceinline__ int simXchgWordsDev(int A, int channels, int W32) { return 5 * (A + (A & 1)) + 12 + 16 + channels * W32; }
 
 // ... and so does the path of the simulation (node ids, moves, length): written by the walk, read by the leaf and by expand + backup
 __device__ __forceinline__ PoolView simPathView(PoolView pv, int* lds_path, int g)
@@ -229,8 +229,27 @@ __device__ __forceinline__ void simCandRank(int A, int k, int wave, int lane, fl
     candRankPart(dense, k, wave, 8, lane, reinterpret_cast<int*>(dense + kCandCoopMax));
 }
 
+// The backup of a simulation on its own wave (wave 1) beside wave 0's scatter + expand: it only needs the leaf's value (the heads' output, or
+// the game result at a terminal leaf: zero_actor.cpp:85) and the path.  Not with value rescaling (its multiset shares the scratch).
 template <int WPE>
-__device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, float* xchg)
+__device__ __noinline__ void simBackupOnly(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, float* xchg)
+{
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
+    const PoolView pv = simPathView(ldc(&a->pv), reinterpret_cast<int*>(xchg) - 2 * a->pv.max_depth - 2, g);
+    const SimXchg x{gv.A + (gv.A & 1)};
+    float* sc = xchg + x.scalars();
+    if (lane == 0) {
+        sc[8] = gv.terminal[g] != 0 ? gv.eval[g] : sc[0];
+        sc[9] = 0.0f; // board games have no rewards (go.h:50)
+    }
+    waveSync();
+    expandBackupBody(pv, nullptr, nullptr, nullptr, nullptr, nullptr, sc + 8 - g, sc + 9 - g, slot, a->err, g, lane, tiles, 2);
+}
+
+template <int WPE>
+__device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, float* xchg, int part)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -256,7 +275,7 @@ __device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, in
     waveSync();
     MZ_LPROF(9);
     expandBackupBody(pv, cand_count, cand_action, xchg + x.cpolicy() - ga, xchg + x.clogit() - ga, cand_player, sc + 3 - g, sc + 4 - g, slot, a->err, g,
-                     lane, tiles);
+                     lane, tiles, part);
     MZ_LPROF(12);
 }
 
@@ -428,7 +447,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
             if (a->cand_coop) { simCandRank(A, reinterpret_cast<const int*>(xchg + x.scalars())[1], wave, lane, tiles); }
         }
         __syncthreads();
-        if (wave == 0) { simCandExpand<WPE>(a, rot, slot, g, lane, tiles, xchg); }
+        {
+            const bool split = !a->pv.value_rescale; // backup beside expand on a second wave
+            if (wave == 0) { simCandExpand<WPE>(a, rot, slot, g, lane, tiles, xchg, split ? 1 : 0); }
+            else if (wave == 1 && split) { simBackupOnly<WPE>(a, slot, g, lane, tiles, xchg); }
+        }
         __syncthreads();
         if (prof && tid == 0) {
             t4 = wall_clock64();
@@ -665,7 +688,7 @@ void Net::dumpSimProf()
     {
         unsigned long long h[16];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hp), sizeof(h)) == hipSuccess && h[15]) {
-            fprintf(stderr, "[mz sim hprof] us per phase of discreteHead (game 0, avg over %llu calls):", h[15]);
+            fprintf(stderr, "[mz sim hprof] us per section of the heads (game 0, avg over %llu calls; board games: [1] tail wait, [5] setup, [6] conv1x1, [7] FCs, [8] FC2 / softmax):", h[15]);
             for (int i = 1; i < 10; ++i) { fprintf(stderr, " %.2f", double(h[i]) / double(h[15]) * 0.01); }
             fprintf(stderr, "\n");
         }
