@@ -1,23 +1,34 @@
 #!/bin/bash
 # Regenerates the round's evidence under gpurun_out/refresh/ on the GPU box (copy what should be judged into profiles/):
-#   bench.json                default bench line (un-profiled)
-#   kernel_stats.csv          rocprofv3 --kernel-trace --stats of the same command
-#   pmc_sim.json              FETCH_SIZE / WRITE_SIZE pass of the same command -> HBM bytes per step of sim_kernel
+#   bench.json                default bench line (un-profiled): 20 timed moves + the 164-move games/s leg + cpu_baseline
+#   bench_bf16x3.json         the opt-in bf16x3 line (own roofline against the bf16 peak)
+#   kernel_stats.csv          rocprofv3 --kernel-trace --stats of `bench.py --steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline` (5 moves = 2005 cycles)
+#   pmc_sim.json              FETCH_SIZE / WRITE_SIZE passes of the same command -> HBM bytes per lock-step cycle of sim_kernel
 #   pmc_util.json             MFMA-busy / LDS-conflict pass
-#   configs.json              all five BASELINE configs (tools/run_configs.py)
-#   cycle_hist.txt            per-cycle histogram + cgroup throttle counters
+#   configs.json              all five BASELINE configs with a roofline block each (tools/run_configs.py)
+#   kernel_stats_c{3,4,5}.csv + pmc_c{3,4,5}.json   rocprofv3 stats / PMC of the other configs' simulation kernels
+#   sim_prof.txt              in-kernel phase profile (MZ_SIM_PROF=1)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 O=gpurun_out/refresh
 rm -rf $O; mkdir -p $O
-timeout 300 python bench.py > $O/bench.json 2> $O/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline > $O/bench_profiled.json 2> $O/stats.err
+SHORT="--steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline"
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 python bench.py --precision bf16x3 --no-cpu-baseline > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py $SHORT > $O/bench_profiled.json 2> $O/stats.err
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
 # FETCH_SIZE takes 3 of the 4 TCC slots and WRITE_SIZE 2: one pass each (MI355X_MICROARCH.md, PMC section)
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc1a -- python bench.py --no-cpu-baseline > $O/bench_pmc1a.json 2> $O/pmc1a.err
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc1b -- python bench.py --no-cpu-baseline > $O/bench_pmc1b.json 2> $O/pmc1b.err
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc2 -- python bench.py --no-cpu-baseline > $O/bench_pmc2.json 2> $O/pmc2.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc1a -- python bench.py $SHORT > $O/bench_pmc1a.json 2> $O/pmc1a.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc1b -- python bench.py $SHORT > $O/bench_pmc1b.json 2> $O/pmc1b.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc2 -- python bench.py $SHORT > $O/bench_pmc2.json 2> $O/pmc2.err
+for k in c3 c4 c5; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$k -- python tools/run_configs.py $k --out $O/configs_prof_$k.json > $O/stats_$k.log 2>&1
+  cp $(find $O/stats_$k -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$k.csv 2>/dev/null
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcA_$k -- python tools/run_configs.py $k --out $O/tmp.json > $O/pmcA_$k.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmcB_$k -- python tools/run_configs.py $k --out $O/tmp.json > $O/pmcB_$k.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmcC_$k -- python tools/run_configs.py $k --out $O/tmp.json > $O/pmcC_$k.log 2>&1
+done
 python - <<'PY'
 import csv, glob, json, collections
 O = "gpurun_out/refresh"
@@ -29,26 +40,33 @@ def load(d):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] in ("FETCH_SIZE", "GRBM_GUI_ACTIVE"): n[k] += 1
     return acc, n
-steps = 802 + 40
-a, n = load("pmc1a")
-aw, _ = load("pmc1b")
-if "sim_kernel" in a and "sim_kernel" in aw:
-    s = dict(a["sim_kernel"]); s["WRITE_SIZE"] = aw["sim_kernel"]["WRITE_SIZE"]
-    json.dump({"kernel": "sim_kernel", "dispatches": n["sim_kernel"], "steps": steps, "FETCH_SIZE_KB_total": s["FETCH_SIZE"], "WRITE_SIZE_KB_total": s["WRITE_SIZE"],
-               "bytes_per_step": (2.0 * s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024.0 / steps,
-               "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950: FETCH_SIZE counts 64-B units as 32 B; re-calibrated on a copy kernel), over all launches of "
-                       "`python bench.py --no-cpu-baseline` (40 warm-up + 802 timed steps)"}, open(f"{O}/pmc_sim.json", "w"), indent=1)
-b, n2 = load("pmc2")
-if "sim_kernel" in b:
-    s = b["sim_kernel"]
-    # SQ_VALU_MFMA_BUSY_CYCLES = sum over the 1024 SIMDs of their MFMA-pipe busy cycles (checked: 32 cycles x the kernel's MFMA count);
-    # GRBM_GUI_ACTIVE = GPU-active cycles summed over the 8 XCDs -> SIMD-cycles available = GRBM_GUI_ACTIVE / 8 * 1024
-    json.dump({"kernel": "sim_kernel", "SQ_VALU_MFMA_BUSY_CYCLES": s["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": s["GRBM_GUI_ACTIVE"],
-               "mfma_busy_frac_of_all_simd_cycles": s["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1.0, s["GRBM_GUI_ACTIVE"] * 128.0),
-               "SQ_LDS_BANK_CONFLICT": s["SQ_LDS_BANK_CONFLICT"], "SQ_LDS_IDX_ACTIVE": s["SQ_LDS_IDX_ACTIVE"],
-               "lds_conflict_frac": s["SQ_LDS_BANK_CONFLICT"] / max(1.0, s["SQ_LDS_IDX_ACTIVE"])}, open(f"{O}/pmc_util.json", "w"), indent=1)
+def summarize(tag, a_dir, b_dir, c_dir, cycles, note):
+    a, n = load(a_dir); aw, _ = load(b_dir); b, _ = load(c_dir)
+    out = {}
+    if "sim_kernel" in a and "sim_kernel" in aw:
+        f, w = a["sim_kernel"]["FETCH_SIZE"], aw["sim_kernel"]["WRITE_SIZE"]
+        out.update({"kernel": "sim_kernel", "dispatches": n["sim_kernel"], "lockstep_cycles": cycles, "FETCH_SIZE_KB_total": f, "WRITE_SIZE_KB_total": w,
+                    "bytes_per_cycle": (2.0 * f + w) * 1024.0 / cycles,
+                    "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950: FETCH_SIZE reports half of the bytes, MI355X_MICROARCH.md HBM section; re-calibrated on a copy kernel), " + note})
+    if "sim_kernel" in b:
+        s = b["sim_kernel"]
+        out.update({"SQ_VALU_MFMA_BUSY_CYCLES": s["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": s["GRBM_GUI_ACTIVE"],
+                    "mfma_busy_frac_of_all_simd_cycles": s["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1.0, s["GRBM_GUI_ACTIVE"] * 128.0),
+                    "lds_conflict_frac": s["SQ_LDS_BANK_CONFLICT"] / max(1.0, s["SQ_LDS_IDX_ACTIVE"])})
+    json.dump(out, open(f"{O}/{tag}.json", "w"), indent=1)
+summarize("pmc_sim", "pmc1a", "pmc1b", "pmc2", 5 * 401, "over all launches of `python bench.py --steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline` (5 moves x 401 cycles x 256 games)")
+MOVES = {"c3": (40 + 2) * 17, "c4": (20 + 2) * 51, "c5": (12 + 2) * 51}
+for k, cyc in MOVES.items():
+    summarize(f"pmc_{k}", f"pmcA_{k}", f"pmcB_{k}", f"pmcC_{k}", cyc, f"over all simulation-kernel launches of `python tools/run_configs.py {k}` ({cyc} lock-step cycles incl. warm-up)")
 PY
-timeout 600 python tools/run_configs.py > $O/configs.log 2>&1; cp gpurun_out/configs.json $O/configs.json 2>/dev/null
-timeout 300 python tools/cycle_hist.py 600 > $O/cycle_hist.txt 2>&1
-MZ_SIM_PROF=1 timeout 200 python bench.py --no-cpu-baseline 2>&1 | grep "sim prof" > $O/sim_prof.txt
-ls -la $O | head -30; cat $O/pmc_sim.json $O/pmc_util.json 2>/dev/null; tail -c 1500 $O/bench.json; cat $O/sim_prof.txt
+timeout 900 python tools/run_configs.py --out $O/configs.json > $O/configs.log 2>&1
+MZ_SIM_PROF=1 timeout 200 python bench.py $SHORT 2>&1 | grep "sim prof" > $O/sim_prof.txt
+rm -rf $O/stats $O/stats_c* $O/pmc1a $O/pmc1b $O/pmc2 $O/pmcA_* $O/pmcB_* $O/pmcC_* $O/tmp.json
+ls -la $O | head -40; cat $O/pmc_sim.json; for k in c3 c4 c5; do cat $O/pmc_$k.json; done; python tools/kstats.py $O/kernel_stats.csv | head -6
+python - <<'PY'
+import json
+j = json.load(open("gpurun_out/refresh/bench.json")); print("f32", round(j["value"]), j["ms_per_step"], j["games_per_sec"], j["roofline"]["frac"], j["cpu_baseline"]["value"])
+j = json.load(open("gpurun_out/refresh/bench_bf16x3.json")); print("bf16x3", round(j["value"]), j["ms_per_step"], j["games_per_sec"], j["roofline"]["frac"])
+d = json.load(open("gpurun_out/refresh/configs.json"))
+for k, v in d.items(): print(k, round(v["leaf_evals_per_sec"]), v["roofline"]["frac"], v["roofline"]["wall_frac"])
+PY

@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import minizero_amd as mz  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3
-MOVES = {"c1": 400, "c2": 4, "c3": 40, "c4": 20, "c5": 12}
+MOVES = {"c1": 400, "c2": 4, "c3": 40, "c4": 20, "c5": 40}
+WARM = {"c5": 14}  # moves before the timed region (default 2): the Atari-shaped worker's first moves pay one-off host allocations
 KERNEL = {"c1": "sim_kernel<3,3,4,16,-1>", "c2": "sim_kernel<9,9,20,64,2>", "c3": "sim_kernel<8,8,4,64,0>", "c4": "sim_kernel_mz<9,9,20,68,64>",
           "c5": "sim_kernel_mz<6,6,64,84,64>"}
 
@@ -56,7 +57,7 @@ def main():
         wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
         wk.command("start")
         moves = moves_override or MOVES[key]
-        wk.run_cycles(2 * (n + 1))
+        wk.run_cycles(WARM.get(key, 2) * (n + 1))
         s0 = wk.stats()
         t0 = time.perf_counter()
         for _ in range(moves):
