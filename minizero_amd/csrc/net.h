@@ -145,7 +145,11 @@ private:
     DevBuf<unsigned long long> sim_prof_; // MZ_SIM_PROF=1: per-phase tick counters of sim_kernel
     void dumpSimProf();
     DevBuf<unsigned> sim_sink_;
+    DevBuf<char> sim_cluster_mem_; // cluster mode of the MuZero simulation kernel (sim_cluster.h): per-game exchange blocks
+    int cu_count_ = 0;
+    bool coop_launch_ = false;
 public:
+    bool sim_cluster_ = true;   // four workgroups per game when 4 x games <= CUs (muzero_atari instances); false: always one workgroup per game
     bool use_fused_ = true;     // fused persistent tower kernel (same arithmetic as the per-layer kernels)
 };
 

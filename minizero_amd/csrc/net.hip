@@ -177,6 +177,10 @@ int Net::init(int device, const mz_net_desc& d, const float* raw, size_t n)
     MZ_HIP(hipSetDevice(device));
     if (!stream_) {
         MZ_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess) { cu_count_ = v; }
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeCooperativeLaunch, device_) == hipSuccess) { coop_launch_ = v != 0; }
+        if (const char* e = getenv("MZ_SIM_CLUSTER")) { sim_cluster_ = atoi(e) != 0; }
         own_stream_ = true;
     }
     return reload(raw, n);

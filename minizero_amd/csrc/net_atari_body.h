@@ -52,10 +52,113 @@ __device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
     return s;
 }
 
-template <int NT>
-__device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool active, const float* xs, int C, int P, float* f, float* h1, float* lg, float* red,
-                             float* out, int t)
+// One fully connected layer with the weights STREAMED through LDS (sim_cluster.h: a head alone on its CU).  y[o] = the ordered f32 chain over
+// i < n of x[i] * W[i][o] (weights wT[n][ws], 16-byte aligned), o = t and, K == 2, t + NT.  The chain length is fixed, so its time is
+// (rows / rows in flight) x memory latency — and the weights of the 601-bin heads do not stay in the 4-MB L2 next to the tower's
+// (measured: 1.3 us per batch of 60 rows, FC1 14 us).  Here ALL NT threads fetch chunk c + D - 1 (R rows, 16-byte loads, D - 1 chunks in flight in
+// registers = 170 KB) while chunk c is consumed from an LDS ring of two chunks, so the layer runs at the CU's L2-port bandwidth whatever the
+// hit rate.  Needs n % 4 == 0, (R * ws) % 4 == 0, LPT * NT * 4 >= R * ws; ring = 2 * R * ws floats (16-byte aligned), x 16-byte aligned.
+template <int NT, int R, int D, int LPT, int K, int NCH>
+__device__ __forceinline__ void fcStream(const float* __restrict__ x, const float* __restrict__ W, int ws, int n, int nout, float* __restrict__ ring, int t,
+                                         float (&acc)[K])
 {
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    static_assert(R % 4 == 0, "four rows per step");
+    constexpr int SLOT = LPT * NT * 4; // floats per ring slot: every thread writes all its LPT vectors, whatever the chunk size
+    const int chunk4 = R * ws / 4, nchunks = (n + R - 1) / R, total4 = n * (ws / 4) + n * (ws % 4) / 4; // = n * ws / 4
+    // the weights are in global memory: say so, or the loads are FLAT loads, which also count on lgkmcnt — every wait for an LDS read would then
+    // wait for all weight loads in flight
+    typedef __attribute__((address_space(1))) const vf4 GV4;
+    GV4* W4 = (GV4*)(W);
+    vf4 buf[D][LPT];
+    int o[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { acc[k] = 0.0f; o[k] = t + k * NT < nout ? t + k * NT : 0; }
+    // No branch around a global load or around an iteration (chunks beyond the layer fetch element 0 and compute nothing): the compiler counts the
+    // loads in flight per PATH and waits for the oldest chunk with s_waitcnt vmcnt(N), N = the loads it can prove to be younger — with
+    // conditional iterations N shrinks towards 0 and every chunk pays the full memory latency (measured: 1 us per chunk).  Straight-line for
+    // the same reason: inside a loop the prefetch would be loop-carried and waited for with vmcnt(0).
+    auto issue = [&](vf4 (&b)[LPT], int c) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int k4 = t + j * NT, g4 = c * chunk4 + k4;
+            const bool ok = c < nchunks && k4 < chunk4 && g4 < total4;
+            b[j] = W4[ok ? g4 : 0];
+        }
+    };
+    auto drain = [&](const vf4 (&b)[LPT], int c) {
+        vf4* dst = reinterpret_cast<vf4*>(ring + size_t(c & 1) * SLOT);
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) { dst[t + j * NT] = b[j]; }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) { issue(buf[d], d); }
+    drain(buf[0], 0);
+    __syncthreads();
+    const bool mine = t < nout;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        issue(buf[c % D], c + D);
+        drain(buf[(c + 1) % D], c + 1);
+        const int rows = n - c * R < R ? n - c * R : R;
+        if (mine && rows > 0) {
+            const float* rs = ring + size_t(c & 1) * SLOT;
+            auto step4 = [&](int r) {
+                const vf4 xv = *reinterpret_cast<const vf4*>(x + c * R + r);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float a = acc[k];
+                    a = __builtin_fmaf(xv.x, rs[(r + 0) * ws + o[k]], a);
+                    a = __builtin_fmaf(xv.y, rs[(r + 1) * ws + o[k]], a);
+                    a = __builtin_fmaf(xv.z, rs[(r + 2) * ws + o[k]], a);
+                    a = __builtin_fmaf(xv.w, rs[(r + 3) * ws + o[k]], a);
+                    acc[k] = a;
+                }
+            };
+            if (rows == R) { // all LDS reads of the chunk first, then the dependent fmas (left alone the scheduler puts every read right in
+                             // front of its fma: 24 LDS round trips in a row, 0.9 us per chunk)
+                vf4 xv[R / 4];
+                float wv[K][R];
+#pragma unroll
+                for (int r = 0; r < R; r += 4) { xv[r / 4] = *reinterpret_cast<const vf4*>(x + c * R + r); }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { wv[k][r] = rs[r * ws + o[k]]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float a = acc[k];
+#pragma unroll
+                    for (int r = 0; r < R; r += 4) {
+                        a = __builtin_fmaf(xv[r / 4].x, wv[k][r + 0], a);
+                        a = __builtin_fmaf(xv[r / 4].y, wv[k][r + 1], a);
+                        a = __builtin_fmaf(xv[r / 4].z, wv[k][r + 2], a);
+                        a = __builtin_fmaf(xv[r / 4].w, wv[k][r + 3], a);
+                    }
+                    acc[k] = a;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                for (int r = 0; r < rows; r += 4) { step4(r); }
+            }
+        }
+        __syncthreads();
+    }
+}
+constexpr int kFcStreamR1 = 24, kFcStreamR2 = 8; // rows per chunk of FC1 / FC2
+constexpr int kFcStreamN1 = 26, kFcStreamN2 = 32; // chunks the straight-line code covers (FC1: <= 624 inputs, FC2: <= 256)
+inline size_t fcStreamRingFloats(int, int) { return size_t(2) * 3 * 512 * 4 + 8; } // two slots of LPT * NT 16-byte vectors
+
+// WIDE (one head per workgroup, sim_cluster.h): one hidden unit / two bins per thread, so that more waves have weight loads in flight
+template <int NT, bool WIDE = false>
+__device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool active, const float* xs, int C, int P, float* f, float* h1, float* lg, float* red,
+                             float* out, int t, float* ring = nullptr)
+{
+    // ring != nullptr (WIDE): FC layers whose shapes fit stream their weights through it (fcStream)
+    const bool stream1 = WIDE && ring && (d.hc * P) % 4 == 0 && d.hidden % 4 == 0 && d.hidden <= NT && kFcStreamR1 * d.hidden <= 3 * NT * 4 && d.hc * P <= kFcStreamN1 * kFcStreamR1;
+    const bool stream2 = WIDE && ring && d.hidden % 4 == 0 && d.size <= 2 * NT && kFcStreamR2 * d.size <= 3 * NT * 4 && d.hidden <= kFcStreamN2 * kFcStreamR2;
     const int lane = t & 63, wave = t >> 6;
     constexpr int K = NT >= 512 ? 2 : 3; // outputs per thread and pass: 601 bins / 612 conv outputs in one pass of the half
     if (active) {
@@ -83,6 +186,18 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
     MZ_HPROF(1);
     if (active) {
         const int n1 = d.hc * P;
+        if (WIDE && stream1) {
+            if constexpr (WIDE) {
+                float acc[1];
+                fcStream<NT, kFcStreamR1, 8, 3, 1, kFcStreamN1>(f, d.fc1_wT, d.hidden, n1, d.hidden, ring, t, acc);
+                if (t < d.hidden) { const float v = acc[0] + d.fc1_b[t]; h1[t] = v > 0.0f ? v : 0.0f; }
+            }
+        } else if constexpr (WIDE) {
+            for (int o = t; o < d.hidden; o += NT) {
+                const float v = dotChain<60>(f, 1, d.fc1_wT + o, d.hidden, n1) + d.fc1_b[o];
+                h1[o] = v > 0.0f ? v : 0.0f;
+            }
+        } else
         for (int o = 4 * t; o < d.hidden; o += 4 * NT) { // four adjacent hidden units per thread, 16-byte weight loads (dotChain4)
             float acc[4];
             dotChain4<32>(f, d.fc1_wT, d.hidden, o, d.hidden, n1, acc);
@@ -95,8 +210,39 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
     __syncthreads();
     MZ_HPROF(2);
     float m = -3.4e38f;
+    if (active && WIDE && stream2) {
+        if constexpr (WIDE) {
+            float acc[2];
+            fcStream<NT, kFcStreamR2, 8, 3, 2, kFcStreamN2>(h1, d.fc2_wT, d.size, d.hidden, d.size, ring, t, acc);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int o = t + k * NT;
+                if (o < d.size) {
+                    const float v = acc[k] + d.fc2_b[o];
+                    lg[o] = v;
+                    m = v > m ? v : m;
+                }
+            }
+        }
+    } else if (active && WIDE) {
+        for (int o = 2 * t; o < d.size; o += 2 * NT) {
+            const int o1 = o + 1 < d.size ? o + 1 : o;
+            const float* xk[2] = {h1, h1};
+            const float* wk[2] = {d.fc2_wT + o, d.fc2_wT + o1};
+            float acc[2];
+            dotChainK<30, 2>(xk, 1, wk, d.size, d.hidden, acc);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (o + k < d.size) {
+                    const float v = acc[k] + d.fc2_b[o + k];
+                    lg[o + k] = v;
+                    m = v > m ? v : m;
+                }
+            }
+        }
+    }
     if (active) {
-        for (int o = 4 * t; o < d.size; o += 4 * NT) {
+        for (int o = 4 * t; o < d.size && !WIDE; o += 4 * NT) {
             float acc[4];
             dotChain4<32>(h1, d.fc2_wT, d.size, o, d.size, d.hidden, acc);
 #pragma unroll

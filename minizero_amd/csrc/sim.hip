@@ -20,11 +20,14 @@ __shared__ int s_tp_idx;
     } while (0)
 #endif
 #ifdef MZ_SIM_HPROF // experiment: where the time of the in-kernel 601-bin heads goes (game 0)
+#ifndef MZ_HPROF_BLOCK
+#define MZ_HPROF_BLOCK 0 // cluster mode: 64 = member 1 (reward head) of game 0 in a pool of 64 games
+#endif
 __device__ unsigned long long g_hp[16];
 __shared__ unsigned long long s_hp_prev;
 #define MZ_HPROF(k)                                                                                   \
     do {                                                                                              \
-        if (threadIdx.x == 0 && blockIdx.x == 0) {                                                    \
+        if (threadIdx.x == 0 && blockIdx.x == MZ_HPROF_BLOCK) {                                       \
             const unsigned long long t_ = wall_clock64();                                             \
             if ((k) > 0) { g_hp[(k)] += t_ - s_hp_prev; } else { g_hp[15] += 1; }                     \
             s_hp_prev = t_;                                                                           \
@@ -91,6 +94,8 @@ struct SimArgs {
     // opt-in bf16x3 tower (net_bf16_body.h): fragments + layer table; used by the BF instantiations of sim_kernel
     const uint4* wfrag;
     TowerArgsBf16 tb;
+    unsigned* cluster;                // cluster mode (sim_cluster.h): per-game exchange block of `cluster_words` words; nullptr: one workgroup per game
+    int cluster_words, pad_cluster_;
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
 
@@ -651,6 +656,10 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     }
 }
 
+} // namespace mz
+#include "sim_cluster.h"
+namespace mz {
+
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
 static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
 {
@@ -665,6 +674,9 @@ static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, i
     X(9, 9, 20, 12, 8)   /* small 9x9 test nets */ \
     X(6, 6, 64, 84, 64)  /* muzero_atari dynamics, 64 channels + 18 action planes (BASELINE configs[4]); the representation runs stand-alone */ \
     X(6, 6, 32, 52, 32)  /* small muzero_atari test nets */
+#define MZ_SIM_MZ_CLUSTER_CASES(X) /* the instances that also exist as four-workgroup clusters */ \
+    X(6, 6, 64, 84, 64) \
+    X(6, 6, 32, 52, 32)
 
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL, bool BF = false>
 static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
@@ -689,7 +701,7 @@ void Net::dumpSimProf()
         unsigned long long h[16];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hp), sizeof(h)) == hipSuccess && h[15]) {
             fprintf(stderr, "[mz sim hprof] us per section of the heads (game 0, avg over %llu calls; board games: [1] tail wait, [5] setup, [6] conv1x1, [7] FCs, [8] FC2 / softmax):", h[15]);
-            for (int i = 1; i < 10; ++i) { fprintf(stderr, " %.2f", double(h[i]) / double(h[15]) * 0.01); }
+            for (int i = 1; i < 12; ++i) { fprintf(stderr, " %.2f", double(h[i]) / double(h[15]) * 0.01); }
             fprintf(stderr, "\n");
         }
     }
@@ -930,11 +942,30 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) + size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int) +
                        head_floats * sizeof(float);
     if (lds > 160 * 1024) { return MZ_OK; }
+    // cluster mode (sim_cluster.h): four workgroups per game when the pool leaves three quarters of the CUs idle (muzero_atari instances only)
+    const int gpad = (pool.v_.games + 7) / 8 * 8;
+    const bool cluster = atari && sim_cluster_ && H * W <= 36 && kClMembers * gpad <= cu_count_ && coop_launch_;
+    size_t lds_cluster = lds;
+    if (cluster) {
+        lds_cluster = lds + (clusterHeadsSmemFloats(a.ahp) - head_floats) * sizeof(float);
+        if (lds_cluster > 160 * 1024) { setError("simLaunchMz: the cluster mode needs %zu bytes of LDS", lds_cluster); return MZ_ERR_ARG; }
+        const size_t words = clusterWords(C, H * W);
+        if (!sim_cluster_mem_.ensure(size_t(pool.v_.games) * words * sizeof(unsigned))) { setError("hipMalloc of the cluster exchange blocks failed"); return MZ_ERR_DEVICE; }
+        a.cluster = reinterpret_cast<unsigned*>(sim_cluster_mem_.p);
+        a.cluster_words = static_cast<int>(words);
+        MZ_HIP(hipMemsetAsync(sim_cluster_mem_.p, 0, size_t(pool.v_.games) * words * sizeof(unsigned), stream_));
+    }
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
         if (!sim_args_.ensure(sizeof(SimArgs))) { setError("hipMalloc of the simulation arguments failed"); return MZ_ERR_DEVICE; }
         MZ_HIP(hipStreamSynchronize(stream_));
         MZ_HIP(hipMemcpy(sim_args_.p, &a, sizeof(SimArgs), hipMemcpyHostToDevice));
         sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
+    }
+    if (cluster) {
+#define MZ_SIM_MZ_CL_LAUNCH(h, w, cin0, cdyn, cpad) \
+        if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzClusterT<h, w, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, host_start ? 1 : 0, lds_cluster, stream_); }
+        MZ_SIM_MZ_CLUSTER_CASES(MZ_SIM_MZ_CL_LAUNCH)
+#undef MZ_SIM_MZ_CL_LAUNCH
     }
 #define MZ_SIM_MZ_LAUNCH(h, w, cin0, cdyn, cpad) \
     if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, host_start ? 1 : 0, lds, stream_); }

@@ -1,0 +1,401 @@
+// Cluster mode of the MuZero simulation kernel (included by sim.hip): FOUR workgroups per game.
+//
+// A pool of 64 games (BASELINE configs[4]: muzero_atari, 64 games per GPU) leaves 192 of the 256 CUs idle with one workgroup per game, and inside
+// a game every phase is a dependent chain, so the only way to use them is to spread ONE simulation over several CUs:
+//  * dynamics tower: member m of the cluster computes oc-tile m (16 output channels) of every layer on three of its waves (one pixel tile
+//    each); after each layer the four members swap their 16 x P outputs through a buffer in global memory, i.e. through the L2 of the XCD
+//    they share (workgroup ids congruent mod 8 are dispatched to the same XCD; the kernel checks XCC_ID and refuses to run otherwise).
+//    tools/xcu_sync_bench.hip: such an exchange costs 1.5 us with relaxed L2 atomics + cache-bypassing loads; with agent-scope
+//    release / acquire (L2 write-back + invalidate on this multi-XCD part) it costs 21 us, hence the hand-made protocol;
+//  * heads: member 0 rescales + stores the hidden state and runs the policy head, member 1 the reward head, member 2 the value head, each
+//    with all 512 threads and its own CU's L2 port (the 601-bin heads stream 1.24 MB of weights each);
+//  * the tree phases stay on member 0 (the owner), which sends (parent slot, action) to the helpers and collects value / reward.
+// The arithmetic of every output is the same chain as in the one-workgroup kernel: records are bit-identical (tests/test_gpu_cluster.py).
+// Every wait is bounded: a member that times out raises the pool's error flag and the whole cluster leaves the kernel.
+#pragma once
+
+namespace mz {
+
+// per-game block in global memory (32-bit words); the host clears it before every launch
+constexpr int kClCmd = 0;      // [0..3] = {parent slot, action, -, sequence number} written by the owner with one 16-byte store
+constexpr int kClArrive = 32;  // arrivals at the layer exchanges (monotonic)
+constexpr int kClRes = 64;     // [0,1] = (reward bits, seq), [2,3] = (value bits, seq)
+constexpr int kClXcc = 96;     // [0..3] XCC_ID of the members, [4] arrivals of the placement check
+constexpr int kClXbuf = 128;   // 2 x [C][P] floats
+constexpr int kClMembers = 4;
+constexpr int kClPollLimit = 1 << 21;
+typedef unsigned clu4 __attribute__((ext_vector_type(4)));
+typedef unsigned clu2 __attribute__((ext_vector_type(2)));
+// LDS floats of clusterAtariHeads: the one-workgroup layout with aligned sub-buffers + the weight ring of fcStream
+inline size_t clusterHeadsSmemFloats(const AtariHeadParams& hp)
+{
+    const int hidmax = hp.value.hidden > hp.reward.hidden ? hp.value.hidden : hp.reward.hidden;
+    const int sizemax = hp.value.size > hp.reward.size ? hp.value.size : hp.reward.size;
+    return atariHeadsSmemFloats(hp) + 64 + fcStreamRingFloats(hidmax, sizemax);
+}
+inline size_t clusterWords(int C, int P) { return size_t(kClXbuf) + 2 * size_t(C) * P + 32; }
+
+__device__ __forceinline__ unsigned clLoadU(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a load that is served by the L2 (relaxed agent-scope atomic load = global_load_dword sc1; the compiler tracks its vmcnt like any load)
+__device__ __forceinline__ float clLoadF(const float* p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void clDrain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until *p >= want (unsigned, monotonic counter); false: timed out
+__device__ __forceinline__ bool clWaitGE(const unsigned* p, unsigned want)
+{
+    for (int i = 0; i < kClPollLimit; ++i) {
+        if (clLoadU(p) >= want) { return true; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+struct ClusterCtx {
+    unsigned* cm;   // this game's block
+    int member, C, P, OT;
+    unsigned xseq;  // layer exchanges done so far in this launch
+    int* abort_lds; // workgroup-wide abort flag
+    int* err;
+};
+
+// my 16 x P block of the exchange buffer for the NEXT exchange
+__device__ __forceinline__ float* clPart(const ClusterCtx& c, int ot) { return reinterpret_cast<float*>(c.cm + kClXbuf) + size_t(c.xseq & 1) * c.C * c.P + size_t(ot) * 16 * c.P; }
+
+// All 512 threads of every member, after a layer: my outputs are in LDS (`tout`, padded planes) and on their way to the exchange buffer; on return
+// the other members' channels are in `tout` too.  false: a member went missing (the caller leaves the kernel).
+template <int H, int W, int CPAD>
+__device__ __forceinline__ bool clExchange(ClusterCtx& c, float* __restrict__ tout, int tid)
+{
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
+    clDrain(); // this wave's stores have reached the L2
+    __syncthreads();
+    const unsigned k = ++c.xseq;
+    if (tid == 0) {
+        __hip_atomic_fetch_add(c.cm + kClArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!clWaitGE(c.cm + kClArrive, k * kClMembers)) { *c.abort_lds = 1; atomicExch(c.err, 90); }
+    }
+    __syncthreads();
+    if (*c.abort_lds) { return false; }
+    const float* xb = reinterpret_cast<const float*>(c.cm + kClXbuf) + size_t((k - 1) & 1) * c.C * c.P;
+    constexpr int K = (CPAD * P + 511) / 512;
+    const int n = c.OT * 16 * P, mine0 = c.member * 16 * P;
+    float got[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int i = tid + j * 512;
+        const bool want = i < n && (i < mine0 || i >= mine0 + 16 * P);
+        got[j] = clLoadF(xb + (want ? i : 0));
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int i = tid + j * 512;
+        const bool want = i < n && (i < mine0 || i >= mine0 + 16 * P) && i < c.C * P;
+        if (want) {
+            const int ch = i / P, p = i - ch * P;
+            tout[ch * CS + (p / W + 1) * PW + (p % W) + 1] = got[j];
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// the layer sequence of one wave of a member: oc-tile `ot` x pixel tile `tile` (waves without a tile: ot < 0), every wave takes part in the exchanges
+template <int H, int W, int CIN0_PAD, int CPAD, bool NTW>
+__device__ __forceinline__ bool towerRunCluster(const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ T0, float* __restrict__ T1, int lane,
+                                                int tid, int ot, int tile, ClusterCtx& c)
+{
+    const bool work = ot >= 0;
+    const PixSet<1> px = makePixSet<H, W, 1>(lane, work ? tile : 0);
+    float aS[CIN0_PAD / 4], aA[CPAD / 4], aB[CPAD / 4];
+    bool have = false;
+    if (ta.has_stem) {
+        if (work) {
+            const float* nw = ta.nlayers > 1 ? params + ta.w_off[1] : nullptr;
+            tower_layer<H, W, CIN0_PAD / 4, 1, CPAD / 4, false, NTW, true>(T0, nullptr, T1, nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT, lane, ot, px,
+                                                                           false, aS, nw, aA, clPart(c, ot));
+            have = nw != nullptr;
+        }
+        if (!clExchange<H, W, CPAD>(c, T1, tid)) { return false; }
+    }
+    float *x = T1, *tmp = T0;
+#pragma unroll 1
+    for (int l = ta.has_stem; l < ta.nlayers; ++l) {
+        const bool second = ((l - ta.has_stem) & 1) != 0, last = l + 1 == ta.nlayers;
+        if (work) {
+            tower_layer<H, W, CPAD / 4, 1, CPAD / 4, false, NTW, true>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, nullptr, params + ta.w_off[l],
+                                                                       params + ta.b_off[l], ta.C, ta.OT, lane, ot, px, have, aA,
+                                                                       last ? nullptr : params + ta.w_off[l + 1], aB, clPart(c, ot));
+#pragma unroll
+            for (int cg = 0; cg < CPAD / 4; ++cg) { aA[cg] = aB[cg]; }
+            have = !last;
+        }
+        if (!clExchange<H, W, CPAD>(c, second ? x : tmp, tid)) { return false; }
+    }
+    return true;
+}
+
+// dynamics trunk of one simulation on a cluster: every member fills its own copy of the input (parent hidden state + action planes), computes its
+// oc-tile of every layer and ends with the complete output x in its LDS tile T1.  nullptr: aborted.
+template <int H, int W, int CDYN_PAD, int CPAD>
+__device__ __forceinline__ float* towerBodyCluster(const float* __restrict__ params, const TowerArgs& ta, int tid, float* __restrict__ tiles,
+                                                   const float* __restrict__ hidden_src, int action, int action_planes, ClusterCtx& c)
+{
+    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
+    constexpr int CMAX = CDYN_PAD > CPAD ? CDYN_PAD : CPAD;
+    using TM = TileMap<H, W>;
+    static_assert(!TM::kCorner && TM::PT <= 8, "cluster mode: one wave per pixel tile, no corner tile");
+    const int lane = tid & 63, wave = tid >> 6;
+    float* T0 = tiles;
+    float* T1 = tiles + CMAX * CS;
+    for (int i = tid; i < kTowerTiles * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
+    __syncthreads();
+    float* Tin = ta.has_stem ? T0 : T1;
+    const int CH = ta.cin0 - (action_planes > 1 ? action_planes : 1);
+    {
+        constexpr int K = (CMAX * P + 511) / 512; // the slab slot may have been written by another CU: read it past the vector cache
+        float got[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { const int i = tid + j * 512; got[j] = clLoadF(hidden_src + (i < CH * P ? i : 0)); }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int i = tid + j * 512;
+            if (i < CH * P) { const int ch = i / P, p = i - ch * P; Tin[ch * CS + (p / W + 1) * PW + (p % W) + 1] = got[j]; }
+        }
+    }
+    if (action_planes > 1) {
+        if (action >= 0 && action < action_planes) {
+            for (int p = tid; p < P; p += 512) { Tin[(CH + action) * CS + (p / W + 1) * PW + (p % W) + 1] = 1.0f; }
+        }
+    } else if (tid == 0 && action >= 0 && action < P) { Tin[CH * CS + (action / W + 1) * PW + (action % W) + 1] = 1.0f; }
+    __syncthreads();
+    const bool work = c.member < ta.OT && wave < TM::PT;
+    if (!towerRunCluster<H, W, CDYN_PAD, CPAD, false>(params, ta, T0, T1, lane, tid, work ? c.member : -1, wave, c)) { return nullptr; }
+    return T1;
+}
+
+// heads of one simulation, split by member (net_atari_body.h atariHeadsBody is the one-workgroup version): 0 = rescale + slab store + policy,
+// 1 = reward head (on the UNscaled state), 2 = value head; results of 1 and 2 -> the cluster block as (bits, seq) pairs
+__device__ __forceinline__ void clusterAtariHeads(const float* __restrict__ xlds, int xcs, int xpw, const AtariHeadParams& hp, float* __restrict__ policy,
+                                                  float* __restrict__ logit, float* __restrict__ hd, int b, int tid, float* __restrict__ sm, ClusterCtx& c,
+                                                  unsigned seq)
+{
+    if (c.member == 3) { return; }
+    const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC;
+    const int hcmax = hp.value.hc > hp.reward.hc ? hp.value.hc : hp.reward.hc;
+    const int hidmax = hp.value.hidden > hp.reward.hidden ? hp.value.hidden : hp.reward.hidden;
+    const int sizemax = hp.value.size > hp.reward.size ? hp.value.size : hp.reward.size;
+    const int lane = tid & 63, wave = tid >> 6;
+    MZ_HPROF(8);
+    if (c.member == 0) { MZ_HPROF(0); }
+    // `sm` is 16-byte aligned (the kernel pads it) and so is every sub-buffer (fcStream reads its input vector with 16-byte LDS loads)
+    auto up4 = [](int v) { return (v + 3) & ~3; };
+    float* xr = sm;
+    float* xs = xr + up4(C * P);
+    float* pf = xs + up4(C * P);
+    float* lgp = pf + up4(PC * P);
+    float* redp = lgp + up4(A);
+    float* f = redp + 32;
+    float* h1 = f + up4(hcmax * P);
+    float* lg = h1 + up4(hidmax);
+    float* red = lg + up4(sizemax);
+    float* ring = red + 16;
+    {
+        const int Wb = xpw - 2;
+        for (int i = tid; i < C * P; i += 512) {
+            const int ch = i / P, p = i - ch * P;
+            xr[i] = xlds[ch * xcs + (p / Wb + 1) * xpw + p % Wb + 1];
+        }
+    }
+    __syncthreads();
+    if (c.member != 1) { // scale_hidden_state (ref muzero_atari_network.py:189-198); member 2 keeps its own copy, member 0 also fills the slab slot
+        float mn = 3.4e38f, mx = -3.4e38f;
+        for (int i = tid; i < C * P; i += 512) { const float v = xr[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
+            mn = m2 < mn ? m2 : mn;
+            mx = x2 > mx ? x2 : mx;
+        }
+        if (lane == 0) { redp[wave] = mn; redp[16 + wave] = mx; }
+        __syncthreads();
+        mn = redp[0]; mx = redp[16];
+        for (int w = 1; w < 8; ++w) { mn = redp[w] < mn ? redp[w] : mn; mx = redp[16 + w] > mx ? redp[16 + w] : mx; }
+        float scale = mx - mn;
+        if (scale < 1e-5f) { scale += 1e-5f; }
+        for (int i = tid; i < C * P; i += 512) {
+            const float v = (xr[i] - mn) / scale;
+            xs[i] = v;
+            if (c.member == 0) { hd[i] = v; }
+        }
+        __syncthreads();
+    }
+    if (c.member != 0) {
+        __shared__ float s_out;
+        MZ_HPROF(0);
+        discreteHead<512, true>(c.member == 1 ? hp.reward : hp.value, true, c.member == 1 ? xr : xs, C, P, f, h1, lg, red, &s_out, tid, ring);
+        if (tid == 0) {
+            clu2 pr;
+            pr.x = __float_as_uint(invertValueDev(s_out));
+            pr.y = seq;
+            clu2* dst = reinterpret_cast<clu2*>(c.cm + kClRes) + (c.member - 1);
+            asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(pr) : "memory");
+        }
+        return;
+    }
+    for (int i = tid; i < PC * P; i += 512) {
+        const int j = i / P, p = i - j * P;
+        const float v = dotChain<16>(xs + p, P, hp.pconv_w + j * C, 1, C) + hp.pconv_b[j];
+        pf[i] = v > 0.0f ? v : 0.0f;
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += 512) {
+        const float v = dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
+        lgp[a] = v;
+        logit[size_t(b) * A + a] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float m = -3.4e38f;
+        for (int a = lane; a < A; a += 64) { m = lgp[a] > m ? lgp[a] : m; }
+        for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
+        for (int a = lane; a < A; a += 64) { lgp[a] = mz_expf(lgp[a] - m); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float s = 0.0f;
+        for (int a = 0; a < A; ++a) { s += lgp[a]; }
+        for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lgp[a] / s; }
+    }
+    MZ_HPROF(9);
+}
+
+// grid = 4 * gpad workgroups (cooperative launch: all of them resident), workgroup id = member * gpad + game, gpad a multiple of 8
+template <int H, int W, int CDYN_PAD, int CPAD>
+__global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start, int games, int gpad)
+{
+    CSimArgs* a = (CSimArgs*)a_;
+    extern __shared__ __attribute__((aligned(16))) float tiles[];
+    const int g = blockIdx.x % gpad, member = blockIdx.x / gpad, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (g >= games) { return; }
+    constexpr int CM = CDYN_PAD > CPAD ? CDYN_PAD : CPAD;
+    constexpr int kTileFloats = kTowerTiles * CM * planeStride(H, W);
+    __shared__ int s_abort, s_cmd[4], s_cand_k;
+    double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
+    const int rcp_n = a->rcp_n;
+    const int tab_n = rcp_n - 2;
+    double* sqrt_w = rcp_w + rcp_n;
+    float* bias_w = reinterpret_cast<float*>(sqrt_w + tab_n);
+    int* spec_w = reinterpret_cast<int*>(bias_w + tab_n + (tab_n & 1));
+    if (member == 0) {
+        for (int i = tid; i < rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
+        for (int i = tid; i < tab_n; i += 512) { sqrt_w[i] = a->pv.sqrt_tab[i]; bias_w[i] = a->pv.bias_tab[i]; }
+    }
+    if (tid == 0) { s_abort = 0; }
+    __syncthreads();
+    LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
+    SpecMem spec{nullptr, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
+    float* head_scratch = reinterpret_cast<float*>(spec_w + kSpecWords);
+    head_scratch += (-static_cast<int>(head_scratch - tiles)) & 3; // 16-byte aligned, by pointer arithmetic only: the pointer stays an LDS pointer
+    const PoolView v = ldc(&a->pv);
+    ClusterCtx c;
+    c.cm = a->cluster + size_t(g) * a->cluster_words;
+    c.member = member; c.C = a->hp.C; c.P = a->hp.P; c.OT = a->ta_dyn.OT; c.xseq = 0; c.abort_lds = &s_abort; c.err = a->err;
+    // placement check: the four members of a game must share an XCD (one L2), else the exchanges would read stale data
+    if (tid == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        __hip_atomic_store(c.cm + kClXcc + member, (id & 15u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        clDrain();
+        __hip_atomic_fetch_add(c.cm + kClXcc + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = clWaitGE(c.cm + kClXcc + 4, kClMembers);
+        for (int m = 0; ok && m < kClMembers; ++m) { ok = clLoadU(c.cm + kClXcc + m) == (id & 15u) + 1u; }
+        if (!ok) { s_abort = 1; atomicExch(a->err, 91); }
+    }
+    __syncthreads();
+    if (s_abort) { return; }
+    unsigned long long* prof = (a->prof && member == 0) ? a->prof + size_t(g) * 8 : nullptr;
+    for (int s = 0; s < nsims; ++s) {
+        const int slot = sim0 + s;
+        const unsigned seq = unsigned(s) + 1u;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (prof) { t0 = wall_clock64(); }
+        if (member == 0) {
+            if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds, spec); }
+            __syncthreads();
+            {
+                if (tid == 0) {
+                    const int len = v.path_len[g];
+                    const int* path = v.path + size_t(g) * v.max_depth;
+                    clu4 cmd;
+                    cmd.x = unsigned(v.hslot[size_t(g) * v.cap + path[len - 2]]);
+                    cmd.y = unsigned(v.path_action[size_t(g) * v.max_depth + len - 1]);
+                    cmd.z = 0;
+                    cmd.w = seq;
+                    s_cmd[0] = int(cmd.x); s_cmd[1] = int(cmd.y);
+                    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(c.cm + kClCmd), "v"(cmd) : "memory");
+                }
+            }
+        } else if (tid == 0) {
+            bool ok = false;
+            clu4 cmd;
+            for (int i = 0; i < kClPollLimit && !ok; ++i) {
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(cmd) : "v"(c.cm + kClCmd) : "memory");
+                ok = cmd.w == seq;
+                if (!ok) { __builtin_amdgcn_s_sleep(1); }
+            }
+            if (!ok) { s_abort = 1; atomicExch(a->err, 92); }
+            s_cmd[0] = int(cmd.x); s_cmd[1] = int(cmd.y);
+        }
+        __syncthreads();
+        if (s_abort) { return; }
+        if (prof) { t1 = wall_clock64(); }
+        const int src = s_cmd[0], action = s_cmd[1];
+        const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;
+        float* xt = towerBodyCluster<H, W, CDYN_PAD, CPAD>(a->params, *(const TowerArgs*)&a->ta_dyn, tid, tiles, hsrc, action, a->action_planes, c);
+        if (!xt) { return; }
+        if (prof) { t2 = wall_clock64(); }
+        {
+            const AtariHeadParams hp = ldc(&a->ahp);
+            float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
+            clusterAtariHeads(xt, planeStride(H, W), W + 2, hp, a->policy, a->logit, hd, g, tid, head_scratch, c, seq);
+        }
+        if (member != 0) { __syncthreads(); continue; }
+        if (tid == 0) { // value and reward from the helpers
+            bool ok = false;
+            clu4 r;
+            for (int i = 0; i < kClPollLimit && !ok; ++i) {
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(c.cm + kClRes) : "memory");
+                ok = r.y == seq && r.w == seq;
+                if (!ok) { __builtin_amdgcn_s_sleep(1); }
+            }
+            if (!ok) { s_abort = 1; atomicExch(a->err, 93); }
+            a->reward[g] = __uint_as_float(r.x);
+            a->value[g] = __uint_as_float(r.z);
+        }
+        __syncthreads();
+        if (s_abort) { return; }
+        MZ_HPROF(10);
+        if (prof) { t3 = wall_clock64(); }
+        if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
+        __syncthreads();
+        const int cand_k = s_cand_k;
+        if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
+        __syncthreads();
+        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k); }
+        __syncthreads();
+        if (prof && tid == 0) {
+            const unsigned long long t4 = wall_clock64();
+            prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
+        }
+    }
+}
+
+template <int H, int W, int CDYN_PAD, int CPAD>
+static int launchSimMzClusterT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
+{
+    MZ_LDS_ATTR((sim_kernel_mz_cluster<H, W, CDYN_PAD, CPAD>), lds);
+    int gpad = (games + 7) / 8 * 8;
+    void* params[] = {(void*)&d_args, (void*)&sim0, (void*)&nsims, (void*)&host_start, (void*)&games, (void*)&gpad};
+    MZ_HIP(hipLaunchCooperativeKernel(reinterpret_cast<void*>(sim_kernel_mz_cluster<H, W, CDYN_PAD, CPAD>), dim3(kClMembers * gpad), dim3(512), params,
+                                      static_cast<unsigned>(lds), s));
+    return MZ_OK;
+}
+
+} // namespace mz

@@ -436,6 +436,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         if (rc) { return rc; }
         if (cfg_.mz_nn_precision != "f32" && cfg_.mz_nn_precision != "bf16x3") { setError("mz_nn_precision '%s' unknown (f32 | bf16x3)", cfg_.mz_nn_precision.c_str()); return MZ_ERR_ARG; }
         if ((rc = L->net.setPrecision(cfg_.mz_nn_precision == "bf16x3" ? 1 : 0))) { return rc; }
+        if (!cfg_.mz_sim_cluster) { L->net.sim_cluster_ = false; }
         L->stream = L->net.stream_;
         // ref actor_group.cpp:183: tree_node_size = (n + 1) * action_size; tree.h:66: 1 + tree_node_size nodes
         rc = L->pool.init(device, L->n, 1 + (n_ + 1) * A_, A_, sc, L->stream);
@@ -1599,7 +1600,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
         MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
-        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
 #undef MZ_FIXED
         if (fixed) { setError("update_config: %s is fixed when the worker is created (restart the worker to change it)", fixed); return MZ_ERR_ARG; }
         cfg_ = nc;

@@ -299,9 +299,13 @@ def test_atari_execution_modes_are_equivalent(mz):
     lockstep = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=false", ATARI_ARGS, [total], total)
     sim_whole = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true", ATARI_ARGS, [total], total)
     sim_chunks = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true", ATARI_ARGS, [1, 2, 5, 9, 3, 40, 10, 8], total)
+    # the default is the cluster mode (sim_cluster.h: four workgroups per game, tower split by output-channel tile, one 601-bin head per
+    # workgroup); mz_sim_cluster=false = one workgroup per game
+    sim_single = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true:mz_sim_cluster=false", ATARI_ARGS, [3, 40, 9], total)
     assert len(lockstep) >= 10
     assert lockstep == sim_whole
     assert lockstep == sim_chunks
+    assert lockstep == sim_single
 
 
 def test_go_muzero_gumbel_execution_modes_are_equivalent(mz, oracle):
