@@ -149,6 +149,7 @@ private:
     int cu_count_ = 0;
     bool coop_launch_ = false;
 public:
+    bool sim_octet_ = true;     // cluster mode: the 601-bin heads of the games that share an XCD are computed together (sim_cluster.h octetHead)
     bool sim_cluster_ = true;   // four workgroups per game when 4 x games <= CUs (muzero_atari instances); false: always one workgroup per game
     bool use_fused_ = true;     // fused persistent tower kernel (same arithmetic as the per-layer kernels)
 };

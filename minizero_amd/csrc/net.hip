@@ -181,6 +181,7 @@ int Net::init(int device, const mz_net_desc& d, const float* raw, size_t n)
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess) { cu_count_ = v; }
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeCooperativeLaunch, device_) == hipSuccess) { coop_launch_ = v != 0; }
         if (const char* e = getenv("MZ_SIM_CLUSTER")) { sim_cluster_ = atoi(e) != 0; }
+        if (const char* e = getenv("MZ_SIM_OCTET")) { sim_octet_ = atoi(e) != 0; }
         own_stream_ = true;
     }
     return reload(raw, n);

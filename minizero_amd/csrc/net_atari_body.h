@@ -4,6 +4,9 @@
 #include "net_dev.h"
 #include "net_body.h"
 
+#ifndef MZ_HPROF2
+#define MZ_HPROF2()
+#endif
 #ifndef MZ_HPROF
 #define MZ_HPROF(k) // experiment hook (sim.hip -DMZ_SIM_HPROF): time stamps inside the 601-bin heads
 #endif
@@ -52,104 +55,265 @@ __device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
     return s;
 }
 
-// One fully connected layer with the weights STREAMED through LDS (sim_cluster.h: a head alone on its CU).  y[o] = the ordered f32 chain over
-// i < n of x[i] * W[i][o] (weights wT[n][ws], 16-byte aligned), o = t and, K == 2, t + NT.  The chain length is fixed, so its time is
-// (rows / rows in flight) x memory latency — and the weights of the 601-bin heads do not stay in the 4-MB L2 next to the tower's
-// (measured: 1.3 us per batch of 60 rows, FC1 14 us).  Here ALL NT threads fetch chunk c + D - 1 (R rows, 16-byte loads, D - 1 chunks in flight in
-// registers = 170 KB) while chunk c is consumed from an LDS ring of two chunks, so the layer runs at the CU's L2-port bandwidth whatever the
-// hit rate.  Needs n % 4 == 0, (R * ws) % 4 == 0, LPT * NT * 4 >= R * ws; ring = 2 * R * ws floats (16-byte aligned), x 16-byte aligned.
-template <int NT, int R, int D, int LPT, int K, int NCH>
-__device__ __forceinline__ void fcStream(const float* __restrict__ x, const float* __restrict__ W, int ws, int n, int nout, float* __restrict__ ring, int t,
-                                         float (&acc)[K])
+// A slice of a fully connected layer with the weights STREAMED through LDS (sim_cluster.h: a 601-bin head alone on its CU, or a column slice of
+// it for the games of an octet).  Chain k of thread t: acc[k] = the ordered f32 chain over i < n of xk[k][i] * W[i][col0 + uk[k]] (weights
+// wT[n][ws] in global memory, uk[k] < seg; xk[k] = an LDS vector, 16-byte aligned).  The chain length is fixed, so what counts is how fast the
+// rows arrive: ALL NT threads fetch chunk c + D - 1 (R rows x seg columns, D - 1 chunks in flight in registers) while chunk c is consumed from
+// an LDS ring of two slots.  VEC4: 16-byte loads (needs ws, col0, seg multiples of 4), else 4-byte loads.  G = rows per straight-line compute
+// group (n % 4 == 0, G % 4 == 0).  The caller checks ceil(n / R) <= NCH with R = fcSegRows<..>(seg).  Ring = 2 * fcSegSlot floats, 16-byte aligned.
+//
+// Three things this code is shaped by (each measured on BASELINE configs[4], 20 -> 5 us per layer):
+//  * no branch around a global load and no loop around the chunks: the compiler counts the loads in flight per PATH and waits for the oldest
+//    chunk with s_waitcnt vmcnt(N), N = the loads it can prove to be younger; behind a conditional load N shrinks towards 0, and a loop-carried
+//    prefetch is waited for with vmcnt(0) — either way every chunk pays the full memory latency;
+//  * the weight pointer is cast to the global address space: through a generic pointer the loads are FLAT loads, which also count on lgkmcnt,
+//    so every wait for an LDS operand waits for all weight loads in flight;
+//  * inside a group all LDS reads come first (sched_barrier), then the dependent fmas: left alone the scheduler puts every read right in front of
+//    its fma, i.e. G LDS round trips in a row.
+template <int NT, bool VEC4, int LPT>
+__host__ __device__ constexpr int fcSegSlot() { return LPT * NT * (VEC4 ? 4 : 1); }
+template <int NT, bool VEC4, int G, int LPT>
+__host__ __device__ inline int fcSegRows(int seg) { const int r = fcSegSlot<NT, VEC4, LPT>() / seg / G * G; return r < G ? G : r; }
+
+// f(integral_constant<0>), f(<1>), ... while C < n: straight-line code with compile-time indices, each step nested in the previous one's test
+// (a `break` in an unrolled loop kept the loop: the register ring became an array in scratch memory)
+template <int C, int NCH, class F>
+__device__ __forceinline__ void unrollWhile(int n, F& f)
 {
+    if constexpr (C < NCH) {
+        if (C < n) {
+            f(std::integral_constant<int, C>{});
+            unrollWhile<C + 1, NCH>(n, f);
+        }
+    }
+}
+
+// XU: the K chains of a thread and all lanes of its wave share ONE input vector xk[0] (a wave = one game): its G values of a group are fetched by
+// one ds_read_b32 (lane l holds row l) and handed to the fmas as scalar operands (v_readlane), which halves the LDS traffic of the layer — with
+// per-lane vectors the 16-byte reads of x cost as much LDS bandwidth as the weights (the octet heads were LDS-bound: 11 us per layer).
+// RS > 0: seg == RS at compile time — the LDS reads of a group then differ only in their immediate offsets (tools/fc_chain_bench.hip: 14.7 instead of
+// 22 cycles per row; the v_readlane variant XU needs 33).
+template <int NT, bool VEC4, int G, int K, int D, int LPT, int NCH, bool XU = false, int RS = 0>
+__device__ __forceinline__ void fcStreamSeg(const float* const (&xk)[K], const int (&uk)[K], bool mine, const float* __restrict__ W, int ws, int col0, int seg_, int n,
+                                            float* __restrict__ ring, int t, float (&acc)[K])
+{
+    const int seg = RS > 0 ? RS : seg_;
     typedef float vf4 __attribute__((ext_vector_type(4)));
-    static_assert(R % 4 == 0, "four rows per step");
-    constexpr int SLOT = LPT * NT * 4; // floats per ring slot: every thread writes all its LPT vectors, whatever the chunk size
-    const int chunk4 = R * ws / 4, nchunks = (n + R - 1) / R, total4 = n * (ws / 4) + n * (ws % 4) / 4; // = n * ws / 4
-    // the weights are in global memory: say so, or the loads are FLAT loads, which also count on lgkmcnt — every wait for an LDS read would then
-    // wait for all weight loads in flight
-    typedef __attribute__((address_space(1))) const vf4 GV4;
-    GV4* W4 = (GV4*)(W);
-    vf4 buf[D][LPT];
-    int o[K];
+    typedef typename std::conditional<VEC4, vf4, float>::type LT;
+    typedef __attribute__((address_space(1))) const LT GLT;
+    static_assert(G % 4 == 0, "four rows per step");
+    constexpr int SLOT = fcSegSlot<NT, VEC4, LPT>(), E = VEC4 ? 4 : 1;
+    const int R = fcSegRows<NT, VEC4, G, LPT>(seg), nchunks = (n + R - 1) / R, per = seg / E; // load elements per row
+    GLT* Wg = (GLT*)(W);
+    LT buf[D][LPT];
+    int rowj[LPT], offj[LPT]; // row within a chunk and element offset within the matrix of this thread's LPT loads (chunk 0)
 #pragma unroll
-    for (int k = 0; k < K; ++k) { acc[k] = 0.0f; o[k] = t + k * NT < nout ? t + k * NT : 0; }
-    // No branch around a global load or around an iteration (chunks beyond the layer fetch element 0 and compute nothing): the compiler counts the
-    // loads in flight per PATH and waits for the oldest chunk with s_waitcnt vmcnt(N), N = the loads it can prove to be younger — with
-    // conditional iterations N shrinks towards 0 and every chunk pays the full memory latency (measured: 1 us per chunk).  Straight-line for
-    // the same reason: inside a loop the prefetch would be loop-carried and waited for with vmcnt(0).
-    auto issue = [&](vf4 (&b)[LPT], int c) {
+    for (int j = 0; j < LPT; ++j) {
+        const int e = t + j * NT;
+        rowj[j] = e / per;
+        offj[j] = (rowj[j] * ws + col0) / E + (e - rowj[j] * per);
+        if (rowj[j] >= R) { rowj[j] = 1 << 28; } // beyond the chunk: never fetched (element 0 instead)
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { acc[k] = 0.0f; }
+    const int cstep = R * ws / E; // element offset between consecutive chunks (R * ws is a multiple of 4 for VEC4: ws is)
+    auto issue = [&](LT (&b)[LPT], int c) {
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            const int k4 = t + j * NT, g4 = c * chunk4 + k4;
-            const bool ok = c < nchunks && k4 < chunk4 && g4 < total4;
-            b[j] = W4[ok ? g4 : 0];
+            const bool ok = c * R + rowj[j] < n;
+            b[j] = Wg[ok ? c * cstep + offj[j] : 0];
         }
     };
-    auto drain = [&](const vf4 (&b)[LPT], int c) {
-        vf4* dst = reinterpret_cast<vf4*>(ring + size_t(c & 1) * SLOT);
+    auto drain = [&](const LT (&b)[LPT], int c) {
+        LT* dst = reinterpret_cast<LT*>(ring + size_t(c & 1) * SLOT);
 #pragma unroll
         for (int j = 0; j < LPT; ++j) { dst[t + j * NT] = b[j]; }
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) { issue(buf[d], d); }
+    MZ_HPROF2();
     drain(buf[0], 0);
     __syncthreads();
-    const bool mine = t < nout;
+    MZ_HPROF2();
+    // Rounds of D chunks: a real loop, so that the code of a round stays in the instruction cache (the fully straight-line version — 26 + 32
+    // copies of the chunk code, each executed once per simulation — ran at 20 cycles per instruction: every line came from the L2).  Chunks
+    // beyond the layer in the last round fetch element 0 and compute nothing.
+    for (int c0 = 0; c0 < nchunks; c0 += D) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        issue(buf[c % D], c + D);
-        drain(buf[(c + 1) % D], c + 1);
+    for (int d = 0; d < D; ++d) {
+        const int c = c0 + d;
+        issue(buf[d], c + D);
+        drain(buf[(d + 1) % D], c + 1);
+        MZ_HPROF2();
         const int rows = n - c * R < R ? n - c * R : R;
         if (mine && rows > 0) {
             const float* rs = ring + size_t(c & 1) * SLOT;
-            auto step4 = [&](int r) {
-                const vf4 xv = *reinterpret_cast<const vf4*>(x + c * R + r);
+            int r0 = 0;
+            for (; r0 + G <= rows; r0 += G) {
+                if constexpr (XU) {
+                    static_assert(G <= 64, "one row per lane");
+                    const int lane = t & 63;
+                    const float xl = xk[0][c * R + r0 + (lane < G ? lane : 0)];
+                    float wv[K][G];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+#pragma unroll
+                        for (int r = 0; r < G; ++r) { wv[k][r] = rs[(r0 + r) * seg + uk[k]]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < G; ++r) {
+                        const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xl), r));
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { acc[k] = __builtin_fmaf(xs, wv[k][r], acc[k]); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                vf4 xv[K][G / 4];
+                float wv[K][G];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    float a = acc[k];
-                    a = __builtin_fmaf(xv.x, rs[(r + 0) * ws + o[k]], a);
-                    a = __builtin_fmaf(xv.y, rs[(r + 1) * ws + o[k]], a);
-                    a = __builtin_fmaf(xv.z, rs[(r + 2) * ws + o[k]], a);
-                    a = __builtin_fmaf(xv.w, rs[(r + 3) * ws + o[k]], a);
-                    acc[k] = a;
-                }
-            };
-            if (rows == R) { // all LDS reads of the chunk first, then the dependent fmas (left alone the scheduler puts every read right in
-                             // front of its fma: 24 LDS round trips in a row, 0.9 us per chunk)
-                vf4 xv[R / 4];
-                float wv[K][R];
+                    const float* rp = rs + r0 * seg + uk[k];
 #pragma unroll
-                for (int r = 0; r < R; r += 4) { xv[r / 4] = *reinterpret_cast<const vf4*>(x + c * R + r); }
+                    for (int r = 0; r < G; r += 4) { xv[k][r / 4] = *reinterpret_cast<const vf4*>(xk[k] + c * R + r0 + r); }
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) { wv[k][r] = rs[r * ws + o[k]]; }
+                    for (int r = 0; r < G; ++r) { wv[k][r] = rp[r * seg]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     float a = acc[k];
 #pragma unroll
-                    for (int r = 0; r < R; r += 4) {
-                        a = __builtin_fmaf(xv[r / 4].x, wv[k][r + 0], a);
-                        a = __builtin_fmaf(xv[r / 4].y, wv[k][r + 1], a);
-                        a = __builtin_fmaf(xv[r / 4].z, wv[k][r + 2], a);
-                        a = __builtin_fmaf(xv[r / 4].w, wv[k][r + 3], a);
+                    for (int r = 0; r < G; r += 4) {
+                        a = __builtin_fmaf(xv[k][r / 4].x, wv[k][r + 0], a);
+                        a = __builtin_fmaf(xv[k][r / 4].y, wv[k][r + 1], a);
+                        a = __builtin_fmaf(xv[k][r / 4].z, wv[k][r + 2], a);
+                        a = __builtin_fmaf(xv[k][r / 4].w, wv[k][r + 3], a);
                     }
                     acc[k] = a;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            } else {
-                for (int r = 0; r < rows; r += 4) { step4(r); }
+                }
+            }
+            for (; r0 < rows; r0 += 4) { // the layer's tail (n % 4 == 0)
+                const vf4* xp[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const vf4 x4 = *reinterpret_cast<const vf4*>(xk[k] + c * R + r0);
+                    float a = acc[k];
+                    a = __builtin_fmaf(x4.x, rs[(r0 + 0) * seg + uk[k]], a);
+                    a = __builtin_fmaf(x4.y, rs[(r0 + 1) * seg + uk[k]], a);
+                    a = __builtin_fmaf(x4.z, rs[(r0 + 2) * seg + uk[k]], a);
+                    a = __builtin_fmaf(x4.w, rs[(r0 + 3) * seg + uk[k]], a);
+                    acc[k] = a;
+                }
+                (void)xp;
             }
         }
+        MZ_HPROF2();
         __syncthreads();
+        MZ_HPROF2();
+    }
     }
 }
-constexpr int kFcStreamR1 = 24, kFcStreamR2 = 8; // rows per chunk of FC1 / FC2
-constexpr int kFcStreamN1 = 26, kFcStreamN2 = 32; // chunks the straight-line code covers (FC1: <= 624 inputs, FC2: <= 256)
-inline size_t fcStreamRingFloats(int, int) { return size_t(2) * 3 * 512 * 4 + 8; } // two slots of LPT * NT 16-byte vectors
+// the two layers of a 601-bin head: FC1 with 16-byte loads and groups of 24 rows, FC2 (rows of 601 floats: no alignment) with 4-byte loads, two bins
+// per thread and groups of 8 rows
+#define MZ_FC1_STREAM 512, true, 24, 1, 8, 3, 26
+#define MZ_FC2_STREAM 512, false, 8, 2, 6, 10, 32
+#define MZ_FC1_OCTET 512, true, 24, 1, 8, 3, 26, false  /* octet heads: a wave = one game, lane = unit (+ the slice length) */
+#define MZ_FC2_OCTET 512, false, 16, 3, 6, 10, 32, false /* ... lane = bins l, l + 64, l + 128 of the slice */
+constexpr int kFcRingFloats = 2 * 3 * 512 * 4 + 8;
+inline size_t fcStreamRingFloats(int, int) { return kFcRingFloats; }
+__host__ __device__ inline bool fcStream1Fits(int n1, int hidden, int seg) { return n1 % 4 == 0 && hidden % 4 == 0 && seg % 4 == 0 && seg <= 512 && (n1 + fcSegRows<512, true, 24, 3>(seg) - 1) / fcSegRows<512, true, 24, 3>(seg) <= 26; }
+__host__ __device__ inline bool fcStream2Fits(int hidden, int seg) { return hidden % 4 == 0 && seg <= 1024 && (hidden + fcSegRows<512, false, 8, 10>(seg) - 1) / fcSegRows<512, false, 8, 10>(seg) <= 32; }
+
+// conv1x1 (C -> hc channels) + ReLU of a discrete head: xs[C][P] (LDS) -> f[hc * P] (LDS); NT threads, no barrier inside
+template <int NT>
+__device__ __forceinline__ void discreteConv(const DiscreteParams& d, const float* xs, int C, int P, float* f, int t)
+{
+    constexpr int K = NT >= 512 ? 2 : 3; // outputs per thread and pass: 612 conv outputs in one pass
+    const int n0 = d.hc * P;
+    for (int i0 = t; i0 < n0; i0 += NT * K) {
+        const float* xk[K];
+        const float* wk[K];
+        int idx[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            idx[k] = i0 + k * NT < n0 ? i0 + k * NT : n0 - 1; // lanes beyond the end redo the last output and drop it
+            const int j = idx[k] / P, p = idx[k] - j * P;
+            xk[k] = xs + p;
+            wk[k] = d.conv_w + j * C;
+        }
+        float acc[K];
+        dotChainK<32, K>(xk, P, wk, 1, C, acc);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (i0 + k * NT < n0) { const float v = acc[k] + d.conv_b[idx[k] / P]; f[idx[k]] = v > 0.0f ? v : 0.0f; }
+        }
+    }
+}
+
+// the same with the conv weights in LDS (wl[hc][C], bl[hc]: copied once per launch by a kernel that runs many simulations): no global-memory
+// round trip in front of a 64-step chain
+template <int NT>
+__device__ __forceinline__ void discreteConvLds(const float* wl, const float* bl, int hc, const float* xs, int C, int P, float* f, int t)
+{
+    const int n0 = hc * P;
+    for (int i0 = t; i0 < n0; i0 += NT * 2) {
+        const int i1 = i0 + NT < n0 ? i0 + NT : i0;
+        const int j0 = i0 / P, p0 = i0 - j0 * P, j1 = i1 / P, p1 = i1 - j1 * P;
+        const float *x0 = xs + p0, *x1 = xs + p1, *w0 = wl + j0 * C, *w1 = wl + j1 * C;
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll 16
+        for (int c = 0; c < C; ++c) {
+            a0 = __builtin_fmaf(x0[c * P], w0[c], a0);
+            a1 = __builtin_fmaf(x1[c * P], w1[c], a1);
+        }
+        const float v0 = a0 + bl[j0], v1 = a1 + bl[j1];
+        f[i0] = v0 > 0.0f ? v0 : 0.0f;
+        if (i0 + NT < n0) { f[i1] = v1 > 0.0f ? v1 : 0.0f; }
+    }
+}
+
+// softmax expectation of the logits lg[size] (LDS; overwritten) -> *out: m = this thread's maximum over the logits it wrote (or -3.4e38f).
+// All NT threads; `active` = false: barriers only.  The 601 quotients are independent, only the two index-ordered sums are serial.
+template <int NT>
+__device__ __forceinline__ void discreteTail(int size, bool active, float m, float* lg, float* red, float* out, int t)
+{
+    const int lane = t & 63, wave = t >> 6;
+    if (active) {
+        for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
+        if (lane == 0) { red[wave] = m; }
+    }
+    __syncthreads();
+    MZ_HPROF(3);
+    if (active) {
+        m = red[0];
+        for (int w = 1; w < NT / 64; ++w) { m = red[w] > m ? red[w] : m; }
+        for (int o = t; o < size; o += NT) { lg[o] = mz_expf(lg[o] - m); }
+    }
+    __syncthreads();
+    MZ_HPROF(4);
+    if (active && wave == 0) { // index-ordered sum of the exponentials (ref muzero_network.h:157-162)
+        const float s = orderedSumWave(lg, size, lane);
+        if (lane == 0) { red[8] = s; }
+    }
+    __syncthreads();
+    MZ_HPROF(5);
+    if (active) {
+        const float s = red[8];
+        const int start_value = -size / 2;
+        for (int o = t; o < size; o += NT) { lg[o] = (lg[o] / s) * static_cast<float>(start_value + o); } // value * start_value++ (int -> float, exact)
+    }
+    __syncthreads();
+    MZ_HPROF(6);
+    if (active && wave == 0) { // accumulate(sum + value * start_value++), in index order
+        const float e = orderedSumWave(lg, size, lane);
+        if (lane == 0) { *out = e; }
+    }
+    __syncthreads();
+    MZ_HPROF(7);
+}
 
 // WIDE (one head per workgroup, sim_cluster.h): one hidden unit / two bins per thread, so that more waves have weight loads in flight
 template <int NT, bool WIDE = false>
@@ -157,31 +321,9 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
                              float* out, int t, float* ring = nullptr)
 {
     // ring != nullptr (WIDE): FC layers whose shapes fit stream their weights through it (fcStream)
-    const bool stream1 = WIDE && ring && (d.hc * P) % 4 == 0 && d.hidden % 4 == 0 && d.hidden <= NT && kFcStreamR1 * d.hidden <= 3 * NT * 4 && d.hc * P <= kFcStreamN1 * kFcStreamR1;
-    const bool stream2 = WIDE && ring && d.hidden % 4 == 0 && d.size <= 2 * NT && kFcStreamR2 * d.size <= 3 * NT * 4 && d.hidden <= kFcStreamN2 * kFcStreamR2;
-    const int lane = t & 63, wave = t >> 6;
-    constexpr int K = NT >= 512 ? 2 : 3; // outputs per thread and pass: 601 bins / 612 conv outputs in one pass of the half
-    if (active) {
-        const int n0 = d.hc * P;
-        for (int i0 = t; i0 < n0; i0 += NT * K) {
-            const float* xk[K];
-            const float* wk[K];
-            int idx[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                idx[k] = i0 + k * NT < n0 ? i0 + k * NT : n0 - 1; // lanes beyond the end redo the last output and drop it
-                const int j = idx[k] / P, p = idx[k] - j * P;
-                xk[k] = xs + p;
-                wk[k] = d.conv_w + j * C;
-            }
-            float acc[K];
-            dotChainK<32, K>(xk, P, wk, 1, C, acc);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (i0 + k * NT < n0) { const float v = acc[k] + d.conv_b[idx[k] / P]; f[idx[k]] = v > 0.0f ? v : 0.0f; }
-            }
-        }
-    }
+    const bool stream1 = WIDE && ring && NT == 512 && fcStream1Fits(d.hc * P, d.hidden, d.hidden);
+    const bool stream2 = WIDE && ring && NT == 512 && fcStream2Fits(d.hidden, d.size);
+    if (active) { discreteConv<NT>(d, xs, C, P, f, t); }
     __syncthreads();
     MZ_HPROF(1);
     if (active) {
@@ -189,7 +331,9 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
         if (WIDE && stream1) {
             if constexpr (WIDE) {
                 float acc[1];
-                fcStream<NT, kFcStreamR1, 8, 3, 1, kFcStreamN1>(f, d.fc1_wT, d.hidden, n1, d.hidden, ring, t, acc);
+                const float* xk[1] = {f};
+                const int uk[1] = {t < d.hidden ? t : 0};
+                fcStreamSeg<MZ_FC1_STREAM>(xk, uk, t < d.hidden, d.fc1_wT, d.hidden, 0, d.hidden, n1, ring, t, acc);
                 if (t < d.hidden) { const float v = acc[0] + d.fc1_b[t]; h1[t] = v > 0.0f ? v : 0.0f; }
             }
         } else if constexpr (WIDE) {
@@ -213,7 +357,9 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
     if (active && WIDE && stream2) {
         if constexpr (WIDE) {
             float acc[2];
-            fcStream<NT, kFcStreamR2, 8, 3, 2, kFcStreamN2>(h1, d.fc2_wT, d.size, d.hidden, d.size, ring, t, acc);
+            const float* xk[2] = {h1, h1};
+            const int uk[2] = {t < d.size ? t : 0, t + NT < d.size ? t + NT : 0};
+            fcStreamSeg<MZ_FC2_STREAM>(xk, uk, t < d.size, d.fc2_wT, d.size, 0, d.size, d.hidden, ring, t, acc);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int o = t + k * NT;
@@ -254,37 +400,8 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
                 }
             }
         }
-        for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
-        if (lane == 0) { red[wave] = m; }
     }
-    __syncthreads();
-    MZ_HPROF(3);
-    if (active) {
-        m = red[0];
-        for (int w = 1; w < NT / 64; ++w) { m = red[w] > m ? red[w] : m; }
-        for (int o = t; o < d.size; o += NT) { lg[o] = mz_expf(lg[o] - m); }
-    }
-    __syncthreads();
-    MZ_HPROF(4);
-    if (active && wave == 0) { // index-ordered sum of the exponentials (ref muzero_network.h:157-162)
-        const float s = orderedSumWave(lg, d.size, lane);
-        if (lane == 0) { red[8] = s; }
-    }
-    __syncthreads();
-    MZ_HPROF(5);
-    if (active) {
-        const float s = red[8];
-        const int start_value = -d.size / 2;
-        for (int o = t; o < d.size; o += NT) { lg[o] = (lg[o] / s) * static_cast<float>(start_value + o); } // value * start_value++ (int -> float, exact)
-    }
-    __syncthreads();
-    MZ_HPROF(6);
-    if (active && wave == 0) { // accumulate(sum + value * start_value++), in index order
-        const float e = orderedSumWave(lg, d.size, lane);
-        if (lane == 0) { *out = e; }
-    }
-    __syncthreads();
-    MZ_HPROF(7);
+    discreteTail<NT>(d.size, active, m, lg, red, out, t);
 }
 
 // invertValue (ref utils/utils.h:102-108) on the device: the reference evaluates the inner expression in double (C `fabs` / `sqrt` on a

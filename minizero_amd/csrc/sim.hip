@@ -25,11 +25,23 @@ __shared__ int s_tp_idx;
 #endif
 __device__ unsigned long long g_hp[16];
 __shared__ unsigned long long s_hp_prev;
+__device__ unsigned long long g_hp2[96];
+__shared__ int s_hp2_idx;
+#ifdef MZ_SIM_HPROF2 // fine stamps inside fcStreamSeg (each costs ~0.15 us: they distort the coarse sections)
+#define MZ_HPROF2()                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x == MZ_HPROF_BLOCK) {                                       \
+            const unsigned long long t_ = wall_clock64();                                             \
+            if (s_hp2_idx < 96) { g_hp2[s_hp2_idx] += t_ - s_hp_prev; }                               \
+            ++s_hp2_idx; s_hp_prev = t_;                                                              \
+        }                                                                                             \
+    } while (0)
+#endif
 #define MZ_HPROF(k)                                                                                   \
     do {                                                                                              \
         if (threadIdx.x == 0 && blockIdx.x == MZ_HPROF_BLOCK) {                                       \
             const unsigned long long t_ = wall_clock64();                                             \
-            if ((k) > 0) { g_hp[(k)] += t_ - s_hp_prev; } else { g_hp[15] += 1; }                     \
+            if ((k) > 0) { g_hp[(k)] += t_ - s_hp_prev; } else { g_hp[15] += 1; s_hp2_idx = 0; }                     \
             s_hp_prev = t_;                                                                           \
         }                                                                                             \
     } while (0)
@@ -95,7 +107,8 @@ struct SimArgs {
     const uint4* wfrag;
     TowerArgsBf16 tb;
     unsigned* cluster;                // cluster mode (sim_cluster.h): per-game exchange block of `cluster_words` words; nullptr: one workgroup per game
-    int cluster_words, pad_cluster_;
+    int cluster_words, oct_words;
+    unsigned* cluster_oct;            // cluster mode: the blocks of the octet-wide 601-bin heads ([8 octets][2 heads][oct_words]); nullptr: per-game heads
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
 };
 
@@ -701,8 +714,14 @@ void Net::dumpSimProf()
         unsigned long long h[16];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hp), sizeof(h)) == hipSuccess && h[15]) {
             fprintf(stderr, "[mz sim hprof] us per section of the heads (game 0, avg over %llu calls; board games: [1] tail wait, [5] setup, [6] conv1x1, [7] FCs, [8] FC2 / softmax):", h[15]);
-            for (int i = 1; i < 12; ++i) { fprintf(stderr, " %.2f", double(h[i]) / double(h[15]) * 0.01); }
+            for (int i = 1; i < 14; ++i) { if (i != 8) { fprintf(stderr, " [%d] %.2f", i, double(h[i]) / double(h[15]) * 0.01); } }
             fprintf(stderr, "\n");
+            unsigned long long h2[96];
+            if (hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_hp2), sizeof(h2)) == hipSuccess) {
+                fprintf(stderr, "[mz sim hprof] fine stamps (us):");
+                for (int i = 0; i < 96; ++i) { if (h2[i]) { fprintf(stderr, " %d:%.2f", i, double(h2[i]) / double(h[15]) * 0.01); } }
+                fprintf(stderr, "\n");
+            }
         }
     }
 #endif
@@ -950,10 +969,19 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
         lds_cluster = lds + (clusterHeadsSmemFloats(a.ahp) - head_floats) * sizeof(float);
         if (lds_cluster > 160 * 1024) { setError("simLaunchMz: the cluster mode needs %zu bytes of LDS", lds_cluster); return MZ_ERR_ARG; }
         const size_t words = clusterWords(C, H * W);
-        if (!sim_cluster_mem_.ensure(size_t(pool.v_.games) * words * sizeof(unsigned))) { setError("hipMalloc of the cluster exchange blocks failed"); return MZ_ERR_DEVICE; }
+        const DiscreteParams &dv = a.ahp.value, &dr = a.ahp.reward;
+        const int n1 = std::max(dv.hc, dr.hc) * a.ahp.P, hidm = std::max(dv.hidden, dr.hidden), sizem = std::max(dv.size, dr.size);
+        const size_t ow = octetWords(n1, hidm, sizem);
+        const bool octet = sim_octet_ && pool.v_.games >= 64 && size_t(4) * (up4i(n1) + up4i(hidm)) * sizeof(float) <= tile_bytes &&
+                           octetHeadFits(dv, a.ahp.P) && octetHeadFits(dr, a.ahp.P);
+        const size_t total_words = size_t(pool.v_.games) * words + (octet ? 16 * ow : 0);
+        if (!sim_cluster_mem_.ensure(total_words * sizeof(unsigned))) { setError("hipMalloc of the cluster exchange blocks failed"); return MZ_ERR_DEVICE; }
         a.cluster = reinterpret_cast<unsigned*>(sim_cluster_mem_.p);
         a.cluster_words = static_cast<int>(words);
-        MZ_HIP(hipMemsetAsync(sim_cluster_mem_.p, 0, size_t(pool.v_.games) * words * sizeof(unsigned), stream_));
+        a.cluster_oct = octet ? a.cluster + size_t(pool.v_.games) * words : nullptr;
+        a.oct_words = static_cast<int>(ow);
+        if (getenv("MZ_SIM_PROF") && sim_args_host_.empty()) { fprintf(stderr, "[mz sim] cluster mode: %d games, octet heads %s\n", pool.v_.games, octet ? "on" : "off"); }
+        MZ_HIP(hipMemsetAsync(sim_cluster_mem_.p, 0, total_words * sizeof(unsigned), stream_));
     }
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
         if (!sim_args_.ensure(sizeof(SimArgs))) { setError("hipMalloc of the simulation arguments failed"); return MZ_ERR_DEVICE; }

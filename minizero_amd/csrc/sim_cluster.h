@@ -49,13 +49,135 @@ __device__ __forceinline__ bool clWaitGE(const unsigned* p, unsigned want)
     return false;
 }
 
+// Octet block: the (up to) 8 games whose workgroups share an XCD (game % 8) run each 601-bin head TOGETHER — the CU of game j computes column
+// slice j of both FC layers for all games of the octet, so the XCD's L2 delivers every weight once per simulation instead of once per game.
+// (Measured: 16 CUs streaming 1.24 MB each get 0.74 TB/s out of one XCD's L2 together, 27 us per simulation for the FC layers, however deep
+// each CU prefetches.)  One block per (octet, head): [0] arrivals, then F[8][n1p], H1[8][hidp], LG[8][sizep].
+constexpr int kOcHdr = 32;
+__host__ __device__ inline int up4i(int v) { return (v + 3) & ~3; }
+inline size_t octetWords(int n1, int hidden, int size) { return size_t(kOcHdr) + 8 * (size_t(up4i(n1)) + up4i(hidden) + up4i(size)) + 32; }
+
 struct ClusterCtx {
     unsigned* cm;   // this game's block
     int member, C, P, OT;
     unsigned xseq;  // layer exchanges done so far in this launch
     int* abort_lds; // workgroup-wide abort flag
     int* err;
+    unsigned* om;   // this (octet, head)'s block (helpers), nullptr: every game runs its heads alone
+    int NJ, j;      // games in the octet, this game's position
+    unsigned oseq;  // octet exchanges done so far in this launch
+    const float* convw; // helpers: the head's conv1x1 weights + biases in LDS (nullptr: read from global memory)
 };
+
+// the helpers of an octet meet (all 512 threads of each): false = a member went missing
+__device__ __forceinline__ bool octExchange(ClusterCtx& c, int tid)
+{
+    clDrain();
+    __syncthreads();
+    const unsigned k = ++c.oseq;
+    if (tid == 0) {
+        __hip_atomic_fetch_add(c.om, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!clWaitGE(c.om, k * unsigned(c.NJ))) { *c.abort_lds = 1; atomicExch(c.err, 94); }
+    }
+    __syncthreads();
+    return *c.abort_lds == 0;
+}
+
+// One 601-bin head for the 8 games of a full octet, run by the head's helper of each game (512 threads): own conv1x1, then for the four games
+// of this game's half (position j / 4) column slice j % 4 of FC1 and of FC2 — wave w < 4 = game 4 * (j / 4) + w, lane = unit / bins of the
+// slice — then the own game's softmax expectation -> *out.  Every weight leaves the L2 twice per simulation instead of eight times.
+// `stage` = LDS for the half's FC inputs (4 * (n1p + hidp) floats).
+__device__ __forceinline__ bool octetHead(const DiscreteParams& d, const float* xin, int C, int P, float* f, float* lg, float* red, float* ring, float* stage,
+                                          const float* convw, float* out, ClusterCtx& c, int tid)
+{
+    const int n1 = d.hc * P, n1p = up4i(n1), hidp = up4i(d.hidden), sizep = up4i(d.size), j = c.j;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), slice = j & 3, g0 = j & ~3; // games g0 .. g0 + 3 of the octet
+    float* Fg = reinterpret_cast<float*>(c.om + kOcHdr);
+    float* H1g = Fg + 8 * n1p;
+    float* LGg = H1g + 8 * hidp;
+    float* Fall = stage;
+    float* H1all = stage + 4 * n1p;
+    if (convw) { discreteConvLds<512>(convw, convw + d.hc * C, d.hc, xin, C, P, f, tid); } else { discreteConv<512>(d, xin, C, P, f, tid); }
+    __syncthreads();
+    MZ_HPROF(1);
+    for (int i = tid; i < n1; i += 512) { Fg[j * n1p + i] = f[i]; }
+    if (!octExchange(c, tid)) { return false; }
+    MZ_HPROF(10);
+    { // the conv outputs of my half's four games (contiguous in the block)
+        const int tot = 4 * n1p;
+#pragma unroll 2
+        for (int i0 = 0; i0 < tot; i0 += 4 * 512) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int idx = i0 + q * 512 + tid; v[q] = clLoadF(Fg + g0 * n1p + (idx < tot ? idx : 0)); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int idx = i0 + q * 512 + tid; if (idx < tot) { Fall[idx] = v[q]; } }
+        }
+    }
+    __syncthreads();
+    MZ_HPROF(2);
+    { // FC1: hidden units [u0, u0 + seg) of the half's games
+        const int SL = d.hidden / 4, u0 = slice * SL, seg = SL; // octetHeadFits: hidden = 4 * SL, SL = 64, 16 or 8
+        const bool wmine = wave < 4;
+        const float* xv = Fall + (wave < 4 ? wave : 0) * n1p;
+        const float* xk[1] = {xv};
+        const int uk[1] = {lane < seg ? lane : 0};
+        float acc[1];
+        if (SL == 64) { fcStreamSeg<MZ_FC1_OCTET, 64>(xk, uk, wmine, d.fc1_wT, d.hidden, u0, seg, n1, ring, tid, acc); }
+        else if (SL == 16) { fcStreamSeg<MZ_FC1_OCTET, 16>(xk, uk, wmine, d.fc1_wT, d.hidden, u0, seg, n1, ring, tid, acc); }
+        else { fcStreamSeg<MZ_FC1_OCTET, 8>(xk, uk, wmine, d.fc1_wT, d.hidden, u0, seg, n1, ring, tid, acc); } // the small test nets
+        if (wmine && lane < seg) { const float v = acc[0] + d.fc1_b[u0 + lane]; H1g[(g0 + wave) * hidp + u0 + lane] = v > 0.0f ? v : 0.0f; }
+    }
+    MZ_HPROF(11);
+    if (!octExchange(c, tid)) { return false; }
+    MZ_HPROF(12);
+    {
+        const int tot = 4 * hidp;
+        for (int i0 = 0; i0 < tot; i0 += 4 * 512) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int idx = i0 + q * 512 + tid; v[q] = clLoadF(H1g + g0 * hidp + (idx < tot ? idx : 0)); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int idx = i0 + q * 512 + tid; if (idx < tot) { H1all[idx] = v[q]; } }
+        }
+    }
+    __syncthreads();
+    MZ_HPROF(9);
+    { // FC2: bins [b0, b0 + seg) of the half's games, bins lane, lane + 64, lane + 128 of the slice per thread
+        // all four slices have SL = 151 bins: the last one starts at size - SL (three bins are computed by two CUs, with identical results)
+        const int SL = (d.size + 3) / 4, b0 = slice * SL + SL <= d.size ? slice * SL : d.size - SL, seg = SL;
+        const bool wmine = wave < 4;
+        const float* xv = H1all + (wave < 4 ? wave : 0) * hidp;
+        const float* xk[3] = {xv, xv, xv};
+        int uk[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { uk[k] = lane + 64 * k < seg ? lane + 64 * k : 0; }
+        float acc[3];
+        fcStreamSeg<MZ_FC2_OCTET, 151>(xk, uk, wmine, d.fc2_wT, d.size, b0, seg, d.hidden, ring, tid, acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int b = lane + 64 * k;
+            if (wmine && b < seg) { LGg[(g0 + wave) * sizep + b0 + b] = acc[k] + d.fc2_b[b0 + b]; }
+        }
+    }
+    if (!octExchange(c, tid)) { return false; }
+    float m = -3.4e38f;
+    {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int o = tid + q * 512; v[q] = clLoadF(LGg + j * sizep + (o < d.size ? o : 0)); }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int o = tid + q * 512; if (o < d.size) { lg[o] = v[q]; m = v[q] > m ? v[q] : m; } }
+    }
+    discreteTail<512>(d.size, true, m, lg, red, out, tid);
+    return true;
+}
+// shapes the octet heads cover: FC1 slices of <= 64 units, FC2 slices of <= 192 bins (three per lane), at most 1024 bins for the last gather
+__host__ __device__ inline bool octetHeadFits(const DiscreteParams& d, int P)
+{
+    const int n1 = d.hc * P, sl1 = d.hidden / 4, sl2 = (d.size + 3) / 4;
+    return n1 % 4 == 0 && d.hidden % 4 == 0 && (sl1 == 64 || sl1 == 16 || sl1 == 8) && sl1 * 4 == d.hidden && sl2 == 151 && d.size >= sl2 && d.size <= 1024; // the instantiated slice lengths
+}
 
 // my 16 x P block of the exchange buffer for the NEXT exchange
 __device__ __forceinline__ float* clPart(const ClusterCtx& c, int ot) { return reinterpret_cast<float*>(c.cm + kClXbuf) + size_t(c.xseq & 1) * c.C * c.P + size_t(ot) * 16 * c.P; }
@@ -176,7 +298,7 @@ __device__ __forceinline__ float* towerBodyCluster(const float* __restrict__ par
 // 1 = reward head (on the UNscaled state), 2 = value head; results of 1 and 2 -> the cluster block as (bits, seq) pairs
 __device__ __forceinline__ void clusterAtariHeads(const float* __restrict__ xlds, int xcs, int xpw, const AtariHeadParams& hp, float* __restrict__ policy,
                                                   float* __restrict__ logit, float* __restrict__ hd, int b, int tid, float* __restrict__ sm, ClusterCtx& c,
-                                                  unsigned seq)
+                                                  unsigned seq, float* __restrict__ stage)
 {
     if (c.member == 3) { return; }
     const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC;
@@ -230,7 +352,11 @@ __device__ __forceinline__ void clusterAtariHeads(const float* __restrict__ xlds
     if (c.member != 0) {
         __shared__ float s_out;
         MZ_HPROF(0);
-        discreteHead<512, true>(c.member == 1 ? hp.reward : hp.value, true, c.member == 1 ? xr : xs, C, P, f, h1, lg, red, &s_out, tid, ring);
+        if (c.om) {
+            if (!octetHead(c.member == 1 ? hp.reward : hp.value, c.member == 1 ? xr : xs, C, P, f, lg, red, ring, stage, c.convw, &s_out, c, tid)) { return; }
+        } else {
+            discreteHead<512, true>(c.member == 1 ? hp.reward : hp.value, true, c.member == 1 ? xr : xs, C, P, f, h1, lg, red, &s_out, tid, ring);
+        }
         if (tid == 0) {
             clu2 pr;
             pr.x = __float_as_uint(invertValueDev(s_out));
@@ -297,6 +423,8 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
     ClusterCtx c;
     c.cm = a->cluster + size_t(g) * a->cluster_words;
     c.member = member; c.C = a->hp.C; c.P = a->hp.P; c.OT = a->ta_dyn.OT; c.xseq = 0; c.abort_lds = &s_abort; c.err = a->err;
+    c.NJ = (games - (g & 7) + 7) / 8; c.j = g >> 3; c.oseq = 0;
+    c.om = (a->cluster_oct && c.NJ == 8 && (member == 1 || member == 2)) ? a->cluster_oct + size_t((g & 7) * 2 + member - 1) * a->oct_words : nullptr;
     // placement check: the four members of a game must share an XCD (one L2), else the exchanges would read stale data
     if (tid == 0) {
         unsigned id;
@@ -310,6 +438,18 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
     }
     __syncthreads();
     if (s_abort) { return; }
+    c.convw = nullptr;
+    if (c.om) { // the head's conv1x1 weights stay in LDS for the whole launch: in the tables of the tree walk, which only the owner uses
+        const AtariHeadParams hp = ldc(&a->ahp);
+        const DiscreteParams& d = member == 1 ? hp.reward : hp.value;
+        float* cw = reinterpret_cast<float*>(rcp_w);
+        if (d.hc * (hp.C + 1) <= static_cast<int>(head_scratch - cw)) {
+            for (int i = tid; i < d.hc * hp.C; i += 512) { cw[i] = d.conv_w[i]; }
+            for (int i = tid; i < d.hc; i += 512) { cw[d.hc * hp.C + i] = d.conv_b[i]; }
+            c.convw = cw;
+        }
+        __syncthreads();
+    }
     unsigned long long* prof = (a->prof && member == 0) ? a->prof + size_t(g) * 8 : nullptr;
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s;
@@ -354,7 +494,8 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         {
             const AtariHeadParams hp = ldc(&a->ahp);
             float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
-            clusterAtariHeads(xt, planeStride(H, W), W + 2, hp, a->policy, a->logit, hd, g, tid, head_scratch, c, seq);
+            clusterAtariHeads(xt, planeStride(H, W), W + 2, hp, a->policy, a->logit, hd, g, tid, head_scratch, c, seq, tiles);
+            if (s_abort) { return; }
         }
         if (member != 0) { __syncthreads(); continue; }
         if (tid == 0) { // value and reward from the helpers

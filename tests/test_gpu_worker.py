@@ -308,6 +308,29 @@ def test_atari_execution_modes_are_equivalent(mz):
     assert lockstep == sim_single
 
 
+@pytest.mark.parametrize("games", [13, 64])
+def test_atari_cluster_pools_are_equivalent(mz, games):
+    """Cluster mode on pools that span several games per XCD.  64 games: full octets — the 8 games that share an XCD (game % 8) compute their 601-bin
+    heads together (sim_cluster.h octetHead: the CU of a game takes one column slice of both FC layers for four games); 13 games: ragged octets,
+    every game keeps its own heads.  Against one workgroup per game."""
+    conf = ATARI_SMALL.replace("zero_num_parallel_games=5", f"zero_num_parallel_games={games}")
+    kw = dict(vh=ATARI_ARGS[10], dv=ATARI_ARGS[11], type_name=ATARI_ARGS[12])
+    d = mz.make_desc(*ATARI_ARGS[:10], **kw)
+
+    def run(extra, chunks):
+        wk = mz.Worker(conf + extra + ":program_seed=11:nn_file_name=x.pt:zero_num_threads=2", d, mz.generate_weights(d, 3))
+        wk.command("start")
+        for c in chunks:
+            assert wk.run_cycles(c) == c
+        return wk.pop_lines()
+
+    total = 9 * (40 if games < 64 else 24)
+    single = run(":mz_sim_cluster=false", [total])
+    cluster = run("", [5, 9, 100, total - 114])
+    assert len(single) >= 20
+    assert single == cluster
+
+
 def test_go_muzero_gumbel_execution_modes_are_equivalent(mz, oracle):
     """MuZero board game with a Gumbel root: device Gumbel step + noise on the logits inside sim_kernel_mz vs lock-step vs oracle."""
     conf = ("env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=12:zero_num_parallel_games=5:actor_use_dirichlet_noise=false:"
