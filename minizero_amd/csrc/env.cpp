@@ -747,6 +747,20 @@ public:
         }
         memcpy(dst + size_t(kHist) * kFrame, av, sizeof(av));
     }
+    uint64_t rawSerial() const override { return serial_; }
+    int rawValidCount() const override { int k = 0; for (bool v : valid_) { k += v; } return k; }
+    int rawFrameBytes() const override { return kFrame; }
+    void rawNewest(uint8_t* frame, uint8_t* meta) const override
+    {
+        memcpy(frame, frames_.data() + size_t((head_ + kHist - 1) % kHist) * kFrame, kFrame);
+        float av[kHist];
+        for (int i = 0; i < kHist; ++i) {
+            const int slot = (head_ + i) % kHist;
+            av[i] = action_plane_[slot];
+            meta[kHist * 4 + i] = valid_[slot] ? 1 : 0;
+        }
+        memcpy(meta, av, sizeof(av));
+    }
     int numInputChannels() const override { return kHist * 4; }
     int boardSize() const override { return kRes; }
     int policySize() const override { return kActions; }
@@ -785,7 +799,9 @@ private:
         valid_[slot] = true;
         action_plane_[slot] = with_action ? action_value : 0.0f;
         head_ = (head_ + 1) % kHist;
+        ++serial_;
     }
+    uint64_t serial_ = 0;
     std::string name_;
     int episode_length_, seed_ = 0, head_ = 0, lost_ = 0;
     size_t recent_;

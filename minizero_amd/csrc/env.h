@@ -56,6 +56,13 @@ public:
     // rawFeatureBytes() > 0 = supported; layout documented at the implementation
     virtual int rawFeatureBytes() const { return 0; }
     virtual void rawFeatures(uint8_t* /*dst*/) const {}
+    // incremental form: the newest screen alone + the trailing (action values, valid flags) block of rawFeatures(); rawSerial() counts the screens
+    // pushed so far, rawValidCount() the valid ones in the window — a consumer that saw serial - 1 (or a window with one valid screen) can rebuild
+    // rawFeatures() from its previous copy shifted by one screen (worker.cpp: 1.8 MB instead of 14 MB per move over PCIe for 64 games)
+    virtual uint64_t rawSerial() const { return 0; }
+    virtual int rawValidCount() const { return 0; }
+    virtual int rawFrameBytes() const { return 0; }
+    virtual void rawNewest(uint8_t* /*frame*/, uint8_t* /*meta*/) const {}
     virtual bool hasDeviceTwin() const { return false; }
     virtual int deviceKind() const { return 0; } // GoDevView::kind (0 Go, 1 Othello)
     virtual void exportDeviceRoot(void* /*GoRootSnapshot*/) const {}

@@ -92,7 +92,8 @@ public:
                     int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start);
     bool hasSimKernelMz(int num_simulation = 0) const;
-    int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)
+    int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat);
+    int shiftExpandAtariFeatures(const uint8_t* d_prev, const uint8_t* d_newest, const uint8_t* d_meta, uint8_t* d_cur, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)
     void makeAtariHeadParams(AtariHeadParams* out) const; // net_atari.hip
     // opt-in 16-bit-input tower (net_bf16_body.h): 0 = f32 (default, bit-exact against the oracle), 1 = bf16x3 (split bf16 operands on
     // v_mfma_f32_16x16x32_bf16, f32 accumulation; outputs within 1e-3 of the f32 path, records not bit-identical to the reference)

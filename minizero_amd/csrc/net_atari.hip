@@ -281,6 +281,38 @@ __global__ __launch_bounds__(256) void atari_expand_features(const uint8_t* __re
     for (int p = threadIdx.x; p < frame; p += 256) { dst[pix + p] = valid ? static_cast<float>(f[p]) / 255.0f : 0.0f; }
 }
 
+// the same from the PREVIOUS move's raw block shifted by one screen + the newest screen (uploaded alone) + the new (action values, valid flags):
+// writes the new raw block (`cur`) and the float planes; one block per (history step, sample)
+__global__ __launch_bounds__(256) void atari_shift_expand_features(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ newest, const uint8_t* __restrict__ meta,
+                                                                   uint8_t* __restrict__ cur, int raw_bytes, int hist, int res, float* __restrict__ out)
+{
+    const int b = blockIdx.y, i = blockIdx.x;
+    const int pix = res * res, frame = 3 * pix;
+    const uint8_t* m = meta + size_t(b) * hist * 5;
+    float av;
+    memcpy(&av, m + size_t(i) * 4, 4);
+    const bool valid = m[size_t(hist) * 4 + i] != 0;
+    const uint8_t* f = i + 1 < hist ? prev + size_t(b) * raw_bytes + size_t(i + 1) * frame : newest + size_t(b) * frame;
+    uint8_t* c = cur + size_t(b) * raw_bytes + size_t(i) * frame;
+    float* dst = out + (size_t(b) * hist + i) * 4 * pix;
+    for (int p = threadIdx.x; p < pix; p += 256) { dst[p] = av; }
+    for (int p = threadIdx.x; p < frame; p += 256) {
+        const uint8_t v = f[p];
+        c[p] = v;
+        dst[pix + p] = valid ? static_cast<float>(v) / 255.0f : 0.0f;
+    }
+    if (i == 0) { for (int p = threadIdx.x; p < hist * 5; p += 256) { cur[size_t(b) * raw_bytes + size_t(hist) * frame + p] = m[p]; } }
+}
+
+int Net::shiftExpandAtariFeatures(const uint8_t* d_prev, const uint8_t* d_newest, const uint8_t* d_meta, uint8_t* d_cur, int raw_bytes, int B, float* d_feat)
+{
+    const int res = desc_.input_channel_height, hist = desc_.num_input_channels / 4;
+    if (desc_.input_channel_width != res || raw_bytes != hist * 3 * res * res + hist * 5) { setError("shiftExpandAtariFeatures: unexpected observation layout"); return MZ_ERR_ARG; }
+    hipLaunchKernelGGL(atari_shift_expand_features, dim3(hist, B), dim3(256), 0, stream_, d_prev, d_newest, d_meta, d_cur, raw_bytes, hist, res, d_feat);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
 int Net::expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat)
 {
     const int res = desc_.input_channel_height, hist = desc_.num_input_channels / 4;

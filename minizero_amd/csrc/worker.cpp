@@ -236,21 +236,22 @@ struct Game {
     std::vector<int> candidates;
     int sample_size = 0, simulation_budget = 0;
     int selected = -1; // index of the chosen root child
+    uint64_t raw_seen = ~0ull; // rawSerial() of the observation block last sent to the device
     std::vector<ActionInfo> action_info_history;
 };
 
 // optional host-side phase trace (MZ_TRACE=1): prints per-sub-step averages to stderr when the worker is destroyed
 struct PhaseTrace {
     bool on = getenv("MZ_TRACE") != nullptr;
-    double acc[16] = {0};
-    uint64_t cnt[16] = {0};
-    const char* names[16] = {"p1.sync", "p1.cand", "p1.expand_launch", "p1.rootread", "p1.serial", "p1.noise_reset", "p1.select_launch", "p2.sync", "p2.leaf",
-                             "p2.fwd_launch", "", "", "", "", "", ""};
+    double acc[20] = {0};
+    uint64_t cnt[20] = {0};
+    const char* names[20] = {"p1.sync", "p1.cand", "p1.expand_launch", "p1.rootread", "p1.serial", "p1.noise_reset", "p1.select_launch", "p2.sync", "p2.leaf",
+                             "p2.fwd_launch", "p1.observations", "p1.noise_up", "p1.reset", "p1.upload_roots", "root.flush", "sim.prep", "iter.root", "iter.presim", "iter.simwait", ""};
     void add(int i, double ms) { acc[i] += ms; ++cnt[i]; }
     ~PhaseTrace()
     {
         if (!on) { return; }
-        for (int i = 0; i < 10; ++i) { if (cnt[i]) { fprintf(stderr, "[mz trace] %-18s calls %8llu  avg %8.4f ms  total %10.2f ms\n", names[i], (unsigned long long)cnt[i], acc[i] / cnt[i], acc[i]); } }
+        for (int i = 0; i < 20; ++i) { if (cnt[i]) { fprintf(stderr, "[mz trace] %-18s calls %8llu  avg %8.4f ms  total %10.2f ms\n", names[i], (unsigned long long)cnt[i], acc[i] / cnt[i], acc[i]); } }
     }
 };
 
@@ -306,6 +307,12 @@ private:
         PinBuf<float> h_feat, h_out;
         PinBuf<uint8_t> h_raw;   // raw root observations (muzero_atari: bytes up, planes expanded on the device)
         DevBuf<uint8_t> d_raw;
+        // incremental form: the device keeps the previous move's raw block (d_raw / d_raw2 alternate), the host sends the newest screen + 40 bytes per game
+        PinBuf<uint8_t> h_new, h_meta;
+        DevBuf<uint8_t> d_new, d_meta, d_raw2;
+        int raw_cur = 0;          // which of (d_raw, d_raw2) holds the last uploaded / rebuilt block
+        bool raw_have = false;    // ... and whether it holds one at all
+        bool raw_incremental = false; // this root cycle: every game of the lane can be rebuilt from the previous block
         DevBuf<float> d_feat, d_out, d_hidden;
         Pool::View<float> h_policy, h_logit, h_value, h_reward, d_policy, d_logit, d_value, d_reward;
         DevBuf<int> d_src_idx, d_dst_idx, d_action_ids;
@@ -477,6 +484,12 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     if (raw_bytes_ > 0) {
         for (auto& L : lanes_) {
             if (!L->h_raw.alloc(size_t(L->n) * raw_bytes_) || !L->d_raw.alloc(size_t(L->n) * raw_bytes_)) { setError("worker: allocation failed (raw observations)"); return MZ_ERR_DEVICE; }
+            const int fb = games_[0].env->rawFrameBytes(), mb = raw_bytes_ - 8 * fb;
+            if (fb > 0 && mb > 0 && mb <= 64 &&
+                (!L->h_new.alloc(size_t(L->n) * fb) || !L->d_new.alloc(size_t(L->n) * fb) || !L->h_meta.alloc(size_t(L->n) * mb) || !L->d_meta.alloc(size_t(L->n) * mb) ||
+                 !L->d_raw2.alloc(size_t(L->n) * raw_bytes_))) {
+                setError("worker: allocation failed (raw observations)"); return MZ_ERR_DEVICE;
+            }
         }
     }
     use_signal_ = cfg_.mz_signal_wait;
@@ -710,8 +723,14 @@ void Worker::buildLeaf(int gi)
         if (feat_bits_) { g.leaf->featureBits(g.rot, reinterpret_cast<uint32_t*>(L.h_feat.p) + size_t(j) * g.env->featureWords()); }
         else { g.leaf->features(g.rot, feat); }
     } else if (sims_done_ == 0) {
-        if (raw_bytes_ > 0) { g.env->rawFeatures(L.h_raw.p + size_t(j) * raw_bytes_); }
-        else { g.env->features(0, feat); }
+        if (raw_bytes_ > 0 && L.raw_incremental) {
+            const int fb = g.env->rawFrameBytes(), mb = raw_bytes_ - 8 * fb;
+            g.env->rawNewest(L.h_new.p + size_t(j) * fb, L.h_meta.p + size_t(j) * mb);
+            g.raw_seen = g.env->rawSerial();
+        } else if (raw_bytes_ > 0) {
+            g.env->rawFeatures(L.h_raw.p + size_t(j) * raw_bytes_);
+            g.raw_seen = g.env->rawSerial();
+        } else { g.env->features(0, feat); }
         g.env->legalMask(g.legal.data());
     }
 }
@@ -1131,18 +1150,25 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
                 gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
             }
         }
+        const double tobs = nowMs();
         if ((rc = finishObservations())) { return rc; }
         const double ts = nowMs();
+        trace_.add(10, ts - tobs);
         trace_.add(4, ts - t2);
         if (want_noise) {
             const size_t o = size_t(g0) * A_;
             if ((rc = L.pool.rootSetNoise(noise_mask_.data() + g0, noise_policy_.data() + o, noise_logit_.data() + o, noise_noise_.data() + o))) { return rc; }
+            trace_.add(11, nowMs() - ts);
         }
         if (done && !cfg_.mz_manual_step) {
             std::vector<int> rp(L.n);
             for (int j = 0; j < L.n; ++j) { rp[j] = rootPlayerFor(games_[g0 + j]); }
+            const double tr0 = nowMs();
             if ((rc = L.pool.resetSearch(nullptr, rp.data()))) { return rc; }
+            const double tr1 = nowMs();
+            trace_.add(12, tr1 - tr0);
             if ((resident_ || sim_mz_) && (rc = uploadRoots(L))) { return rc; }
+            trace_.add(13, nowMs() - tr1);
         }
         if (done && cfg_.mz_manual_step) { return MZ_OK; } // no next selection: the caller acts and resets the search first
         t0 = nowMs();
@@ -1221,6 +1247,14 @@ int Worker::phase2(Lane& L)
     const double t1 = nowMs();
     stats_.ms_select += t1 - t0;
     trace_.add(7, t1 - t0);
+    if (raw_bytes_ > 0 && sims_done_ == 0) { // root observations: newest screen only when every game's previous block is on the device
+        bool inc = L.raw_have && L.d_raw2.p != nullptr;
+        for (int j = 0; inc && j < L.n; ++j) {
+            const Game& gm = games_[g0 + j];
+            inc = gm.env->rawSerial() == gm.raw_seen + 1 || gm.env->rawValidCount() == 1;
+        }
+        L.raw_incremental = inc;
+    }
     threads_->parallelFor(L.n, [this, g0](int j) { buildLeaf(g0 + j); });
     const double t2 = nowMs();
     stats_.ms_env += t2 - t1;
@@ -1243,9 +1277,19 @@ int Worker::phase2(Lane& L)
             return MZ_OK;
         }
     } else if (sims_done_ == 0) {
-        if (raw_bytes_ > 0) {
-            MZ_HIP(hipMemcpyAsync(L.d_raw.p, L.h_raw.p, size_t(L.n) * raw_bytes_, hipMemcpyHostToDevice, L.stream));
-            if ((rc = L.net.expandAtariFeatures(L.d_raw.p, raw_bytes_, L.n, L.d_feat.p))) { return rc; }
+        if (raw_bytes_ > 0 && L.raw_incremental) {
+            const int fb = games_[g0].env->rawFrameBytes(), mb = raw_bytes_ - 8 * fb;
+            uint8_t* prev = L.raw_cur == 0 ? L.d_raw.p : L.d_raw2.p;
+            uint8_t* cur = L.raw_cur == 0 ? L.d_raw2.p : L.d_raw.p;
+            MZ_HIP(hipMemcpyAsync(L.d_new.p, L.h_new.p, size_t(L.n) * fb, hipMemcpyHostToDevice, L.stream));
+            MZ_HIP(hipMemcpyAsync(L.d_meta.p, L.h_meta.p, size_t(L.n) * mb, hipMemcpyHostToDevice, L.stream));
+            if ((rc = L.net.shiftExpandAtariFeatures(prev, L.d_new.p, L.d_meta.p, cur, raw_bytes_, L.n, L.d_feat.p))) { return rc; }
+            L.raw_cur ^= 1;
+        } else if (raw_bytes_ > 0) {
+            uint8_t* cur = L.raw_cur == 0 ? L.d_raw.p : L.d_raw2.p;
+            MZ_HIP(hipMemcpyAsync(cur, L.h_raw.p, size_t(L.n) * raw_bytes_, hipMemcpyHostToDevice, L.stream));
+            if ((rc = L.net.expandAtariFeatures(cur, raw_bytes_, L.n, L.d_feat.p))) { return rc; }
+            L.raw_have = true;
         } else {
             MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, size_t(L.n) * L.net.featSize() * sizeof(float), hipMemcpyHostToDevice, L.stream));
         }
@@ -1352,15 +1396,18 @@ int Worker::runCyclesSim(int n)
                 int rc = phase2(*L);
                 if (rc) { return rc; }
             }
-            flushDeferred();
+            { const double tf = nowMs(); flushDeferred(); trace_.add(14, nowMs() - tf); }
             root_host_pending_ = true;
             pending_ = true;
             stats_.cycles += 1;
             stats_.leaf_evals += uint64_t(G_);
             i += 1;
             stats_.ms_total += nowMs() - t0;
+            trace_.add(16, nowMs() - t0);
             continue;
         }
+        const double tprep = nowMs();
+        trace_.add(17, tprep - t0);
         int batch = 1;
         // Cycles after this one join the launch while they need nothing from the host but RNG draws.  The cycle behind the root
         // expansion (sim index 1) needs the Dirichlet noise of the root children: its values only depend on the RNG stream and on
@@ -1411,6 +1458,7 @@ int Worker::runCyclesSim(int n)
             ++stats_.sim_launches;
         }
         stats_.sim_cycles += batch;
+        trace_.add(15, nowMs() - tprep);
         flushDeferred(); // the record strings of the move just decided: built while the launch runs
         sims_done_ = sim0 + batch - 1;
         pending_ = true;
@@ -1419,6 +1467,7 @@ int Worker::runCyclesSim(int n)
         i += batch;
         // the batch has to finish before the next host part (root statistics) or the return; its GPU time goes to ms_forward
         float ms_gpu = 0.0f;
+        const double twait = nowMs();
         for (auto& L : lanes_) {
             MZ_HIP(hipStreamSynchronize(L->stream));
             float ms = 0.0f;
@@ -1427,6 +1476,7 @@ int Worker::runCyclesSim(int n)
         }
         stats_.ms_forward += ms_gpu;
         stats_.ms_total += nowMs() - t0;
+        trace_.add(18, nowMs() - twait);
     }
     for (auto& L : lanes_) {
         int rc = L->pool.checkError();
