@@ -4,9 +4,6 @@
 #include "net_dev.h"
 #include "net_body.h"
 
-#ifndef MZ_HPROF2
-#define MZ_HPROF2()
-#endif
 #ifndef MZ_HPROF
 #define MZ_HPROF(k) // experiment hook (sim.hip -DMZ_SIM_HPROF): time stamps inside the 601-bin heads
 #endif
@@ -56,44 +53,29 @@ __device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
 }
 
 // A slice of a fully connected layer with the weights STREAMED through LDS (sim_cluster.h: a 601-bin head alone on its CU, or a column slice of
-// it for the games of an octet).  Chain k of thread t: acc[k] = the ordered f32 chain over i < n of xk[k][i] * W[i][col0 + uk[k]] (weights
-// wT[n][ws] in global memory, uk[k] < seg; xk[k] = an LDS vector, 16-byte aligned).  The chain length is fixed, so what counts is how fast the
-// rows arrive: ALL NT threads fetch chunk c + D - 1 (R rows x seg columns, D - 1 chunks in flight in registers) while chunk c is consumed from
-// an LDS ring of two slots.  VEC4: 16-byte loads (needs ws, col0, seg multiples of 4), else 4-byte loads.  G = rows per straight-line compute
-// group (n % 4 == 0, G % 4 == 0).  The caller checks ceil(n / R) <= NCH with R = fcSegRows<..>(seg).  Ring = 2 * fcSegSlot floats, 16-byte aligned.
+// it for four games of an octet).  Chain k of thread t: acc[k] = the ordered f32 chain over i < n of xk[k][i] * W[i][col0 + uk[k]] (weights
+// wT[n][ws] in global memory, uk[k] < seg; xk[k] = an LDS vector, 16-byte aligned).  ALL NT threads fetch chunk c + D - 1 (R rows x seg columns,
+// D - 1 chunks in flight in registers) while chunk c is consumed from an LDS ring of two slots, so a layer does not pay the memory latency once per
+// batch of rows.  VEC4: 16-byte loads (ws, col0, seg multiples of 4), else 4-byte loads.  G = rows per straight-line compute group (n % 4 == 0,
+// G % 4 == 0).  RS > 0: seg == RS at compile time.  Ring = 2 * fcSegSlot floats, 16-byte aligned.
 //
-// Three things this code is shaped by (each measured on BASELINE configs[4], 20 -> 5 us per layer):
-//  * no branch around a global load and no loop around the chunks: the compiler counts the loads in flight per PATH and waits for the oldest
-//    chunk with s_waitcnt vmcnt(N), N = the loads it can prove to be younger; behind a conditional load N shrinks towards 0, and a loop-carried
-//    prefetch is waited for with vmcnt(0) — either way every chunk pays the full memory latency;
-//  * the weight pointer is cast to the global address space: through a generic pointer the loads are FLAT loads, which also count on lgkmcnt,
-//    so every wait for an LDS operand waits for all weight loads in flight;
+// What shaped this code (measured on BASELINE configs[4] and with tools/fc_chain_bench.hip):
+//  * no branch around a global load: the compiler counts the loads in flight per PATH and waits for the oldest chunk with s_waitcnt vmcnt(N),
+//    N = the loads it can prove to be younger; behind a conditional load N shrinks towards 0 and every chunk pays the full latency.  Chunks beyond
+//    the layer in the last round therefore fetch element 0 and compute nothing;
+//  * the weight pointer is cast to the global address space: through a generic pointer the loads are FLAT loads, which also count on lgkmcnt, so
+//    every wait for an LDS operand waits for all weight loads in flight;
+//  * rounds of D chunks form a real loop (loop-carried loads in flight do get exact vmcnt values): with the chunks fully unrolled — 58 copies of
+//    the chunk code, each executed once per simulation — the heads ran out of the instruction cache;
 //  * inside a group all LDS reads come first (sched_barrier), then the dependent fmas: left alone the scheduler puts every read right in front of
-//    its fma, i.e. G LDS round trips in a row.
+//    its fma, G LDS round trips in a row.  With a compile-time row stride the reads differ only in their immediate offsets: 14.7 instead of 22
+//    cycles per row; handing x to the fmas as a scalar (v_readlane of a row-per-lane register) costs 33, a dependent fma alone ~8.
 template <int NT, bool VEC4, int LPT>
 __host__ __device__ constexpr int fcSegSlot() { return LPT * NT * (VEC4 ? 4 : 1); }
 template <int NT, bool VEC4, int G, int LPT>
 __host__ __device__ inline int fcSegRows(int seg) { const int r = fcSegSlot<NT, VEC4, LPT>() / seg / G * G; return r < G ? G : r; }
 
-// f(integral_constant<0>), f(<1>), ... while C < n: straight-line code with compile-time indices, each step nested in the previous one's test
-// (a `break` in an unrolled loop kept the loop: the register ring became an array in scratch memory)
-template <int C, int NCH, class F>
-__device__ __forceinline__ void unrollWhile(int n, F& f)
-{
-    if constexpr (C < NCH) {
-        if (C < n) {
-            f(std::integral_constant<int, C>{});
-            unrollWhile<C + 1, NCH>(n, f);
-        }
-    }
-}
-
-// XU: the K chains of a thread and all lanes of its wave share ONE input vector xk[0] (a wave = one game): its G values of a group are fetched by
-// one ds_read_b32 (lane l holds row l) and handed to the fmas as scalar operands (v_readlane), which halves the LDS traffic of the layer — with
-// per-lane vectors the 16-byte reads of x cost as much LDS bandwidth as the weights (the octet heads were LDS-bound: 11 us per layer).
-// RS > 0: seg == RS at compile time — the LDS reads of a group then differ only in their immediate offsets (tools/fc_chain_bench.hip: 14.7 instead of
-// 22 cycles per row; the v_readlane variant XU needs 33).
-template <int NT, bool VEC4, int G, int K, int D, int LPT, int NCH, bool XU = false, int RS = 0>
+template <int NT, bool VEC4, int G, int K, int D, int LPT, int RS = 0>
 __device__ __forceinline__ void fcStreamSeg(const float* const (&xk)[K], const int (&uk)[K], bool mine, const float* __restrict__ W, int ws, int col0, int seg_, int n,
                                             float* __restrict__ ring, int t, float (&acc)[K])
 {
@@ -131,101 +113,70 @@ __device__ __forceinline__ void fcStreamSeg(const float* const (&xk)[K], const i
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) { issue(buf[d], d); }
-    MZ_HPROF2();
     drain(buf[0], 0);
     __syncthreads();
-    MZ_HPROF2();
-    // Rounds of D chunks: a real loop, so that the code of a round stays in the instruction cache (the fully straight-line version — 26 + 32
-    // copies of the chunk code, each executed once per simulation — ran at 20 cycles per instruction: every line came from the L2).  Chunks
-    // beyond the layer in the last round fetch element 0 and compute nothing.
     for (int c0 = 0; c0 < nchunks; c0 += D) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int c = c0 + d;
-        issue(buf[d], c + D);
-        drain(buf[(d + 1) % D], c + 1);
-        MZ_HPROF2();
-        const int rows = n - c * R < R ? n - c * R : R;
-        if (mine && rows > 0) {
-            const float* rs = ring + size_t(c & 1) * SLOT;
-            int r0 = 0;
-            for (; r0 + G <= rows; r0 += G) {
-                if constexpr (XU) {
-                    static_assert(G <= 64, "one row per lane");
-                    const int lane = t & 63;
-                    const float xl = xk[0][c * R + r0 + (lane < G ? lane : 0)];
+        for (int d = 0; d < D; ++d) {
+            const int c = c0 + d;
+            issue(buf[d], c + D);
+            drain(buf[(d + 1) % D], c + 1);
+            const int rows = n - c * R < R ? n - c * R : R;
+            if (mine && rows > 0) {
+                const float* rs = ring + size_t(c & 1) * SLOT;
+                int r0 = 0;
+                for (; r0 + G <= rows; r0 += G) {
+                    vf4 xv[K][G / 4];
                     float wv[K][G];
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
+                        const float* rp = rs + r0 * seg + uk[k];
 #pragma unroll
-                        for (int r = 0; r < G; ++r) { wv[k][r] = rs[(r0 + r) * seg + uk[k]]; }
+                        for (int r = 0; r < G; r += 4) { xv[k][r / 4] = *reinterpret_cast<const vf4*>(xk[k] + c * R + r0 + r); }
+#pragma unroll
+                        for (int r = 0; r < G; ++r) { wv[k][r] = rp[r * seg]; }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int r = 0; r < G; ++r) {
-                        const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xl), r));
+                    for (int k = 0; k < K; ++k) {
+                        float a = acc[k];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) { acc[k] = __builtin_fmaf(xs, wv[k][r], acc[k]); }
+                        for (int r = 0; r < G; r += 4) {
+                            a = __builtin_fmaf(xv[k][r / 4].x, wv[k][r + 0], a);
+                            a = __builtin_fmaf(xv[k][r / 4].y, wv[k][r + 1], a);
+                            a = __builtin_fmaf(xv[k][r / 4].z, wv[k][r + 2], a);
+                            a = __builtin_fmaf(xv[k][r / 4].w, wv[k][r + 3], a);
+                        }
+                        acc[k] = a;
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                } else {
-                vf4 xv[K][G / 4];
-                float wv[K][G];
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float* rp = rs + r0 * seg + uk[k];
-#pragma unroll
-                    for (int r = 0; r < G; r += 4) { xv[k][r / 4] = *reinterpret_cast<const vf4*>(xk[k] + c * R + r0 + r); }
-#pragma unroll
-                    for (int r = 0; r < G; ++r) { wv[k][r] = rp[r * seg]; }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                for (; r0 < rows; r0 += 4) { // the layer's tail (n % 4 == 0)
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    float a = acc[k];
-#pragma unroll
-                    for (int r = 0; r < G; r += 4) {
-                        a = __builtin_fmaf(xv[k][r / 4].x, wv[k][r + 0], a);
-                        a = __builtin_fmaf(xv[k][r / 4].y, wv[k][r + 1], a);
-                        a = __builtin_fmaf(xv[k][r / 4].z, wv[k][r + 2], a);
-                        a = __builtin_fmaf(xv[k][r / 4].w, wv[k][r + 3], a);
+                    for (int k = 0; k < K; ++k) {
+                        const vf4 x4 = *reinterpret_cast<const vf4*>(xk[k] + c * R + r0);
+                        float a = acc[k];
+                        a = __builtin_fmaf(x4.x, rs[(r0 + 0) * seg + uk[k]], a);
+                        a = __builtin_fmaf(x4.y, rs[(r0 + 1) * seg + uk[k]], a);
+                        a = __builtin_fmaf(x4.z, rs[(r0 + 2) * seg + uk[k]], a);
+                        a = __builtin_fmaf(x4.w, rs[(r0 + 3) * seg + uk[k]], a);
+                        acc[k] = a;
                     }
-                    acc[k] = a;
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            for (; r0 < rows; r0 += 4) { // the layer's tail (n % 4 == 0)
-                const vf4* xp[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const vf4 x4 = *reinterpret_cast<const vf4*>(xk[k] + c * R + r0);
-                    float a = acc[k];
-                    a = __builtin_fmaf(x4.x, rs[(r0 + 0) * seg + uk[k]], a);
-                    a = __builtin_fmaf(x4.y, rs[(r0 + 1) * seg + uk[k]], a);
-                    a = __builtin_fmaf(x4.z, rs[(r0 + 2) * seg + uk[k]], a);
-                    a = __builtin_fmaf(x4.w, rs[(r0 + 3) * seg + uk[k]], a);
-                    acc[k] = a;
-                }
-                (void)xp;
-            }
+            __syncthreads();
         }
-        MZ_HPROF2();
-        __syncthreads();
-        MZ_HPROF2();
-    }
     }
 }
-// the two layers of a 601-bin head: FC1 with 16-byte loads and groups of 24 rows, FC2 (rows of 601 floats: no alignment) with 4-byte loads, two bins
-// per thread and groups of 8 rows
-#define MZ_FC1_STREAM 512, true, 24, 1, 8, 3, 26
-#define MZ_FC2_STREAM 512, false, 8, 2, 6, 10, 32
-#define MZ_FC1_OCTET 512, true, 24, 1, 8, 3, 26, false  /* octet heads: a wave = one game, lane = unit (+ the slice length) */
-#define MZ_FC2_OCTET 512, false, 16, 3, 6, 10, 32, false /* ... lane = bins l, l + 64, l + 128 of the slice */
+// the two layers of a 601-bin head: FC1 with 16-byte loads and groups of 24 rows; FC2 (rows of 601 floats: no alignment) with 4-byte loads
+#define MZ_FC1_STREAM 512, true, 24, 1, 8, 3      /* a head alone: one hidden unit per thread */
+#define MZ_FC2_STREAM 512, false, 8, 2, 6, 10     /* ... bins t and t + 512 */
+#define MZ_FC1_OCTET 512, true, 24, 1, 8, 3       /* octet heads: a wave = one game, lane = unit of the slice (+ the slice length as RS) */
+#define MZ_FC2_OCTET 512, false, 16, 3, 6, 10     /* ... lane = bins l, l + 64, l + 128 of the slice */
 constexpr int kFcRingFloats = 2 * 3 * 512 * 4 + 8;
 inline size_t fcStreamRingFloats(int, int) { return kFcRingFloats; }
-__host__ __device__ inline bool fcStream1Fits(int n1, int hidden, int seg) { return n1 % 4 == 0 && hidden % 4 == 0 && seg % 4 == 0 && seg <= 512 && (n1 + fcSegRows<512, true, 24, 3>(seg) - 1) / fcSegRows<512, true, 24, 3>(seg) <= 26; }
-__host__ __device__ inline bool fcStream2Fits(int hidden, int seg) { return hidden % 4 == 0 && seg <= 1024 && (hidden + fcSegRows<512, false, 8, 10>(seg) - 1) / fcSegRows<512, false, 8, 10>(seg) <= 32; }
+__host__ __device__ inline bool fcStream1Fits(int n1, int hidden, int seg) { return n1 % 4 == 0 && hidden % 4 == 0 && seg % 4 == 0 && seg <= 512; }
+__host__ __device__ inline bool fcStream2Fits(int hidden, int seg) { return hidden % 4 == 0 && seg <= 1024; }
 
 // conv1x1 (C -> hc channels) + ReLU of a discrete head: xs[C][P] (LDS) -> f[hc * P] (LDS); NT threads, no barrier inside
 template <int NT>

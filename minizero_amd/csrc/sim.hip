@@ -25,23 +25,11 @@ __shared__ int s_tp_idx;
 #endif
 __device__ unsigned long long g_hp[16];
 __shared__ unsigned long long s_hp_prev;
-__device__ unsigned long long g_hp2[96];
-__shared__ int s_hp2_idx;
-#ifdef MZ_SIM_HPROF2 // fine stamps inside fcStreamSeg (each costs ~0.15 us: they distort the coarse sections)
-#define MZ_HPROF2()                                                                                   \
-    do {                                                                                              \
-        if (threadIdx.x == 0 && blockIdx.x == MZ_HPROF_BLOCK) {                                       \
-            const unsigned long long t_ = wall_clock64();                                             \
-            if (s_hp2_idx < 96) { g_hp2[s_hp2_idx] += t_ - s_hp_prev; }                               \
-            ++s_hp2_idx; s_hp_prev = t_;                                                              \
-        }                                                                                             \
-    } while (0)
-#endif
 #define MZ_HPROF(k)                                                                                   \
     do {                                                                                              \
         if (threadIdx.x == 0 && blockIdx.x == MZ_HPROF_BLOCK) {                                       \
             const unsigned long long t_ = wall_clock64();                                             \
-            if ((k) > 0) { g_hp[(k)] += t_ - s_hp_prev; } else { g_hp[15] += 1; s_hp2_idx = 0; }                     \
+            if ((k) > 0) { g_hp[(k)] += t_ - s_hp_prev; } else { g_hp[15] += 1; }                     \
             s_hp_prev = t_;                                                                           \
         }                                                                                             \
     } while (0)
@@ -716,12 +704,6 @@ void Net::dumpSimProf()
             fprintf(stderr, "[mz sim hprof] us per section of the heads (game 0, avg over %llu calls; board games: [1] tail wait, [5] setup, [6] conv1x1, [7] FCs, [8] FC2 / softmax):", h[15]);
             for (int i = 1; i < 14; ++i) { if (i != 8) { fprintf(stderr, " [%d] %.2f", i, double(h[i]) / double(h[15]) * 0.01); } }
             fprintf(stderr, "\n");
-            unsigned long long h2[96];
-            if (hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_hp2), sizeof(h2)) == hipSuccess) {
-                fprintf(stderr, "[mz sim hprof] fine stamps (us):");
-                for (int i = 0; i < 96; ++i) { if (h2[i]) { fprintf(stderr, " %d:%.2f", i, double(h2[i]) / double(h[15]) * 0.01); } }
-                fprintf(stderr, "\n");
-            }
         }
     }
 #endif

@@ -5,13 +5,19 @@
 //  * dynamics tower: member m of the cluster computes oc-tile m (16 output channels) of every layer on three of its waves (one pixel tile
 //    each); after each layer the four members swap their 16 x P outputs through a buffer in global memory, i.e. through the L2 of the XCD
 //    they share (workgroup ids congruent mod 8 are dispatched to the same XCD; the kernel checks XCC_ID and refuses to run otherwise).
-//    tools/xcu_sync_bench.hip: such an exchange costs 1.5 us with relaxed L2 atomics + cache-bypassing loads; with agent-scope
-//    release / acquire (L2 write-back + invalidate on this multi-XCD part) it costs 21 us, hence the hand-made protocol;
-//  * heads: member 0 rescales + stores the hidden state and runs the policy head, member 1 the reward head, member 2 the value head, each
-//    with all 512 threads and its own CU's L2 port (the 601-bin heads stream 1.24 MB of weights each);
+//    tools/xcu_sync_bench.hip: such an exchange costs 1.5 us with relaxed L2 atomics + loads that bypass the vector cache; with agent-scope
+//    release / acquire (L2 write-back + invalidate on this multi-XCD part) it costs 21 us, hence the hand-made protocol.  Weights are read with
+//    ordinary (temporal) loads: the three waves of a member fetch the same fragments, and with streaming loads each of them went to the L2
+//    (63 -> 51 us per simulation);
+//  * heads: member 0 rescales + stores the hidden state and runs the policy head, member 1 the reward head, member 2 the value head.  In a pool
+//    of full octets (>= 64 games) the eight games that share an XCD run each 601-bin head TOGETHER (octetHead): 16 CUs streaming 1.24 MB each got
+//    0.74 TB/s out of one XCD's L2 together (27 us per simulation for the FC layers however deep each CU prefetched), so the CU of game j takes
+//    column slice j % 4 of both FC layers for the four games of its half and every weight leaves the L2 twice instead of eight times;
 //  * the tree phases stay on member 0 (the owner), which sends (parent slot, action) to the helpers and collects value / reward.
-// The arithmetic of every output is the same chain as in the one-workgroup kernel: records are bit-identical (tests/test_gpu_cluster.py).
+// The arithmetic of every output is the same chain as in the one-workgroup kernel: records are bit-identical (tests/test_gpu_worker.py
+// test_atari_cluster_pools_are_equivalent, test_atari_execution_modes_are_equivalent; tests/test_gpu_baseline_nets.py against the oracle).
 // Every wait is bounded: a member that times out raises the pool's error flag and the whole cluster leaves the kernel.
+// BASELINE configs[4]: 154 -> 116 us per simulation (tower 93 -> 51, heads 43 -> 43 with 1/4 of the L2 traffic, tree phases 18 -> 19).
 #pragma once
 
 namespace mz {

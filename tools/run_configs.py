@@ -15,7 +15,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 MOVES = {"c1": 400, "c2": 4, "c3": 40, "c4": 20, "c5": 40}
 WARM = {"c5": 14}  # moves before the timed region (default 2): the Atari-shaped worker's first moves pay one-off host allocations
 KERNEL = {"c1": "sim_kernel<3,3,4,16,-1>", "c2": "sim_kernel<9,9,20,64,2>", "c3": "sim_kernel<8,8,4,64,0>", "c4": "sim_kernel_mz<9,9,20,68,64>",
-          "c5": "sim_kernel_mz<6,6,64,84,64>"}
+          "c5": "sim_kernel_mz_cluster<6,6,84,64> (4 workgroups per game; MZ_SIM_CLUSTER=0: sim_kernel_mz<6,6,64,84,64>)"}
 
 
 def flops_per_leaf_eval(d):
@@ -26,9 +26,12 @@ def flops_per_leaf_eval(d):
     pc = -(-A // P)
     heads = 2.0 * (P * C * pc + pc * P * A)  # policy conv1x1 + FC
     if d.discrete_value_size > 1:
-        hc, hid, sz = 0, d.num_value_hidden_channels, d.discrete_value_size
-        # DiscreteValueNetwork (value and reward): conv1x1 C->C, FC C*P->hidden, FC hidden->601 (ref network_unit.py:67-87)
-        heads += 2 * 2.0 * (P * C * C + C * P * hid + hid * sz)
+        # DiscreteValueNetwork (ref network_unit.py:67-87): conv1x1 C -> hc = ceil(size / P), FC hc*P -> hidden, FC hidden -> size;
+        # value head: hidden = num_value_hidden_channels, reward head: hidden = C (ref muzero_atari_network.py:48,65)
+        sz = d.discrete_value_size
+        hc = -(-sz // P)
+        for hid in (d.num_value_hidden_channels, C):
+            heads += 2.0 * (P * C * hc + hc * P * hid + hid * sz)
     else:
         heads += 2.0 * (P * C * 1 + P * d.num_value_hidden_channels + d.num_value_hidden_channels)
     return conv, heads
