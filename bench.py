@@ -210,8 +210,7 @@ def main():
                          "frac": issued / peak, "f32_equivalent_tflops": achieved, "traffic": None if bf else traffic, "traffic_source": None if bf else traffic_src,
                          "launches": launches, "avg_launch_ms": gpu_ms / launches, "flops_per_avg_launch": flops_total / launches,
                          "flops_per_leaf_eval": flops_per_eval, "gpu_ms_per_step": gpu_ms / args.steps,
-                         "timing": "HIP events on the worker's stream around every sim_kernel launch of the timed region (2 launches per move: "
-                                   "1 root-expansion cycle + 400 cycles)",
+                         "timing": "HIP events on the worker's stream around every sim_kernel launch of the timed region (one launch of 401 cycles per move)",
                          # per cycle, without the weights (1.9 MB: they stay in the XCDs' L2s): a children block written + one read per game
                          "compulsory_bytes_per_avg_launch": args.games * 2.0 * 2600 * cpm * args.steps / launches,
                          "tower_alone": {"kernel": "tower_fused<9,9,20,64> (the same tower as a stand-alone launch of 256 samples)",

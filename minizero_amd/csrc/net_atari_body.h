@@ -196,7 +196,7 @@ __device__ __forceinline__ void discreteConv(const DiscreteParams& d, const floa
             wk[k] = d.conv_w + j * C;
         }
         float acc[K];
-        dotChainK<32, K>(xk, P, wk, 1, C, acc);
+        dotChainK<32, K, true>(xk, P, wk, 1, C, acc);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (i0 + k * NT < n0) { const float v = acc[k] + d.conv_b[idx[k] / P]; f[idx[k]] = v > 0.0f ? v : 0.0f; }
@@ -289,13 +289,13 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
             }
         } else if constexpr (WIDE) {
             for (int o = t; o < d.hidden; o += NT) {
-                const float v = dotChain<60>(f, 1, d.fc1_wT + o, d.hidden, n1) + d.fc1_b[o];
+                const float v = dotChain<60, true>(f, 1, d.fc1_wT + o, d.hidden, n1) + d.fc1_b[o];
                 h1[o] = v > 0.0f ? v : 0.0f;
             }
         } else
         for (int o = 4 * t; o < d.hidden; o += 4 * NT) { // four adjacent hidden units per thread, 16-byte weight loads (dotChain4)
             float acc[4];
-            dotChain4<32>(f, d.fc1_wT, d.hidden, o, d.hidden, n1, acc);
+            dotChain4<32, true>(f, d.fc1_wT, d.hidden, o, d.hidden, n1, acc);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (o + k < d.hidden) { const float v = acc[k] + d.fc1_b[o + k]; h1[o + k] = v > 0.0f ? v : 0.0f; }
@@ -327,7 +327,7 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
             const float* xk[2] = {h1, h1};
             const float* wk[2] = {d.fc2_wT + o, d.fc2_wT + o1};
             float acc[2];
-            dotChainK<30, 2>(xk, 1, wk, d.size, d.hidden, acc);
+            dotChainK<30, 2, true>(xk, 1, wk, d.size, d.hidden, acc);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (o + k < d.size) {
@@ -341,7 +341,7 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
     if (active) {
         for (int o = 4 * t; o < d.size && !WIDE; o += 4 * NT) {
             float acc[4];
-            dotChain4<32>(h1, d.fc2_wT, d.size, o, d.size, d.hidden, acc);
+            dotChain4<32, true>(h1, d.fc2_wT, d.size, o, d.size, d.hidden, acc);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (o + k < d.size) {
@@ -436,12 +436,12 @@ __device__ __forceinline__ void atariHeadsBody(const float* __restrict__ xg, con
     // policy head (all threads; its barriers come after the discrete heads')
     for (int i = tid; i < PC * P; i += NT2) {
         const int j = i / P, p = i - j * P;
-        const float v = dotChain<16>(xs + p, P, hp.pconv_w + j * C, 1, C) + hp.pconv_b[j];
+        const float v = dotChain<16, true>(xs + p, P, hp.pconv_w + j * C, 1, C) + hp.pconv_b[j];
         pf[i] = v > 0.0f ? v : 0.0f;
     }
     __syncthreads();
     for (int a = tid; a < A; a += NT2) {
-        const float v = dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
+        const float v = dotChain<16, true>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
         lgp[a] = v;
         logit[size_t(b) * A + a] = v;
     }

@@ -364,11 +364,15 @@ struct HeadParams {
 // ahead of the CH dependent fmas: the chain is latency-bound, and with the load issued next to each fma every step paid an L2 trip
 // The weights of these chains are always in global memory; a pointer that was loaded from a parameter block is a GENERIC pointer to the compiler,
 // its loads FLAT loads, and those count on lgkmcnt as well: every wait for an LDS operand (x) would wait for all weight loads in flight.
-typedef __attribute__((address_space(1))) const float GFloat;
-template <int CH>
+// GW = true makes them global loads (the muzero_atari heads; the board-game heads keep the pointers they always had: their code is unchanged).
+template <bool GW, class T>
+struct WPtr { typedef const T* type; };
+template <class T>
+struct WPtr<true, T> { typedef __attribute__((address_space(1))) const T* type; };
+template <int CH, bool GW = false>
 __device__ __forceinline__ void dotChainPart(float& acc, int& i0, const float* __restrict__ x, int xs, const float* __restrict__ w_, size_t ws, int n)
 {
-    GFloat* w = (GFloat*)w_;
+    typename WPtr<GW, float>::type w = (typename WPtr<GW, float>::type)w_;
     for (; i0 + CH <= n; i0 += CH) {
         float wv[CH];
 #pragma unroll
@@ -377,26 +381,26 @@ __device__ __forceinline__ void dotChainPart(float& acc, int& i0, const float* _
         for (int k = 0; k < CH; ++k) { acc = __builtin_fmaf(x[(i0 + k) * xs], wv[k], acc); }
     }
 }
-template <int CH>
+template <int CH, bool GW = false>
 __device__ __forceinline__ float dotChain(const float* __restrict__ x, int xs, const float* __restrict__ w, size_t ws, int n)
 {
     float acc = 0.0f;
     int i0 = 0;
-    dotChainPart<CH>(acc, i0, x, xs, w, ws, n);
-    if (CH > 16) { dotChainPart<16>(acc, i0, x, xs, w, ws, n); } // the tail of a deep prefetch in shallower groups, not one load at a time
-    if (CH > 4) { dotChainPart<4>(acc, i0, x, xs, w, ws, n); }
-    for (; i0 < n; ++i0) { acc = __builtin_fmaf(x[i0 * xs], ((GFloat*)w)[size_t(i0) * ws], acc); }
+    dotChainPart<CH, GW>(acc, i0, x, xs, w, ws, n);
+    if (CH > 16) { dotChainPart<16, GW>(acc, i0, x, xs, w, ws, n); } // the tail of a deep prefetch in shallower groups, not one load at a time
+    if (CH > 4) { dotChainPart<4, GW>(acc, i0, x, xs, w, ws, n); }
+    for (; i0 < n; ++i0) { acc = __builtin_fmaf(x[i0 * xs], ((typename WPtr<GW, float>::type)w)[size_t(i0) * ws], acc); }
     return acc;
 }
 
 // K independent chains per thread (each one the same ordered f32 chain as dotChain): the weights of CH steps of all K chains are in flight
 // together and the K dependent fma sequences interleave, so a latency-bound thread with several outputs finishes them in the time of one
-template <int CH, int K>
+template <int CH, int K, bool GW = false>
 __device__ __forceinline__ void dotChainK(const float* const (&x)[K], int xs, const float* const (&w_)[K], size_t ws, int n, float (&acc)[K])
 {
-    GFloat* w[K];
+    typename WPtr<GW, float>::type w[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { acc[k] = 0.0f; w[k] = (GFloat*)w_[k]; }
+    for (int k = 0; k < K; ++k) { acc[k] = 0.0f; w[k] = (typename WPtr<GW, float>::type)w_[k]; }
     int i0 = 0;
     for (; i0 + CH <= n; i0 += CH) {
         float wv[K][CH];
@@ -421,11 +425,10 @@ __device__ __forceinline__ void dotChainK(const float* const (&x)[K], int xs, co
 // ordered f32 chain over i, and every step fetches the four weights with ONE 16-byte load — a wave has at most 63 loads in flight, so four
 // times the bytes per load is what a bandwidth-starved GEMV needs (one sample per CU: the weights of the 601-bin heads stream from L2).
 // nvalid < 4: the tail of the layer (outputs beyond it are computed from clamped addresses and dropped by the caller).
-template <int CH>
+template <int CH, bool GW = false>
 __device__ __forceinline__ void dotChain4(const float* __restrict__ x, const float* __restrict__ wT, size_t ws, int o, int nout, int n, float (&acc)[4])
 {
     typedef float vf4u __attribute__((ext_vector_type(4), aligned(4)));
-    typedef __attribute__((address_space(1))) const vf4u GV4u;
     const int oc = o + 3 < nout ? o : (nout >= 4 ? nout - 4 : 0); // clamped so that the 16 bytes stay inside the row
     const int sh = o - oc;                                         // outputs of this thread start at component `sh` of the clamped load
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
@@ -435,7 +438,7 @@ __device__ __forceinline__ void dotChain4(const float* __restrict__ x, const flo
         for (; i0 + C2 <= n; i0 += C2) {
             vf4u wv[C2];
 #pragma unroll
-            for (int k = 0; k < C2; ++k) { wv[k] = *(GV4u*)(wT + size_t(i0 + k) * ws + oc); }
+            for (int k = 0; k < C2; ++k) { wv[k] = *(typename WPtr<GW, vf4u>::type)(wT + size_t(i0 + k) * ws + oc); }
 #pragma unroll
             for (int k = 0; k < C2; ++k) {
                 const float xv = x[i0 + k];

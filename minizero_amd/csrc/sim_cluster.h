@@ -374,12 +374,12 @@ __device__ __forceinline__ void clusterAtariHeads(const float* __restrict__ xlds
     }
     for (int i = tid; i < PC * P; i += 512) {
         const int j = i / P, p = i - j * P;
-        const float v = dotChain<16>(xs + p, P, hp.pconv_w + j * C, 1, C) + hp.pconv_b[j];
+        const float v = dotChain<16, true>(xs + p, P, hp.pconv_w + j * C, 1, C) + hp.pconv_b[j];
         pf[i] = v > 0.0f ? v : 0.0f;
     }
     __syncthreads();
     for (int a = tid; a < A; a += 512) {
-        const float v = dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
+        const float v = dotChain<16, true>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
         lgp[a] = v;
         logit[size_t(b) * A + a] = v;
     }

@@ -338,6 +338,7 @@ private:
     int phase2(Lane& L);
     int phase2Resident(Lane& L);
     int runCyclesSim(int n);
+    void drawCycle(int batch, bool noise_cycle);
     int uploadRoots(Lane& L);
     int setupDeviceGumbel();
     int cycle();
@@ -1364,6 +1365,31 @@ int Worker::syncGumbel(Lane& L, bool to_device)
     return MZ_OK;
 }
 
+// The RNG draws of one cycle that joins a launch (its own function: the hot loop of a 400-simulation move — 102 400 rotation draws and 20 k gamma
+// draws per move on BASELINE configs[1] — must not depend on the inlining decisions inside runCyclesSim, which cost 1.4 ms per move once)
+__attribute__((noinline)) void Worker::drawCycle(int batch, bool noise_cycle)
+{
+    const bool az = desc_.type == 0, rotate = cfg_.actor_use_random_rotation_features;
+    for (auto& L : lanes_) {
+        uint8_t* rot_row = L->h_rot.p + size_t(batch) * L->n;
+        for (int j = 0; j < L->n; ++j) {
+            Game& gm = games_[L->g0 + j];
+            if (noise_cycle) {
+                gm.env->legalMask(gm.legal.data());
+                int k = 0;
+                for (int a = 0; a < A_; ++a) { k += gm.legal[a] != 0; }
+                if (cfg_.actor_use_dirichlet_noise) { rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise_scratch_); }
+                else { rng_.gumbel(k, noise_scratch_); }
+                memcpy(L->h_noise.p + size_t(j) * A_, noise_scratch_.data(), size_t(k) * sizeof(float));
+            }
+            if (az) { // AlphaZero: the only draw of a plain cycle (zero_actor.cpp:56); MuZero draws nothing
+                gm.rot = rotate ? rng_.randInt() % 8 : 0;
+                rot_row[j] = static_cast<uint8_t>(gm.rot);
+            }
+        }
+    }
+}
+
 // Device-resident cycles in batches: the host part of a cycle (per-move logic in RNG order, rotation draws) runs exactly as in
 // cycle(); every following cycle that needs nothing from the host but its rotation draws joins the same launch of the per-game
 // simulation kernel.  A 400-simulation move is two launches: the root expansion, then (after the root noise) the other 400.
@@ -1417,23 +1443,7 @@ int Worker::runCyclesSim(int n)
         bool noise_in_batch = false;
         while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg && !device_noise)) {
             const bool noise_cycle = (sim0 + batch == 1) && noise_cfg;
-            for (auto& L : lanes_) {
-                for (int j = 0; j < L->n; ++j) {
-                    Game& gm = games_[L->g0 + j];
-                    if (noise_cycle) {
-                        gm.env->legalMask(gm.legal.data());
-                        int k = 0;
-                        for (int a = 0; a < A_; ++a) { k += gm.legal[a] != 0; }
-                        if (cfg_.actor_use_dirichlet_noise) { rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise_scratch_); }
-                        else { rng_.gumbel(k, noise_scratch_); }
-                        memcpy(L->h_noise.p + size_t(j) * A_, noise_scratch_.data(), size_t(k) * sizeof(float));
-                    }
-                    if (desc_.type == 0) { // AlphaZero: the only draw of a plain cycle (zero_actor.cpp:56); MuZero draws nothing
-                        gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
-                        L->h_rot.p[size_t(batch) * L->n + j] = static_cast<uint8_t>(gm.rot);
-                    }
-                }
-            }
+            drawCycle(batch, noise_cycle);
             noise_in_batch |= noise_cycle;
             ++batch;
         }

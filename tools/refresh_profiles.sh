@@ -14,8 +14,8 @@ export TMPDIR=/tmp
 O=gpurun_out/refresh
 rm -rf $O; mkdir -p $O
 SHORT="--steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline"
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
-timeout 600 python bench.py --precision bf16x3 --no-cpu-baseline > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 --precision bf16x3 --no-cpu-baseline > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py $SHORT > $O/bench_profiled.json 2> $O/stats.err
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
 # FETCH_SIZE takes 3 of the 4 TCC slots and WRITE_SIZE 2: one pass each (MI355X_MICROARCH.md, PMC section)
@@ -55,7 +55,7 @@ def summarize(tag, a_dir, b_dir, c_dir, cycles, note):
                     "lds_conflict_frac": s["SQ_LDS_BANK_CONFLICT"] / max(1.0, s["SQ_LDS_IDX_ACTIVE"])})
     json.dump(out, open(f"{O}/{tag}.json", "w"), indent=1)
 summarize("pmc_sim", "pmc1a", "pmc1b", "pmc2", 5 * 401, "over all launches of `python bench.py --steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline` (5 moves x 401 cycles x 256 games)")
-MOVES = {"c3": (40 + 2) * 17, "c4": (20 + 2) * 51, "c5": (12 + 2) * 51}
+MOVES = {"c3": (40 + 2) * 17, "c4": (20 + 2) * 51, "c5": (40 + 14) * 51}
 for k, cyc in MOVES.items():
     summarize(f"pmc_{k}", f"pmcA_{k}", f"pmcB_{k}", f"pmcC_{k}", cyc, f"over all simulation-kernel launches of `python tools/run_configs.py {k}` ({cyc} lock-step cycles incl. warm-up)")
 PY
