@@ -973,7 +973,11 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     }
     if (cluster) {
 #define MZ_SIM_MZ_CL_LAUNCH(h, w, cin0, cdyn, cpad) \
-        if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzClusterT<h, w, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, host_start ? 1 : 0, lds_cluster, stream_); }
+        if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { \
+            const int rcl = launchSimMzClusterT<h, w, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, host_start ? 1 : 0, lds_cluster, stream_); \
+            if (rcl <= 0) { *launched = rcl == MZ_OK; return rcl; } \
+            sim_cluster_ = false; /* the GPU cannot hold 4 workgroups per game right now: one workgroup per game from here on (same records) */ \
+        }
         MZ_SIM_MZ_CLUSTER_CASES(MZ_SIM_MZ_CL_LAUNCH)
 #undef MZ_SIM_MZ_CL_LAUNCH
     }

@@ -540,8 +540,11 @@ static int launchSimMzClusterT(const SimArgs* d_args, int games, int sim0, int n
     MZ_LDS_ATTR((sim_kernel_mz_cluster<H, W, CDYN_PAD, CPAD>), lds);
     int gpad = (games + 7) / 8 * 8;
     void* params[] = {(void*)&d_args, (void*)&sim0, (void*)&nsims, (void*)&host_start, (void*)&games, (void*)&gpad};
-    MZ_HIP(hipLaunchCooperativeKernel(reinterpret_cast<void*>(sim_kernel_mz_cluster<H, W, CDYN_PAD, CPAD>), dim3(kClMembers * gpad), dim3(512), params,
-                                      static_cast<unsigned>(lds), s));
+    // all 4 * gpad workgroups must be resident at once (they wait for each other): a cooperative launch guarantees it or fails
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<void*>(sim_kernel_mz_cluster<H, W, CDYN_PAD, CPAD>), dim3(kClMembers * gpad), dim3(512), params,
+                                                    static_cast<unsigned>(lds), s);
+    if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; } // not enough free CUs: the caller falls back to one workgroup per game
+    MZ_HIP(e);
     return MZ_OK;
 }
 
