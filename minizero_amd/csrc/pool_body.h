@@ -638,11 +638,18 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
+    // the records of the path's nodes are fetched by 64 lanes at once (lane k = the k-th node from the leaf) instead of one L2 round trip per level
+    float pmean = 0.0f, pcnt = 0.0f, prew = 0.0f;
+    if (lane < len) {
+        const NodeRec* pn = v.rec + base + path[len - 1 - lane];
+        pmean = pn->mean; pcnt = pn->count; prew = pn->reward;
+    }
     float updated = val;
     for (int i = len - 1; i >= 0; --i) {
         NodeRec* n = v.rec + base + path[i];
-        const float r = (i == len - 1) ? rew : n->reward;
-        float mean = n->mean, cnt = n->count;
+        const int kk = len - 1 - i; // wave-uniform
+        const float r = (i == len - 1) ? rew : (kk < 64 ? laneF(prew, kk) : n->reward);
+        float mean = kk < 64 ? laneF(pmean, kk) : n->mean, cnt = kk < 64 ? laneF(pcnt, kk) : n->count;
         const float old_mean = r + v.gamma * mean;
         // MCTSNode::add(value, 1.0f) (ref mcts.cpp:20-28); count + 1 <= 0 cannot happen for count >= 0
         cnt += 1.0f;

@@ -702,7 +702,7 @@ void Net::dumpSimProf()
         unsigned long long h[16];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hp), sizeof(h)) == hipSuccess && h[15]) {
             fprintf(stderr, "[mz sim hprof] us per section of the heads (game 0, avg over %llu calls; board games: [1] tail wait, [5] setup, [6] conv1x1, [7] FCs, [8] FC2 / softmax):", h[15]);
-            for (int i = 1; i < 14; ++i) { if (i != 8) { fprintf(stderr, " [%d] %.2f", i, double(h[i]) / double(h[15]) * 0.01); } }
+            for (int i = 1; i < 15; ++i) { if (i != 8) { fprintf(stderr, " [%d] %.2f", i, double(h[i]) / double(h[15]) * 0.01); } }
             fprintf(stderr, "\n");
         }
     }

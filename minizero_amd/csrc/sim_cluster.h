@@ -465,6 +465,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         if (member == 0) {
             if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds, spec); }
             __syncthreads();
+            MZ_HPROF(14);
             {
                 if (tid == 0) {
                     const int len = v.path_len[g];
@@ -522,11 +523,14 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         if (prof) { t3 = wall_clock64(); }
         if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
         __syncthreads();
+        MZ_HPROF(11);
         const int cand_k = s_cand_k;
         if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
         __syncthreads();
+        MZ_HPROF(12);
         if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k); }
         __syncthreads();
+        MZ_HPROF(13);
         if (prof && tid == 0) {
             const unsigned long long t4 = wall_clock64();
             prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
