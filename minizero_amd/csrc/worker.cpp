@@ -444,7 +444,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         if (rc) { return rc; }
         if (cfg_.mz_nn_precision != "f32" && cfg_.mz_nn_precision != "bf16x3") { setError("mz_nn_precision '%s' unknown (f32 | bf16x3)", cfg_.mz_nn_precision.c_str()); return MZ_ERR_ARG; }
         if ((rc = L->net.setPrecision(cfg_.mz_nn_precision == "bf16x3" ? 1 : 0))) { return rc; }
-        if (!cfg_.mz_sim_cluster) { L->net.sim_cluster_ = false; }
+        if (!cfg_.mz_sim_cluster || nl > 1) { L->net.sim_cluster_ = false; } // two lanes = two concurrent cooperative launches: not with clusters that wait for each other
         L->stream = L->net.stream_;
         // ref actor_group.cpp:183: tree_node_size = (n + 1) * action_size; tree.h:66: 1 + tree_node_size nodes
         rc = L->pool.init(device, L->n, 1 + (n_ + 1) * A_, A_, sc, L->stream);
