@@ -114,13 +114,13 @@ __device__ __forceinline__ PixSet<NT> makePixSet(int lane, int tile0)
     return px;
 }
 
-// XOUT (cluster mode of the simulation kernel, sim_cluster.h): the oc-tile's outputs also go to `xout` ([16][P] floats in global memory), from
-// where the other workgroups of the game's cluster fetch them
+// XOUT (cluster mode of the simulation kernel, sim_cluster.h): the oc-tile's outputs also go to `xout` ([16][P] floats in global memory, tagged with
+// `xsign` in the sign bit), from where the other workgroups of the game's cluster fetch them
 template <int H, int W, int CG, int NT, int CGN, bool CORNER, bool NTW = false, bool XOUT = false>
 __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
                                             float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
                                             int lane, int ot, const PixSet<NT>& px, bool have_first, float (&a_first)[CG],
-                                            const float* __restrict__ next_wp, float (&a_next)[CGN], float* __restrict__ xout = nullptr)
+                                            const float* __restrict__ next_wp, float (&a_next)[CGN], float* __restrict__ xout = nullptr, unsigned xsign = 0)
 {
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
     const int (&pixoff)[NT] = px.off;
@@ -245,7 +245,9 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
                 v = v > 0.0f ? v : 0.0f;
                 float* d = (ocb + r < cout) ? dstp + r * CS : dump;
                 *d = v;
-                if constexpr (XOUT) { if (pixq[j] >= 0 && ocb + r < cout) { xout[(4 * (lane >> 4) + r) * P + pixq[j]] = v; } }
+                if constexpr (XOUT) { // v >= +0 (ReLU): its sign bit carries the exchange's phase (sim_cluster.h clExchange)
+                    if (pixq[j] >= 0 && ocb + r < cout) { xout[(4 * (lane >> 4) + r) * P + pixq[j]] = __uint_as_float(__float_as_uint(v) | xsign); }
+                }
             }
         }
     }

@@ -5,8 +5,9 @@
 //  * dynamics tower: member m of the cluster computes oc-tile m (16 output channels) of every layer on three of its waves (one pixel tile
 //    each); after each layer the four members swap their 16 x P outputs through a buffer in global memory, i.e. through the L2 of the XCD
 //    they share (workgroup ids congruent mod 8 are dispatched to the same XCD; the kernel checks XCC_ID and refuses to run otherwise).
-//    tools/xcu_sync_bench.hip: such an exchange costs 1.5 us with relaxed L2 atomics + loads that bypass the vector cache; with agent-scope
-//    release / acquire (L2 write-back + invalidate on this multi-XCD part) it costs 21 us, hence the hand-made protocol.  Weights are read with
+//    tools/xcu_sync_bench.hip: such an exchange costs 1.1 - 1.5 us with loads that bypass the vector cache (clExchange); with agent-scope
+//    release / acquire (L2 write-back + invalidate on this multi-XCD part) it costs 21 us, hence the hand-made protocol.  A layer is 3.4 us of
+//    dependent MFMAs (a chain of v_mfma_f32_16x16x4_f32 issues every 57 cycles) + 1 us of exchange.  Weights are read with
 //    ordinary (temporal) loads: the three waves of a member fetch the same fragments, and with streaming loads each of them went to the L2
 //    (63 -> 51 us per simulation);
 //  * heads: member 0 rescales + stores the hidden state and runs the policy head, member 1 the reward head, member 2 the value head.  In a pool
@@ -185,45 +186,54 @@ __host__ __device__ inline bool octetHeadFits(const DiscreteParams& d, int P)
     return n1 % 4 == 0 && d.hidden % 4 == 0 && (sl1 == 64 || sl1 == 16 || sl1 == 8) && sl1 * 4 == d.hidden && sl2 == 151 && d.size >= sl2 && d.size <= 1024; // the instantiated slice lengths
 }
 
-// my 16 x P block of the exchange buffer for the NEXT exchange
+// my 16 x P block of the exchange buffer for the NEXT exchange, and the tag its words carry
 __device__ __forceinline__ float* clPart(const ClusterCtx& c, int ot) { return reinterpret_cast<float*>(c.cm + kClXbuf) + size_t(c.xseq & 1) * c.C * c.P + size_t(ot) * 16 * c.P; }
+__device__ __forceinline__ unsigned clSign(const ClusterCtx& c) { return (((c.xseq >> 1) & 1u) ^ 1u) << 31; }
 
 // All 512 threads of every member, after a layer: my outputs are in LDS (`tout`, padded planes) and on their way to the exchange buffer; on return
 // the other members' channels are in `tout` too.  false: a member went missing (the caller leaves the kernel).
+// Every word of the buffer validates itself: the layer outputs are >= +0 (ReLU), so their sign bit is free to carry the PHASE of the exchange — the
+// two buffers alternate, and the phase flips each time a buffer is reused (the host clears them: phase 0 = "never written", the first use writes 1).
+// A reader simply loads the words it needs past the vector cache until all of them show the expected phase: no store drain, no counter, no second
+// round trip (tools/xcu_sync_bench.hip, variant 3 against 1: 1.08 instead of 1.47 us per exchange).  A member can overwrite a buffer only after it
+// has read the exchange in between from ALL members, i.e. after all of them have finished reading this one.
 template <int H, int W, int CPAD>
 __device__ __forceinline__ bool clExchange(ClusterCtx& c, float* __restrict__ tout, int tid)
 {
     constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
-    clDrain(); // this wave's stores have reached the L2
-    __syncthreads();
-    const unsigned k = ++c.xseq;
-    if (tid == 0) {
-        __hip_atomic_fetch_add(c.cm + kClArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!clWaitGE(c.cm + kClArrive, k * kClMembers)) { *c.abort_lds = 1; atomicExch(c.err, 90); }
-    }
-    __syncthreads();
-    if (*c.abort_lds) { return false; }
-    const float* xb = reinterpret_cast<const float*>(c.cm + kClXbuf) + size_t((k - 1) & 1) * c.C * c.P;
+    const unsigned sign = clSign(c);
+    const float* xb = reinterpret_cast<const float*>(c.cm + kClXbuf) + size_t(c.xseq & 1) * c.C * c.P;
+    ++c.xseq;
+    __syncthreads(); // the member's own waves are done with the layer: all waves start polling together (idle waves polling for a whole layer slowed the others' loads)
     constexpr int K = (CPAD * P + 511) / 512;
     const int n = c.OT * 16 * P, mine0 = c.member * 16 * P;
-    float got[K];
+    unsigned got[K];
+    bool ok = false;
+    for (int polls = 0; polls < kClPollLimit; ++polls) {
+        ok = true;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const int i = tid + j * 512;
-        const bool want = i < n && (i < mine0 || i >= mine0 + 16 * P);
-        got[j] = clLoadF(xb + (want ? i : 0));
+        for (int j = 0; j < K; ++j) {
+            const int i = tid + j * 512;
+            const bool want = i < n && (i < mine0 || i >= mine0 + 16 * P);
+            got[j] = __float_as_uint(clLoadF(xb + (want ? i : 0)));
+            ok = ok && (!want || (got[j] & 0x80000000u) == sign);
+        }
+        ok = __all(ok);
+        if (ok) { break; }
+        __builtin_amdgcn_s_sleep(2);
     }
+    if (!ok && (tid & 63) == 0) { *c.abort_lds = 1; atomicExch(c.err, 90); }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int i = tid + j * 512;
         const bool want = i < n && (i < mine0 || i >= mine0 + 16 * P) && i < c.C * P;
         if (want) {
             const int ch = i / P, p = i - ch * P;
-            tout[ch * CS + (p / W + 1) * PW + (p % W) + 1] = got[j];
+            tout[ch * CS + (p / W + 1) * PW + (p % W) + 1] = __uint_as_float(got[j] & 0x7FFFFFFFu);
         }
     }
     __syncthreads();
-    return true;
+    return *c.abort_lds == 0;
 }
 
 // the layer sequence of one wave of a member: oc-tile `ot` x pixel tile `tile` (waves without a tile: ot < 0), every wave takes part in the exchanges
@@ -239,7 +249,7 @@ __device__ __forceinline__ bool towerRunCluster(const float* __restrict__ params
         if (work) {
             const float* nw = ta.nlayers > 1 ? params + ta.w_off[1] : nullptr;
             tower_layer<H, W, CIN0_PAD / 4, 1, CPAD / 4, false, NTW, true>(T0, nullptr, T1, nullptr, params + ta.w_off[0], params + ta.b_off[0], ta.C, ta.OT, lane, ot, px,
-                                                                           false, aS, nw, aA, clPart(c, ot));
+                                                                           false, aS, nw, aA, clPart(c, ot), clSign(c));
             have = nw != nullptr;
         }
         if (!clExchange<H, W, CPAD>(c, T1, tid)) { return false; }
@@ -251,12 +261,14 @@ __device__ __forceinline__ bool towerRunCluster(const float* __restrict__ params
         if (work) {
             tower_layer<H, W, CPAD / 4, 1, CPAD / 4, false, NTW, true>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, nullptr, params + ta.w_off[l],
                                                                        params + ta.b_off[l], ta.C, ta.OT, lane, ot, px, have, aA,
-                                                                       last ? nullptr : params + ta.w_off[l + 1], aB, clPart(c, ot));
+                                                                       last ? nullptr : params + ta.w_off[l + 1], aB, clPart(c, ot), clSign(c));
 #pragma unroll
             for (int cg = 0; cg < CPAD / 4; ++cg) { aA[cg] = aB[cg]; }
             have = !last;
         }
+        MZ_HPROF(1);
         if (!clExchange<H, W, CPAD>(c, second ? x : tmp, tid)) { return false; }
+        MZ_HPROF(2);
     }
     return true;
 }

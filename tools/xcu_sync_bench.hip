@@ -2,7 +2,9 @@
 // every workgroup stores its 16 x 36 floats, the four meet at a counter in global memory, every workgroup reads the other three parts.
 // Variants: (0) agent-scope release/acquire atomics as the compiler emits them (L2 write-back + invalidate on a multi-XCD part),
 // (1) relaxed atomics at L2 + loads that bypass the CU's vector cache — only valid when the four workgroups share an XCD (one L2); the
-// kernel reads XCC_ID to check that workgroup ids congruent mod 8 do land on one XCD.
+// kernel reads XCC_ID to check that workgroup ids congruent mod 8 do land on one XCD; (2) 8-byte (value, sequence) words polled by every
+// thread at once; (3) 16-byte words (three values + sequence) polled after a short delay with a pause between polls; (4) the counter of (1)
+// with every wave arriving and polling for itself.
 // build: hipcc --offload-arch=gfx950 -O2 -o gpurun_out/xcu_sync_bench tools/xcu_sync_bench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(kThreads) void bench(Args a)
     for (int it = 0; it < a.iters; ++it) {
         float* x = a.xchg + (size_t(cluster) * 2 + (it & 1)) * kMembers * kPart;
         // my part: values that depend on (iteration, member, index) so that a stale read shows up in the checksum
-        if (a.variant != 2) { for (int i = tid; i < kPart; i += kThreads) { x[member * kPart + i] = float((it * 7 + member * 3 + i) & 1023); } }
+        if (a.variant != 2 && a.variant != 3) { for (int i = tid; i < kPart; i += kThreads) { x[member * kPart + i] = float((it * 7 + member * 3 + i) & 1023); } }
         if (a.variant == 0) {
             __syncthreads();
             if (tid == 0) {
@@ -82,6 +84,59 @@ __global__ __launch_bounds__(kThreads) void bench(Args a)
             if (polls >= 100000) { acc += 1.0f; }
 #pragma unroll
             for (int k = 0; k < kPer; ++k) { const int i = tid + k * kThreads; if (i < kMembers * kPart) { lds[i] = __uint_as_float(got[k].x); } }
+        } else if (a.variant == 3) { // 16-byte words: three values + the iteration number; the readers wait a little before the first poll
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            u4* xx = reinterpret_cast<u4*>(a.xchg) + (size_t(cluster) * 2 + (it & 1)) * kMembers * (kPart / 3);
+            const unsigned seq = unsigned(it + 1);
+            constexpr int kW = kPart / 3; // words per member
+            for (int i = tid; i < kW; i += kThreads) {
+                u4 w;
+                w.x = __float_as_uint(float((it * 7 + member * 3 + 3 * i) & 1023));
+                w.y = __float_as_uint(float((it * 7 + member * 3 + 3 * i + 1) & 1023));
+                w.z = __float_as_uint(float((it * 7 + member * 3 + 3 * i + 2) & 1023));
+                w.w = seq;
+                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(xx + member * kW + i), "v"(w) : "memory");
+            }
+            constexpr int kPer = (kMembers * kW + kThreads - 1) / kThreads;
+            u4 got[kPer];
+            bool ok;
+            int polls = 0;
+            __builtin_amdgcn_s_sleep(8);
+            do {
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) {
+                    const int i = tid + k * kThreads;
+                    const u4* src = xx + (i < kMembers * kW ? i : 0);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(got[k]) : "v"(src) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ok = true;
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) { ok = ok && (got[k].w == seq || tid + k * kThreads >= kMembers * kW); }
+                if (!__all(ok)) { __builtin_amdgcn_s_sleep(2); }
+            } while (!__all(ok) && ++polls < 100000);
+            if (polls >= 100000) { acc += 1.0f; }
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int i = tid + k * kThreads;
+                if (i < kMembers * kW) { lds[3 * i] = __uint_as_float(got[k].x); lds[3 * i + 1] = __uint_as_float(got[k].y); lds[3 * i + 2] = __uint_as_float(got[k].z); }
+            }
+        } else if (a.variant == 4) { // counter protocol, every wave arrives and polls for itself (no barrier before / after the rendezvous)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int nw = kThreads / 64;
+            if ((tid & 63) == 0) { __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            const unsigned want = unsigned(it + 1) * kMembers * nw;
+            for (int polls = 0; polls < 1000000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++polls) { __builtin_amdgcn_s_sleep(1); }
+            constexpr int kPer = (kMembers * kPart + kThreads - 1) / kThreads;
+            float got[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int i = tid + k * kThreads;
+                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(got[k]) : "v"(x + (i < kMembers * kPart ? i : 0)) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) { const int i = tid + k * kThreads; if (i < kMembers * kPart) { lds[i] = got[k]; } }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my stores have reached the L2
             __syncthreads();
@@ -133,7 +188,7 @@ int main(int argc, char** argv)
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bench, kThreads, 0));
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("cooperative launch %d, blocks per CU %d, CUs %d\n", coop, per_cu, prop.multiProcessorCount);
-    for (int variant = 0; variant < 3; ++variant) {
+    for (int variant = 0; variant < 5; ++variant) {
         a.variant = variant;
         CK(hipMemset(a.counter, 0, clusters * 32 * 4));
         void* params[] = {&a};
