@@ -165,8 +165,8 @@ __device__ __forceinline__ GoDevView simLeafView(GoDevView gv, float* xchg, int 
 // the MFMA loop.  SimArgs lives in device memory (not in 1.3 KB of kernel arguments pinned in SGPRs for the whole kernel).
 typedef __attribute__((address_space(3))) const double LdsCDouble;
 
-template <int CPL, int WPE>
-__device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
+template <int CPL, int WPE, class RcpPtr>
+__device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, RcpPtr rcp, SpecMem spec,
                                            float* xchg, const uint64_t* seen_lds)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform

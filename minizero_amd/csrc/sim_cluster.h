@@ -67,6 +67,7 @@ inline size_t octetWords(int n1, int hidden, int size) { return size_t(kOcHdr) +
 struct ClusterCtx {
     unsigned* cm;   // this game's block
     int member, C, P, OT;
+    int mine0, mine1; // floats [mine0, mine1) of an exchange buffer are this member's own channels
     unsigned xseq;  // layer exchanges done so far in this launch
     int* abort_lds; // workgroup-wide abort flag
     int* err;
@@ -206,7 +207,7 @@ __device__ __forceinline__ bool clExchange(ClusterCtx& c, float* __restrict__ to
     ++c.xseq;
     __syncthreads(); // the member's own waves are done with the layer: all waves start polling together (idle waves polling for a whole layer slowed the others' loads)
     constexpr int K = (CPAD * P + 511) / 512;
-    const int n = c.OT * 16 * P, mine0 = c.member * 16 * P;
+    const int n = (c.OT * 16 < c.C ? c.OT * 16 : c.C) * P, mine0 = c.mine0, mine1 = c.mine1; // channels beyond C are never written
     unsigned got[K];
     bool ok = false;
     for (int polls = 0; polls < kClPollLimit; ++polls) {
@@ -214,7 +215,7 @@ __device__ __forceinline__ bool clExchange(ClusterCtx& c, float* __restrict__ to
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int i = tid + j * 512;
-            const bool want = i < n && (i < mine0 || i >= mine0 + 16 * P);
+            const bool want = i < n && (i < mine0 || i >= mine1);
             got[j] = __float_as_uint(clLoadF(xb + (want ? i : 0)));
             ok = ok && (!want || (got[j] & 0x80000000u) == sign);
         }
@@ -226,7 +227,7 @@ __device__ __forceinline__ bool clExchange(ClusterCtx& c, float* __restrict__ to
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int i = tid + j * 512;
-        const bool want = i < n && (i < mine0 || i >= mine0 + 16 * P) && i < c.C * P;
+        const bool want = i < n && (i < mine0 || i >= mine1) && i < c.C * P;
         if (want) {
             const int ch = i / P, p = i - ch * P;
             tout[ch * CS + (p / W + 1) * PW + (p % W) + 1] = __uint_as_float(got[j] & 0x7FFFFFFFu);
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
     ClusterCtx c;
     c.cm = a->cluster + size_t(g) * a->cluster_words;
     c.member = member; c.C = a->hp.C; c.P = a->hp.P; c.OT = a->ta_dyn.OT; c.xseq = 0; c.abort_lds = &s_abort; c.err = a->err;
+    c.mine0 = member * 16 * c.P; c.mine1 = c.mine0 + 16 * c.P;
     c.NJ = (games - (g & 7) + 7) / 8; c.j = g >> 3; c.oseq = 0;
     c.om = (a->cluster_oct && c.NJ == 8 && (member == 1 || member == 2)) ? a->cluster_oct + size_t((g & 7) * 2 + member - 1) * a->oct_words : nullptr;
     // placement check: the four members of a game must share an XCD (one L2), else the exchanges would read stale data
