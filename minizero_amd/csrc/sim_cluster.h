@@ -25,7 +25,6 @@ namespace mz {
 
 // per-game block in global memory (32-bit words); the host clears it before every launch
 constexpr int kClCmd = 0;      // [0..3] = {parent slot, action, -, sequence number} written by the owner with one 16-byte store
-constexpr int kClArrive = 32;  // arrivals at the layer exchanges (monotonic)
 constexpr int kClRes = 64;     // [0,1] = (reward bits, seq), [2,3] = (value bits, seq)
 constexpr int kClXcc = 96;     // [0..3] XCC_ID of the members, [4] arrivals of the placement check
 constexpr int kClXbuf = 128;   // 2 x [C][P] floats
