@@ -392,3 +392,40 @@ def test_atari_raw_observation_path_is_equivalent(mz):
     assert len(raw) >= 8
     assert raw == host
     assert raw == lock
+
+
+def test_atari_manual_steps_with_extra_moves_keep_the_observation_block_right(mz):
+    """BaseActor-style stepping (mz_manual_step) on the Atari-shaped env: after a search the caller plays the searched action and sometimes a second
+    one without a search in between (console `play`), so the device's copy of the last 8 screens is NOT the previous block shifted by one screen — the
+    worker must notice (GameEnv::rawSerial) and send the whole block again.  Byte observations vs float planes built on the host: same actions, same record."""
+    import ctypes as C
+    kw = dict(vh=ATARI_ARGS[10], dv=ATARI_ARGS[11], type_name=ATARI_ARGS[12])
+    d = mz.make_desc(*ATARI_ARGS[:10], **kw)
+    conf = ATARI_SMALL.replace("zero_num_parallel_games=5", "zero_num_parallel_games=1") + ":mz_manual_step=true:program_seed=3:nn_file_name=x.pt:zero_num_threads=1"
+
+    def play(extra):
+        wk = mz.Worker(conf + extra, d, mz.generate_weights(d, 3))
+        L = wk.L
+        L.mz_worker_search_action.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mz_worker_act.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        for f in (L.mz_worker_search_done, L.mz_worker_reset_search):
+            f.argtypes = [C.c_void_p]
+        L.mz_worker_emit_game.argtypes = [C.c_void_p, C.c_int]
+        wk.command("start")
+        actions = []
+        for move in range(7):
+            while not L.mz_worker_search_done(wk.h):
+                assert wk.run_cycles(9) >= 0
+            a, p, r = C.c_int(), C.c_int(), C.c_int()
+            assert L.mz_worker_search_action(wk.h, 0, C.byref(a), C.byref(p), C.byref(r)) == 0
+            actions.append(a.value)
+            assert L.mz_worker_act(wk.h, 0, a.value, p.value) == 1
+            if move % 3 == 1:  # a move the search did not choose, played without a search
+                assert L.mz_worker_act(wk.h, 0, (a.value + 5) % 18, p.value) == 1
+            assert L.mz_worker_reset_search(wk.h) == 0
+        assert L.mz_worker_emit_game(wk.h, 0) == 0
+        return actions, wk.pop_lines()
+
+    raw = play(":mz_raw_observations=true")
+    host = play(":mz_raw_observations=false")
+    assert len(raw[1]) == 1 and raw == host
