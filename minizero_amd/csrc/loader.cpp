@@ -12,6 +12,7 @@
 #include "go_dev.h"
 #include "loader_dev.h"
 #include "net.h"
+#include <chrono>
 #include <zlib.h>
 #include <algorithm>
 #include <cmath>
@@ -117,11 +118,21 @@ public:
     void finishLoading() { game_priority_sum_ = std::accumulate(game_priorities_.begin(), game_priorities_.end(), 0.0f); }
     int loadFile(const char* path);
     int sample(float* features, float* action_features, float* policy, float* value, float* reward, float* loss_scale, int* sampled_index, int where);
+    bool trace_ = getenv("MZ_TRACE") != nullptr; // prints the host / device split of sample_data when the loader is destroyed
+    double trace_ms_[3] = {0, 0, 0};
+
     int updatePriority(const int* sampled_index, const float* batch_values);
     int numData() const { return num_data_; }
     int numGames() const { return static_cast<int>(games_.size()); }
     int shape(int what) const;
-    ~Loader() { if (stream_) { (void)hipStreamDestroy(stream_); } }
+    ~Loader()
+    {
+        if (trace_ && trace_ms_[2] > 0) {
+            fprintf(stderr, "[mz trace] loader: %.3f ms host (draws, targets, staging) + %.3f ms device (uploads, replay, downloads) per batch over %.0f batches\n",
+                    trace_ms_[0] / trace_ms_[2], trace_ms_[1] / trace_ms_[2], trace_ms_[2]);
+        }
+        if (stream_) { (void)hipStreamDestroy(stream_); }
+    }
 
 private:
     bool parse(const std::string& content, LGame* g);
@@ -502,6 +513,8 @@ int Loader::sample(float* features, float* action_features, float* policy, float
     int rc = ensureDevice(B);
     if (rc) { return rc; }
     MZ_HIP(hipSetDevice(device_));
+    const auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = tnow();
     const int MD = slots_ + 1;
     const size_t np = size_t(shape(3)), nv = size_t(shape(4)), nr = size_t(shape(5)), na = size_t(shape(2));
     std::vector<float> h_policy(B * np), h_value(B * nv), h_reward(B * std::max<size_t>(nr, 1)), h_af(B * std::max<size_t>(na, 1)), h_ls(B);
@@ -566,6 +579,7 @@ int Loader::sample(float* features, float* action_features, float* policy, float
         if (!ok) { setError("sample_data: game %d lacks the V / R tags its targets need", env_id); return MZ_ERR_STATE; }
     }
     // ---- features on the device ----
+    const double t_host = tnow();
     float* d_out = where == MZ_DEVICE ? features : d_feat_.p;
     MZ_HIP(hipMemcpyAsync(d_rot_.p, h_rot_.p, B, hipMemcpyHostToDevice, stream_));
     if (atari_) {
@@ -586,6 +600,7 @@ int Loader::sample(float* features, float* action_features, float* policy, float
         (rc = put(loss_scale, h_ls.data(), B * sizeof(float))) || (rc = put(sampled_index, h_si.data(), 2 * size_t(B) * sizeof(int)))) { return rc; }
     if (muzero_ && ((rc = put(action_features, h_af.data(), B * na * sizeof(float))) || (rc = put(reward, h_reward.data(), B * nr * sizeof(float))))) { return rc; }
     MZ_HIP(hipStreamSynchronize(stream_));
+    if (trace_) { const double t_end = tnow(); trace_ms_[0] += t_host - t_start; trace_ms_[1] += t_end - t_host; trace_ms_[2] += 1; }
     return MZ_OK;
 }
 
