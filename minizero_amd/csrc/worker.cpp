@@ -44,9 +44,9 @@ struct Rng {
     std::uniform_int_distribution<int> int_dist;
     std::uniform_real_distribution<double> real_dist;
     void seed(int s) { gen.seed(s); }
-    int randInt() { return int_dist(gen); }
+    __attribute__((always_inline)) int randInt() { return int_dist(gen); }
     double randReal(double range = 1.0f) { return real_dist(gen) * range; }
-    void dirichlet(float alpha, int size, std::vector<float>& out)
+    __attribute__((always_inline)) void dirichlet(float alpha, int size, std::vector<float>& out)
     {
         out.clear();
         std::gamma_distribution<float> gamma(alpha);
@@ -1367,7 +1367,7 @@ int Worker::syncGumbel(Lane& L, bool to_device)
 
 // The RNG draws of one cycle that joins a launch (its own function: the hot loop of a 400-simulation move — 102 400 rotation draws and 20 k gamma
 // draws per move on BASELINE configs[1] — must not depend on the inlining decisions inside runCyclesSim, which cost 1.4 ms per move once)
-__attribute__((noinline)) void Worker::drawCycle(int batch, bool noise_cycle)
+__attribute__((noinline, aligned(64))) void Worker::drawCycle(int batch, bool noise_cycle)
 {
     const bool az = desc_.type == 0, rotate = cfg_.actor_use_random_rotation_features;
     for (auto& L : lanes_) {
