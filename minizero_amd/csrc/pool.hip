@@ -225,8 +225,12 @@ int Pool::checkError()
     MZ_HIP(hipMemcpyAsync(&e, game_i_.p + size_t(v_.games) * 3, sizeof(int), hipMemcpyDeviceToHost, stream_));
     MZ_HIP(hipStreamSynchronize(stream_));
     if (e) {
-        setError("search pool capacity exceeded (nodes_per_game = %d)", v_.cap);
         (void)hipMemsetAsync(game_i_.p + size_t(v_.games) * 3, 0, sizeof(int), stream_);
+        if (e >= 90 && e < 100) { // sim_cluster.h: 90 layer exchange, 91 placement (members on different XCDs), 92 command, 93 results, 94 octet exchange
+            setError("simulation kernel: a workgroup of a game's cluster did not arrive (wait %d timed out); the search state of this move is lost", e);
+            return MZ_ERR_DEVICE;
+        }
+        setError("search pool capacity exceeded (nodes_per_game = %d)", v_.cap);
         return e;
     }
     return MZ_OK;

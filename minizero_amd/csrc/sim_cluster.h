@@ -505,6 +505,9 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         }
         __syncthreads();
         if (s_abort) { return; }
+        // fault injection for tests/test_gpu_worker.py (MZ_NO_SPEC=4): a helper of game 0 disappears in the third simulation — every wait of the others must
+        // time out, raise the pool's error flag and leave the kernel
+        if ((a->no_spec & 4) && g == 0 && member == 1 && s == 2) { return; }
         if (prof) { t1 = wall_clock64(); }
         const int src = s_cmd[0], action = s_cmd[1];
         const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;

@@ -429,3 +429,21 @@ def test_atari_manual_steps_with_extra_moves_keep_the_observation_block_right(mz
     raw = play(":mz_raw_observations=true")
     host = play(":mz_raw_observations=false")
     assert len(raw[1]) == 1 and raw == host
+
+
+@pytest.mark.parametrize("games", [5, 64])
+def test_cluster_member_going_missing_ends_in_an_error_not_a_hang(mz, monkeypatch, games):
+    """Cluster mode (sim_cluster.h): the four workgroups of a game wait for each other in global memory; every wait is bounded.  With a helper of game 0
+    made to leave the kernel (fault injection: MZ_NO_SPEC=4) the launch has to come back — within seconds — and the worker has to report the error."""
+    import time
+    monkeypatch.setenv("MZ_NO_SPEC", "4")
+    kw = dict(vh=ATARI_ARGS[10], dv=ATARI_ARGS[11], type_name=ATARI_ARGS[12])
+    d = mz.make_desc(*ATARI_ARGS[:10], **kw)
+    conf = ATARI_SMALL.replace("zero_num_parallel_games=5", f"zero_num_parallel_games={games}")  # 64 games: the heads of an octet wait for each other too
+    wk = mz.Worker(conf + ":program_seed=11:nn_file_name=x.pt:zero_num_threads=2", d, mz.generate_weights(d, 3))
+    wk.command("start")
+    t0 = time.time()
+    with pytest.raises(mz.MzError):
+        for _ in range(4):
+            wk.run_cycles(9)
+    assert time.time() - t0 < 60
