@@ -10,6 +10,143 @@ namespace mz {
 
 namespace {
 
+
+// Go: the moves 1 .. upto of sample g applied ONE AFTER THE OTHER ON THE SAME WAVE STATE (stones and group ids in registers + LDS, the hash in a register)
+// instead of one goLeafBody per move through the position slots in global memory (load the parent, apply, store: 3 us per move, 0.5 ms for a
+// 160-move sample).  Same observable effects as the "leaf = parent + one move" part of goLeafBody (ref go.cpp:132-190); every position's hash and
+// move counters are stored, stones and group ids only for the last `keep` positions — what the planes of the sampled position (8 positions of
+// history) and the final goLeafBody (its parent slot) read.
+template <int CPL>
+__device__ __forceinline__ void goReplayMoves(const GoDevView& v, const PoolView& pv, int g, int lane, uint64_t* __restrict__ smem, int upto, int keep)
+{
+    const int P = v.P, n = v.n, W = v.W, Ppad = v.Ppad, MD = pv.max_depth;
+    uint64_t* gh = smem;
+    uint64_t* ph = gh + Ppad;
+    uint64_t* hb = ph + MD + 4;
+    uint64_t* cur = hb + 16 * W;
+    int* libs = reinterpret_cast<int*>(cur + 2 * W);
+    uint16_t* lab = reinterpret_cast<uint16_t*>(libs + Ppad); // same LDS layout as goLeafBody
+    uint8_t* col = reinterpret_cast<uint8_t*>(lab + Ppad);
+    const int* pact = pv.path_action + size_t(g) * MD;
+    const size_t sb = size_t(g) * v.slots;
+    const int root_turn = v.snap[g].turn;
+    int c[CPL], l[CPL];
+    short nb[CPL][4];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int p = i * 64 + lane;
+        const uint64_t sbw = v.stones[((sb + 0) * 2 + 0) * W + i], sww = v.stones[((sb + 0) * 2 + 1) * W + i];
+        c[i] = 3;
+        l[i] = 0;
+        nb[i][0] = nb[i][1] = nb[i][2] = nb[i][3] = -1;
+        if (p < P) {
+            c[i] = ((sbw >> lane) & 1) ? 1 : (((sww >> lane) & 1) ? 2 : 0);
+            l[i] = v.lab[(sb + 0) * Ppad + p];
+            const int x = p % n, y = p / n;
+            if (y + 1 < n) { nb[i][0] = static_cast<short>(p + n); }
+            if (x + 1 < n) { nb[i][1] = static_cast<short>(p + 1); }
+            if (y > 0) { nb[i][2] = static_cast<short>(p - n); }
+            if (x > 0) { nb[i][3] = static_cast<short>(p - 1); }
+        }
+        col[p] = static_cast<uint8_t>(c[i]);
+        lab[p] = static_cast<uint16_t>(l[i]);
+    }
+    uint64_t hash = v.hash[sb + 0];
+    int nmoves = v.meta[(sb + 0) * 2], passes = v.meta[(sb + 0) * 2 + 1];
+    waveSync();
+    for (int d = 1; d <= upto; ++d) {
+        const int t = (d & 1) ? 3 - root_turn : root_turn; // the player to move AFTER move d
+        const int a = pact[d], m = 3 - t;
+        ++nmoves;
+        hash ^= v.turn_key;
+        if (a >= P) {
+            passes = passes + 1 > 2 ? 2 : passes + 1;
+        } else {
+            passes = 0;
+            const int ax = a % n, ay = a / n;
+            const int an[4] = {ay + 1 < n ? a + n : -1, ax + 1 < n ? a + 1 : -1, ay > 0 ? a - n : -1, ax > 0 ? a - 1 : -1};
+            int own[4], en[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                own[k] = -1;
+                en[k] = -1;
+                if (an[k] >= 0) {
+                    const int cq = col[an[k]];
+                    if (cq == m) { own[k] = lab[an[k]]; }
+                    else if (cq == 3 - m) { en[k] = lab[an[k]]; }
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                for (int j = 0; j < k; ++j) { if (en[j] == en[k]) { en[k] = -1; } }
+            }
+            waveSync();
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int p = i * 64 + lane;
+                if (p == a) { c[i] = m; l[i] = a; }
+                else if (c[i] == m && (l[i] == own[0] || l[i] == own[1] || l[i] == own[2] || l[i] == own[3])) { l[i] = a; }
+                col[p] = static_cast<uint8_t>(c[i]);
+                lab[p] = static_cast<uint16_t>(l[i]);
+            }
+            waveSync();
+            unsigned flags = 0;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                if (c[i] != 0) { continue; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = nb[i][k];
+                    if (q >= 0 && col[q] == 3 - m) {
+                        const int lq = lab[q];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { if (lq == en[j]) { flags |= 1u << j; } }
+                    }
+                }
+            }
+            bool cap[4], any_cap = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cap[j] = en[j] >= 0 && __ballot((flags >> j) & 1) == 0;
+                any_cap |= cap[j];
+            }
+            uint64_t hx = 0;
+            if (any_cap) {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    const int p = i * 64 + lane;
+                    if (c[i] == 3 - m && ((cap[0] && l[i] == en[0]) || (cap[1] && l[i] == en[1]) || (cap[2] && l[i] == en[2]) || (cap[3] && l[i] == en[3]))) {
+                        c[i] = 0;
+                        col[p] = 0;
+                        hx ^= v.key[size_t(2 - m) * P + p];
+                    }
+                }
+                hx = waveXor64(hx);
+            }
+            hash ^= v.key[size_t(m - 1) * P + a] ^ hx;
+            waveSync();
+        }
+        if (lane == 0) {
+            v.hash[sb + d] = hash;
+            v.meta[(sb + d) * 2] = nmoves;
+            v.meta[(sb + d) * 2 + 1] = passes;
+        }
+        if (d > upto - keep) { // one of the last positions: the planes of the sampled position and the final goLeafBody read its slot
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int p = i * 64 + lane;
+                const uint64_t sbw = __ballot(c[i] == 1), sww = __ballot(c[i] == 2);
+                if (lane == 0) {
+                    v.stones[((sb + d) * 2 + 0) * W + i] = sbw;
+                    v.stones[((sb + d) * 2 + 1) * W + i] = sww;
+                }
+                if (p < P) { v.lab[(sb + d) * Ppad + p] = static_cast<uint16_t>(l[i]); }
+            }
+        }
+    }
+    waveSync();
+}
+
 // sample g: moves pact[g][1 .. pos[g]] replayed from the root snapshot (slot 0); the planes of the last position under rot[g] end in v.feat
 template <int KIND, int CPL>
 __global__ __launch_bounds__(64) void replay_kernel(GoDevView v, PoolView pv, const int* __restrict__ pos, const uint8_t* __restrict__ rot)
@@ -17,7 +154,11 @@ __global__ __launch_bounds__(64) void replay_kernel(GoDevView v, PoolView pv, co
     extern __shared__ uint64_t smem[];
     const int g = blockIdx.x, lane = threadIdx.x;
     const int n = pos[g], r = rot[g];
-    for (int d = 0; d <= n; ++d) {
+    int d0 = 0;
+    if constexpr (KIND == 0) { // Go: all moves but the last on one wave state; the last one (the sampled position) through goLeafBody
+        if (n > 1) { goReplayMoves<CPL>(v, pv, g, lane, smem, n - 1, 8); d0 = n; }
+    }
+    for (int d = d0; d <= n; ++d) {
         if (lane == 0) { pv.path_len[g] = d + 1; }
         waveSync();
         if (d == 0 && n > 0) { continue; } // slot 0 is the uploaded root: only evaluate it when it is the sampled position itself
