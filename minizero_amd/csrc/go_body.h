@@ -45,10 +45,8 @@ template <int CPL, bool EXT_PLANES = false>
 // EXT_PLANES: the caller builds the feature planes itself from the history block this body leaves in `smem` (goPlanesPart, all waves)
 // seen_lds: optional LDS copy of the root's positional-superko table (GoRootSnapshot::seen; constant during a move) — the simulation kernel
 // makes one per launch so that the probes of every candidate point are LDS reads instead of dependent trips to L2
-// slot_only (the learner-side replay of a record, loader_kernels.hip): a position on the way to the sampled one — its slot (stones, groups, hash) is all
-// the next move needs; liberties, legal mask, planes and score are skipped
 __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& pv, int rot, int slot, int g, int lane, uint64_t* __restrict__ smem,
-                                           const uint64_t* __restrict__ seen_lds = nullptr, bool slot_only = false)
+                                           const uint64_t* __restrict__ seen_lds = nullptr)
 {
     const int P = v.P, n = v.n, W = v.W, Ppad = v.Ppad, MD = pv.max_depth;
     uint64_t* gh = smem;                                   // [Ppad] XOR of the keys of a group, by group id
@@ -193,7 +191,6 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         if (lane == 0) { cur[i] = sbw[i]; cur[W + i] = sww[i]; }
     }
     MZ_LPROF(2); // move applied, slot stored
-    if (slot_only) { return; }
     const bool terminal = passes >= 2 || nmoves > 2 * P; // ref go.cpp:246-257
     // ---- hashes along the path (d = 1 .. depth; the root and everything before it is in the root's table) ----
     for (int d = 1 + lane; d <= depth; d += 64) { ph[d - 1] = normH(d == depth ? hash : v.hash[sb + hs[path[d]]]); }

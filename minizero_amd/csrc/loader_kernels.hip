@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void replay_kernel(GoDevView v, PoolView pv, co
         if (d == 0 && n > 0) { continue; } // slot 0 is the uploaded root: only evaluate it when it is the sampled position itself
         if constexpr (KIND == 2) { tttLeafBody(v, pv, r, d, g, lane); }
         else if constexpr (KIND == 1) { othLeafBody(v, pv, r, d, g, lane); }
-        else { goLeafBody<CPL>(v, pv, r, d, g, lane, smem, nullptr, d < n); }
+        else { goLeafBody<CPL>(v, pv, r, d, g, lane, smem); }
         waveSync();
     }
 }
