@@ -3,7 +3,7 @@
 games (BASELINE configs[1] shapes; the games are produced here by the self-play worker with a short search), on the product's DataLoader
 (records -> flat arrays once, features replayed on the GPU per batch) and on the oracle's restatement of the reference's DataLoader (every sample
 replays its game from the first move on the CPU, one thread — the reference runs `learner_num_thread` of those).
-usage: loader_bench.py [games=512] [batches=20]"""
+usage: loader_bench.py [games=512] [batches=20] [go|othello]"""
 import os
 import sys
 import tempfile
@@ -17,14 +17,16 @@ import minizero_amd as mz  # noqa: E402
 
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 batches = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-d = mz.DESCS["c2"]()
-conf = f"env_game=go:env_board_size=9:actor_num_simulation=8:zero_num_parallel_games={min(games, 256)}"
+game = sys.argv[3] if len(sys.argv) > 3 else "go"
+d = mz.DESCS["c2" if game == "go" else "c3"]()
+conf = (f"env_game=go:env_board_size=9:actor_num_simulation=8:zero_num_parallel_games={min(games, 256)}" if game == "go" else
+        f"env_game=othello:env_board_size=8:actor_num_simulation=8:zero_num_parallel_games={min(games, 256)}")
 wk = mz.Worker(conf + f":program_seed=1:nn_file_name=weight_iter_0.pt:zero_num_threads={max(1, mz.usable_cpus() - 1)}", d, mz.generate_weights(d, 0))
 wk.command("start")
 lines = []
 t0 = time.perf_counter()
 while len(lines) < games:
-    wk.run_cycles(9 * 170)
+    wk.run_cycles(9 * (170 if game == "go" else 62))
     lines += wk.pop_lines()
 print(f"{len(lines)} games ({sum(l.count(';B[') + l.count(';W[') for l in lines)} positions) from the worker in {time.perf_counter() - t0:.1f} s", flush=True)
 del wk
@@ -42,7 +44,7 @@ def run(make, name):
     t0 = time.perf_counter()
     dl.load_data_from_file(path)
     t_load = time.perf_counter() - t0
-    B, nf, na, npol, nv, nr = dl.shapes() if hasattr(dl, "shapes") else (1024, 18 * 81, 0, 82, 1, 0)
+    B, nf, na, npol, nv, nr = dl.shapes() if hasattr(dl, "shapes") else (1024, d.num_input_channels * d.input_channel_height * d.input_channel_width, 0, d.action_size, 1, 0)
     bufs = [np.zeros((B, max(n, 1)), np.float32) for n in (nf, na, npol, nv, nr)] + [np.zeros(B, np.float32), np.zeros((B, 2), np.int32)]
     dl.sample_data(*bufs)  # warm-up
     t0 = time.perf_counter()
