@@ -148,6 +148,7 @@ private:
     DevBuf<unsigned> sim_sink_;
     DevBuf<char> sim_cluster_mem_; // cluster mode of the MuZero simulation kernel (sim_cluster.h): per-game exchange blocks
     int cu_count_ = 0;
+    int sim_cluster_checked_ = 0; // pool size (padded) whose cluster placement has been probed
     bool coop_launch_ = false;
 public:
     bool sim_octet_ = true;     // cluster mode: the 601-bin heads of the games that share an XCD are computed together (sim_cluster.h octetHead)

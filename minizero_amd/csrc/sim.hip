@@ -945,7 +945,11 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     if (lds > 160 * 1024) { return MZ_OK; }
     // cluster mode (sim_cluster.h): four workgroups per game when the pool leaves three quarters of the CUs idle (muzero_atari instances only)
     const int gpad = (pool.v_.games + 7) / 8 * 8;
-    const bool cluster = atari && sim_cluster_ && H * W <= 36 && kClMembers * gpad <= cu_count_ && coop_launch_;
+    bool cluster = atari && sim_cluster_ && H * W <= 36 && kClMembers * gpad <= cu_count_ && coop_launch_;
+    if (cluster && sim_cluster_checked_ != gpad) { // once per pool size: do the members of a cluster share an XCD on this device?
+        if (clusterPlacementOk(gpad, stream_)) { sim_cluster_checked_ = gpad; }
+        else { sim_cluster_ = false; cluster = false; } // one workgroup per game (same records)
+    }
     size_t lds_cluster = lds;
     if (cluster) {
         lds_cluster = lds + (clusterHeadsSmemFloats(a.ahp) - head_floats) * sizeof(float);

@@ -554,6 +554,31 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
     }
 }
 
+// which XCD does workgroup i of a launch land on?  (the dispatcher deals workgroups to the XCDs round-robin: i % 8 on this part)
+__global__ void xcc_probe_kernel(unsigned* out)
+{
+    if (threadIdx.x == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        out[blockIdx.x] = id & 15u;
+    }
+}
+// true if workgroups whose ids differ by a multiple of `gpad` share an XCD, i.e. if the members of a cluster will (checked once per network before the
+// first cluster launch; the kernel checks again and refuses to run otherwise)
+static bool clusterPlacementOk(int gpad, hipStream_t s)
+{
+    const int n = kClMembers * gpad;
+    unsigned* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), size_t(n) * sizeof(unsigned)) != hipSuccess) { return false; }
+    std::vector<unsigned> h(n, 99u);
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, s, d);
+    const bool copied = hipMemcpyAsync(h.data(), d, size_t(n) * sizeof(unsigned), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(d);
+    if (!copied) { return false; }
+    for (int i = gpad; i < n; ++i) { if (h[i] != h[i % gpad]) { return false; } }
+    return true;
+}
+
 template <int H, int W, int CDYN_PAD, int CPAD>
 static int launchSimMzClusterT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
 {
