@@ -55,8 +55,8 @@ __device__ __forceinline__ bool clWaitGE(const unsigned* p, unsigned want)
     return false;
 }
 
-// Octet block: the (up to) 8 games whose workgroups share an XCD (game % 8) run each 601-bin head TOGETHER — the CU of game j computes column
-// slice j of both FC layers for all games of the octet, so the XCD's L2 delivers every weight once per simulation instead of once per game.
+// Octet block: the 8 games whose workgroups share an XCD (game % 8) run each 601-bin head TOGETHER — the CU of game j computes column slice j % 4 of
+// both FC layers for the four games of its half (j / 4), so the XCD's L2 delivers every weight twice per simulation instead of eight times.
 // (Measured: 16 CUs streaming 1.24 MB each get 0.74 TB/s out of one XCD's L2 together, 27 us per simulation for the FC layers, however deep
 // each CU prefetches.)  One block per (octet, head): [0] arrivals, then F[8][n1p], H1[8][hidp], LG[8][sizep].
 constexpr int kOcHdr = 32;
