@@ -39,7 +39,11 @@ struct LGame {
     std::vector<uint32_t> p_off;         // CSR over moves: entries of the P tag in string order
     std::vector<int> p_action;
     std::vector<float> p_count;
-    std::vector<std::string> obs;        // Atari: observation bytes per step ("" = not kept)
+    // Atari: the screens of steps obs_first .. obs_n - 1 (the record keeps the LAST ones) live in device memory, 3 x 96 x 96 bytes each, for as long as
+    // the game is in the replay buffer: a sample then costs eight pointers instead of 221 KB of host copies + PCIe (a 1000-step game is 27 MB:
+    // 288 GB of HBM hold ten thousand of them)
+    int obs_n = 0, obs_first = 0;
+    std::shared_ptr<uint8_t> d_obs;
     int size() const { return static_cast<int>(action.size()); }
 };
 
@@ -171,10 +175,10 @@ private:
     GoDevice godev_;
     int dev_batch_ = 0, slots_ = 0;
     DevBuf<int> d_path_, d_int_;        // identity path / hslot; per batch: path_len, path_action, pos
-    DevBuf<uint8_t> d_rot_, d_raw_;
+    DevBuf<uint8_t> d_rot_, d_meta_;
     DevBuf<float> d_feat_;
     PinBuf<int> h_int_;
-    PinBuf<uint8_t> h_rot_, h_raw_;
+    PinBuf<uint8_t> h_rot_, h_meta_;
     PoolView pv_{};
 };
 
@@ -316,14 +320,21 @@ bool Loader::parse(const std::string& content, LGame* g)
         g->p_off[i + 1] = static_cast<uint32_t>(g->p_action.size());
     }
     if (atari_) { // atari.cpp:179-184,237-249: observations aligned to the END of the game
-        g->obs.assign(n + 1, std::string());
+        g->obs_n = n + 1;
+        g->obs_first = n + 1;
         const std::string* obs = tag("OBS");
         if (obs && !obs->empty()) {
             std::string raw;
             const size_t frame = size_t(3) * 96 * 96;
             if (!hexGunzip(*obs, &raw) || raw.size() % frame) { setError("loader: the OBS tag does not hold whole 3x96x96 screens"); return false; }
-            int index = n + 1;
-            for (size_t end = raw.size(); end > 0 && index > 0; end -= frame) { g->obs[--index] = raw.substr(end - frame, frame); }
+            const size_t kept = std::min(raw.size() / frame, size_t(n) + 1);
+            if (kept > 0) {
+                uint8_t* d = nullptr;
+                if (hipSetDevice(device_) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d), kept * frame) != hipSuccess) { setError("loader: no device memory for the observations of a game (%zu bytes)", kept * frame); return false; }
+                g->d_obs = std::shared_ptr<uint8_t>(d, [](uint8_t* q) { (void)hipFree(q); });
+                if (hipMemcpy(d, raw.data() + raw.size() - kept * frame, kept * frame, hipMemcpyHostToDevice) != hipSuccess) { setError("loader: upload of the observations failed"); return false; }
+                g->obs_first = n + 1 - static_cast<int>(kept);
+            }
         }
     }
     return true;
@@ -478,8 +489,7 @@ int Loader::ensureDevice(int B)
     slots_ = std::max(slots, slots_);
     if (!d_feat_.alloc(size_t(dev_batch_) * feat_size_) || !d_rot_.alloc(dev_batch_) || !h_rot_.alloc(dev_batch_)) { setError("loader: allocation failed"); return MZ_ERR_DEVICE; }
     if (atari_) {
-        const size_t raw = size_t(proto_->rawFeatureBytes());
-        if (!d_raw_.alloc(size_t(dev_batch_) * raw) || !h_raw_.alloc(size_t(dev_batch_) * raw)) { setError("loader: allocation failed (observations)"); return MZ_ERR_DEVICE; }
+        if (!d_meta_.alloc(size_t(dev_batch_) * kAtariMetaBytes) || !h_meta_.alloc(size_t(dev_batch_) * kAtariMetaBytes)) { setError("loader: allocation failed (observation descriptors)"); return MZ_ERR_DEVICE; }
         return MZ_OK;
     }
     const int MD = slots_ + 1;
@@ -520,7 +530,6 @@ int Loader::sample(float* features, float* action_features, float* policy, float
     std::vector<float> h_policy(B * np), h_value(B * nv), h_reward(B * std::max<size_t>(nr, 1)), h_af(B * std::max<size_t>(na, 1)), h_ls(B);
     std::vector<int> h_si(2 * size_t(B));
     if (!game_dis_valid_) { game_dis_ = std::discrete_distribution<>(game_priorities_.begin(), game_priorities_.end()); game_dis_valid_ = true; }
-    const size_t raw_bytes = atari_ ? size_t(proto_->rawFeatureBytes()) : 0;
     for (int b = 0; b < B; ++b) {
         // ReplayBuffer::sampleEnvAndPos + the rotation draw (data_loader.cpp:52-63,148 / 166)
         const int env_id = sampleIndex(game_dis_);
@@ -538,24 +547,27 @@ int Loader::sample(float* features, float* action_features, float* policy, float
         h_si[2 * b + 1] = pos;
         // ---- features: staged for the device ----
         h_rot_.p[b] = static_cast<uint8_t>(atari_ ? 0 : rot);
-        if (atari_) { // atari.cpp:199-221
-            uint8_t* raw = h_raw_.p + size_t(b) * raw_bytes;
+        if (atari_) { // atari.cpp:199-221: per sample eight (screen pointer, action value, valid) triples
+            uint8_t* m = h_meta_.p + size_t(b) * kAtariMetaBytes;
             const size_t frame = size_t(3) * 96 * 96;
             float av[8];
+            uint64_t ptr[8];
             for (int k = 0; k < 8; ++k) {
                 const int i = pos - 7 + k;
                 const int action_id = (i - 1 < 0 ? 0 : (i - 1 >= g.size() ? randInt() % 18 : g.action[i - 1]));
                 av[k] = action_id * 1.0f / 18;
                 uint8_t valid = 0;
+                ptr[k] = 0;
                 if (i >= 0) {
-                    const std::string& o = (i < static_cast<int>(g.obs.size()) ? g.obs[i] : g.obs.back());
-                    if (o.empty()) { setError("sample_data: the record of game %d keeps no observation for step %d (replay of the Atari environment is not available)", env_id, i); return MZ_ERR_STATE; }
-                    memcpy(raw + size_t(k) * frame, o.data(), frame);
+                    const int idx = i < g.obs_n ? i : g.obs_n - 1;
+                    if (idx < g.obs_first || !g.d_obs) { setError("sample_data: the record of game %d keeps no observation for step %d (replay of the Atari environment is not available)", env_id, i); return MZ_ERR_STATE; }
+                    ptr[k] = reinterpret_cast<uint64_t>(g.d_obs.get() + size_t(idx - g.obs_first) * frame);
                     valid = 1;
                 }
-                raw[8 * frame + 32 + k] = valid;
+                m[96 + k] = valid;
             }
-            memcpy(raw + 8 * frame, av, sizeof(av));
+            memcpy(m, ptr, sizeof(ptr));
+            memcpy(m + 64, av, sizeof(av));
         } else {
             int* hi = h_int_.p;
             hi[size_t(dev_batch_) + b] = std::min(pos, g.size());                 // moves to replay
@@ -583,8 +595,8 @@ int Loader::sample(float* features, float* action_features, float* policy, float
     float* d_out = where == MZ_DEVICE ? features : d_feat_.p;
     MZ_HIP(hipMemcpyAsync(d_rot_.p, h_rot_.p, B, hipMemcpyHostToDevice, stream_));
     if (atari_) {
-        MZ_HIP(hipMemcpyAsync(d_raw_.p, h_raw_.p, size_t(B) * raw_bytes, hipMemcpyHostToDevice, stream_));
-        if ((rc = loaderExpandAtari(d_raw_.p, static_cast<int>(raw_bytes), B, d_out, stream_))) { return rc; }
+        MZ_HIP(hipMemcpyAsync(d_meta_.p, h_meta_.p, size_t(B) * kAtariMetaBytes, hipMemcpyHostToDevice, stream_));
+        if ((rc = loaderExpandAtari(d_meta_.p, B, d_out, stream_))) { return rc; }
     } else {
         MZ_HIP(hipMemcpyAsync(d_int_.p + size_t(dev_batch_), h_int_.p + size_t(dev_batch_), (size_t(dev_batch_) + size_t(dev_batch_) * MD) * sizeof(int), hipMemcpyHostToDevice, stream_));
         if ((rc = loaderReplayFeatures(godev_, pv_, B, d_int_.p + size_t(dev_batch_), d_rot_.p, d_out, stream_))) { return rc; }

@@ -179,19 +179,21 @@ __global__ __launch_bounds__(256) void expand_bits_kernel(const uint32_t* __rest
     }
 }
 
-// Atari-shaped samples (ref atari.cpp:199-221): raw[b] = 8 screens of 3 x 96 x 96 bytes (oldest first), then 8 f32 action-plane values, then
-// 8 valid flags; planes: for each step [action_id / 18 everywhere][R][G][B] / 255 (invalid screen: zeros)
-__global__ __launch_bounds__(256) void expand_atari_kernel(const uint8_t* __restrict__ raw, int raw_bytes, float* __restrict__ out)
+// Atari-shaped samples (ref atari.cpp:199-221): meta[b] = 8 pointers to screens of 3 x 96 x 96 bytes in device memory (oldest first), then 8 f32
+// action-plane values, then 8 valid flags; planes: for each step [action_id / 18 everywhere][R][G][B] / 255 (invalid screen: zeros)
+__global__ __launch_bounds__(256) void expand_atari_kernel(const uint8_t* __restrict__ meta, float* __restrict__ out)
 {
     constexpr int kRes2 = 96 * 96, kFrame = 3 * kRes2, kHist = 8;
     const int b = blockIdx.y, step = blockIdx.x;
-    const uint8_t* r = raw + size_t(b) * raw_bytes;
+    const uint8_t* m = meta + size_t(b) * kAtariMetaBytes;
+    uint64_t fp;
     float av;
-    memcpy(&av, r + size_t(kHist) * kFrame + step * 4, 4);
-    const bool valid = r[size_t(kHist) * kFrame + kHist * 4 + step] != 0;
+    memcpy(&fp, m + step * 8, 8);
+    memcpy(&av, m + 64 + step * 4, 4);
+    const bool valid = m[96 + step] != 0;
     float* o = out + (size_t(b) * kHist + step) * 4 * kRes2;
     for (int p = threadIdx.x; p < kRes2; p += 256) { o[p] = av; }
-    const uint8_t* f = r + size_t(step) * kFrame;
+    const uint8_t* f = reinterpret_cast<const uint8_t*>(fp);
     for (int i = threadIdx.x; i < kFrame; i += 256) { o[kRes2 + i] = valid ? static_cast<float>(f[i]) / 255.0f : 0.0f; }
 }
 
@@ -218,9 +220,9 @@ int loaderReplayFeatures(GoDevice& gd, const PoolView& pv, int B, const int* d_p
     return MZ_OK;
 }
 
-int loaderExpandAtari(const uint8_t* d_raw, int raw_bytes, int B, float* d_out, hipStream_t stream)
+int loaderExpandAtari(const uint8_t* d_meta, int B, float* d_out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(expand_atari_kernel, dim3(8, B), dim3(256), 0, stream, d_raw, raw_bytes, d_out);
+    hipLaunchKernelGGL(expand_atari_kernel, dim3(8, B), dim3(256), 0, stream, d_meta, d_out);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }

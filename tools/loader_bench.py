@@ -3,7 +3,7 @@
 games (BASELINE configs[1] shapes; the games are produced here by the self-play worker with a short search), on the product's DataLoader
 (records -> flat arrays once, features replayed on the GPU per batch) and on the oracle's restatement of the reference's DataLoader (every sample
 replays its game from the first move on the CPU, one thread — the reference runs `learner_num_thread` of those).
-usage: loader_bench.py [games=512] [batches=20] [go|othello]"""
+usage: loader_bench.py [games=512] [batches=20] [go|othello|atari]   (atari: the Atari-shaped env, batches of 256 samples of 32 x 96 x 96 planes)"""
 import os
 import sys
 import tempfile
@@ -18,15 +18,23 @@ import minizero_amd as mz  # noqa: E402
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 batches = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 game = sys.argv[3] if len(sys.argv) > 3 else "go"
-d = mz.DESCS["c2" if game == "go" else "c3"]()
-conf = (f"env_game=go:env_board_size=9:actor_num_simulation=8:zero_num_parallel_games={min(games, 256)}" if game == "go" else
-        f"env_game=othello:env_board_size=8:actor_num_simulation=8:zero_num_parallel_games={min(games, 256)}")
+batch = 1024
+if game == "atari":
+    batch = 256
+    d = mz.make_desc("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, type_name="muzero_atari")
+    conf = ("env_game=atari:nn_type_name=muzero:actor_num_simulation=8:actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:"
+            "actor_gumbel_sample_size=4:actor_mcts_value_rescale=true:actor_mcts_reward_discount=0.997:atari_init_q=true:zero_actor_intermediate_sequence_length=0:"
+            f"learner_n_step_return=5:learner_muzero_unrolling_step=5:env_atari_episode_length=120:actor_resign_threshold=-2:zero_num_parallel_games={min(games, 64)}")
+else:
+    d = mz.DESCS["c2" if game == "go" else "c3"]()
+    conf = (f"env_game=go:env_board_size=9:actor_num_simulation=8:zero_num_parallel_games={min(games, 256)}" if game == "go" else
+            f"env_game=othello:env_board_size=8:actor_num_simulation=8:zero_num_parallel_games={min(games, 256)}")
 wk = mz.Worker(conf + f":program_seed=1:nn_file_name=weight_iter_0.pt:zero_num_threads={max(1, mz.usable_cpus() - 1)}", d, mz.generate_weights(d, 0))
 wk.command("start")
 lines = []
 t0 = time.perf_counter()
 while len(lines) < games:
-    wk.run_cycles(9 * (170 if game == "go" else 62))
+    wk.run_cycles(9 * {"go": 170, "othello": 62, "atari": 121}[game])
     lines += wk.pop_lines()
 print(f"{len(lines)} games ({sum(l.count(';B[') + l.count(';W[') for l in lines)} positions) from the worker in {time.perf_counter() - t0:.1f} s", flush=True)
 del wk
@@ -34,7 +42,10 @@ lines = lines[:games]
 path = os.path.join(tempfile.mkdtemp(), "0.sgf")
 with open(path, "w") as f:
     f.write("\n".join(l.split(" ", 5)[5][:-2] for l in lines) + "\n")
-lconf = conf + ":nn_type_name=alphazero:learner_batch_size=1024:program_seed=13:zero_replay_buffer=20:zero_num_games_per_iteration=" + str(games)
+lconf = conf + ("" if game == "atari" else ":nn_type_name=alphazero") + f":learner_batch_size={batch}:program_seed=13:zero_replay_buffer=20:zero_num_games_per_iteration=" + str(games)
+
+
+SHAPES = None
 
 
 def run(make, name):
@@ -44,7 +55,10 @@ def run(make, name):
     t0 = time.perf_counter()
     dl.load_data_from_file(path)
     t_load = time.perf_counter() - t0
-    B, nf, na, npol, nv, nr = dl.shapes() if hasattr(dl, "shapes") else (1024, d.num_input_channels * d.input_channel_height * d.input_channel_width, 0, d.action_size, 1, 0)
+    global SHAPES
+    if hasattr(dl, "shapes"):
+        SHAPES = dl.shapes()
+    B, nf, na, npol, nv, nr = SHAPES
     bufs = [np.zeros((B, max(n, 1)), np.float32) for n in (nf, na, npol, nv, nr)] + [np.zeros(B, np.float32), np.zeros((B, 2), np.int32)]
     dl.sample_data(*bufs)  # warm-up
     t0 = time.perf_counter()
@@ -77,7 +91,8 @@ def run_device():
     dl = mz.DataLoader(lconf)
     dl.load_data_from_file(path)
     B, nf, na, npol, nv, nr = dl.shapes()
-    bufs = [DevArray(B * n * 4) for n in (nf,)] + [None] + [DevArray(B * n * 4) for n in (npol, nv)] + [None, DevArray(B * 4), DevArray(B * 8)]
+    bufs = [DevArray(B * nf * 4), DevArray(B * na * 4) if na else None, DevArray(B * npol * 4), DevArray(B * nv * 4), DevArray(B * nr * 4) if nr else None,
+            DevArray(B * 4), DevArray(B * 8)]
     dl.sample_data(*bufs)
     t0 = time.perf_counter()
     for _ in range(batches):
