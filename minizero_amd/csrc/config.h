@@ -63,6 +63,7 @@ struct WorkerConfig {
     int mz_cpu_base = -1;
     // not a reference key: wait for the GPU on a pinned completion word (spin) instead of hipStreamSynchronize
     bool mz_signal_wait = true;
+    bool mz_sim_split = true;   // a move's simulation-kernel launch in up to three parts, so that the host's noise / rotation draws overlap the parts already running
     bool mz_sim_cluster = true; // muzero_atari simulation kernel: four workgroups per game when 4 x games <= CUs (sim_cluster.h)
     bool mz_sim_kernel = true; // with mz_device_env: whole runs of cycles as one launch of the per-game simulation kernel (sim.hip)
     bool mz_raw_observations = true; // muzero_atari roots: ship the observation ring as bytes, expand the float planes on the device

@@ -243,15 +243,21 @@ struct Game {
 // optional host-side phase trace (MZ_TRACE=1): prints per-sub-step averages to stderr when the worker is destroyed
 struct PhaseTrace {
     bool on = getenv("MZ_TRACE") != nullptr;
-    double acc[20] = {0};
+    double acc[20] = {0}, lo[20] = {0}, hi[20] = {0};
     uint64_t cnt[20] = {0};
     const char* names[20] = {"p1.sync", "p1.cand", "p1.expand_launch", "p1.rootread", "p1.serial", "p1.noise_reset", "p1.select_launch", "p2.sync", "p2.leaf",
                              "p2.fwd_launch", "p1.observations", "p1.noise_up", "p1.reset", "p1.upload_roots", "root.flush", "sim.prep", "iter.root", "iter.presim", "iter.simwait", ""};
-    void add(int i, double ms) { acc[i] += ms; ++cnt[i]; }
+    void add(int i, double ms)
+    {
+        if (!cnt[i] || ms < lo[i]) { lo[i] = ms; }
+        if (!cnt[i] || ms > hi[i]) { hi[i] = ms; }
+        acc[i] += ms; ++cnt[i];
+        if (on && i < 18 && ms > 1.5) { fprintf(stderr, "[mz trace] slow %s #%llu: %.3f ms\n", names[i], (unsigned long long)cnt[i], ms); }
+    }
     ~PhaseTrace()
     {
         if (!on) { return; }
-        for (int i = 0; i < 20; ++i) { if (cnt[i]) { fprintf(stderr, "[mz trace] %-18s calls %8llu  avg %8.4f ms  total %10.2f ms\n", names[i], (unsigned long long)cnt[i], acc[i] / cnt[i], acc[i]); } }
+        for (int i = 0; i < 20; ++i) { if (cnt[i]) { fprintf(stderr, "[mz trace] %-18s calls %8llu  avg %8.4f ms  (min %8.4f, max %8.4f)  total %10.2f ms\n", names[i], (unsigned long long)cnt[i], acc[i] / cnt[i], lo[i], hi[i], acc[i]); } }
     }
 };
 
@@ -330,8 +336,24 @@ private:
         PinBuf<int> h_gum; DevBuf<int> d_gum; // Gumbel state of every game (gumbel.h): the device runs the halving between simulations
         PinBuf<float> h_noise;   // Dirichlet noise of the root children drawn ahead of the launch [game][A]
         DevBuf<float> d_noise;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr; // GPU time of the simulation-kernel launches (stats: ms_forward)
-        ~Lane() { if (ev0) { (void)hipEventDestroy(ev0); } if (ev1) { (void)hipEventDestroy(ev1); } }
+        // GPU time of the simulation-kernel launches (stats: ms_forward): one pair of events per part of a move's launch (runCyclesSim)
+        static constexpr int kSimParts = 3;
+        hipEvent_t ev0[kSimParts] = {}, ev1[kSimParts] = {};
+        hipStream_t up_stream = nullptr; // uploads of the draws for a later part while an earlier part runs on `stream`
+        hipEvent_t ev_up = nullptr;
+        int makeSimEvents()
+        {
+            for (int k = 0; k < kSimParts; ++k) { MZ_HIP(hipEventCreate(&ev0[k])); MZ_HIP(hipEventCreate(&ev1[k])); }
+            MZ_HIP(hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking));
+            MZ_HIP(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+            return MZ_OK;
+        }
+        ~Lane()
+        {
+            for (int k = 0; k < kSimParts; ++k) { if (ev0[k]) { (void)hipEventDestroy(ev0[k]); } if (ev1[k]) { (void)hipEventDestroy(ev1[k]); } }
+            if (ev_up) { (void)hipEventDestroy(ev_up); }
+            if (up_stream) { (void)hipStreamDestroy(up_stream); }
+        }
     };
     Lane& laneOf(int g) { return *lanes_[g / lane_size_ < int(lanes_.size()) ? g / lane_size_ : int(lanes_.size()) - 1]; }
     int phase1(Lane& L, bool root_expansion, bool done, bool launch_select = true);
@@ -516,8 +538,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             for (auto& L : lanes_) {
                 if (!L->h_rot.alloc(size_t(n_ + 1) * L->n) || !L->d_rot.alloc(size_t(n_ + 1) * L->n)) { setError("worker: allocation failed (rot table)"); return MZ_ERR_DEVICE; }
                 if (!L->h_noise.alloc(size_t(L->n) * A_) || !L->d_noise.alloc(size_t(L->n) * A_)) { setError("worker: allocation failed (noise)"); return MZ_ERR_DEVICE; }
-                MZ_HIP(hipEventCreate(&L->ev0));
-                MZ_HIP(hipEventCreate(&L->ev1));
+                { int rce = L->makeSimEvents(); if (rce) { return rce; } }
             }
         }
     }
@@ -537,8 +558,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
                 setError("worker: allocation failed (MuZero root staging)");
                 return MZ_ERR_DEVICE;
             }
-            MZ_HIP(hipEventCreate(&L->ev0));
-            MZ_HIP(hipEventCreate(&L->ev1));
+            { int rce = L->makeSimEvents(); if (rce) { return rce; } }
             int rc = uploadRoots(*L);
             if (rc) { return rc; }
         }
@@ -1372,6 +1392,10 @@ __attribute__((noinline, aligned(64))) void Worker::drawCycle(int batch, bool no
     const bool az = desc_.type == 0, rotate = cfg_.actor_use_random_rotation_features;
     for (auto& L : lanes_) {
         uint8_t* rot_row = L->h_rot.p + size_t(batch) * L->n;
+        if (!noise_cycle) { // a plain cycle only fills its row of the rotation table (Game::rot is drawn again by the next phase1 before anybody reads it)
+            if (az) { for (int j = 0; j < L->n; ++j) { rot_row[j] = rotate ? static_cast<uint8_t>(rng_.randInt() % 8) : 0; } }
+            continue;
+        }
         for (int j = 0; j < L->n; ++j) {
             Game& gm = games_[L->g0 + j];
             if (noise_cycle) {
@@ -1434,38 +1458,58 @@ int Worker::runCyclesSim(int n)
         }
         const double tprep = nowMs();
         trace_.add(17, tprep - t0);
-        int batch = 1;
         // Cycles after this one join the launch while they need nothing from the host but RNG draws.  The cycle behind the root
         // expansion (sim index 1) needs the Dirichlet noise of the root children: its values only depend on the RNG stream and on
         // the NUMBER of root children = legal moves of the root position, which the host engine knows, so they are drawn here in the
         // reference's order ([noise][rotation] per actor, zero_actor.cpp:194-213 then :56) and applied by the kernel before simulation 1.
         const bool device_noise = cfg_.actor_use_dirichlet_noise || cfg_.actor_use_gumbel_noise; // the kernel applies either kind
-        bool noise_in_batch = false;
-        while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg && !device_noise)) {
-            const bool noise_cycle = (sim0 + batch == 1) && noise_cfg;
-            drawCycle(batch, noise_cycle);
-            noise_in_batch |= noise_cycle;
-            ++batch;
+        int batch = 1;
+        while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg && !device_noise)) { ++batch; }
+        const bool noise_in_batch = noise_cfg && sim0 == 0 && batch > 1;
+        // The launch goes out in up to three parts (mz_sim_split): simulation 0 needs no draw of this loop (its rotation was drawn in phase1), so it
+        // runs while the host draws the root noise; a few simulations later the rest follows, whose rotation draws (AlphaZero: one per game and
+        // simulation, 102 400 per move on BASELINE configs[1]) are made while the second part runs.  Same draws in the same order: nothing a record
+        // could show.  The parts are queued back to back on the lane's stream; the draws of a later part travel on a second stream.
+        const bool az_draws = desc_.type == 0 && cfg_.actor_use_random_rotation_features;
+        int cuts[Lane::kSimParts + 1] = {0, batch, batch, batch}, parts = 1;
+        if (cfg_.mz_sim_split && sim0 == 0 && batch > 1 && (noise_in_batch || az_draws)) {
+            constexpr int kSecond = 8; // simulations of the middle part: long enough for the draws of the rest
+            cuts[parts++] = 1;
+            static const long min_draws = getenv("MZ_SIM_SPLIT_MIN_DRAWS") ? atol(getenv("MZ_SIM_SPLIT_MIN_DRAWS")) : 32768; // (tests: 0 = three parts on small pools too)
+            if (az_draws && batch > 1 + kSecond && long(batch - 1 - kSecond) * G_ >= min_draws) { cuts[parts++] = 1 + kSecond; }
+            cuts[parts] = batch;
         }
-        for (auto& L : lanes_) {
-            MZ_HIP(hipMemcpyAsync(L->d_rot.p, L->h_rot.p, size_t(batch) * L->n, hipMemcpyHostToDevice, L->stream));
-            if (noise_in_batch) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, L->stream)); }
-            bool launched = false;
-            MZ_HIP(hipEventRecord(L->ev0, L->stream));
-            GumbelView gv = gum_;
-            gv.state = L->d_gum.p;
-            const int noise_kind = cfg_.actor_use_dirichlet_noise ? 1 : 2;
-            int rc = sim_mz_ ? L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
-                                                  games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_reward.p, sim0, batch,
-                                                  &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
-                                                  dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, host_gumbel)
-                              : L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p, sim0, batch, &launched,
-                                                 noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
-                                                 dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, host_gumbel);
-            if (rc) { return rc; }
-            if (!launched) { const std::string why = mz_last_error(); setError("worker: the simulation kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
-            MZ_HIP(hipEventRecord(L->ev1, L->stream));
-            ++stats_.sim_launches;
+        int drawn = 1; // rows of the rotation table (= cycles of the batch) whose draws are made
+        for (int part = 0; part < parts; ++part) {
+            const int c0 = cuts[part], c1 = cuts[part + 1];
+            for (; drawn < c1; ++drawn) { drawCycle(drawn, drawn == 1 && noise_in_batch); }
+            for (auto& L : lanes_) {
+                // the first part's uploads go in front of its kernel on the lane's stream (nothing is running); later ones overlap the running part
+                hipStream_t us = part == 0 ? L->stream : L->up_stream;
+                if (desc_.type == 0 || part == 0) { MZ_HIP(hipMemcpyAsync(L->d_rot.p + size_t(c0) * L->n, L->h_rot.p + size_t(c0) * L->n, size_t(c1 - c0) * L->n, hipMemcpyHostToDevice, us)); }
+                if (noise_in_batch && c0 <= 1 && 1 < c1) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, us)); }
+                if (part > 0) {
+                    MZ_HIP(hipEventRecord(L->ev_up, us));
+                    MZ_HIP(hipStreamWaitEvent(L->stream, L->ev_up, 0));
+                }
+                bool launched = false;
+                MZ_HIP(hipEventRecord(L->ev0[part], L->stream));
+                GumbelView gv = gum_;
+                gv.state = L->d_gum.p;
+                const int noise_kind = cfg_.actor_use_dirichlet_noise ? 1 : 2;
+                const bool hg = host_gumbel && part == 0;
+                int rc = sim_mz_ ? L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
+                                                      games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_reward.p, sim0 + c0, c1 - c0,
+                                                      &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
+                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg)
+                                  : L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p + size_t(c0) * L->n, sim0 + c0, c1 - c0,
+                                                     &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
+                                                     dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg);
+                if (rc) { return rc; }
+                if (!launched) { const std::string why = mz_last_error(); setError("worker: the simulation kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
+                MZ_HIP(hipEventRecord(L->ev1[part], L->stream));
+                ++stats_.sim_launches;
+            }
         }
         stats_.sim_cycles += batch;
         trace_.add(15, nowMs() - tprep);
@@ -1481,7 +1525,11 @@ int Worker::runCyclesSim(int n)
         for (auto& L : lanes_) {
             MZ_HIP(hipStreamSynchronize(L->stream));
             float ms = 0.0f;
-            MZ_HIP(hipEventElapsedTime(&ms, L->ev0, L->ev1));
+            for (int part = 0; part < parts; ++part) {
+                float msp = 0.0f;
+                MZ_HIP(hipEventElapsedTime(&msp, L->ev0[part], L->ev1[part]));
+                ms += msp;
+            }
             ms_gpu = std::max(ms_gpu, ms);
         }
         stats_.ms_forward += ms_gpu;
@@ -1660,7 +1708,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
         MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
-        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
 #undef MZ_FIXED
         if (fixed) { setError("update_config: %s is fixed when the worker is created (restart the worker to change it)", fixed); return MZ_ERR_ARG; }
         cfg_ = nc;

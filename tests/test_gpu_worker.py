@@ -204,6 +204,26 @@ def test_go_execution_modes_are_equivalent(mz, noise):
     assert host == sim_chunks
 
 
+@pytest.mark.parametrize("variant", ["dirichlet", "no_noise", "gumbel", "muzero"])
+def test_split_launches_are_equivalent(mz, monkeypatch, variant):
+    """mz_sim_split (default): a move's launch goes out in up to three parts so that the host's noise and rotation draws overlap the parts already
+    running; the records must be those of the single launch (mz_sim_split=false).  MZ_SIM_SPLIT_MIN_DRAWS=0 makes the small pool take all three parts."""
+    monkeypatch.setenv("MZ_SIM_SPLIT_MIN_DRAWS", "0")
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "muzero" if variant == "muzero" else "alphazero")
+    n = 20
+    conf = {"dirichlet": "env_game=go:env_board_size=9:zero_num_parallel_games=5",
+            "no_noise": "env_game=go:env_board_size=9:zero_num_parallel_games=5:actor_use_dirichlet_noise=false",
+            "gumbel": GO_GUMBEL,
+            "muzero": "env_game=go:env_board_size=9:nn_type_name=muzero:zero_num_parallel_games=5"}[variant] + f":actor_num_simulation={n}"
+    total = (n + 1) * 200
+    one = _lines_of(mz, conf + ":mz_sim_split=false", args, [total], total)
+    split = _lines_of(mz, conf, args, [total], total)
+    split_chunks = _lines_of(mz, conf, args, [n + 1, 2 * (n + 1), 5, 40, n], total)
+    assert len(one) >= 2
+    assert one == split
+    assert one == split_chunks
+
+
 def test_go_muzero_execution_modes_are_equivalent(mz):
     """MuZero: lock-step kernels with host candidate lists vs the per-game simulation kernel (initial + recurrent inference, hidden-state
     slab, candidate sort and expand + backup in one launch per run of cycles)."""

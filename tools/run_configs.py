@@ -13,7 +13,7 @@ import minizero_amd as mz  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3
 MOVES = {"c1": 400, "c2": 4, "c3": 40, "c4": 20, "c5": 40}
-WARM = {"c5": 14}  # moves before the timed region (default 2): the Atari-shaped worker's first moves pay one-off host allocations
+WARM = {"c5": 14}  # moves before the timed region (default 3: the first synchronisation of the third move takes 8 ms once): the Atari-shaped worker's first moves pay one-off host allocations
 KERNEL = {"c1": "sim_kernel<3,3,4,16,-1>", "c2": "sim_kernel<9,9,20,64,2>", "c3": "sim_kernel<8,8,4,64,0>", "c4": "sim_kernel_mz<9,9,20,68,64>",
           "c5": "sim_kernel_mz_cluster<6,6,84,64> (4 workgroups per game; MZ_SIM_CLUSTER=0: sim_kernel_mz<6,6,64,84,64>)"}
 
@@ -41,11 +41,14 @@ def main():
     argv = sys.argv[1:]
     out_path = os.path.join("gpurun_out", "configs.json")
     moves_override = None
+    extra_conf = ""
     keys = []
     i = 0
     while i < len(argv):
         if argv[i] == "--moves":
             moves_override = int(argv[i + 1]); i += 2
+        elif argv[i] == "--conf":  # extra configuration keys for every worker, e.g. mz_sim_split=false
+            extra_conf = ":" + argv[i + 1]; i += 2
         elif argv[i] == "--out":
             out_path = argv[i + 1]; i += 2
         else:
@@ -54,13 +57,13 @@ def main():
     threads = max(1, mz.usable_cpus() - 1)
     for key in keys or ["c1", "c2", "c3", "c4", "c5"]:
         d = mz.DESCS[key]()
-        conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_cpu_base=0"
+        conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_cpu_base=0{extra_conf}"
         n = int(mz.CONFIGS[key].split("actor_num_simulation=")[1].split(":")[0])
         games = int(mz.CONFIGS[key].split("zero_num_parallel_games=")[1].split(":")[0])
         wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
         wk.command("start")
         moves = moves_override or MOVES[key]
-        wk.run_cycles(WARM.get(key, 2) * (n + 1))
+        wk.run_cycles(WARM.get(key, 3) * (n + 1))
         s0 = wk.stats()
         t0 = time.perf_counter()
         for _ in range(moves):
