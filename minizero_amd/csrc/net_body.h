@@ -36,8 +36,11 @@ struct TowerArgs {
 //    top-right CORNER pixel: only 4 of its 9 taps are inside the board, the other 5 read zero padding for every channel, and
 //    a k-step whose B operand is all zero leaves the accumulator as it is (the chain starts at +0 and fma(a, 0, acc) = acc), so the
 //    last tile issues 4 / 9 of its MFMAs (9x9: 784 instead of 864 MFMAs per SIMD and layer).
-//    (Computing that pixel on the vector ALUs instead — 5 full tiles, 150 us per launch without it — was tried: the 256 dependent
-//    fmas + 256 LDS reads per layer cost more issue slots beside the MFMAs than the tile saves: 181 us.)
+//    (Computing that pixel on the vector ALUs instead — 5 full tiles, 150 us per launch without it — was tried twice: the 256 dependent
+//    fmas + 256 LDS reads per layer cost more issue slots beside the MFMAs than the tile saves: 181 us; round 2, with the A fragments the
+//    wave already holds spread over the rows by v_permlane16_swap / v_permlane32_swap (no extra weight traffic, bit-identical outputs):
+//    ~14 vector instructions per k-group instead of one MFMA, tower 148 -> 178 us per simulation.  A vector instruction beside the MFMAs
+//    costs 8-11 cycles of MFMA issue on this SIMD, so the corner would have to fit in 3 instructions per k-group; the chain alone has 4.)
 template <int H, int W>
 struct TileMap {
     static constexpr int P = H * W, PW = W + 2;
