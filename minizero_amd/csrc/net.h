@@ -90,7 +90,7 @@ public:
     // runs as stand-alone kernels), value / reward come out of the kernel in game scale (d_reward: [games])
     int simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                     int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
-                    const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start);
+                    const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given = false);
     bool hasSimKernelMz(int num_simulation = 0) const;
     int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat);
     int shiftExpandAtariFeatures(const uint8_t* d_prev, const uint8_t* d_newest, const uint8_t* d_meta, uint8_t* d_cur, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)

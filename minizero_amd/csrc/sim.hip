@@ -491,7 +491,8 @@ __device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, in
     if (lane == 0) { *kshare = k; }
 }
 
-__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k)
+// given: the network outputs of this leaf come from the stand-alone kernels (the muzero_atari root: value / reward still in the transformed scale)
+__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -514,8 +515,9 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
         const int rt = a->root_turn[g];
         a->cand_count[g] = k;
         a->cand_player[g] = (a->num_players == 2 && (depth & 1)) ? 3 - rt : rt; // the children are moved by the player to move at the leaf
-        a->value_io[g] = a->value[g];
-        a->reward_io[g] = a->atari ? a->reward[g] : 0.0f; // board games have no reward head (ref muzero_network.h:129)
+        const bool inv = given && a->atari; // the host path's invertValueHost() of both (worker.cpp buildCandidates)
+        a->value_io[g] = inv ? invertValueDev(a->value[g]) : a->value[g];
+        a->reward_io[g] = a->atari ? (inv ? invertValueDev(a->reward[g]) : a->reward[g]) : 0.0f; // board games have no reward head (ref muzero_network.h:129)
     }
     waveSync();
     expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles);
@@ -622,11 +624,15 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (prof) { t0 = wall_clock64(); }
-        if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds, spec); }
+        // host_start bit 1: the root's network outputs are given (policy / logit / value / reward arrays, hidden state in slab slot 0: the muzero_atari
+        // root, whose 96x96 representation runs as stand-alone kernels) — simulation 0 is only its candidate list + expand + backup
+        const bool given = slot == 0 && (host_start & 2) != 0;
+        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec); }
         __syncthreads();
         if (prof) { t1 = wall_clock64(); }
-        float* xt;
-        if (slot == 0) { // initial inference: representation trunk on the root planes (board games; muzero_atari roots never come here)
+        float* xt = nullptr;
+        if (given) {
+        } else if (slot == 0) { // initial inference: representation trunk on the root planes (board games; muzero_atari roots never come here)
             xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
         } else { // recurrent inference: dynamics trunk on (parent hidden state, move)
             const int len = v.path_len[g];
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         }
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
-        simMzHeads<H, W>(a, slot, g, tid, tiles, head_scratch, xt);
+        if (!given) { simMzHeads<H, W>(a, slot, g, tid, tiles, head_scratch, xt); }
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
         __shared__ int s_cand_k;
@@ -648,9 +654,9 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         const int cand_k = s_cand_k;
         if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
         __syncthreads();
-        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k); }
+        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k, given); }
         __syncthreads();
-        if (prof && tid == 0) {
+        if (prof && tid == 0 && !given) {
             const unsigned long long t4 = wall_clock64();
             prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
         }
@@ -885,12 +891,13 @@ bool Net::hasSimKernelMz(int num_simulation) const
 
 int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                      int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
-                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start)
+                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given)
 {
     *launched = false;
     const bool atari = desc_.type == 2;
     if (desc_.type != 1 && !atari) { return MZ_OK; }
-    if (atari && sim0 < 1) { setError("simLaunchMz: the muzero_atari root is evaluated by the stand-alone kernels"); return MZ_ERR_ARG; }
+    if (root_given && (sim0 != 0 || nsims != 1)) { setError("simLaunchMz: a given root is simulation 0 alone"); return MZ_ERR_ARG; }
+    if (atari && sim0 < 1 && !root_given) { setError("simLaunchMz: the muzero_atari root is evaluated by the stand-alone kernels"); return MZ_ERR_ARG; }
     SimArgs a;
     memset(&a, 0, sizeof(a));
     int c0 = 0, cd = 0;
@@ -967,7 +974,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
         a.cluster_oct = octet ? a.cluster + size_t(pool.v_.games) * words : nullptr;
         a.oct_words = static_cast<int>(ow);
         if (getenv("MZ_SIM_PROF") && sim_args_host_.empty()) { fprintf(stderr, "[mz sim] cluster mode: %d games, octet heads %s\n", pool.v_.games, octet ? "on" : "off"); }
-        MZ_HIP(hipMemsetAsync(sim_cluster_mem_.p, 0, total_words * sizeof(unsigned), stream_));
+        if (!root_given) { MZ_HIP(hipMemsetAsync(sim_cluster_mem_.p, 0, total_words * sizeof(unsigned), stream_)); }
     }
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
         if (!sim_args_.ensure(sizeof(SimArgs))) { setError("hipMalloc of the simulation arguments failed"); return MZ_ERR_DEVICE; }
@@ -975,7 +982,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
         MZ_HIP(hipMemcpy(sim_args_.p, &a, sizeof(SimArgs), hipMemcpyHostToDevice));
         sim_args_host_.assign(reinterpret_cast<const char*>(&a), reinterpret_cast<const char*>(&a) + sizeof(SimArgs));
     }
-    if (cluster) {
+    if (cluster && !root_given) { // (a given root is one workgroup per game: the same argument block, no exchange)
 #define MZ_SIM_MZ_CL_LAUNCH(h, w, cin0, cdyn, cpad) \
         if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { \
             const int rcl = launchSimMzClusterT<h, w, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, host_start ? 1 : 0, lds_cluster, stream_); \
@@ -986,7 +993,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
 #undef MZ_SIM_MZ_CL_LAUNCH
     }
 #define MZ_SIM_MZ_LAUNCH(h, w, cin0, cdyn, cpad) \
-    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, host_start ? 1 : 0, lds, stream_); }
+    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, (host_start ? 1 : 0) | (root_given ? 2 : 0), lds, stream_); }
     MZ_SIM_MZ_CASES(MZ_SIM_MZ_LAUNCH)
 #undef MZ_SIM_MZ_LAUNCH
     return MZ_OK;

@@ -1440,21 +1440,43 @@ int Worker::runCyclesSim(int n)
         }
         if (done && cfg_.mz_manual_step) { search_done_ = true; pending_ = false; sims_done_ = 0; stats_.ms_total += nowMs() - t0; return i; }
         if (pending_) { sims_done_ = done ? 0 : sim_post_; }
-        const int sim0 = sims_done_;
+        int sim0 = sims_done_;
+        bool root_on_device = false;
         if (root_cycle) {
             for (auto& L : lanes_) {
                 int rc = phase2(*L);
                 if (rc) { return rc; }
             }
             { const double tf = nowMs(); flushDeferred(); trace_.add(14, nowMs() - tf); }
-            root_host_pending_ = true;
             pending_ = true;
             stats_.cycles += 1;
             stats_.leaf_evals += uint64_t(G_);
             i += 1;
-            stats_.ms_total += nowMs() - t0;
+            // mz_sim_split: when simulations follow in this call, the root is expanded on the device from the stand-alone kernels' outputs (simulation 0 of
+            // the one-workgroup kernel with a given root) and the launch of simulations 1..n follows on the stream without a host round trip; the Gumbel /
+            // Dirichlet noise of the root children is drawn meanwhile (its values only depend on the RNG stream and the number of legal actions).
+            root_on_device = cfg_.mz_sim_split && i < n && n_ >= 1;
+            if (!root_on_device) {
+                root_host_pending_ = true; // the next phase1 expands the root on the host
+                stats_.ms_total += nowMs() - t0;
+                trace_.add(16, nowMs() - t0);
+                continue;
+            }
+            for (auto& L : lanes_) {
+                GumbelView gv = gum_;
+                gv.state = L->d_gum.p;
+                bool launched = false;
+                int rc = L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p, games_[0].env->numPlayers(), L->d_policy.p,
+                                            L->d_logit.p, L->d_value.p, L->d_reward.p, 0, 1, &launched, noise_cfg ? L->d_noise.p : nullptr,
+                                            cfg_.actor_dirichlet_noise_epsilon, cfg_.actor_use_dirichlet_noise ? 1 : 2, dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p,
+                                            host_gumbel, true);
+                if (rc) { return rc; }
+                if (!launched) { const std::string why = mz_last_error(); setError("worker: the root expansion kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
+            }
+            root_host_pending_ = false;
+            sims_done_ = 0;
+            sim0 = 1;
             trace_.add(16, nowMs() - t0);
-            continue;
         }
         const double tprep = nowMs();
         trace_.add(17, tprep - t0);
@@ -1465,7 +1487,9 @@ int Worker::runCyclesSim(int n)
         const bool device_noise = cfg_.actor_use_dirichlet_noise || cfg_.actor_use_gumbel_noise; // the kernel applies either kind
         int batch = 1;
         while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg && !device_noise)) { ++batch; }
-        const bool noise_in_batch = noise_cfg && sim0 == 0 && batch > 1;
+        // (root_on_device: the launch starts AT simulation 1, its noise is drawn right here)
+        const bool noise_in_batch = noise_cfg && ((sim0 == 0 && batch > 1) || root_on_device);
+        if (root_on_device && noise_cfg) { drawCycle(0, true); }
         // The launch goes out in up to three parts (mz_sim_split): simulation 0 needs no draw of this loop (its rotation was drawn in phase1), so it
         // runs while the host draws the root noise; a few simulations later the rest follows, whose rotation draws (AlphaZero: one per game and
         // simulation, 102 400 per move on BASELINE configs[1]) are made while the second part runs.  Same draws in the same order: nothing a record
@@ -1482,12 +1506,12 @@ int Worker::runCyclesSim(int n)
         int drawn = 1; // rows of the rotation table (= cycles of the batch) whose draws are made
         for (int part = 0; part < parts; ++part) {
             const int c0 = cuts[part], c1 = cuts[part + 1];
-            for (; drawn < c1; ++drawn) { drawCycle(drawn, drawn == 1 && noise_in_batch); }
+            for (; drawn < c1; ++drawn) { drawCycle(drawn, drawn == 1 && noise_in_batch && !root_on_device); }
             for (auto& L : lanes_) {
                 // the first part's uploads go in front of its kernel on the lane's stream (nothing is running); later ones overlap the running part
                 hipStream_t us = part == 0 ? L->stream : L->up_stream;
                 if (desc_.type == 0 || part == 0) { MZ_HIP(hipMemcpyAsync(L->d_rot.p + size_t(c0) * L->n, L->h_rot.p + size_t(c0) * L->n, size_t(c1 - c0) * L->n, hipMemcpyHostToDevice, us)); }
-                if (noise_in_batch && c0 <= 1 && 1 < c1) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, us)); }
+                if (noise_in_batch && (root_on_device ? part == 0 : (c0 <= 1 && 1 < c1))) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, us)); }
                 if (part > 0) {
                     MZ_HIP(hipEventRecord(L->ev_up, us));
                     MZ_HIP(hipStreamWaitEvent(L->stream, L->ev_up, 0));
@@ -1497,7 +1521,7 @@ int Worker::runCyclesSim(int n)
                 GumbelView gv = gum_;
                 gv.state = L->d_gum.p;
                 const int noise_kind = cfg_.actor_use_dirichlet_noise ? 1 : 2;
-                const bool hg = host_gumbel && part == 0;
+                const bool hg = host_gumbel && part == 0 && !root_on_device;
                 int rc = sim_mz_ ? L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
                                                       games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_reward.p, sim0 + c0, c1 - c0,
                                                       &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,

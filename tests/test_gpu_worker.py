@@ -322,10 +322,14 @@ def test_atari_execution_modes_are_equivalent(mz):
     # the default is the cluster mode (sim_cluster.h: four workgroups per game, tower split by output-channel tile, one 601-bin head per
     # workgroup); mz_sim_cluster=false = one workgroup per game
     sim_single = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true:mz_sim_cluster=false", ATARI_ARGS, [3, 40, 9], total)
+    # mz_sim_split (default): the root is expanded on the device from the stand-alone kernels' outputs and simulations 1..n follow without a host
+    # round trip (device-side Gumbel noise and first halving step); false = the root's candidate list, noise and first Gumbel step on the host
+    sim_host_root = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true:mz_sim_split=false", ATARI_ARGS, [total], total)
     assert len(lockstep) >= 10
     assert lockstep == sim_whole
     assert lockstep == sim_chunks
     assert lockstep == sim_single
+    assert lockstep == sim_host_root
 
 
 @pytest.mark.parametrize("games", [13, 64])
