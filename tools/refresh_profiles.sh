@@ -55,7 +55,7 @@ def summarize(tag, a_dir, b_dir, c_dir, cycles, note):
                     "lds_conflict_frac": s["SQ_LDS_BANK_CONFLICT"] / max(1.0, s["SQ_LDS_IDX_ACTIVE"])})
     json.dump(out, open(f"{O}/{tag}.json", "w"), indent=1)
 summarize("pmc_sim", "pmc1a", "pmc1b", "pmc2", 5 * 401, "over all launches of `python bench.py --steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline` (5 moves x 401 cycles x 256 games)")
-MOVES = {"c3": (40 + 2) * 17, "c4": (20 + 2) * 51, "c5": (40 + 14) * 51}
+MOVES = {"c3": (40 + 3) * 17, "c4": (20 + 3) * 51, "c5": (40 + 14) * 51}
 for k, cyc in MOVES.items():
     summarize(f"pmc_{k}", f"pmcA_{k}", f"pmcB_{k}", f"pmcC_{k}", cyc, f"over all simulation-kernel launches of `python tools/run_configs.py {k}` ({cyc} lock-step cycles incl. warm-up)")
 PY
