@@ -14,3 +14,12 @@ def test_division_shortcuts_are_exact():
                        check=True, timeout=120)
         out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and out.stdout.startswith("OK "), out.stdout + out.stderr
+
+
+def test_powf_with_exponent_one_is_the_identity():
+    """worker.cpp selectChildBySoftmaxCount skips std::pow for the default temperature 1."""
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "pow_one_check")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "csrc", "pow_one_check.cpp")], check=True, timeout=120)
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.startswith("OK "), out.stdout + out.stderr
