@@ -87,7 +87,9 @@ public:
     bool hasSimKernel(int board_n, int env_kind = 0, int num_simulation = 0) const; // env_kind: GoDevView::kind
     // MuZero (board games): the same for initial + recurrent inference; hidden states live in the caller's slab [games][slots][C * P]
     // nsims simulations (slots sim0 ..) of every game in one launch of sim_kernel_mz; muzero_atari: sim0 >= 1 (the root's 96x96 representation
-    // runs as stand-alone kernels), value / reward come out of the kernel in game scale (d_reward: [games])
+    // runs as stand-alone kernels), value / reward come out of the kernel in game scale (d_reward: [games]).  root_given (sim0 == 0, nsims == 1): the
+    // root's network outputs already lie in d_policy / d_logit / d_value / d_reward (transformed scale) and its hidden state in slab slot 0 — written by
+    // initial() — and simulation 0 is only the root's candidate list + expand + backup, one workgroup per game
     int simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                     int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given = false);

@@ -1433,7 +1433,8 @@ int Worker::runCyclesSim(int n)
         const bool root_expansion = pending_ && (sim_post_ == 1), done = pending_ && (sim_post_ == n_ + 1);
         const bool host_gumbel = dev_gumbel_ && pending_; // the host runs this cycle's Gumbel step itself: state down, step, state up
         // muzero_atari: the root's 96x96 representation is not part of the kernel; simulation 0 of a move runs as one lock-step cycle
-        // (select, host planes, stand-alone kernels) whose outputs the next phase1 expands on the host, the other n as one launch
+        // (select, host planes, stand-alone kernels); its outputs are expanded on the device when simulations follow in this call (below), otherwise by
+        // the next phase1 on the host; the other n simulations are one launch
         const bool root_cycle = sim_root_host_ && (!pending_ || done);
         for (auto& L : lanes_) {
             int rc = MZ_OK;
