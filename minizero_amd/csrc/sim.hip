@@ -492,35 +492,44 @@ __device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, in
 }
 
 // given: the network outputs of this leaf come from the stand-alone kernels (the muzero_atari root: value / reward still in the transformed scale)
-__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false)
+// part 0: everything; part 1: the candidate list and the new children (needs the policy only); part 2: value / reward + backup (the cluster kernel runs
+// part 1 while the value and reward heads of the game's other workgroups are still busy)
+__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false, int part = 0)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
     slot = __builtin_amdgcn_readfirstlane(slot);
     k = __builtin_amdgcn_readfirstlane(k);
+    part = __builtin_amdgcn_readfirstlane(part);
     const PoolView v = ldc(&a->pv);
     const int A = a->A, len = v.path_len[g], depth = len - 1;
-    Cand* cs = reinterpret_cast<Cand*>(tiles);
-    Cand* out = cs + A;
-    if (k > 0 && k <= kCandCoopMax && a->cand_coop) {
-        float* dense = simCandDense(tiles, A);
-        candScatter(cs, out, reinterpret_cast<int*>(out + A), k, 8, lane, reinterpret_cast<const int*>(dense + kCandCoopMax), a->err);
-    }
-    for (int i = lane; i < k; i += 64) {
-        a->cand_action[size_t(g) * A + i] = out[i].action;
-        a->cand_policy[size_t(g) * A + i] = out[i].policy;
-        a->cand_logit[size_t(g) * A + i] = out[i].logit;
+    if (part != 2) {
+        Cand* cs = reinterpret_cast<Cand*>(tiles);
+        Cand* out = cs + A;
+        if (k > 0 && k <= kCandCoopMax && a->cand_coop) {
+            float* dense = simCandDense(tiles, A);
+            candScatter(cs, out, reinterpret_cast<int*>(out + A), k, 8, lane, reinterpret_cast<const int*>(dense + kCandCoopMax), a->err);
+        }
+        for (int i = lane; i < k; i += 64) {
+            a->cand_action[size_t(g) * A + i] = out[i].action;
+            a->cand_policy[size_t(g) * A + i] = out[i].policy;
+            a->cand_logit[size_t(g) * A + i] = out[i].logit;
+        }
     }
     if (lane == 0) {
-        const int rt = a->root_turn[g];
-        a->cand_count[g] = k;
-        a->cand_player[g] = (a->num_players == 2 && (depth & 1)) ? 3 - rt : rt; // the children are moved by the player to move at the leaf
-        const bool inv = given && a->atari; // the host path's invertValueHost() of both (worker.cpp buildCandidates)
-        a->value_io[g] = inv ? invertValueDev(a->value[g]) : a->value[g];
-        a->reward_io[g] = a->atari ? (inv ? invertValueDev(a->reward[g]) : a->reward[g]) : 0.0f; // board games have no reward head (ref muzero_network.h:129)
+        if (part != 2) {
+            const int rt = a->root_turn[g];
+            a->cand_count[g] = k;
+            a->cand_player[g] = (a->num_players == 2 && (depth & 1)) ? 3 - rt : rt; // the children are moved by the player to move at the leaf
+        }
+        if (part != 1) {
+            const bool inv = given && a->atari; // the host path's invertValueHost() of both (worker.cpp buildCandidates)
+            a->value_io[g] = inv ? invertValueDev(a->value[g]) : a->value[g];
+            a->reward_io[g] = a->atari ? (inv ? invertValueDev(a->reward[g]) : a->reward[g]) : 0.0f; // board games have no reward head (ref muzero_network.h:129)
+        }
     }
     waveSync();
-    expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles);
+    expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, part);
 }
 
 __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec)

@@ -521,7 +521,19 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
             if (s_abort) { return; }
         }
         if (member != 0) { __syncthreads(); continue; }
-        if (tid == 0) { // value and reward from the helpers
+        // The candidate list and the new children only need the policy, which this workgroup has just computed: they are built while the value and reward
+        // heads of the game's other workgroups are still at work (their 601-bin heads take three times as long as the policy head); the backup follows
+        // when their results have arrived.
+        MZ_HPROF(10);
+        if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
+        __syncthreads();
+        MZ_HPROF(11);
+        const int cand_k = s_cand_k;
+        if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
+        __syncthreads();
+        MZ_HPROF(12);
+        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k, false, 1); }
+        if (tid == 64) { // value and reward from the helpers (wave 1 polls while wave 0 writes the children)
             bool ok = false;
             clu4 r;
             for (int i = 0; i < kClPollLimit && !ok; ++i) {
@@ -535,16 +547,8 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         }
         __syncthreads();
         if (s_abort) { return; }
-        MZ_HPROF(10);
-        if (prof) { t3 = wall_clock64(); }
-        if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
-        __syncthreads();
-        MZ_HPROF(11);
-        const int cand_k = s_cand_k;
-        if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
-        __syncthreads();
-        MZ_HPROF(12);
-        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k); }
+        if (prof) { t3 = wall_clock64(); } // (MZ_SIM_PROF: "heads" ends when the helpers' results are in; the candidate list was built meanwhile)
+        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k, false, 2); }
         __syncthreads();
         MZ_HPROF(13);
         if (prof && tid == 0) {
