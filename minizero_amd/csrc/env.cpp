@@ -689,6 +689,8 @@ public:
         for (auto& v : valid_) { v = false; }
         for (auto& a : action_plane_) { a = 0.0f; }
         head_ = 0;
+        pending_.clear();
+        pushed_ = 0;
         lives_.clear();
         lives_.push_back(livesAt(0)); // ref atari.cpp:61-62
         lost_ = 0;
@@ -720,6 +722,7 @@ public:
     float reward() const override { return reward_; }
     void features(int, float* out) const override
     {
+        materialize();
         for (int i = 0; i < kHist; ++i) { // oldest first; slot = (head_ + i) % kHist
             const int slot = (head_ + i) % kHist;
             float* dst = out + size_t(i) * 4 * kRes * kRes;
@@ -738,6 +741,7 @@ public:
     int rawFeatureBytes() const override { return kHist * kFrame + kHist * 4 + kHist; }
     void rawFeatures(uint8_t* dst) const override
     {
+        materialize();
         float av[kHist];
         for (int i = 0; i < kHist; ++i) {
             const int slot = (head_ + i) % kHist;
@@ -748,10 +752,11 @@ public:
         memcpy(dst + size_t(kHist) * kFrame, av, sizeof(av));
     }
     uint64_t rawSerial() const override { return serial_; }
-    int rawValidCount() const override { int k = 0; for (bool v : valid_) { k += v; } return k; }
+    int rawValidCount() const override { return pushed_ < kHist ? pushed_ : kHist; } // (no screen is drawn for this)
     int rawFrameBytes() const override { return kFrame; }
     void rawNewest(uint8_t* frame, uint8_t* meta) const override
     {
+        materialize();
         memcpy(frame, frames_.data() + size_t((head_ + kHist - 1) % kHist) * kFrame, kFrame);
         float av[kHist];
         for (int i = 0; i < kHist; ++i) {
@@ -768,12 +773,29 @@ public:
     std::string name() const override { return "atari_" + name_; }
     std::vector<std::pair<std::string, std::string>> loaderTags() const override { return {{"SD", std::to_string(seed_)}}; }
     bool hasObservations() const override { return true; }
-    void appendObservations(std::string* out) const override { for (const auto& o : observations_) { out->append(o); } }
+    void appendObservations(std::string* out) const override { materialize(); for (const auto& o : observations_) { out->append(o); } }
     const std::vector<int>* livesHistory() const override { return &lives_; }
 
 private:
     int livesAt(int) const { return 3; }
+    // A step only notes which screen is due: the 27-KB screen and its observation string are drawn when somebody looks at them (the
+    // worker's leaf / record builders, which run one game per thread), not inside the RNG-ordered serial section of a move, where the 64
+    // games of a pool would draw theirs one after the other with the GPU waiting (0.3 ms of a 7-ms move on BASELINE configs[4]).
+    struct PendingFrame { int step; float action_value; bool with_action; };
     void pushFrame(int step, float action_value, bool with_action)
+    {
+        pending_.push_back(PendingFrame{step, action_value, with_action});
+        ++pushed_;
+        ++serial_;
+    }
+    void materialize() const
+    {
+        if (pending_.empty()) { return; }
+        AtariSynth* self = const_cast<AtariSynth*>(this); // the ring and the observation list are caches of (seed, steps)
+        for (const PendingFrame& p : pending_) { self->drawFrame(p.step, p.action_value, p.with_action); }
+        self->pending_.clear();
+    }
+    void drawFrame(int step, float action_value, bool with_action)
     {
         // ring of the last 8 (action, screen) pairs: overwrite the oldest slot, which then becomes the newest
         const int slot = head_;
@@ -799,9 +821,10 @@ private:
         valid_[slot] = true;
         action_plane_[slot] = with_action ? action_value : 0.0f;
         head_ = (head_ + 1) % kHist;
-        ++serial_;
     }
     uint64_t serial_ = 0;
+    mutable std::vector<PendingFrame> pending_;
+    int pushed_ = 0;
     std::string name_;
     int episode_length_, seed_ = 0, head_ = 0, lost_ = 0;
     size_t recent_;
