@@ -27,7 +27,10 @@ struct GumbelByCount { // fewest visits first, then the larger logit (gumbel_zer
 inline size_t gumbelSmemBytes(int A) { return size_t(A) * (3 * sizeof(float) + sizeof(int)) + (kGumbelMaxSample + 3 * 40) * sizeof(int) + 64; }
 
 // sim_post = simulations of this search completed so far (>= 1).  Returns the node the next selection starts from.
-__device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelView& gv, int sim_post, int g, int lane, float* smem)
+// bump >= 0: the step is computed AHEAD of the backup of the simulation in flight — that backup will add one visit to root child `bump` (the child on the
+// current path) and to nothing else this step reads, unless the candidates have all reached their budget (the halving ranks them by their means, which
+// the backup changes): then nothing is written and -1 comes back, and the step runs again after the backup (sim_cluster.h).
+__device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelView& gv, int sim_post, int g, int lane, float* smem, int bump = -1)
 {
     const size_t base = size_t(g) * v.cap;
     const NodeRec root = v.rec[base];
@@ -44,7 +47,7 @@ __device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelVie
     float mx = 0.0f;
     for (int i = lane; i < nc; i += 64) {
         const NodeRec c = v.rec[base + fc + i];
-        cnt[i] = c.count;
+        cnt[i] = i == bump ? c.count + 1.0f : c.count;
         lg[i] = v.logit[base + fc + i];
         mx = c.count > mx ? c.count : mx;
         // score of gumbelSortByScore: logit + (c_visit + max count) * c_scale * normalized mean; the max count is added below
@@ -58,6 +61,7 @@ __device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelVie
     int start = 0;
     if (lane == 0) {
         int ncand = st[0], sample = st[1], budget = st[2];
+        bool defer = false;
         if (sim_post != 1) { for (int i = 0; i < ncand; ++i) { cand[i] = st[3 + i]; } }
         if (sim_post == 1) { // the root has just been expanded: sample the top-m children by (noisy) logit
             StdSortEmul<int, GumbelByLogit> s{idx, GumbelByLogit{lg}};
@@ -69,7 +73,8 @@ __device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelVie
         } else {
             bool all = true;
             for (int i = 0; i < ncand; ++i) { if (!(cnt[cand[i]] >= static_cast<float>(budget))) { all = false; break; } }
-            if (all) {
+            if (all && bump >= 0) { defer = true; }
+            if (all && bump < 0) {
                 // int / (double * int / int): three IEEE double operations, no contraction (the reference's promotions)
                 const double nb = __builtin_floor(static_cast<double>(gv.num_simulation) / (gv.log2_m * static_cast<double>(sample) / 2.0));
                 const int next_budget = nb >= 2147483647.0 ? 2147483647 : static_cast<int>(nb);
@@ -87,11 +92,15 @@ __device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelVie
                 }
             }
         }
-        StdSortEmul<int, GumbelByCount> s2{cand, GumbelByCount{cnt, lg}};
-        s2.sort(ncand, stack);
-        st[0] = ncand; st[1] = sample; st[2] = budget;
-        for (int i = 0; i < ncand; ++i) { st[3 + i] = cand[i]; }
-        start = fc + cand[0];
+        if (defer) {
+            start = -1;
+        } else {
+            StdSortEmul<int, GumbelByCount> s2{cand, GumbelByCount{cnt, lg}};
+            s2.sort(ncand, stack);
+            st[0] = ncand; st[1] = sample; st[2] = budget;
+            for (int i = 0; i < ncand; ++i) { st[3 + i] = cand[i]; }
+            start = fc + cand[0];
+        }
     }
     return __builtin_amdgcn_readfirstlane(start);
 }

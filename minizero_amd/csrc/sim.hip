@@ -532,13 +532,31 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
     expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, part);
 }
 
-__device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec)
+// The Gumbel step of simulation `next_slot`, ahead of the backup of the simulation in flight (gumbel_body.h `bump`): true if a->start[g] and the state are
+// those the step after the backup would write.  The cluster kernel runs it on its owner while the other workgroups' value / reward heads are still busy.
+__device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_slot, int g, int lane, float* tiles)
+{
+    g = __builtin_amdgcn_readfirstlane(g);
+    next_slot = __builtin_amdgcn_readfirstlane(next_slot);
+    const PoolView pv = ldc(&a->pv);
+    const GumbelView gum = ldc(&a->gum);
+    const int len = pv.path_len[g];
+    if (len < 2) { return false; }
+    const int child = pv.path[size_t(g) * pv.max_depth + 1] - pv.rec[size_t(g) * pv.cap].first_child;
+    const int st = gumbelStepBody(pv, gum, next_slot, g, lane, tiles, child);
+    if (st >= 0 && lane == 0) { a->start[g] = st; }
+    waveSync();
+    return st >= 0;
+}
+
+__device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
+                                         bool gumbel_done = false)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     slot = __builtin_amdgcn_readfirstlane(slot);
     g = __builtin_amdgcn_readfirstlane(g);
     if (slot == 1 && a->root_noise) { simApplyRootNoise<2>(a, g, lane); }
-    if (a->use_gumbel) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
+    if (a->use_gumbel && !gumbel_done) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
     const PoolView pv = ldc(&a->pv);
     selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
 }

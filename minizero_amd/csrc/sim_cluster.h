@@ -470,13 +470,14 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         __syncthreads();
     }
     unsigned long long* prof = (a->prof && member == 0) ? a->prof + size_t(g) * 8 : nullptr;
+    bool gumbel_ahead = false; // (wave 0 of the owner) the Gumbel step of this simulation was computed during the previous one
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s;
         const unsigned seq = unsigned(s) + 1u;
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (prof) { t0 = wall_clock64(); }
         if (member == 0) {
-            if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds, spec); }
+            if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds, spec, gumbel_ahead); }
             __syncthreads();
             MZ_HPROF(14);
             {
@@ -532,7 +533,11 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
         __syncthreads();
         MZ_HPROF(12);
-        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k, false, 1); }
+        if (wave == 0) {
+            simMzCandExpand(a, slot, g, lane, tiles, cand_k, false, 1);
+            // ... and so is the next simulation's Gumbel step (which candidate it starts from): the backup to come only adds a visit to the child on this path
+            gumbel_ahead = a->use_gumbel && s + 1 < nsims && simGumbelAhead(a, slot + 1, g, lane, tiles);
+        }
         if (tid == 64) { // value and reward from the helpers (wave 1 polls while wave 0 writes the children)
             bool ok = false;
             clu4 r;
