@@ -473,19 +473,25 @@ def test_cluster_member_going_missing_ends_in_an_error_not_a_hang(mz, monkeypatc
     assert time.time() - t0 < 60
 
 
-@pytest.mark.parametrize("variant", ["puct_dirichlet", "no_rescale"])
+@pytest.mark.parametrize("variant", ["puct_dirichlet", "no_rescale", "gumbel_m3_n21", "gumbel_m16_n40"])
 def test_atari_cluster_other_search_settings(mz, variant):
-    """The cluster kernel under search settings BASELINE configs[4] does not use: PUCT roots with Dirichlet noise instead of Gumbel, and no value
-    rescaling (the backup then runs on a second wave beside expand) — against the lock-step kernels and against one workgroup per game."""
+    """The cluster kernel under search settings BASELINE configs[4] does not use: PUCT roots with Dirichlet noise instead of Gumbel, no value
+    rescaling (the backup then runs on a second wave beside expand), and other Gumbel shapes (sample sizes 3 and 16, more simulations: the
+    Gumbel step the owner computes ahead of the backup must fall back to the real step whenever a halving is due) — against the lock-step kernels
+    and against one workgroup per game."""
     conf = ATARI_SMALL
-    if variant == "puct_dirichlet":
+    n = 8
+    if variant.startswith("gumbel_"):
+        m, n = int(variant.split("_")[1][1:]), int(variant.split("_")[2][1:])
+        conf = conf.replace("actor_gumbel_sample_size=4", f"actor_gumbel_sample_size={m}").replace("actor_num_simulation=8", f"actor_num_simulation={n}")
+    elif variant == "puct_dirichlet":
         conf = conf.replace("actor_use_dirichlet_noise=false", "actor_use_dirichlet_noise=true").replace("actor_use_gumbel=true", "actor_use_gumbel=false").replace(
             "actor_use_gumbel_noise=true", "actor_use_gumbel_noise=false")
     else:
         conf = conf.replace("actor_mcts_value_rescale=true", "actor_mcts_value_rescale=false")
-    total = 9 * 50
+    total = (n + 1) * 50
     lockstep = _lines_of(mz, conf + ":mz_sim_kernel=false", ATARI_ARGS, [total], total)
-    cluster = _lines_of(mz, conf, ATARI_ARGS, [4, 9, 100, 7], total)
+    cluster = _lines_of(mz, conf, ATARI_ARGS, [4, n + 1, 100, 7], total)
     single = _lines_of(mz, conf + ":mz_sim_cluster=false", ATARI_ARGS, [total], total)
     assert len(lockstep) >= 8
     assert lockstep == cluster
