@@ -151,7 +151,7 @@ def main():
         evals = args.games * cpm * args.steps * world
         value = evals / dt
         # dominant kernel: sim_kernel (sim.hip) — every game's whole simulations (select, Go leaf, residual tower on the f32 MFMA pipe,
-        # heads, candidates, expand + backup); a move's 401 simulations go out as three launches queued back to back (1 + 8 + 392 simulations:
+        # heads, candidates, expand + backup); a move's 401 simulations go out as three launches queued back to back (1 + 16 + 384 simulations:
         # the host's noise and rotation draws for the later parts overlap the earlier ones, worker.cpp runCyclesSim).  Its GPU time
         # inside the timed region comes from HIP events recorded on the worker's own stream around every launch (worker stats:
         # ms_forward); the algorithmic work per leaf evaluation is 73.3 MFLOP of 3x3 convolutions.
@@ -211,7 +211,7 @@ def main():
                          "frac": issued / peak, "f32_equivalent_tflops": achieved, "traffic": None if bf else traffic, "traffic_source": None if bf else traffic_src,
                          "launches": launches, "avg_launch_ms": gpu_ms / launches, "flops_per_avg_launch": flops_total / launches,
                          "flops_per_leaf_eval": flops_per_eval, "gpu_ms_per_step": gpu_ms / args.steps,
-                         "timing": "HIP events on the worker's stream around every sim_kernel launch of the timed region (a move = three launches of 1 + 8 + 392 cycles queued back to back, so that the host's noise / rotation draws overlap them)",
+                         "timing": "HIP events on the worker's stream around every sim_kernel launch of the timed region (a move = three launches of 1 + 16 + 384 cycles queued back to back, so that the host's noise / rotation draws overlap them)",
                          # per cycle, without the weights (1.9 MB: they stay in the XCDs' L2s): a children block written + one read per game
                          "compulsory_bytes_per_avg_launch": args.games * 2.0 * 2600 * cpm * args.steps / launches,
                          "tower_alone": {"kernel": "tower_fused<9,9,20,64> (the same tower as a stand-alone launch of 256 samples)",

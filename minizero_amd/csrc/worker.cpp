@@ -1502,7 +1502,7 @@ int Worker::runCyclesSim(int n)
         const bool az_draws = desc_.type == 0 && cfg_.actor_use_random_rotation_features;
         int cuts[Lane::kSimParts + 1] = {0, batch, batch, batch}, parts = 1;
         if (cfg_.mz_sim_split && sim0 == 0 && batch > 1 && (noise_in_batch || az_draws)) {
-            constexpr int kSecond = 8; // simulations of the middle part: long enough for the draws of the rest
+            constexpr int kSecond = 16; // simulations of the middle part: 3 ms on BASELINE configs[1], three times what the draws of the rest take on this host
             cuts[parts++] = 1;
             static const long min_draws = getenv("MZ_SIM_SPLIT_MIN_DRAWS") ? atol(getenv("MZ_SIM_SPLIT_MIN_DRAWS")) : 32768; // (tests: 0 = three parts on small pools too)
             if (az_draws && batch > 1 + kSecond && long(batch - 1 - kSecond) * G_ >= min_draws) { cuts[parts++] = 1 + kSecond; }
