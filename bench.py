@@ -50,6 +50,9 @@ def cpu_baseline(conf, seconds):
     dt = time.time() - t0
     evals = cycles * 256
     out = {"value": evals / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
+           # the REAL reference (its own actor + LibTorch-CPU forward) was timed once, in the build container, on this workload: BASELINE.md "C2" row.
+           # It cannot travel to the GPU box; the port's k-ordered fmaf forward is slower than LibTorch's, so read the GPU / port ratio with that in mind.
+           "reference_in_build_container": {"value": 3300.0, "unit": "leaf-evals/s", "cores": 8, "source": "BASELINE.md (8 vCPU, 35 s sample of the same workload)"},
            "sample": f"{cycles} lock-step cycles x 256 games of the same workload ({dt:.1f} s): tree+env phase on "
                      f"{host_threads} threads, network forward (f32, same arithmetic as the GPU path) on {cores} threads",
            "moves_per_sec": evals / dt / (N_SIM + 1), "games_per_sec_at_163_moves": evals / dt / (N_SIM + 1) / 163.0}
@@ -83,6 +86,7 @@ def main():
     ap.add_argument("--pin", type=int, default=1, help="pin the host threads of rank r to CPUs [r*threads, (r+1)*threads)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-moves", type=int, default=30, help="timed moves of the short C3 / C4 / C5 legs after the headline (0 = skip; N=1 only)")
     ap.add_argument("--extra-conf", default="", help="extra k=v:k=v keys (profiling variants only)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="arithmetic of the residual tower: f32 (default, the headline: bit-exact against the oracle) or the opt-in bf16x3 "
@@ -218,6 +222,18 @@ def main():
                                          "us_per_launch": ms_tower * 1e3, "achieved": fl_tower / (ms_tower * 1e-3) / 1e12,
                                          "frac": fl_tower / (ms_tower * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}},
         }
+        if world == 1 and args.other_moves > 0 and not bf:
+            # BASELINE configs[2..4] on the same box, same worker code as tools/run_configs.py: a fresh worker per config, a few warm-up moves,
+            # then `--other-moves` timed moves (one run_cycles call per move); leaf-evals/s by wall clock, roofline by HIP events around the launches
+            worker.close()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import run_configs
+            out["other_configs"] = {}
+            for key in ("c3", "c4", "c5"):
+                r = run_configs.run_config(key, moves=args.other_moves)
+                out["other_configs"][key] = {"workload": r["config"], "leaf_evals_per_sec": r["leaf_evals_per_sec"], "ms_per_move": r["ms_per_move"],
+                                             "games_in_pool": r["games_in_pool"], "moves_timed": r["moves_timed"], "host_threads": r["host_threads"],
+                                             "roofline": {k: r["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "flops_per_leaf_eval", "wall_frac")}}
         if world == 1 and not args.no_cpu_baseline:
             del worker
             out["cpu_baseline"] = cpu_baseline(base_conf + ":program_seed=1:nn_file_name=synthetic_go_6bx64_seed0.pt", args.cpu_seconds)

@@ -14,8 +14,10 @@
 #include "network.h"
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <deque>
 #include <mutex>
+#include <sstream>
 #include <string>
 #include <thread>
 
@@ -59,11 +61,23 @@ protected:
         if (visible < 1) { std::cerr << "ActorGroup: no GPU visible (libmzgpu has no CPU path)" << std::endl; exit(0); }
         auto number = [&](const char* key, int def) { const std::string v = config::mzgpuConfValue(conf_, key); return v.empty() ? def : std::stoi(v); };
         const int total_games = number("zero_num_parallel_games", 32), seed = number("program_seed", 0), threads = number("zero_num_threads", 4);
-        const int G = gpu_id_ >= 0 ? 1 : std::max(1, std::min(visible, total_games));
+        // MZ_DEVICE_MAP=0,0 (test hook): logical device g -> physical ordinal map[g], so that the multi-device logic below (game split i % G,
+        // seed + g, one host thread per device, the shared stdout mutex) runs with G > 1 on a one-GPU box: tests/test_gpu_protocol.py
+        std::vector<int> map;
+        if (const char* m = getenv("MZ_DEVICE_MAP")) {
+            std::istringstream iss(m);
+            for (std::string tok; std::getline(iss, tok, ',');) {
+                const int o = tok.empty() ? -1 : atoi(tok.c_str());
+                if (o < 0 || o >= visible) { std::cerr << "ActorGroup: MZ_DEVICE_MAP names device " << tok << ", " << visible << " visible" << std::endl; exit(0); }
+                map.push_back(o);
+            }
+        }
+        const int ndev = map.empty() ? visible : static_cast<int>(map.size());
+        const int G = gpu_id_ >= 0 ? 1 : std::max(1, std::min(ndev, total_games));
         devices_.resize(G);
         for (int g = 0; g < G; ++g) {
             Device& d = devices_[g];
-            d.gpu = gpu_id_ >= 0 ? gpu_id_ : g;
+            d.gpu = gpu_id_ >= 0 ? gpu_id_ : (map.empty() ? g : map[g]);
             d.games = (total_games - g + G - 1) / G; // |{i < total : i % G == g}| (ref actor_group.cpp:185)
             const std::string conf = conf_ + ":zero_num_parallel_games=" + std::to_string(d.games) + ":program_seed=" + std::to_string(seed + g) +
                                      ":zero_num_threads=" + std::to_string(std::max(1, threads / G));
@@ -133,9 +147,15 @@ protected:
 
     void flushGames(Device& d)
     {
-        static thread_local std::vector<char> buf(1 << 22);
-        int n;
-        while ((n = mz_worker_pop_line(d.worker, buf.data(), static_cast<int>(buf.size()))) > 0) {
+        static thread_local std::vector<char> buf(1 << 20);
+        while (true) {
+            // size first: an Atari record carries its observations as hex (OBS tag) and can be tens of megabytes with
+            // zero_actor_intermediate_sequence_length=0; a line that does not fit must never block the lines behind it
+            const int need = mz_worker_pop_line(d.worker, nullptr, 0);
+            if (need == 0) { break; }
+            if (need > 0 && static_cast<size_t>(need) >= buf.size()) { buf.resize(static_cast<size_t>(need) + 1); }
+            const int n = need < 0 ? need : mz_worker_pop_line(d.worker, buf.data(), static_cast<int>(buf.size()));
+            if (n < 0) { std::cerr << mz_last_error() << std::endl; exit(0); }
             std::lock_guard<std::mutex> lock(out_mutex_); // ref actor_group.cpp:42-49
             std::cout << buf.data() << std::endl;
         }

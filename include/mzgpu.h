@@ -96,6 +96,8 @@ int mz_net_recurrent(mz_net* net, const float* hidden_in, const float* action_pl
  * library returns the decoded scalars; with MZ_DEVICE buffers it leaves the softmax expectation in the transformed space
  * h(x) = sign(x)(sqrt(|x|+1)-1) + 0.001x and the caller applies mz_invert_value (ref utils/utils.h:102-108). */
 float mz_invert_value(float v);
+/* its forward direction h(x), the scale of the learner's 601-bin value / reward targets (ref utils/utils.h:93-100, atari.h:115-116) */
+float mz_transform_value(float v);
 /* measurement hook for bench.py: runs `iters` forwards of batch B on resident synthetic inputs and
  * returns HIP-event times on the network's own stream: total ms per forward, and ms spent in the
  * 3x3-convolution kernels per forward (the dominant kernel; roofline numerator in DESIGN.md). */
@@ -164,6 +166,11 @@ typedef struct mz_worker mz_worker;
 /* desc == NULL and weights == NULL: the network is read from the configuration's nn_file_name (mz_net_read_weight_file), as
  * ActorGroup::createNeuralNetworks does (ref actor_group.cpp:168-177). */
 mz_worker* mz_worker_create(int device, const char* conf, const mz_net_desc* desc, const float* weights, size_t count);
+/* BaseActor::setNetwork(std::shared_ptr<Network>) (ref actor/zero_actor.cpp:100-112, actor_group.cpp:183-187): the worker runs on the CALLER's
+ * network instead of loading a second copy — `net` must live on `device` and outlive the worker; a later mz_net_reload on it is what the
+ * worker's next search sees; the worker's own `load_model <path>` then only renames (EV tag).  One host thread drives the worker and the
+ * network (they share the network's stream). */
+mz_worker* mz_worker_create_shared(int device, const char* conf, mz_net* net);
 void mz_worker_destroy(mz_worker* w);
 /* one stdin line: start | stop | load_model <path> | update_config k=v:.. | reset_actors | quit | other (ignored)
  * (ref actor_group.cpp:200-252).  load_model <path> reads the file itself (mz_net_read_weight_file) and checks that its hyper-parameters
@@ -178,7 +185,9 @@ int mz_worker_set_weights(mz_worker* w, const float* weights, size_t count);
  * run as ONE kernel launch: call with mz_worker_cycles_per_move() (= actor_num_simulation + 1) and poll commands between calls. */
 int mz_worker_run_cycles(mz_worker* w, int n);
 int mz_worker_cycles_per_move(const mz_worker* w);
-/* next pending stdout line ("SelfPlay ... #", ref actor_group.cpp:24-50); returns its length, 0 if none */
+/* next pending stdout line ("SelfPlay ... #", ref actor_group.cpp:24-50); returns its length, 0 if none.  buf == NULL: the length of the
+ * next line without popping it (Atari records carry their observations as hex and can be tens of megabytes); a buffer that is too small
+ * gives MZ_ERR_CAPACITY and leaves the line queued.  mz_worker_peek_record / mz_worker_record answer buf == NULL the same way. */
 int mz_worker_pop_line(mz_worker* w, char* buf, int cap);
 /* test / monitoring access: the record of game `game` as it stands, unfinished games included (BaseActor::getRecord with no extra
  * tags, ref actor/base_actor.cpp:39-57); returns its length.  Does not disturb the search. */
@@ -203,6 +212,23 @@ int mz_worker_reset_search(mz_worker* w);
 int mz_worker_reset_game(mz_worker* w, int game);
 int mz_worker_emit_game(mz_worker* w, int game);
 int mz_worker_env_query(const mz_worker* w, int game, int what, float* out);
+/*   mz_worker_act_string             BaseActor::act(const std::vector<std::string>&) (ref base_actor.cpp:32-40): args = {player char, action string}
+ *                                    ("B" "E5" / "w" "pass" for board games — ref utils/sgf_loader.cpp:89-99 —, an ALE action name such as "UPFIRE" for the
+ *                                    Atari-shaped game, ref atari.cpp:9-39); 1 = played, 0 = not an action / illegal
+ *   mz_worker_action_info_history    BaseActor::getActionInfoHistory() (ref base_actor.h:33-34): moves joined by 0x1e, inside a move key 0x1f value 0x1f ...;
+ *                                    returns the length (buf == NULL: length only)
+ *   mz_worker_env_features           Environment::getFeatures(rotation) of the game's position (ref base_env.h:88); returns the float count (out == NULL: count only)
+ *   mz_worker_env_legal_mask         isLegalAction(a) for every action id, for the player to move (ref base_env.h:83-84); out[action_size]
+ *   mz_worker_env_set_turn           Environment::setTurn (ref base_env.h:103)
+ *   mz_worker_env_reset_seed         Environment::reset(seed) (ref atari.h:55) — games without a seed just reset
+ *   mz_worker_env_rotate_action      Environment::getRotateAction(action_id, rotation) (ref base_env.h:99) */
+int mz_worker_act_string(mz_worker* w, int game, const char* const* args, int nargs);
+int mz_worker_action_info_history(mz_worker* w, int game, char* buf, int cap);
+int mz_worker_env_features(const mz_worker* w, int game, int rotation, float* out, int capacity);
+int mz_worker_env_legal_mask(const mz_worker* w, int game, uint8_t* out, int capacity);
+int mz_worker_env_set_turn(mz_worker* w, int game, int player);
+int mz_worker_env_reset_seed(mz_worker* w, int game, int seed);
+int mz_worker_env_rotate_action(const mz_worker* w, int game, int action_id, int rotation);
 typedef struct mz_worker_stats {
     uint64_t cycles, leaf_evals, moves, games;
     double ms_select, ms_env, ms_forward, ms_expand, ms_move, ms_total;
@@ -260,6 +286,9 @@ int mz_env_policy_size(const mz_env* e);
 int mz_env_feature_size(const mz_env* e);
 int mz_env_legal_mask(const mz_env* e, uint8_t* out);
 int mz_env_features(const mz_env* e, int rotation, float* out);
+/* the action id of an action string as BaseEnv::act(const std::vector<std::string>&) reads its second argument (ref utils/sgf_loader.cpp:89-99
+ * boardCoordinateStringToActionID for the board games — the value is NOT range-checked there either —, ref atari.cpp:9-39 for the Atari-shaped game: -1 = unknown) */
+int mz_env_action_from_string(const mz_env* e, const char* action_string);
 /* the same planes bit-packed (the device format): channel c = ceil(P/32) words, bit p%32 of word p/32 */
 int mz_env_feature_bits(const mz_env* e, int rotation, uint32_t* out);
 

@@ -9,6 +9,8 @@
 #include "env.h"
 #include "go_dev.h"
 #include "common.h"
+#include <cctype>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -79,6 +81,19 @@ static inline float scoreOf(int winner) { return winner == 1 ? 1.0f : (winner ==
 // ---------------------------------------------------------------------------------------------
 // TicTacToe (ref tictactoe.cpp:11-146)
 // ---------------------------------------------------------------------------------------------
+// ref utils/sgf_loader.cpp:89-99 boardCoordinateStringToActionID (the conversion behind BaseBoardAction(action_string_args), base_env.h:326-333)
+int GameEnv::actionFromString(const std::string& str) const
+{
+    const int n = boardSize();
+    std::string up = str;
+    for (char& c : up) { c = static_cast<char>(std::toupper(static_cast<unsigned char>(c))); }
+    if (up == "PASS") { return n * n; }
+    if (str.size() < 2) { return -1; }
+    const int x = up[0] - 'A' + (up[0] > 'I' ? -1 : 0);
+    const int y = atoi(str.substr(1).c_str()) - 1;
+    return y * n + x;
+}
+
 class TicTacToe final : public GameEnv {
 public:
     TicTacToe() { rot_ = rotationTables(3, 9); reset(); }
@@ -771,6 +786,15 @@ public:
     int policySize() const override { return kActions; }
     int numPlayers() const override { return 1; }
     std::string name() const override { return "atari_" + name_; }
+    int actionFromString(const std::string& str) const override // ref atari.cpp:9-39: ALE's action names without their PLAYER_A_ prefix, upper-cased
+    {
+        static const char* const kNames[18] = {"NOOP", "FIRE", "UP", "RIGHT", "LEFT", "DOWN", "UPRIGHT", "UPLEFT", "DOWNRIGHT", "DOWNLEFT", "UPFIRE", "RIGHTFIRE", "LEFTFIRE",
+                                               "DOWNFIRE", "UPRIGHTFIRE", "UPLEFTFIRE", "DOWNRIGHTFIRE", "DOWNLEFTFIRE"};
+        std::string up = str;
+        for (char& c : up) { c = static_cast<char>(std::toupper(static_cast<unsigned char>(c))); }
+        for (int a = 0; a < 18; ++a) { if (up == kNames[a]) { return a; } }
+        return -1;
+    }
     std::vector<std::pair<std::string, std::string>> loaderTags() const override { return {{"SD", std::to_string(seed_)}}; }
     bool hasObservations() const override { return true; }
     void appendObservations(std::string* out) const override { materialize(); for (const auto& o : observations_) { out->append(o); } }

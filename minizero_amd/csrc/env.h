@@ -69,6 +69,10 @@ public:
     virtual const uint64_t* zobristKeys() const { return nullptr; } // [2][points]
     virtual uint64_t turnKey() const { return 0; }                  // Go, situational superko: XORed into the hash on every move
     int turn() const { return turn_; }
+    void setTurn(int player) { turn_ = player; } // BaseEnv::setTurn (ref base_env.h:103): the console's `genmove <colour>`
+    // the action id of the second argument of BaseEnv::act(const std::vector<std::string>&) = {player char, action string}: board coordinates
+    // ("E5", "pass"; the letter I is skipped: ref utils/sgf_loader.cpp:89-99) or an Atari action name (ref atari.cpp:9-39); -1 = not an action
+    virtual int actionFromString(const std::string& s) const;
     int featureSize() const { return numInputChannels() * boardSize() * boardSize(); }
     const std::vector<int16_t>& actionIds() const { return action_ids_; }
     const std::vector<uint8_t>& actionPlayers() const { return action_players_; }

@@ -90,10 +90,13 @@ bool hexGunzip(const std::string& hex, std::string* out)
 
 float transformValue(float value) // utils.h:93-100
 {
+    // With <cmath> alone (utils.h:3-12) the unqualified sqrt / fabs of the reference's expression are the C library's DOUBLE functions (libstdc++ puts the
+    // float overloads in namespace std only: tests/csrc/overload_check.cpp), so `sign * (sqrt(fabs(v) + 1) - 1) + epsilon * v` is a double expression with
+    // one float product (epsilon * v), rounded once by the assignment.  The promotions are spelled out so that no other header can change them.
     const float epsilon = 0.001;
     const float sign_value = (value > 0.0f ? 1.0f : (value == 0.0f ? 0.0f : -1.0f));
-    value = sign_value * (sqrt(fabs(value) + 1) - 1) + epsilon * value;
-    return value;
+    const double r = static_cast<double>(sign_value) * (::sqrt(::fabs(static_cast<double>(value)) + 1) - 1) + static_cast<double>(epsilon * value);
+    return static_cast<float>(r);
 }
 
 void toDiscreteValue(float value, float* out) // atari.cpp:279-292, out[601]
@@ -157,6 +160,7 @@ private:
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     bool atari_ = false, muzero_ = false;
+    bool device_failure_ = false; // parse(): the record failed for lack of device memory, not for its content
     int A_ = 0, P_ = 0, feat_size_ = 0, act_feat_size_ = 0, value_size_ = 1, max_len_ = 0;
     std::unique_ptr<GameEnv> proto_; // a fresh environment of the configured game: rotation tables, root snapshot, shapes
     // ReplayBuffer (data_loader.cpp:15-82)
@@ -285,6 +289,14 @@ bool Loader::parse(const std::string& content, LGame* g)
     const int n = g->size();
     if (!atari_ && board_size != proto_->boardSize()) { setError("loader: record of a %dx%d board, the loader is configured for %dx%d", board_size, board_size, proto_->boardSize(), proto_->boardSize()); return false; }
     for (int i = 0; i < n; ++i) { if (g->action[i] < 0 || g->action[i] >= A_) { setError("loader: action %d out of range in a record", g->action[i]); return false; } }
+    // The device replay (loader_kernels.hip) takes the mover from the move's parity: the reference replays act(action) with the RECORDED player
+    // (base_env.h:235-241), so a record whose colours do not alternate from the first player (handicap stones, hand-edited files) would give other
+    // planes there.  Self-play records always alternate; anything else is refused by name instead of being replayed differently.
+    if (!atari_) {
+        for (int i = 0; i < n; ++i) {
+            if (g->player[i] != 1 + (i & 1)) { setError("loader: move %d of a record is played by %s, the device replay needs alternating colours from B", i, g->player[i] == 1 ? "B" : g->player[i] == 2 ? "W" : "nobody"); return false; }
+        }
+    }
     // getReturn() = stof(RE) (base_env.h:300); only read for board games, but every record carries it
     if (const std::string* re = tag("RE")) { if (!parseFloat(*re, &g->ret)) { g->ret = 0.0f; } }
     if (const std::string* sd = tag("SD")) { (void)parseInt(*sd, &g->seed); }
@@ -330,9 +342,9 @@ bool Loader::parse(const std::string& content, LGame* g)
             const size_t kept = std::min(raw.size() / frame, size_t(n) + 1);
             if (kept > 0) {
                 uint8_t* d = nullptr;
-                if (hipSetDevice(device_) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d), kept * frame) != hipSuccess) { setError("loader: no device memory for the observations of a game (%zu bytes)", kept * frame); return false; }
+                if (hipSetDevice(device_) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d), kept * frame) != hipSuccess) { device_failure_ = true; setError("loader: no device memory for the observations of a game (%zu bytes)", kept * frame); return false; }
                 g->d_obs = std::shared_ptr<uint8_t>(d, [](uint8_t* q) { (void)hipFree(q); });
-                if (hipMemcpy(d, raw.data() + raw.size() - kept * frame, kept * frame, hipMemcpyHostToDevice) != hipSuccess) { setError("loader: upload of the observations failed"); return false; }
+                if (hipMemcpy(d, raw.data() + raw.size() - kept * frame, kept * frame, hipMemcpyHostToDevice) != hipSuccess) { device_failure_ = true; setError("loader: upload of the observations failed"); return false; }
                 g->obs_first = n + 1 - static_cast<int>(kept);
             }
         }
@@ -418,8 +430,10 @@ void Loader::actionFeaturesOf(const LGame& g, int pos, int rot, float* out)
     } else if (pos < size) { // go.cpp:725-737, othello.cpp:264-276
         if (g.action[pos] != P_) { out[rotateAction(g.action[pos], rot)] = 1.0f; }
     } else {
+        // the reference's index can be P_ (one past its private P_-wide vector, go.cpp:733-734) when the game has more than P_ moves: the draw
+        // is kept, the stray write is not — every value the reference hands on is unchanged
         const int a = randInt() % (P_ + 1);
-        if (a < size) { out[a] = 1.0f; }
+        if (a < size && a < P_) { out[a] = 1.0f; }
     }
 }
 
@@ -436,7 +450,8 @@ int Loader::addRecord(const std::string& line_in)
         if (e != std::string::npos) { content = content.substr(0, e); }
     }
     LGame g;
-    if (!parse(content, &g)) { return 0; } // like DataLoaderThread::addEnvironmentLoader: a record that does not load is skipped
+    device_failure_ = false;
+    if (!parse(content, &g)) { return device_failure_ ? MZ_ERR_DEVICE : 0; } // like DataLoaderThread::addEnvironmentLoader: a record that does not load is skipped — but a record the DEVICE had no room for is an error, not a silent loss of training data
     if (g.d1 >= g.size() + 1 && g.size() > 0) { setError("loader: data range beyond the game"); return 0; }
     // ReplayBuffer::addData (data_loader.cpp:24-50)
     std::deque<float> position_priorities(g.d1 + 1, 0.0f);
@@ -674,6 +689,7 @@ int mz_loader_update_priority(mz_loader* l, const int* sampled_index, const floa
     if (!l || !sampled_index || !batch_values) { mz::setError("mz_loader_update_priority: NULL argument"); return MZ_ERR_ARG; }
     return l->l.updatePriority(sampled_index, batch_values);
 }
+float mz_transform_value(float v) { return mz::transformValue(v); }
 int mz_loader_num_data(const mz_loader* l) { return l ? l->l.numData() : MZ_ERR_ARG; }
 int mz_loader_num_games(const mz_loader* l) { return l ? l->l.numGames() : MZ_ERR_ARG; }
 int mz_loader_shape(const mz_loader* l, int what) { return l ? l->l.shape(what) : MZ_ERR_ARG; }

@@ -277,7 +277,8 @@ std::string escapeSGF(const std::string& s) // ref base_env.h:303-313
 
 class Worker {
 public:
-    int init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count);
+    // shared != nullptr: the worker runs on the caller's network (BaseActor::setNetwork's shared_ptr, ref zero_actor.cpp:100-112) instead of its own copy
+    int init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count, Net* shared = nullptr);
     int command(const std::string& line);
     int setWeights(const float* w, size_t n)
     {
@@ -296,8 +297,15 @@ public:
     int resetGameAt(int g);
     int emitGame(int g);
     int envQuery(int g, int what, float* out) const;
+    int actString(int g, const char* const* args, int nargs);
+    int actionInfoHistory(int g, char* buf, int cap);
+    int envFeatures(int g, int rotation, float* out, int capacity) const;
+    int envLegalMask(int g, uint8_t* out, int capacity) const;
+    int envSetTurn(int g, int player);
+    int envResetSeed(int g, int seed);
+    int envRotateAction(int g, int action_id, int rotation) const;
     mz_worker_stats stats_{};
-    Net& net0() { return lanes_[0]->net; }
+    Net& net0() { return *lanes_[0]->net; }
 
 private:
     // A lane = a contiguous slice of the games with its own device pool, network instance, HIP stream and staging.
@@ -307,7 +315,8 @@ private:
     // the lane count: the RNG-ordered serial section still visits the games in index order.
     struct Lane {
         int g0 = 0, n = 0;
-        Net net;
+        Net* net = nullptr;            // the lane's network: its own (own_net) or the caller's (mz_worker_create_shared)
+        std::unique_ptr<Net> own_net;
         Pool pool;
         hipStream_t stream = nullptr;
         PinBuf<float> h_feat, h_out;
@@ -429,11 +438,12 @@ private:
     bool root_host_pending_ = false; // ... whose outputs the next phase1 still has to turn into the root's children (host candidate lists)
     int syncGumbel(Lane& L, bool to_device);
     bool sim_mz_ = false;     // MuZero board game on sim_kernel_mz (no device rules needed: the leaves have no environment)
+    bool shared_net_ = false; // the network belongs to the caller (mz_worker_create_shared): load_model only renames, the caller reloads
     bool sim_kernel_ = false; // ... and whole runs of cycles are ONE launch of the per-game simulation kernel (sim.hip)
 };
 
 // ------------------------------------------------------------------------------------------------
-int Worker::init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count)
+int Worker::init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count, Net* shared)
 {
     if (!conf || !cfg_.loadFromString(conf)) { return MZ_ERR_ARG; }
     desc_ = desc;
@@ -455,19 +465,28 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     sc.flipping_player = flipping_player_;
     sc.atari_init_q = cfg_.atari_init_q;
     int nl = std::max(1, cfg_.mz_pipeline_lanes);
-    if (G_ < 2 * nl) { nl = 1; }
+    if (G_ < 2 * nl || shared) { nl = 1; } // a shared network has one stream: one lane
+    shared_net_ = shared != nullptr;
     lane_size_ = (G_ + nl - 1) / nl;
     lanes_.clear();
     for (int l = 0; l < nl; ++l) {
         auto L = std::make_unique<Lane>();
         L->g0 = l * lane_size_;
         L->n = std::min(lane_size_, G_ - L->g0);
-        int rc = L->net.init(device, desc, weights, count);
-        if (rc) { return rc; }
+        int rc = MZ_OK;
+        if (shared) {
+            if (shared->device_ != device) { setError("worker: the shared network lives on device %d, the worker on %d", shared->device_, device); return MZ_ERR_ARG; }
+            L->net = shared;
+        } else {
+            L->own_net = std::make_unique<Net>();
+            L->net = L->own_net.get();
+            if ((rc = L->net->init(device, desc, weights, count))) { return rc; }
+        }
         if (cfg_.mz_nn_precision != "f32" && cfg_.mz_nn_precision != "bf16x3") { setError("mz_nn_precision '%s' unknown (f32 | bf16x3)", cfg_.mz_nn_precision.c_str()); return MZ_ERR_ARG; }
-        if ((rc = L->net.setPrecision(cfg_.mz_nn_precision == "bf16x3" ? 1 : 0))) { return rc; }
-        if (!cfg_.mz_sim_cluster || nl > 1) { L->net.sim_cluster_ = false; } // two lanes = two concurrent cooperative launches: not with clusters that wait for each other
-        L->stream = L->net.stream_;
+        // (a shared network keeps the precision its owner chose with mz_net_set_precision)
+        if (!shared && (rc = L->net->setPrecision(cfg_.mz_nn_precision == "bf16x3" ? 1 : 0))) { return rc; }
+        if (!cfg_.mz_sim_cluster || nl > 1) { L->net->sim_cluster_ = false; } // two lanes = two concurrent cooperative launches: not with clusters that wait for each other
+        L->stream = L->net->stream_;
         // ref actor_group.cpp:183: tree_node_size = (n + 1) * action_size; tree.h:66: 1 + tree_node_size nodes
         rc = L->pool.init(device, L->n, 1 + (n_ + 1) * A_, A_, sc, L->stream);
         if (rc) { return rc; }
@@ -477,7 +496,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             L->pool.v_.host_path_len = L->pool.h_path_len_.p;
             L->pool.v_.host_path_action = L->pool.h_path_action_.p;
         }
-        const size_t GA = size_t(L->n) * A_, feat = size_t(L->n) * L->net.featSize(), Gn = L->n;
+        const size_t GA = size_t(L->n) * A_, feat = size_t(L->n) * L->net->featSize(), Gn = L->n;
 #define WALLOC(b, n) \
     if (!(b).alloc(n)) { setError("worker: allocation failed (%s)", #b); return MZ_ERR_DEVICE; }
         WALLOC(L->h_feat, feat); WALLOC(L->d_feat, feat); WALLOC(L->h_out, 2 * GA + 2 * Gn); WALLOC(L->d_out, 2 * GA + 2 * Gn);
@@ -485,7 +504,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         L->d_policy = {L->d_out.p, GA}; L->d_logit = {L->d_out.p + GA, GA}; L->d_value = {L->d_out.p + 2 * GA, Gn}; L->d_reward = {L->d_out.p + 2 * GA + Gn, Gn};
         MZ_HIP(hipMemset(L->d_out.p, 0, L->d_out.n * sizeof(float)));
         if (desc.type >= 1) {
-            WALLOC(L->d_hidden, Gn * (n_ + 1) * L->net.hiddenSize()); // hidden-state slab: one slot per expanded node
+            WALLOC(L->d_hidden, Gn * (n_ + 1) * L->net->hiddenSize()); // hidden-state slab: one slot per expanded node
             WALLOC(L->d_src_idx, Gn); WALLOC(L->d_dst_idx, Gn); WALLOC(L->d_action_ids, Gn);
         }
 #undef WALLOC
@@ -727,7 +746,7 @@ void Worker::buildLeaf(int gi)
     const int j = gi - L.g0;
     const int len = L.pool.h_path_len_.p[j];
     g.path_len = len;
-    float* feat = L.h_feat.p + size_t(j) * L.net.featSize();
+    float* feat = L.h_feat.p + size_t(j) * L.net->featSize();
     if (desc_.type == 0) {
         const int* acts = L.pool.h_path_action_.p + size_t(j) * L.pool.v_.max_depth;
         g.leaf->copyFrom(*g.env);
@@ -1248,7 +1267,7 @@ int Worker::phase2Resident(Lane& L)
     const int slot = sims_done_; // position slot of this simulation's leaf (slot 0 = the root)
     int rc;
     if ((rc = L.godev.leafAsync(L.pool.v_, L.rot, slot))) { return rc; }
-    if ((rc = L.net.forwardAZ(reinterpret_cast<const float*>(L.godev.v_.feat), L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, true))) { return rc; }
+    if ((rc = L.net->forwardAZ(reinterpret_cast<const float*>(L.godev.v_.feat), L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, true))) { return rc; }
     if ((rc = L.godev.candAsync(L.pool, L.d_policy.p, L.d_logit.p, L.d_value.p, L.rot))) { return rc; }
     if ((rc = L.pool.expandBackupAsync(slot, false))) { return rc; }
     // bound the host's run-ahead (kernel-argument ring, launch queue): a completion word every 32 cycles, wait for the one before
@@ -1286,11 +1305,11 @@ int Worker::phase2(Lane& L)
     trace_.add(8, t2 - t1);
     int rc;
     if (az) {
-        const size_t fbytes = feat_bits_ ? size_t(L.n) * games_[0].env->featureWords() * sizeof(uint32_t) : size_t(L.n) * L.net.featSize() * sizeof(float);
+        const size_t fbytes = feat_bits_ ? size_t(L.n) * games_[0].env->featureWords() * sizeof(uint32_t) : size_t(L.n) * L.net->featSize() * sizeof(float);
         // zero-copy: the tower kernel stages its LDS tile straight from pinned host memory / the heads kernel writes the outputs there
         const bool zin = cfg_.mz_zero_copy & 1, zout = cfg_.mz_zero_copy & 2;
         if (!zin) { MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, fbytes, hipMemcpyHostToDevice, L.stream)); }
-        if ((rc = L.net.forwardAZ(zin ? L.h_feat.p : L.d_feat.p, L.n, zout ? L.h_policy.p : L.d_policy.p, zout ? L.h_logit.p : L.d_logit.p,
+        if ((rc = L.net->forwardAZ(zin ? L.h_feat.p : L.d_feat.p, L.n, zout ? L.h_policy.p : L.d_policy.p, zout ? L.h_logit.p : L.d_logit.p,
                                   zout ? L.h_value.p : L.d_value.p, feat_bits_))) {
             return rc;
         }
@@ -1308,23 +1327,23 @@ int Worker::phase2(Lane& L)
             uint8_t* cur = L.raw_cur == 0 ? L.d_raw2.p : L.d_raw.p;
             MZ_HIP(hipMemcpyAsync(L.d_new.p, L.h_new.p, size_t(L.n) * fb, hipMemcpyHostToDevice, L.stream));
             MZ_HIP(hipMemcpyAsync(L.d_meta.p, L.h_meta.p, size_t(L.n) * mb, hipMemcpyHostToDevice, L.stream));
-            if ((rc = L.net.shiftExpandAtariFeatures(prev, L.d_new.p, L.d_meta.p, cur, raw_bytes_, L.n, L.d_feat.p))) { return rc; }
+            if ((rc = L.net->shiftExpandAtariFeatures(prev, L.d_new.p, L.d_meta.p, cur, raw_bytes_, L.n, L.d_feat.p))) { return rc; }
             L.raw_cur ^= 1;
         } else if (raw_bytes_ > 0) {
             uint8_t* cur = L.raw_cur == 0 ? L.d_raw.p : L.d_raw2.p;
             MZ_HIP(hipMemcpyAsync(cur, L.h_raw.p, size_t(L.n) * raw_bytes_, hipMemcpyHostToDevice, L.stream));
-            if ((rc = L.net.expandAtariFeatures(cur, raw_bytes_, L.n, L.d_feat.p))) { return rc; }
+            if ((rc = L.net->expandAtariFeatures(cur, raw_bytes_, L.n, L.d_feat.p))) { return rc; }
             L.raw_have = true;
         } else {
-            MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, size_t(L.n) * L.net.featSize() * sizeof(float), hipMemcpyHostToDevice, L.stream));
+            MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, size_t(L.n) * L.net->featSize() * sizeof(float), hipMemcpyHostToDevice, L.stream));
         }
         if ((rc = L.pool.hiddenIndexAsync(n_ + 1, 0, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
-        if ((rc = L.net.initial(L.d_feat.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_hidden.p, L.d_dst_idx.p))) { return rc; }
+        if ((rc = L.net->initial(L.d_feat.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_hidden.p, L.d_dst_idx.p))) { return rc; }
         MZ_HIP(hipMemsetAsync(L.d_reward.p, 0, L.n * sizeof(float), L.stream));
     } else {
         // device-resident MuZero step: parent hidden state gathered from the slab, action plane synthesised on device
         if ((rc = L.pool.hiddenIndexAsync(n_ + 1, sims_done_, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
-        if ((rc = L.net.recurrent(L.d_hidden.p, L.d_src_idx.p, nullptr, L.d_action_ids.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_reward.p,
+        if ((rc = L.net->recurrent(L.d_hidden.p, L.d_src_idx.p, nullptr, L.d_action_ids.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_reward.p,
                                   L.d_hidden.p, L.d_dst_idx.p))) {
             return rc;
         }
@@ -1471,7 +1490,7 @@ int Worker::runCyclesSim(int n)
                 GumbelView gv = gum_;
                 gv.state = L->d_gum.p;
                 bool launched = false;
-                int rc = L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p, games_[0].env->numPlayers(), L->d_policy.p,
+                int rc = L->net->simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p, games_[0].env->numPlayers(), L->d_policy.p,
                                             L->d_logit.p, L->d_value.p, L->d_reward.p, 0, 1, &launched, noise_cfg ? L->d_noise.p : nullptr,
                                             cfg_.actor_dirichlet_noise_epsilon, cfg_.actor_use_dirichlet_noise ? 1 : 2, dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p,
                                             host_gumbel, true);
@@ -1527,11 +1546,11 @@ int Worker::runCyclesSim(int n)
                 gv.state = L->d_gum.p;
                 const int noise_kind = cfg_.actor_use_dirichlet_noise ? 1 : 2;
                 const bool hg = host_gumbel && part == 0 && !root_on_device;
-                int rc = sim_mz_ ? L->net.simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
+                int rc = sim_mz_ ? L->net->simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
                                                       games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_reward.p, sim0 + c0, c1 - c0,
                                                       &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
                                                       dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg)
-                                  : L->net.simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p + size_t(c0) * L->n, sim0 + c0, c1 - c0,
+                                  : L->net->simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p + size_t(c0) * L->n, sim0 + c0, c1 - c0,
                                                      &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg);
                 if (rc) { return rc; }
@@ -1599,7 +1618,8 @@ int Worker::popLine(char* buf, int cap)
     if (lines_.empty()) { return 0; }
     const std::string& s = lines_.front();
     const int len = static_cast<int>(s.size());
-    if (cap <= len) { setError("pop_line: buffer of %d bytes too small for a %d-byte line", cap, len); return MZ_ERR_ARG; }
+    if (!buf) { return len; } // size query: the line stays queued
+    if (cap <= len) { setError("pop_line: buffer of %d bytes too small for a %d-byte line", cap, len); return MZ_ERR_CAPACITY; }
     memcpy(buf, s.data(), len);
     buf[len] = 0;
     lines_.pop_front();
@@ -1671,6 +1691,79 @@ int Worker::envQuery(int g, int what, float* out) const
     return MZ_OK;
 }
 
+// BaseActor::act(const std::vector<std::string>&) (ref base_actor.cpp:32-40 -> Env::act(action_string_args), base_env.h:326-333 / atari.cpp:24-39)
+int Worker::actString(int g, const char* const* args, int nargs)
+{
+    if (g < 0 || g >= G_) { setError("act: game %d out of range", g); return MZ_ERR_ARG; }
+    if (nargs != 2 || !args || !args[0] || !args[1] || strlen(args[0]) != 1) { setError("act: expected {player char, action string} (ref base_env.h:328-329)"); return MZ_ERR_ARG; }
+    const char c = args[0][0]; // charToPlayer (ref base_env.cpp:15-25)
+    const int player = (c == 'B' || c == 'b') ? 1 : (c == 'W' || c == 'w') ? 2 : 0;
+    const int action = games_[g].env->actionFromString(args[1]);
+    if (player == 0 || action < 0 || action >= A_) { return 0; } // not an action of this game: act() fails like an illegal move
+    return actGame(g, action, player);
+}
+
+// BaseActor::getActionInfoHistory() (ref base_actor.h:33-34): per move its (key, value) pairs.  Serialised as moves joined by '\x1e', inside a move
+// key '\x1f' value '\x1f' ... (neither byte can occur in a tag: the values are numbers, "id:count" lists or hex)
+int Worker::actionInfoHistory(int g, char* buf, int cap)
+{
+    if (g < 0 || g >= G_) { setError("action_info_history: game %d out of range", g); return MZ_ERR_ARG; }
+    flushDeferred();
+    std::string s;
+    const auto& h = games_[g].action_info_history;
+    for (size_t i = 0; i < h.size(); ++i) {
+        if (i) { s += '\x1e'; }
+        for (const auto& kv : h[i]) { s += kv.first; s += '\x1f'; s += kv.second; s += '\x1f'; }
+    }
+    const int len = static_cast<int>(s.size());
+    if (!buf) { return len; }
+    if (cap <= len) { setError("action_info_history: buffer of %d bytes too small for %d", cap, len); return MZ_ERR_CAPACITY; }
+    memcpy(buf, s.data(), len);
+    buf[len] = 0;
+    return len;
+}
+
+int Worker::envFeatures(int g, int rotation, float* out, int capacity) const // Env::getFeatures(rotation) (ref base_env.h:88)
+{
+    if (g < 0 || g >= G_ || rotation < 0 || rotation > 7) { setError("env_features: bad arguments"); return MZ_ERR_ARG; }
+    const int n = games_[g].env->featureSize();
+    if (!out) { return n; }
+    if (capacity < n) { setError("env_features: %d floats needed", n); return MZ_ERR_CAPACITY; }
+    games_[g].env->features(rotation, out);
+    return n;
+}
+
+int Worker::envLegalMask(int g, uint8_t* out, int capacity) const // Env::isLegalAction / getLegalActions for the player to move
+{
+    if (g < 0 || g >= G_ || !out || capacity < A_) { setError("env_legal_mask: bad arguments (%d bytes needed)", A_); return MZ_ERR_ARG; }
+    games_[g].env->legalMask(out);
+    return A_;
+}
+
+int Worker::envSetTurn(int g, int player) // Env::setTurn (ref base_env.h:103)
+{
+    if (g < 0 || g >= G_ || player < 1 || player > games_[g].env->numPlayers()) { setError("env_set_turn: bad arguments"); return MZ_ERR_ARG; }
+    if (!cfg_.mz_manual_step) { setError("env_set_turn: the worker plays on its own (mz_manual_step=false)"); return MZ_ERR_STATE; }
+    games_[g].env->setTurn(player);
+    return MZ_OK;
+}
+
+int Worker::envResetSeed(int g, int seed) // Env::reset(seed) (ref atari.h:55; console.cpp:289): the seed comes from the caller, no draw
+{
+    if (g < 0 || g >= G_) { setError("env_reset_seed: game %d out of range", g); return MZ_ERR_ARG; }
+    if (!cfg_.mz_manual_step) { setError("env_reset_seed: the worker plays on its own (mz_manual_step=false)"); return MZ_ERR_STATE; }
+    games_[g].env->resetSeed(seed);
+    games_[g].action_info_history.clear();
+    return MZ_OK;
+}
+
+int Worker::envRotateAction(int g, int action_id, int rotation) const // Env::getRotateAction (ref base_env.h:99)
+{
+    if (g < 0 || g >= G_ || action_id < 0 || action_id >= A_ || rotation < 0 || rotation > 7) { setError("env_rotate_action: bad arguments"); return MZ_ERR_ARG; }
+    const RotationTables* r = games_[g].env->rot();
+    return r ? r->fwd[rotation][action_id] : action_id; // the Atari-shaped env has no rotations (ref atari.h:77-78)
+}
+
 int Worker::peekRecord(int game, char* buf, int cap, const char* const* keys, const char* const* values, int ntags)
 {
     if (game < 0 || game >= G_) { setError("peek_record: game %d out of range", game); return MZ_ERR_ARG; }
@@ -1679,7 +1772,8 @@ int Worker::peekRecord(int game, char* buf, int cap, const char* const* keys, co
     for (int i = 0; i < ntags; ++i) { extra.push_back({keys[i], values[i]}); }
     const std::string s = record(games_[game], extra);
     const int len = static_cast<int>(s.size());
-    if (cap <= len) { setError("peek_record: buffer of %d bytes too small for a %d-byte record", cap, len); return MZ_ERR_ARG; }
+    if (!buf) { return len; } // size query
+    if (cap <= len) { setError("peek_record: buffer of %d bytes too small for a %d-byte record", cap, len); return MZ_ERR_CAPACITY; }
     memcpy(buf, s.data(), len);
     buf[len] = 0;
     return len;
@@ -1703,6 +1797,11 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
     } else if (prefix == "load_model") {
         if (line.find(' ') == std::string::npos) { setError("load_model needs a path"); return MZ_ERR_ARG; }
         const std::string path = line.substr(line.find(' ') + 1);
+        if (shared_net_) { // the caller's Network::loadModel has (or will have) reloaded the weights; the actor only follows the name (EV tag)
+            pending_weights_.clear();
+            cfg_.nn_file_name = path;
+            return MZ_OK;
+        }
         if (pending_weights_.empty()) { // the reference's path: every network re-reads the file (actor_group.cpp:227-232)
             mz_net_desc nd;
             if (!readWeightFile(path, &nd, &pending_weights_)) { pending_weights_.clear(); return MZ_ERR_ARG; }
@@ -1719,7 +1818,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         }
         for (auto& L : lanes_) {
             MZ_HIP(hipStreamSynchronize(L->stream));
-            int rc = L->net.reload(pending_weights_.data(), pending_weights_.size());
+            int rc = L->net->reload(pending_weights_.data(), pending_weights_.size());
             if (rc) { pending_weights_.clear(); return rc; }
         }
         pending_weights_.clear();
@@ -1738,6 +1837,9 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
         MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
         MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+        // the Atari-shaped environments keep a window of screens sized from these three at creation (ref atari.cpp:87); records of a larger window
+        // would miss frames, so they are fixed where observations are kept (board games: free to change, like the reference)
+        if (games_[0].env->hasObservations()) { MZ_FIXED(zero_actor_intermediate_sequence_length) MZ_FIXED(learner_n_step_return) MZ_FIXED(learner_muzero_unrolling_step) }
 #undef MZ_FIXED
         if (fixed) { setError("update_config: %s is fixed when the worker is created (restart the worker to change it)", fixed); return MZ_ERR_ARG; }
         cfg_ = nc;
@@ -1777,6 +1879,13 @@ mz_worker* mz_worker_create(int device, const char* conf, const mz_net_desc* des
     if (w->w.init(device, conf, *desc, weights, count) != MZ_OK) { return nullptr; }
     return w.release();
 }
+mz_worker* mz_worker_create_shared(int device, const char* conf, mz_net* net)
+{
+    if (!conf || !net) { mz::setError("mz_worker_create_shared: NULL argument"); return nullptr; }
+    std::unique_ptr<mz_worker> w(new mz_worker());
+    if (w->w.init(device, conf, net->net.desc_, nullptr, 0, &net->net) != MZ_OK) { return nullptr; }
+    return w.release();
+}
 int mz_worker_cycles_per_move(const mz_worker* w) { return w ? w->w.cyclesPerMove() : MZ_ERR_ARG; }
 void mz_worker_destroy(mz_worker* w) { delete w; }
 int mz_worker_command(mz_worker* w, const char* line)
@@ -1796,17 +1905,17 @@ int mz_worker_run_cycles(mz_worker* w, int n)
 }
 int mz_worker_pop_line(mz_worker* w, char* buf, int cap)
 {
-    if (!w || !buf) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
+    if (!w) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
     return w->w.popLine(buf, cap);
 }
 int mz_worker_peek_record(mz_worker* w, int game, char* buf, int cap)
 {
-    if (!w || !buf) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
+    if (!w) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
     return w->w.peekRecord(game, buf, cap);
 }
 int mz_worker_record(mz_worker* w, int game, const char* const* keys, const char* const* values, int ntags, char* buf, int cap)
 {
-    if (!w || !buf || ntags < 0 || (ntags > 0 && (!keys || !values))) { mz::setError("mz_worker_record: bad arguments"); return MZ_ERR_ARG; }
+    if (!w || ntags < 0 || (ntags > 0 && (!keys || !values))) { mz::setError("mz_worker_record: bad arguments"); return MZ_ERR_ARG; }
     return w->w.peekRecord(game, buf, cap, keys, values, ntags);
 }
 int mz_worker_search_done(const mz_worker* w) { return w ? (w->w.searchDone() ? 1 : 0) : MZ_ERR_ARG; }
@@ -1839,6 +1948,41 @@ int mz_worker_env_query(const mz_worker* w, int game, int what, float* out)
 {
     if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
     return w->w.envQuery(game, what, out);
+}
+int mz_worker_act_string(mz_worker* w, int game, const char* const* args, int nargs)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.actString(game, args, nargs);
+}
+int mz_worker_action_info_history(mz_worker* w, int game, char* buf, int cap)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.actionInfoHistory(game, buf, cap);
+}
+int mz_worker_env_features(const mz_worker* w, int game, int rotation, float* out, int capacity)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.envFeatures(game, rotation, out, capacity);
+}
+int mz_worker_env_legal_mask(const mz_worker* w, int game, uint8_t* out, int capacity)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.envLegalMask(game, out, capacity);
+}
+int mz_worker_env_set_turn(mz_worker* w, int game, int player)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.envSetTurn(game, player);
+}
+int mz_worker_env_reset_seed(mz_worker* w, int game, int seed)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.envResetSeed(game, seed);
+}
+int mz_worker_env_rotate_action(const mz_worker* w, int game, int action_id, int rotation)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.envRotateAction(game, action_id, rotation);
 }
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out)
 {
@@ -1877,6 +2021,12 @@ int mz_env_features(const mz_env* e, int rotation, float* out)
     if (rotation < 0 || rotation > 7) { mz::setError("rotation %d out of range", rotation); return MZ_ERR_ARG; }
     e->e->features(rotation, out);
     return MZ_OK;
+}
+
+int mz_env_action_from_string(const mz_env* e, const char* action_string)
+{
+    if (!e || !action_string) { mz::setError("mz_env_action_from_string: NULL argument"); return MZ_ERR_ARG; }
+    return e->e->actionFromString(action_string);
 }
 
 int mz_env_feature_bits(const mz_env* e, int rotation, uint32_t* out)

@@ -141,6 +141,9 @@ def load():
         L.mz_env_legal_mask.argtypes = [vp, u8p]
         L.mz_env_features.argtypes = [vp, C.c_int, fp]
         L.mz_env_feature_bits.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
+        L.mz_env_action_from_string.argtypes = [vp, C.c_char_p]
+        L.mz_worker_create_shared.restype = vp
+        L.mz_worker_create_shared.argtypes = [C.c_int, C.c_char_p, vp]
         L.mz_godev_playout.argtypes = [C.c_int, C.c_int, C.c_float, ip, C.c_int, C.c_int, ip, C.POINTER(C.c_uint32), u8p, ip, fp, ip]
         L.mz_envdev_playout.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_float, ip, C.c_int, C.c_int, ip, C.POINTER(C.c_uint32), u8p, ip, fp, ip]
         L.mz_sort_candidates.argtypes = [C.c_int, fp, C.c_int, ip]
@@ -155,6 +158,9 @@ def load():
     for n in ("mz_loader_num_data", "mz_loader_num_games"):
         getattr(L, n).argtypes = [vp]
     L.mz_loader_shape.argtypes = [vp, C.c_int]
+    for n in ("mz_invert_value", "mz_transform_value"):
+        getattr(L, n).restype = C.c_float
+        getattr(L, n).argtypes = [C.c_float]
     _LIB = L
     return L
 
@@ -405,17 +411,23 @@ class Worker:
         out = []
         buf = C.create_string_buffer(1 << 20)
         while True:
-            n = self.L.mz_worker_pop_line(self.h, buf, len(buf))
-            if n <= 0:
+            need = _check(self.L, self.L.mz_worker_pop_line(self.h, None, 0))  # size query: Atari records carry megabytes of OBS hex
+            if need == 0:
                 break
+            if need >= len(buf):
+                buf = C.create_string_buffer(need + 1)
+            _check(self.L, self.L.mz_worker_pop_line(self.h, buf, len(buf)))
             out.append(buf.value.decode())
         return out
 
     def peek_records(self, games):
         """Records of games 0..games-1 as they stand (unfinished ones included)."""
-        buf = C.create_string_buffer(1 << 22)
+        buf = C.create_string_buffer(1 << 20)
         out = []
         for g in range(games):
+            need = _check(self.L, self.L.mz_worker_peek_record(self.h, g, None, 0))
+            if need >= len(buf):
+                buf = C.create_string_buffer(need + 1)
             _check(self.L, self.L.mz_worker_peek_record(self.h, g, buf, len(buf)))
             out.append(buf.value.decode())
         return out
@@ -510,6 +522,7 @@ class Env:
     def is_terminal(self): return bool(self.L.mz_env_is_terminal(self.h))
     def eval_score(self, resign=False): return self.L.mz_env_eval_score(self.h, int(resign))
     def policy_size(self): return self.L.mz_env_policy_size(self.h)
+    def action_from_string(self, s): return self.L.mz_env_action_from_string(self.h, s.encode())
 
     def legal_mask(self):
         m = np.zeros(self.policy_size(), np.uint8)

@@ -171,12 +171,15 @@ static std::string decompressString(const std::string& hex)
     return out;
 }
 
-static float transformValue(float value) // utils.h:93-100
+float transformValue(float value) // utils.h:93-100
 {
+    // With <cmath> alone (utils.h:3-12) the unqualified sqrt / fabs of the reference's expression are the C library's DOUBLE functions (libstdc++ puts the
+    // float overloads in namespace std only: tests/csrc/overload_check.cpp), so `sign * (sqrt(fabs(v) + 1) - 1) + epsilon * v` is a double expression with
+    // one float product (epsilon * v), rounded once by the assignment.  The promotions are spelled out so that no other header can change them.
     const float epsilon = 0.001;
     const float sign_value = (value > 0.0f ? 1.0f : (value == 0.0f ? 0.0f : -1.0f));
-    value = sign_value * (sqrt(fabs(value) + 1) - 1) + epsilon * value;
-    return value;
+    const double r = static_cast<double>(sign_value) * (::sqrt(::fabs(static_cast<double>(value)) + 1) - 1) + static_cast<double>(epsilon * value);
+    return static_cast<float>(r);
 }
 
 // ---- the game loaders ----
@@ -288,7 +291,7 @@ std::vector<float> GameLoader::getActionFeatures(int pos, Rotation rotation, Ran
         if (a != n * n) { f[rotateAction(a, rotation)] = 1.0f; }
     } else {
         int action_id = rng->randInt() % (f.size() + 1);
-        if (action_id < size) { f[action_id] = 1.0f; }
+        if (action_id < size && action_id < static_cast<int>(f.size())) { f[action_id] = 1.0f; } // (the reference's f[P] write lands outside its vector)
     }
     return f;
 }

@@ -282,6 +282,7 @@ public:
 float mz_expf(float x);  // deterministic expf shared (by specification) with the HIP kernels
 float mz_tanhf(float x);
 float invertValue(float value); // ref utils/utils.h:102-108
+float transformValue(float value); // ref utils/utils.h:93-100
 
 // ----------------------------------------------------------------------------
 // search (ref: actor/tree.h, actor/mcts.{h,cpp}, actor/gumbel_zero.{h,cpp})

@@ -12,6 +12,7 @@ for p in (ROOT, HERE, os.path.join(HERE, "golden")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` through gpurun)")
+    config.addinivalue_line("markers", "slow: a BASELINE-size case whose CPU oracle takes tens of seconds (still part of `-m gpu`)")
 
 
 @pytest.fixture(scope="session")

@@ -1,7 +1,8 @@
 // Test driver of the C++ facades (include/minizero/{network,actor,actor_group}.h): built by __graft_entry__.build() into tests/_bin/,
 // run on the GPU by tests/test_gpu_facade.py, which compares what it prints / writes with the ctypes path and with the oracle.
 //   facade_check net <weight file> <out.bin> <batch>     createNetwork -> pushBack* -> forward / initialInference / recurrentInference
-//   facade_check actor <conf> <moves>                     createNetwork + createActor + think()/act() loop, SelfPlay lines on stdout
+//   facade_check actor <conf> <moves> [features.bin]     createNetwork + createActor + think()/act() loop, SelfPlay lines on stdout; every member of
+//                                                         BaseActor / Environment the facade declares is called at least once (HIST / ENV / LEGAL lines)
 #include "minizero/actor.h"
 #include "minizero/actor_group.h"
 #include <cstdio>
@@ -75,13 +76,27 @@ static int runNet(const char* file, const char* out, int B)
 }
 
 // ActorGroup's handleSearchDone (ref actor_group.cpp:116-134) written against the per-actor surface, one actor
-static int runActor(const std::string& conf, int moves)
+// action id -> the strings BaseActor::act(const std::vector<std::string>&) takes (ref utils/sgf_loader.cpp:101-108 actionIDToBoardCoordinateString)
+static std::vector<std::string> actionStrings(const Action& a, int board_size)
+{
+    std::string pos = "PASS";
+    if (a.getActionID() < board_size * board_size) {
+        const int x = a.getActionID() % board_size, y = a.getActionID() / board_size;
+        pos = std::string(1, static_cast<char>('a' + x + ('a' + x >= 'i' ? 1 : 0))) + std::to_string(y + 1); // lower case on purpose: the parser upper-cases
+    }
+    return {std::string(1, env::playerToChar(a.getPlayer())), pos};
+}
+
+static int runActor(const std::string& conf, int moves, const char* feat_out)
 {
     config::mzgpuConfigurationString() = conf;
     const std::string file = config::mzgpuConfValue(conf, "nn_file_name");
     std::shared_ptr<network::Network> net = network::createNetwork(file, 0);
     const int n = std::stoi(config::mzgpuConfValue(conf, "actor_num_simulation"));
     std::shared_ptr<actor::BaseActor> a = actor::createActor(uint64_t(n + 1) * net->getActionSize(), net); // ref actor_group.cpp:183
+    if (a->createSearch() != nullptr) { return 20; }
+    if (net.use_count() < 2) { std::cerr << "setNetwork did not keep the caller's network" << std::endl; return 21; } // shared, not re-read
+    const int board = net->getInputChannelHeight();
     std::vector<char> buf(1 << 22);
     for (int m = 0; m < moves; ++m) {
         if (m % 2 == 0) {
@@ -97,7 +112,15 @@ static int runActor(const std::string& conf, int moves)
             }
             if (pairs != n + 1) { std::cerr << "search took " << pairs << " evaluations, expected " << n + 1 << std::endl; return 4; }
         }
-        if (!a->isResign()) { if (!a->act(a->getSearchAction())) { return 5; } }
+        if (m == 0) { std::cerr << a->getSearchInfo(); }
+        if (!a->isResign()) {
+            const Action sa = a->getSearchAction();
+            const Environment& env = static_cast<const actor::BaseActor&>(*a).getEnvironment();
+            if (!env.isLegalAction(sa) || env.isLegalAction(Action(sa.getActionID(), sa.getPlayer() == env::Player::kPlayer1 ? env::Player::kPlayer2 : env::Player::kPlayer1))) { return 9; }
+            // every third move goes through act(vector<string>) (ref base_actor.cpp:32-40), the others through act(Action)
+            if (m % 3 == 2 ? !a->act(actionStrings(sa, board)) : !a->act(sa)) { return 5; }
+            if (a->act(std::vector<std::string>{"B", "zz99"})) { return 10; } // not an action: refused like an illegal move, nothing recorded
+        }
         if (a->isResign() || a->isEnvTerminal()) {
             if (mz_worker_emit_game(a->handle(), 0) != MZ_OK) { return 6; }
             while (mz_worker_pop_line(a->handle(), buf.data(), static_cast<int>(buf.size())) > 0) { std::cout << buf.data() << std::endl; }
@@ -105,13 +128,44 @@ static int runActor(const std::string& conf, int moves)
         }
     }
     std::cout << "RECORD " << a->getRecord({{"XX", "tag"}}) << std::endl;
+    // getActionInfoHistory (ref base_actor.h:33-34): the test rebuilds the moves' P/V/R tags of the record above from this
+    std::cout << "HIST";
+    for (const auto& move : a->getActionInfoHistory()) {
+        std::cout << " ;";
+        for (const auto& kv : move) { std::cout << kv.first << "[" << kv.second << "]"; }
+    }
+    std::cout << std::endl;
+    // the Environment view: turn, counts, features under a rotation, rotated actions, legal actions, setTurn
+    Environment& env = a->getEnvironment();
+    const utils::Rotation rot = utils::Rotation::kRotation270;
+    std::cout << "ENV turn=" << static_cast<int>(env.getTurn()) << " actions=" << env.getNumActions() << " terminal=" << env.isTerminal() << " eval=" << a->getEvalScore()
+              << " reward=" << env.getReward() << " rot5=" << env.getRotateAction(5, rot) << std::endl;
+    std::cout << "LEGAL";
+    for (const Action& la : env.getLegalActions()) { std::cout << " " << la.getActionID(); }
+    std::cout << std::endl;
+    if (feat_out) {
+        FILE* f = fopen(feat_out, "wb");
+        if (!f) { return 11; }
+        put(f, env.getFeatures(rot));
+        fclose(f);
+    }
+    std::cerr << env.toString();
+    const env::Player other = env.getTurn() == env::Player::kPlayer1 ? env::Player::kPlayer2 : env::Player::kPlayer1;
+    env.setTurn(other);
+    if (a->getEnvironment().getTurn() != other) { return 12; }
+    env.reset(7); // Environment::reset(seed): a new game without a draw from the actor's generator
+    if (env.getNumActions() != 0 || !a->getActionInfoHistory().empty()) { return 13; }
+    // setNetwork with the same network object again = ActorGroup's load_model path (actor_group.cpp:227-232): the actor keeps its worker
+    mz_worker* before = a->handle();
+    a->setNetwork(net);
+    if (a->handle() != before) { return 14; }
     return 0;
 }
 
 int main(int argc, char** argv)
 {
     if (argc >= 5 && !strcmp(argv[1], "net")) { return runNet(argv[2], argv[3], atoi(argv[4])); }
-    if (argc >= 4 && !strcmp(argv[1], "actor")) { return runActor(argv[2], atoi(argv[3])); }
+    if (argc >= 4 && !strcmp(argv[1], "actor")) { return runActor(argv[2], atoi(argv[3]), argc >= 5 ? argv[4] : nullptr); }
     std::cerr << "usage: facade_check net <file> <out> <batch> | actor <conf> <moves>" << std::endl;
     return 1;
 }

@@ -71,6 +71,8 @@ def lib():
     L.mzo_net_recurrent.argtypes = [C.c_void_p, fp, fp, C.c_int, fp, fp, fp, fp, fp]
     L.mzo_invert_value.restype = C.c_float
     L.mzo_invert_value.argtypes = [C.c_float]
+    L.mzo_transform_value.restype = C.c_float
+    L.mzo_transform_value.argtypes = [C.c_float]
     L.mzo_expf.argtypes = [fp, C.c_int, fp]
     L.mzo_tanhf.argtypes = [fp, C.c_int, fp]
     L.mzo_rng_vector.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double)]

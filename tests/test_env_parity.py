@@ -140,3 +140,23 @@ def test_atari_shaped_env_matches_oracle(mz, oracle):
             assert a.reward() == b.reward()
             steps += 1
         assert steps == 12
+
+
+def test_action_strings_match_the_reference_conversion(mz):
+    """BaseEnv::act(const std::vector<std::string>&) reads its second argument through SGFLoader::boardCoordinateStringToActionID
+    (ref base_env.h:326-333, utils/sgf_loader.cpp:89-99): the product's conversion (mz_env_action_from_string, behind
+    mz_worker_act_string / BaseActor::act(vector<string>)) against the outputs of the reference's own function compiled in place
+    (tests/golden/ref_sgf_vectormap.json, made by gen_ref_sgf_golden.py)."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_sgf_vectormap.json")))
+    envs = {3: mz.Env("env_game=tictactoe"), 9: mz.Env("env_game=go:env_board_size=9"), 13: mz.Env("env_game=go:env_board_size=13"),
+            19: mz.Env("env_game=go:env_board_size=19")}
+    checked = 0
+    for e in fx["coords"]:
+        assert envs[e["n"]].action_from_string(e["coord"]) == e["out"][0], e
+        checked += 1
+    assert checked == 40
+    # the Atari-shaped game: ALE's action names without the PLAYER_A_ prefix, any case (ref atari.cpp:9-39); unknown -> -1
+    at = mz.Env("env_game=atari")
+    assert [at.action_from_string(s) for s in ("NOOP", "fire", "Up", "DOWNLEFTFIRE", "jump")] == [0, 1, 2, 17, -1]

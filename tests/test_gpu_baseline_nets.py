@@ -1,6 +1,8 @@
 """Oracle parity of the worker on the BASELINE.json networks (6 blocks x 64 channels) — the very `sim_kernel` / `sim_kernel_mz`
 instantiations `bench.py` and `tools/run_configs.py` time (sim.hip: <9,9,20,64,2>, <8,8,4,64,0>, mz<9,9,20,68,64>, mz<6,6,64,84,64>).
-Fewer games than BASELINE so that the CPU oracle finishes in seconds; simulations per move, network, search options = BASELINE.
+The first group runs fewer games than BASELINE so that the CPU oracle finishes in seconds; simulations per move, network, search options =
+BASELINE.  The `slow` group at the end runs the SHIPPED shapes — BASELINE's own game counts, i.e. every CU busy, the real launch-split
+thresholds, two games per CU (C3), clusters of four workgroups per game with the octet heads (C5) — against the oracle for one or two moves.
 Games that have not finished are compared through their records as they stand (`peek_record`: every move with its P[visit
 distribution] V[root value] R[reward] tags), finished ones through their `SelfPlay` lines.  Every test asserts that the per-game
 simulation kernel did run (worker stats: sim_launches / sim_cycles)."""
@@ -77,3 +79,42 @@ def test_c5_atari_gumbel_muzero_6bx64_n50(mz, oracle):
     extra = ":zero_actor_intermediate_sequence_length=4:learner_n_step_return=1:learner_muzero_unrolling_step=1:env_atari_episode_length=7"
     lines, recs, st = _run(mz, oracle, "c5", 4, [51 * 3 + 9, 51 * 5 - 9 + 1], extra=extra, seed=2)
     assert any(l.startswith("SelfPlay false") for l in lines) and any(l.startswith("SelfPlay true") for l in lines)
+
+
+# ---- the shipped shapes: BASELINE.json's own game counts against the oracle (tens of seconds of CPU oracle each) ----
+
+@pytest.mark.slow
+def test_c2_full_size_256_games_one_move(mz, oracle):
+    """BASELINE configs[1] exactly as bench.py runs it: 256 games x 401 cycles = one whole move of every game (+ 17 cycles of the next, so
+    that the move is decided and recorded and the second move's first two launch parts run), default mz_sim_split (a move = launches of
+    1 + 16 + 384 simulations at this size), one game per CU on all 256 CUs.  ref actor_group.cpp:81-147, zero_actor.cpp:51-98."""
+    lines, recs, st = _run(mz, oracle, "c2", 256, [401, 17], threads=max(2, mz.usable_cpus() - 1))
+    assert st["moves"] == 256 and st["sim_launches"] >= 5  # 3 parts of move 1 + 2 parts of move 2
+    for r in recs:
+        assert r.count(";B[") == 1 and r.count("P[") == 1
+
+
+@pytest.mark.slow
+def test_c3_full_size_1024_games_two_moves(mz, oracle):
+    """BASELINE configs[2] at its own size: 1024 games (four per CU slot pair: the 128-VGPR build with two resident games per CU), Gumbel
+    roots with noise, 2 moves + 3 cycles."""
+    lines, recs, st = _run(mz, oracle, "c3", 1024, [17, 17 + 3], threads=max(2, mz.usable_cpus() - 1))
+    assert st["moves"] == 2048
+
+
+@pytest.mark.slow
+def test_c4_full_size_256_games_one_move(mz, oracle):
+    """BASELINE configs[3] at its own size: 256 games of Go MuZero, one move + 9 cycles of the next."""
+    lines, recs, st = _run(mz, oracle, "c4", 256, [51, 9], threads=max(2, mz.usable_cpus() - 1))
+    assert st["moves"] == 256
+
+
+@pytest.mark.slow
+def test_c5_full_size_64_games_cluster_octet_heads(mz, oracle):
+    """BASELINE configs[4]'s per-GPU shard at its own size AND on the 6-block x 64-channel muzero_atari network: 64 games = 256 workgroups in
+    clusters of four with the 601-bin heads of the eight games of an XCD computed together (sim_cluster.h octetHead — only pools of full
+    octets take that path), 2 moves + 5 cycles, sequence length as in the config (no line is due yet: records as they stand)."""
+    lines, recs, st = _run(mz, oracle, "c5", 64, [51 + 20, 51 - 20 + 5], threads=max(2, mz.usable_cpus() - 1))
+    assert st["moves"] == 128
+    for r in recs:
+        assert r.count(";B[") == 2 and r.count("P[") == 2

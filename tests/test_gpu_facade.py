@@ -109,7 +109,8 @@ def test_actor_facade_against_the_oracle(mz, oracle, tmp_path, name, conf, dargs
     w = mz.generate_weights(d, 1)
     pt = _write(mz, tmp_path, d, w)
     conf = f"{conf}:zero_num_parallel_games=1:program_seed=3:nn_file_name={pt}"
-    p = _run(["actor", conf, str(moves)])
+    feat_file = str(tmp_path / "features.bin")
+    p = _run(["actor", conf, str(moves), feat_file])
     out = p.stdout.strip().split("\n")
     lines, rec = [l for l in out if l.startswith("SelfPlay ")], [l for l in out if l.startswith("RECORD ")]
     n = int(conf.split("actor_num_simulation=")[1].split(":")[0])
@@ -119,4 +120,29 @@ def test_actor_facade_against_the_oracle(mz, oracle, tmp_path, name, conf, dargs
     assert len(olines) >= min_lines
     assert lines == olines
     assert len(rec) == 1 and "XX[tag]" in rec[0]
-    assert rec[0][len("RECORD "):].replace("XX[tag]", "") == og.peek_records(1)[0]
+    record = rec[0][len("RECORD "):].replace("XX[tag]", "")
+    assert record == og.peek_records(1)[0]
+    # ---- the rest of the BaseActor / Environment surface (ref base_actor.h:16-55, base_env.h:74-114) against the oracle's environment ----
+    import json
+    import re
+    moves_part = record[record.index(";", 2):-1]  # ";B[id]P[..]V[..]R[..];W[..]..."
+    played = re.findall(r";([BW])\[(\d+)\]((?:[A-Z]+\[[^\]]*\])*)", moves_part)
+    hist = [l for l in out if l.startswith("HIST")]
+    assert len(hist) == 1
+    # getActionInfoHistory(): exactly the per-move tags of the record, move by move
+    assert hist[0][len("HIST"):] == "".join(" ;" + tags for _, _, tags in played)
+    oe = oracle.OracleEnv(conf)
+    for colour, aid, _ in played:
+        assert oe.act(int(aid), 1 if colour == "B" else 2)
+    envl = [l for l in out if l.startswith("ENV ")][0]
+    kv = dict(t.split("=") for t in envl.split()[1:])
+    board = dargs[2]
+    rot_tab = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_rng_rotation_config.json")))["rotation"][str(board)]
+    assert int(kv["turn"]) == oe.turn() and int(kv["actions"]) == len(played) and int(kv["terminal"]) == int(oe.is_terminal())
+    assert int(kv["rot5"]) == rot_tab[3][5]  # getRotateAction(5, kRotation270): the reference's own table (pinned golden)
+    assert float(kv["reward"]) == oe.reward()
+    legal = [l for l in out if l.startswith("LEGAL")][0].split()[1:]
+    assert [int(a) for a in legal] == [int(a) for a in np.flatnonzero(oe.legal_mask())]
+    got = np.fromfile(feat_file, np.float32)
+    assert np.array_equal(got, oe.features(3).ravel())  # getFeatures(kRotation270)
+    assert "model file name:" in p.stderr and "move number:" in p.stderr  # getSearchInfo()

@@ -172,3 +172,14 @@ def test_invert_value_on_device(mz):
     L.mz_invert_value.argtypes = [__import__("ctypes").c_float]
     host = np.array([L.mz_invert_value(float(x)) for x in v[::7]], np.float32)
     assert np.array_equal(dev[::7].view(np.uint32), host.view(np.uint32))
+
+
+def test_invert_value_on_device_matches_the_closed_form(mz):
+    """... and against the closed form of utils.h:102-108 evaluated in numpy with the reference's promotions (tests/test_value_transform.py): every
+    one of 600 k values, so the device function is pinned to the formula itself, not to a transcription of it."""
+    from test_value_transform import closed_form_invert, vectors
+    rng = np.random.default_rng(6)
+    v = np.concatenate([vectors(), np.linspace(-300, 300, 200001, dtype=np.float32), rng.normal(0, 3, 200000).astype(np.float32),
+                        rng.uniform(-300, 300, 200000).astype(np.float32)])
+    dev = mz.invert_values_device(v)
+    assert np.array_equal(dev.view(np.uint32), closed_form_invert(v).view(np.uint32))

@@ -42,39 +42,61 @@ def test_sp_executable_protocol(mz, oracle, tmp_path):
     assert "[command] start" in p.stderr.read()
 
 
-def test_one_process_drives_every_visible_gpu(mz, oracle, tmp_path):
+MULTI = [
+    ("tictactoe", "tictactoe", "c1", "actor_num_simulation=16", 17, 30, 400),
+    # the per-game simulation kernel + device Go rules from two host threads (per-device LDS attributes, argument blocks, streams)
+    ("go", "go", None, "env_board_size=9:actor_num_simulation=8", 9, 3, 400),
+]
+
+
+@pytest.mark.parametrize("name,game,key,extra,cpm,lines_per_dev,moves", MULTI)
+def test_one_process_drives_every_visible_gpu(mz, oracle, tmp_path, name, game, key, extra, cpm, lines_per_dev, moves):
     """ref actor_group.cpp:168-187 + scripts/zero-worker.sh:159-162: ONE `-mode sp` process, zero_num_parallel_games = batch x #GPUs, actor i on
-    device i % G.  Here: worker g = games {i % G == g} on device g, seed program_seed + g, one stdout mutex."""
+    device i % G.  Here: worker g = games {i % G == g} on device g, seed program_seed + g, one host thread per device, one stdout mutex.
+    On a one-GPU box the same logic runs with two logical devices mapped onto GPU 0 (MZ_DEVICE_MAP=0,0, include/minizero/actor_group.h)."""
+    env = dict(os.environ)
     G = mz.device_count()
     if G < 2:
-        pytest.skip("needs at least 2 GPUs in one node")
+        G = 2
+        env["MZ_DEVICE_MAP"] = "0,0"
     from minizero_amd.export_weights import write_mzw
     exe = os.path.join(ROOT, "apps", "mzgpu_sp")
-    d = mz.DESCS["c1"]()
+    if key:
+        d, od = mz.DESCS[key](), getattr(oracle, "desc_" + key)()
+    else:
+        args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82)
+        d, od = mz.make_desc(*args, vh=16, dv=1, type_name="alphazero"), oracle.make_desc(*args, 16, 1)
     w = mz.generate_weights(d, 0)
     pt = str(tmp_path / "weight_iter_0.pt")
     write_mzw(pt[:-3] + ".mzw", d, w)
     games = 4 * G + 1
-    conf_str = f"nn_file_name={pt}:program_seed=5:actor_num_simulation=16:zero_num_parallel_games={games}:zero_num_threads={G}"
-    p = subprocess.Popen([exe, "-conf_str", conf_str, "-mode", "sp", "-game", "tictactoe"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, text=True)
+    conf_str = f"nn_file_name={pt}:program_seed=5:{extra}:zero_num_parallel_games={games}:zero_num_threads={G}"
+    p = subprocess.Popen([exe, "-conf_str", conf_str, "-mode", "sp", "-game", game], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, env=env)
     p.stdin.write("start\n")
     p.stdin.flush()
-    lines = [p.stdout.readline().rstrip("\n") for _ in range(30 * G)]
-    p.stdin.write("quit\n")
-    p.stdin.flush()
-    p.wait(timeout=60)
-    assert f"{games} games on {G} GPU(s)" in p.stderr.read()
     expected = {}
     for g in range(G):
         n_g = len(range(g, games, G))
-        og = oracle.OracleGroup(f"env_game=tictactoe:actor_num_simulation=16:zero_num_parallel_games={n_g}:program_seed={5 + g}:nn_file_name={pt}", oracle.desc_c1(), w)
-        og.cycles(17 * 200)
+        og = oracle.OracleGroup(f"env_game={game}:{extra}:zero_num_parallel_games={n_g}:program_seed={5 + g}:nn_file_name={pt}:zero_num_threads=1", od, w)
+        og.cycles(cpm * moves)
         expected[g] = og.lines()
+        assert len(expected[g]) >= lines_per_dev
     # every printed line is the next unseen line of exactly one device's stream (per-device order is kept, devices interleave freely)
+    # (the devices run at their own pace: read until each has shown lines_per_dev records, or one of them runs out of expected ones)
     cursor = {g: 0 for g in range(G)}
-    for l in lines:
+    while min(cursor.values()) < lines_per_dev and all(cursor[g] < len(expected[g]) for g in range(G)):
+        l = p.stdout.readline().rstrip("\n")
+        assert l, "the worker stopped printing: " + p.stderr.read()[-2000:]
         owners = [g for g in range(G) if cursor[g] < len(expected[g]) and expected[g][cursor[g]] == l]
         assert owners, "a line that is not the next record of any device: " + l[:120]
         cursor[owners[0]] += 1
-    assert all(c > 0 for c in cursor.values()), "a device printed nothing"
+    p.stdin.write("quit\n")
+    p.stdin.flush()
+    try:  # drain: the device threads may be blocked on a full stdout pipe until they see the quit
+        _, err = p.communicate(timeout=120)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    assert f"{games} games on {G} GPU(s)" in err, err[-2000:]
+    assert min(cursor.values()) >= lines_per_dev, f"per-device records seen: {cursor}"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the five BASELINE.json configs on one GPU (leaf-evals/s) with a roofline block per config; C2 is what bench.py reports.
-usage: run_configs.py [c1 .. c5] [--moves M] [--out file.json]
+usage: run_configs.py [c1 .. c5] [--moves M] [--threads T] [--conf k=v:..] [--out file.json]
 The roofline numerator is the algorithmic work of the leaf evaluations (3x3 convolutions + linear layers of one forward, 2 x MAC),
 the denominator the HIP-event time of the simulation-kernel launches on the worker's stream (worker stats: ms_forward)."""
 import json
@@ -37,11 +37,50 @@ def flops_per_leaf_eval(d):
     return conv, heads
 
 
+def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
+    """One config on device 0: a fresh worker, `warm` untimed moves, `moves` timed moves (one run_cycles call per move, like the `-mode sp`
+    loop).  Returns the block bench.py (`other_configs`) and profiles/rNN_all_configs_n1.json both carry."""
+    d = mz.DESCS[key]()
+    if threads is None:
+        threads = max(1, mz.usable_cpus() - 1)
+    conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_cpu_base=0{extra_conf}"
+    n = int(mz.CONFIGS[key].split("actor_num_simulation=")[1].split(":")[0])
+    games = int(mz.CONFIGS[key].split("zero_num_parallel_games=")[1].split(":")[0])
+    wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
+    wk.command("start")
+    moves = moves or MOVES[key]
+    wk.run_cycles((WARM.get(key, 3) if warm is None else warm) * (n + 1))
+    s0 = wk.stats()
+    t0 = time.perf_counter()
+    for _ in range(moves):
+        wk.run_cycles(n + 1)
+    dt = time.perf_counter() - t0
+    s1 = wk.stats()
+    evals = s1["leaf_evals"] - s0["leaf_evals"]
+    conv, heads = flops_per_leaf_eval(d)
+    gpu_ms = s1["ms_forward"] - s0["ms_forward"]
+    launches = s1["sim_launches"] - s0["sim_launches"]
+    sim_evals = (s1["sim_cycles"] - s0["sim_cycles"]) * games
+    ach = (conv + heads) * sim_evals / (gpu_ms * 1e-3) / 1e12 if launches else None
+    res = {"leaf_evals_per_sec": evals / dt, "ms_per_move": dt / moves * 1e3, "moves_per_sec": (s1["moves"] - s0["moves"]) / dt,
+           "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "host_threads": threads if key != "c1" else 1,
+           "config": mz.CONFIGS[key],
+           "roofline": {"kernel": KERNEL[key], "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": (ach / F32_MFMA_PEAK_TFLOPS) if ach else None, "launches": launches,
+                        "avg_launch_ms": gpu_ms / launches if launches else None, "flops_per_leaf_eval": conv + heads,
+                        "conv3x3_flops_per_leaf_eval": conv, "leaf_evals_in_launches": sim_evals,
+                        "wall_frac": (conv + heads) * evals / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                        "timing": "HIP events on the worker's stream around every simulation-kernel launch"}}
+    wk.close()
+    return res
+
+
 def main():
     argv = sys.argv[1:]
     out_path = os.path.join("gpurun_out", "configs.json")
     moves_override = None
     extra_conf = ""
+    threads = None
     keys = []
     i = 0
     while i < len(argv):
@@ -49,43 +88,16 @@ def main():
             moves_override = int(argv[i + 1]); i += 2
         elif argv[i] == "--conf":  # extra configuration keys for every worker, e.g. mz_sim_split=false
             extra_conf = ":" + argv[i + 1]; i += 2
+        elif argv[i] == "--threads":  # zero_num_threads of every worker (1 = the host budget of one rank of eight on a 16-CPU quota)
+            threads = int(argv[i + 1]); i += 2
         elif argv[i] == "--out":
             out_path = argv[i + 1]; i += 2
         else:
             keys.append(argv[i]); i += 1
     out = {}
-    threads = max(1, mz.usable_cpus() - 1)
     for key in keys or ["c1", "c2", "c3", "c4", "c5"]:
-        d = mz.DESCS[key]()
-        conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_cpu_base=0{extra_conf}"
-        n = int(mz.CONFIGS[key].split("actor_num_simulation=")[1].split(":")[0])
-        games = int(mz.CONFIGS[key].split("zero_num_parallel_games=")[1].split(":")[0])
-        wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
-        wk.command("start")
-        moves = moves_override or MOVES[key]
-        wk.run_cycles(WARM.get(key, 3) * (n + 1))
-        s0 = wk.stats()
-        t0 = time.perf_counter()
-        for _ in range(moves):
-            wk.run_cycles(n + 1)
-        dt = time.perf_counter() - t0
-        s1 = wk.stats()
-        evals = s1["leaf_evals"] - s0["leaf_evals"]
-        conv, heads = flops_per_leaf_eval(d)
-        gpu_ms = s1["ms_forward"] - s0["ms_forward"]
-        launches = s1["sim_launches"] - s0["sim_launches"]
-        sim_evals = (s1["sim_cycles"] - s0["sim_cycles"]) * games
-        ach = (conv + heads) * sim_evals / (gpu_ms * 1e-3) / 1e12 if launches else None
-        out[key] = {"leaf_evals_per_sec": evals / dt, "ms_per_move": dt / moves * 1e3, "moves_per_sec": (s1["moves"] - s0["moves"]) / dt,
-                    "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "config": mz.CONFIGS[key],
-                    "roofline": {"kernel": KERNEL[key], "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": (ach / F32_MFMA_PEAK_TFLOPS) if ach else None, "launches": launches,
-                                 "avg_launch_ms": gpu_ms / launches if launches else None, "flops_per_leaf_eval": conv + heads,
-                                 "conv3x3_flops_per_leaf_eval": conv, "leaf_evals_in_launches": sim_evals,
-                                 "wall_frac": (conv + heads) * evals / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                                 "timing": "HIP events on the worker's stream around every simulation-kernel launch"}}
+        out[key] = run_config(key, moves_override, threads, extra_conf)
         print(key, json.dumps(out[key]), flush=True)
-        del wk
     os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
     json.dump(out, open(out_path, "w"), indent=1)
 
