@@ -119,7 +119,7 @@ static int runActor(const std::string& conf, int moves, const char* feat_out)
             if (!env.isLegalAction(sa) || env.isLegalAction(Action(sa.getActionID(), sa.getPlayer() == env::Player::kPlayer1 ? env::Player::kPlayer2 : env::Player::kPlayer1))) { return 9; }
             // every third move goes through act(vector<string>) (ref base_actor.cpp:32-40), the others through act(Action)
             if (m % 3 == 2 ? !a->act(actionStrings(sa, board)) : !a->act(sa)) { return 5; }
-            if (a->act(std::vector<std::string>{"B", "zz99"})) { return 10; } // not an action: refused like an illegal move, nothing recorded
+            if (a->act(std::vector<std::string>{"B", "?"})) { return 10; } // not an action: refused like an illegal move, nothing recorded
         }
         if (a->isResign() || a->isEnvTerminal()) {
             if (mz_worker_emit_game(a->handle(), 0) != MZ_OK) { return 6; }

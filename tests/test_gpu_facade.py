@@ -125,7 +125,8 @@ def test_actor_facade_against_the_oracle(mz, oracle, tmp_path, name, conf, dargs
     # ---- the rest of the BaseActor / Environment surface (ref base_actor.h:16-55, base_env.h:74-114) against the oracle's environment ----
     import json
     import re
-    moves_part = record[record.index(";", 2):-1]  # ";B[id]P[..]V[..]R[..];W[..]..."
+    k = record.find(";", 2)
+    moves_part = record[k:-1] if k >= 0 else ""  # ";B[id]P[..]V[..]R[..];W[..]..." ("" right after a reset)
     played = re.findall(r";([BW])\[(\d+)\]((?:[A-Z]+\[[^\]]*\])*)", moves_part)
     hist = [l for l in out if l.startswith("HIST")]
     assert len(hist) == 1
