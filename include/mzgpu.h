@@ -234,6 +234,8 @@ typedef struct mz_worker_stats {
     double ms_select, ms_env, ms_forward, ms_expand, ms_move, ms_total;
     uint64_t sim_launches; /* launches of the per-game simulation kernel (sim.hip); 0 = the lock-step kernels ran */
     uint64_t sim_cycles;   /* cycles that ran inside those launches */
+    uint64_t pre_evals;    /* Gumbel rounds (mz_sim_rounds): leaves evaluated ahead of their simulations ... */
+    uint64_t pre_hits;     /* ... and simulations that found their leaf among them (the rest evaluated their own) */
 } mz_worker_stats;
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out);
 mz_net* mz_worker_net(mz_worker* w);

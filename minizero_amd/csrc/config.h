@@ -64,6 +64,9 @@ struct WorkerConfig {
     // not a reference key: wait for the GPU on a pinned completion word (spin) instead of hipStreamSynchronize
     bool mz_signal_wait = true;
     bool mz_sim_split = true;   // a move's simulation-kernel launch in up to three parts, so that the host's noise / rotation draws overlap the parts already running
+    bool mz_sim_rounds = true;  // muzero_atari with a Gumbel root: the leaves of a whole Gumbel round (the simulations between two halvings visit different root children)
+                                // are evaluated side by side ahead of the simulations that consume them in order (sim.hip sim_pre_kernel_mz); false: every simulation evaluates its own leaf
+    int mz_sim_round_min = 2;   // ... for the rounds of at least this many simulations (2 = every round of a 50-simulation, 16-sample search: 16, 8, 4, 4, 4, 2 x 7)
     bool mz_sim_cluster = true; // muzero_atari simulation kernel: four workgroups per game when 4 x games <= CUs (sim_cluster.h)
     bool mz_sim_kernel = true; // with mz_device_env: whole runs of cycles as one launch of the per-game simulation kernel (sim.hip)
     bool mz_raw_observations = true; // muzero_atari roots: ship the observation ring as bytes, expand the float planes on the device

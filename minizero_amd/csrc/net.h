@@ -92,7 +92,15 @@ public:
     // initial() — and simulation 0 is only the root's candidate list + expand + backup, one workgroup per game
     int simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                     int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
-                    const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given = false);
+                    const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given = false,
+                    int pre_epoch = 0, bool noise_applied = false);
+    // Gumbel rounds (sim.hip sim_pre_kernel_mz, muzero_atari): the leaves the next R simulations of every game are expected to reach, evaluated side by
+    // side into the entries of simulations s0 .. s0 + R - 1, tagged with `epoch` (a per-move serial number, != 0); the following simLaunchMz calls of the
+    // move pass the same pre_epoch and consume the entries that turn out to be their leaves.  simRootNoiseMz applies the root noise as a launch of its own
+    // (the first round needs the noisy logits before simulation 1): the simLaunchMz calls after it pass noise_applied = true.
+    int simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched);
+    int simRootNoiseMz(int games);
+    int simPreStats(unsigned* hits, unsigned* evals);
     bool hasSimKernelMz(int num_simulation = 0) const;
     int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat);
     int shiftExpandAtariFeatures(const uint8_t* d_prev, const uint8_t* d_newest, const uint8_t* d_meta, uint8_t* d_cur, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)
@@ -149,10 +157,14 @@ private:
     void dumpSimProf();
     DevBuf<unsigned> sim_sink_;
     DevBuf<char> sim_cluster_mem_; // cluster mode of the MuZero simulation kernel (sim_cluster.h): per-game exchange blocks
+    DevBuf<int> pre_key_;          // leaves evaluated ahead: keys [games][slots][4], outputs [policy | logit | value | reward], counters
+    DevBuf<float> pre_out_;
+    DevBuf<unsigned> pre_stat_;
     int cu_count_ = 0;
     int sim_cluster_checked_ = 0; // pool size (padded) whose cluster placement has been probed
     bool coop_launch_ = false;
 public:
+    bool sim_rounds_ = false;   // the worker evaluates Gumbel rounds ahead (simPreEvalMz): the cluster kernel then runs every game's 601-bin heads alone
     bool sim_octet_ = true;     // cluster mode: the 601-bin heads of the games that share an XCD are computed together (sim_cluster.h octetHead)
     bool sim_cluster_ = true;   // four workgroups per game when 4 x games <= CUs (muzero_atari instances); false: always one workgroup per game
     bool use_fused_ = true;     // fused persistent tower kernel (same arithmetic as the per-layer kernels)

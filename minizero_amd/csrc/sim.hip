@@ -98,6 +98,11 @@ struct SimArgs {
     int cluster_words, oct_words;
     unsigned* cluster_oct;            // cluster mode: the blocks of the octet-wide 601-bin heads ([8 octets][2 heads][oct_words]); nullptr: per-game heads
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
+    // leaves evaluated AHEAD of their simulations (sim_pre_kernel_mz below): one entry per (game, slot of the simulation) of the current move
+    int* pre_key;                     // [games][slots][4] = {parent's slab slot, action, epoch of the move, -}
+    float *pre_policy, *pre_logit;    // [games][slots][A]
+    float *pre_value, *pre_reward;    // [games][slots], game scale
+    unsigned* pre_stat;               // [0] simulations that found their leaf evaluated, [1] leaves evaluated ahead (tests / monitoring)
 };
 
 // SimArgs never changes during a launch: the device functions read it through the CONSTANT address space, i.e. with scalar loads whose
@@ -550,15 +555,39 @@ __device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_s
 }
 
 __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
-                                         bool gumbel_done = false)
+                                         bool gumbel_done = false, bool noise_done = false)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     slot = __builtin_amdgcn_readfirstlane(slot);
     g = __builtin_amdgcn_readfirstlane(g);
-    if (slot == 1 && a->root_noise) { simApplyRootNoise<2>(a, g, lane); }
+    if (slot == 1 && a->root_noise && !noise_done) { simApplyRootNoise<2>(a, g, lane); }
     if (a->use_gumbel && !gumbel_done) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
     const PoolView pv = ldc(&a->pv);
     selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
+}
+
+// Leaves evaluated ahead (sim_pre_kernel_mz): does the entry of simulation `slot` hold THIS leaf — the same parent hidden state (slab slot `src`) and the
+// same action, written in this move (`epoch`)?  Then its hidden state already lies in slab slot `slot` and its network outputs are copied to the game's
+// arrays (one wave; A <= 64 per pass).  The simulation then runs exactly as if the kernel had evaluated the leaf itself: candidates, expand, backup.
+__device__ __forceinline__ bool simPreProbe(CSimArgs* __restrict__ a, int epoch, int g, int slot, int src, int action, int lane)
+{
+    if (epoch == 0 || !a->pre_key) { return false; }
+    const size_t e = size_t(g) * a->slots + slot;
+    const int* key = a->pre_key + e * 4;
+    const bool hit = __builtin_amdgcn_readfirstlane((key[2] == epoch && key[0] == src && key[1] == action) ? 1 : 0) != 0;
+    if (!hit) { return false; }
+    const int A = a->A;
+    for (int i = lane; i < A; i += 64) {
+        a->policy[size_t(g) * A + i] = a->pre_policy[e * A + i];
+        a->logit[size_t(g) * A + i] = a->pre_logit[e * A + i];
+    }
+    if (lane == 0) {
+        a->value[g] = a->pre_value[e];
+        a->reward[g] = a->pre_reward[e];
+        if (a->pre_stat) { atomicAdd(a->pre_stat, 1u); }
+    }
+    waveSync();
+    return true;
 }
 
 // scale_hidden_state (ref muzero_network.py:81-88) of the tower's output where it lies (padded planes in LDS), in place, and the rescaled state
@@ -621,7 +650,7 @@ __device__ __forceinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, i
 }
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
-__global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start)
+__global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start, int pre_epoch)
 {
     CSimArgs* a = (CSimArgs*)a_;
     extern __shared__ __attribute__((aligned(16))) float tiles[];
@@ -654,11 +683,24 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         // host_start bit 1: the root's network outputs are given (policy / logit / value / reward arrays, hidden state in slab slot 0: the muzero_atari
         // root, whose 96x96 representation runs as stand-alone kernels) — simulation 0 is only its candidate list + expand + backup
         const bool given = slot == 0 && (host_start & 2) != 0;
-        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec); }
+        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, false, (host_start & 4) != 0); }
         __syncthreads();
+        // was this leaf evaluated ahead (sim_pre_kernel_mz)?  Then the tower and the heads are skipped: outputs and hidden state are in place
+        __shared__ int s_pre_hit;
+        bool hit = false;
+        if (pre_epoch != 0 && slot >= 1 && !given) {
+            if (wave == 0) {
+                const int len = v.path_len[g];
+                const int* path = v.path + size_t(g) * v.max_depth;
+                const bool h = simPreProbe(a, pre_epoch, g, slot, v.hslot[size_t(g) * v.cap + path[len - 2]], v.path_action[size_t(g) * v.max_depth + len - 1], lane);
+                if (lane == 0) { s_pre_hit = h ? 1 : 0; }
+            }
+            __syncthreads();
+            hit = s_pre_hit != 0;
+        }
         if (prof) { t1 = wall_clock64(); }
         float* xt = nullptr;
-        if (given) {
+        if (given || hit) {
         } else if (slot == 0) { // initial inference: representation trunk on the root planes (board games; muzero_atari roots never come here)
             xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
         } else { // recurrent inference: dynamics trunk on (parent hidden state, move)
@@ -672,7 +714,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         }
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
-        if (!given) { simMzHeads<H, W>(a, slot, g, tid, tiles, head_scratch, xt); }
+        if (!given && !hit) { simMzHeads<H, W>(a, slot, g, tid, tiles, head_scratch, xt); }
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
         __shared__ int s_cand_k;
@@ -690,15 +732,107 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     }
 }
 
+
+// Root exploration noise as its own launch (the leaves of the first Gumbel round are evaluated ahead of simulation 1 and need the noisy logits;
+// the simulation kernels that follow get bit 2 of host_start: already applied)
+__global__ __launch_bounds__(64) void sim_root_noise_kernel(const SimArgs* __restrict__ a_)
+{
+    CSimArgs* a = (CSimArgs*)a_;
+    if (a->root_noise) { simApplyRootNoise<2>(a, blockIdx.x, threadIdx.x); }
+}
+
+// ---- Leaves of a Gumbel ROUND evaluated side by side (muzero_atari, BASELINE configs[4]) -------------------------------------------------------------
+// With a Gumbel root (ref gumbel_zero.cpp:74-119) the simulations between two halvings visit the sampled root children round-robin — fewest visits first,
+// then the larger logit — so the next R simulations (R = the candidates that still have the minimum visit count) walk down R DIFFERENT root children:
+// their leaves only depend on their own subtrees and on the tree-wide value bounds, which rarely move.  A pool of 64 games has one dependent chain of
+// 13 layers + heads per game and simulation and leaves most of the chip idle; this kernel evaluates, for every game, the leaves those R simulations are
+// EXPECTED to reach (workgroup = (game, r): the Gumbel step on a private copy of the state, the PUCT walk below candidate r with the statistics as they
+// stand, dynamics trunk + heads exactly as sim_kernel_mz computes them) into the slab slot and the output entry of simulation s0 + r, tagged with
+// (parent slot, action, epoch).  Nothing of the search state is touched.  The simulation kernel then runs the R simulations IN ORDER as always — true
+// Gumbel step, true walk, expand, backup — and skips tower + heads whenever its leaf is the tagged one (simPreProbe); a walk that ends elsewhere
+// (the bounds moved, a halving fell differently) just evaluates its leaf itself.  Records cannot change: only WHERE an evaluation ran does.
+#ifndef MZ_PRE_WPE
+#define MZ_PRE_WPE 2 // (4 = two workgroups per CU, 128 VGPRs: measured 211 us per launch on average against 198 us — 50 spilled registers, and both towers want the same MFMA pipes)
+#endif
+template <int H, int W, int CDYN_PAD, int CPAD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MZ_PRE_WPE, 4))) void sim_pre_kernel_mz(const SimArgs* __restrict__ a_, int s0, int R, int epoch)
+{
+    CSimArgs* a = (CSimArgs*)a_;
+    extern __shared__ __attribute__((aligned(16))) float tiles[];
+    const int g = blockIdx.x / R, r = blockIdx.x % R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int CM = CDYN_PAD > CPAD ? CDYN_PAD : CPAD;
+    constexpr int kTileFloats = kTowerTiles * CM * planeStride(H, W);
+    const AtariHeadParams hp = ldc(&a->ahp);
+    const PoolView v = ldc(&a->pv);
+    // LDS: the tower tiles | [0] ok [1] parent slot [2] action [3] start node | Gumbel state copy | the walk's path | the heads' scratch (16-byte aligned)
+    int* ctl = reinterpret_cast<int*>(tiles + kTileFloats);
+    int* st_l = ctl + 4;
+    int* path_l = st_l + 4 + kGumbelMaxSample;
+    float* head_scratch = reinterpret_cast<float*>(ctl + ((4 + 4 + kGumbelMaxSample + 2 * v.max_depth + 2 + 3) & ~3));
+    const int slot = s0 + r;
+    if (wave == 0) {
+        const int stride = 3 + kGumbelMaxSample;
+        for (int i = lane; i < stride; i += 64) { st_l[i] = a->gum.state[size_t(g) * stride + i]; }
+        waveSync();
+        GumbelView gl = ldc(&a->gum);
+        gl.state = st_l - size_t(g) * stride; // the step sorts / halves the COPY
+        (void)gumbelStepBody(v, gl, s0, g, lane, tiles);
+        waveSync();
+        const size_t base = size_t(g) * v.cap;
+        const int fc = v.rec[base].first_child, ncand = st_l[0];
+        bool ok = slot < a->slots && r < ncand && r < kGumbelMaxSample;
+        if (ok) { ok = v.rec[base + fc + st_l[3 + r]].count == v.rec[base + fc + st_l[3]].count; } // still in the round of candidate 0
+        ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
+        if (ok) {
+            if (lane == 0) { ctl[3] = fc + st_l[3 + r]; }
+            waveSync();
+            const PoolView pl = simPathView(v, path_l, g);
+            selectBody<false>(pl, ctl + 3 - g, g, lane, v.rcp_tab);
+            waveSync();
+            const int len = path_l[2 * v.max_depth];
+            if (lane == 0) {
+                ctl[1] = v.hslot[base + path_l[len - 2]];
+                ctl[2] = path_l[v.max_depth + len - 1];
+            }
+        }
+        if (lane == 0) { ctl[0] = ok ? 1 : 0; }
+    }
+    __syncthreads();
+    if (ctl[0] == 0) { return; }
+    const int src = ctl[1], action = ctl[2];
+    __syncthreads(); // (the tower zeroes the tiles: the Gumbel scratch in them is done with)
+    const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(hp.C) * hp.P;
+    float* xt = towerBody<H, W, CDYN_PAD, CPAD, (H * W <= 36)>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action, a->action_planes);
+    __syncthreads();
+    const size_t e = size_t(g) * a->slots + slot;
+    float* hd = a->hidden + e * size_t(hp.C) * hp.P;
+    atariHeadsBody<256>(nullptr, xt, planeStride(H, W), W + 2, hp, a->pre_policy, a->pre_logit, a->pre_value, a->pre_reward, hd, 1, 1, static_cast<int>(e), tid, head_scratch);
+    __syncthreads();
+    if (tid == 0) {
+        int* key = a->pre_key + e * 4;
+        key[0] = src; key[1] = action; key[2] = epoch; key[3] = 0;
+        if (a->pre_stat) { atomicAdd(a->pre_stat + 1, 1u); }
+    }
+}
+
 } // namespace mz
 #include "sim_cluster.h"
 namespace mz {
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
-static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
+static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s, int pre_epoch)
 {
     MZ_LDS_ATTR((sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), lds);
-    hipLaunchKernelGGL((sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), dim3(games), dim3(512), lds, s, d_args, sim0, nsims, host_start);
+    hipLaunchKernelGGL((sim_kernel_mz<H, W, CIN0_PAD, CDYN_PAD, CPAD>), dim3(games), dim3(512), lds, s, d_args, sim0, nsims, host_start, pre_epoch);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
+static int launchSimPreMzT(const SimArgs* d_args, int games, int s0, int R, int epoch, size_t lds, hipStream_t s)
+{
+    MZ_LDS_ATTR((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD>), lds);
+    hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD>), dim3(games * R), dim3(512), lds, s, d_args, s0, R, epoch);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
@@ -918,7 +1052,8 @@ bool Net::hasSimKernelMz(int num_simulation) const
 
 int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                      int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
-                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given)
+                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given,
+                     int pre_epoch, bool noise_applied)
 {
     *launched = false;
     const bool atari = desc_.type == 2;
@@ -959,6 +1094,18 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.use_gumbel = gum ? 1 : 0;
     if (gum) { a.gum = *gum; }
     a.start = d_start;
+    if (atari && gum) { // leaves evaluated ahead of their simulations (sim_pre_kernel_mz): one entry per (game, slot)
+        const size_t ne = size_t(pool.v_.games) * slots, A = size_t(desc_.action_size);
+        if (pre_key_.n != ne * 4) {
+            if (!pre_key_.alloc(ne * 4) || !pre_out_.alloc(ne * (2 * A + 2)) || !pre_stat_.alloc(2)) { setError("hipMalloc of the pre-evaluation entries failed"); return MZ_ERR_DEVICE; }
+            MZ_HIP(hipMemset(pre_key_.p, 0, pre_key_.n * sizeof(int)));
+            MZ_HIP(hipMemset(pre_stat_.p, 0, 2 * sizeof(unsigned)));
+        }
+        a.pre_key = pre_key_.p;
+        a.pre_policy = pre_out_.p; a.pre_logit = pre_out_.p + ne * A;
+        a.pre_value = a.pre_logit + ne * A; a.pre_reward = a.pre_value + ne;
+        a.pre_stat = pre_stat_.p;
+    }
     a.no_spec = getenv("MZ_NO_SPEC") ? atoi(getenv("MZ_NO_SPEC")) : 0;
     if (getenv("MZ_SIM_PROF")) {
         if (sim_prof_.n == 0) {
@@ -992,7 +1139,8 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
         const DiscreteParams &dv = a.ahp.value, &dr = a.ahp.reward;
         const int n1 = std::max(dv.hc, dr.hc) * a.ahp.P, hidm = std::max(dv.hidden, dr.hidden), sizem = std::max(dv.size, dr.size);
         const size_t ow = octetWords(n1, hidm, sizem);
-        const bool octet = sim_octet_ && pool.v_.games >= 64 && size_t(4) * (up4i(n1) + up4i(hidm)) * sizeof(float) <= tile_bytes &&
+        // (leaves evaluated ahead make the games of an octet skip tower + heads independently of each other: every game runs its heads alone then)
+        const bool octet = sim_octet_ && !sim_rounds_ && pool.v_.games >= 64 && size_t(4) * (up4i(n1) + up4i(hidm)) * sizeof(float) <= tile_bytes &&
                            octetHeadFits(dv, a.ahp.P) && octetHeadFits(dr, a.ahp.P);
         const size_t total_words = size_t(pool.v_.games) * words + (octet ? 16 * ow : 0);
         if (!sim_cluster_mem_.ensure(total_words * sizeof(unsigned))) { setError("hipMalloc of the cluster exchange blocks failed"); return MZ_ERR_DEVICE; }
@@ -1012,7 +1160,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     if (cluster && !root_given) { // (a given root is one workgroup per game: the same argument block, no exchange)
 #define MZ_SIM_MZ_CL_LAUNCH(h, w, cin0, cdyn, cpad) \
         if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { \
-            const int rcl = launchSimMzClusterT<h, w, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, host_start ? 1 : 0, lds_cluster, stream_); \
+            const int rcl = launchSimMzClusterT<h, w, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, (host_start ? 1 : 0) | (noise_applied ? 4 : 0), lds_cluster, stream_, pre_epoch); \
             if (rcl <= 0) { *launched = rcl == MZ_OK; return rcl; } \
             sim_cluster_ = false; /* the GPU cannot hold 4 workgroups per game right now: one workgroup per game from here on (same records) */ \
         }
@@ -1020,9 +1168,51 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
 #undef MZ_SIM_MZ_CL_LAUNCH
     }
 #define MZ_SIM_MZ_LAUNCH(h, w, cin0, cdyn, cpad) \
-    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, (host_start ? 1 : 0) | (root_given ? 2 : 0), lds, stream_); }
+    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), pool.v_.games, sim0, nsims, (host_start ? 1 : 0) | (root_given ? 2 : 0) | (noise_applied ? 4 : 0), lds, stream_, pre_epoch); }
     MZ_SIM_MZ_CASES(MZ_SIM_MZ_LAUNCH)
 #undef MZ_SIM_MZ_LAUNCH
+    return MZ_OK;
+}
+
+// the root noise as a launch of its own (before the leaves of the first Gumbel round are evaluated ahead); the argument block is the one the last
+// simLaunchMz uploaded (the root expansion of the move)
+int Net::simRootNoiseMz(int games)
+{
+    if (sim_args_host_.size() != sizeof(SimArgs)) { setError("simRootNoiseMz: no simulation launch has set up the argument block"); return MZ_ERR_STATE; }
+    hipLaunchKernelGGL(sim_root_noise_kernel, dim3(games), dim3(64), 0, stream_, reinterpret_cast<const SimArgs*>(sim_args_.p));
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+// sim_pre_kernel_mz for the R simulations s0 .. s0 + R - 1 of every game (muzero_atari with a Gumbel root); *launched = false: no instance / no entries
+int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched)
+{
+    *launched = false;
+    if (desc_.type != 2 || R < 1 || epoch == 0 || pre_key_.n == 0 || sim_args_host_.size() != sizeof(SimArgs)) { return MZ_OK; }
+    const SimArgs& a = *reinterpret_cast<const SimArgs*>(sim_args_host_.data());
+    if (!a.pre_key || !a.use_gumbel) { return MZ_OK; }
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+    TowerArgs t2;
+    int cd = 0;
+    if (!makeTowerArgs(dyn_, false, true, &t2, &cd)) { return MZ_OK; }
+    const int c0 = C, cmax = std::max(cd, C);
+    const size_t tile_bytes = size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float);
+    if (gumbelSmemBytes(a.A) > tile_bytes) { return MZ_OK; }
+    const size_t ctl_words = (4 + 4 + kGumbelMaxSample + 2 * size_t(max_depth) + 2 + 3) & ~size_t(3);
+    const size_t lds = tile_bytes + ctl_words * sizeof(int) + atariHeadsSmemFloats(a.ahp) * sizeof(float);
+    if (lds > 160 * 1024) { return MZ_OK; }
+#define MZ_SIM_PRE_LAUNCH(h, w, cin0, cdyn, cpad) \
+    if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimPreMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), games, s0, R, epoch, lds, stream_); }
+    MZ_SIM_MZ_CLUSTER_CASES(MZ_SIM_PRE_LAUNCH)
+#undef MZ_SIM_PRE_LAUNCH
+    return MZ_OK;
+}
+
+int Net::simPreStats(unsigned* hits, unsigned* evals)
+{
+    unsigned h[2] = {0, 0};
+    if (pre_stat_.n >= 2) { MZ_HIP(hipMemcpy(h, pre_stat_.p, sizeof(h), hipMemcpyDeviceToHost)); }
+    *hits = h[0]; *evals = h[1];
     return MZ_OK;
 }
 

@@ -412,7 +412,7 @@ __device__ __forceinline__ void clusterAtariHeads(const float* __restrict__ xlds
 
 // grid = 4 * gpad workgroups (cooperative launch: all of them resident), workgroup id = member * gpad + game, gpad a multiple of 8
 template <int H, int W, int CDYN_PAD, int CPAD>
-__global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start, int games, int gpad)
+__global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start, int games, int gpad, int pre_epoch)
 {
     CSimArgs* a = (CSimArgs*)a_;
     extern __shared__ __attribute__((aligned(16))) float tiles[];
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
     if (g >= games) { return; }
     constexpr int CM = CDYN_PAD > CPAD ? CDYN_PAD : CPAD;
     constexpr int kTileFloats = kTowerTiles * CM * planeStride(H, W);
-    __shared__ int s_abort, s_cmd[4], s_cand_k;
+    __shared__ int s_abort, s_cmd[4], s_cand_k; // s_cmd: parent slot, action, leaf evaluated ahead (simPreProbe)
     double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
     const int rcp_n = a->rcp_n;
     const int tab_n = rcp_n - 2;
@@ -477,19 +477,22 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (prof) { t0 = wall_clock64(); }
         if (member == 0) {
-            if (wave == 0) { simMzSelect(a, slot, s == 0 && host_start != 0, g, lane, tiles, rcp_lds, spec, gumbel_ahead); }
+            if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, gumbel_ahead, (host_start & 4) != 0); }
             __syncthreads();
             MZ_HPROF(14);
-            {
-                if (tid == 0) {
-                    const int len = v.path_len[g];
-                    const int* path = v.path + size_t(g) * v.max_depth;
+            if (wave == 0) {
+                const int len = v.path_len[g];
+                const int* path = v.path + size_t(g) * v.max_depth;
+                const int src = v.hslot[size_t(g) * v.cap + path[len - 2]], action = v.path_action[size_t(g) * v.max_depth + len - 1];
+                // a leaf that was evaluated ahead (sim_pre_kernel_mz): its outputs are copied in, the whole cluster skips tower + heads
+                const bool hit = simPreProbe(a, pre_epoch, g, slot, src, action, lane);
+                if (lane == 0) {
                     clu4 cmd;
-                    cmd.x = unsigned(v.hslot[size_t(g) * v.cap + path[len - 2]]);
-                    cmd.y = unsigned(v.path_action[size_t(g) * v.max_depth + len - 1]);
-                    cmd.z = 0;
+                    cmd.x = unsigned(src);
+                    cmd.y = unsigned(action);
+                    cmd.z = hit ? 1u : 0u;
                     cmd.w = seq;
-                    s_cmd[0] = int(cmd.x); s_cmd[1] = int(cmd.y);
+                    s_cmd[0] = int(cmd.x); s_cmd[1] = int(cmd.y); s_cmd[2] = int(cmd.z);
                     asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(c.cm + kClCmd), "v"(cmd) : "memory");
                 }
             }
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
                 if (!ok) { __builtin_amdgcn_s_sleep(1); }
             }
             if (!ok) { s_abort = 1; atomicExch(a->err, 92); }
-            s_cmd[0] = int(cmd.x); s_cmd[1] = int(cmd.y);
+            s_cmd[0] = int(cmd.x); s_cmd[1] = int(cmd.y); s_cmd[2] = int(cmd.z);
         }
         __syncthreads();
         if (s_abort) { return; }
@@ -511,16 +514,18 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         if ((a->no_spec & 4) && g == 0 && member == 1 && s == 2) { return; }
         if (prof) { t1 = wall_clock64(); }
         const int src = s_cmd[0], action = s_cmd[1];
-        const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;
-        float* xt = towerBodyCluster<H, W, CDYN_PAD, CPAD>(a->params, *(const TowerArgs*)&a->ta_dyn, tid, tiles, hsrc, action, a->action_planes, c);
-        if (!xt) { return; }
-        if (prof) { t2 = wall_clock64(); }
-        {
+        const bool hit = s_cmd[2] != 0;
+        if (hit && member != 0) { continue; } // (every member of the game sees the same flag: the exchanges stay in step)
+        if (!hit) {
+            const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;
+            float* xt = towerBodyCluster<H, W, CDYN_PAD, CPAD>(a->params, *(const TowerArgs*)&a->ta_dyn, tid, tiles, hsrc, action, a->action_planes, c);
+            if (!xt) { return; }
+            if (prof) { t2 = wall_clock64(); }
             const AtariHeadParams hp = ldc(&a->ahp);
             float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
             clusterAtariHeads(xt, planeStride(H, W), W + 2, hp, a->policy, a->logit, hd, g, tid, head_scratch, c, seq, tiles);
             if (s_abort) { return; }
-        }
+        } else if (prof) { t2 = t1; }
         if (member != 0) { __syncthreads(); continue; }
         // The candidate list and the new children only need the policy, which this workgroup has just computed: they are built while the value and reward
         // heads of the game's other workgroups are still at work (their 601-bin heads take three times as long as the policy head); the backup follows
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
             // ... and so is the next simulation's Gumbel step (which candidate it starts from): the backup to come only adds a visit to the child on this path
             gumbel_ahead = a->use_gumbel && s + 1 < nsims && simGumbelAhead(a, slot + 1, g, lane, tiles);
         }
-        if (tid == 64) { // value and reward from the helpers (wave 1 polls while wave 0 writes the children)
+        if (tid == 64 && !hit) { // value and reward from the helpers (wave 1 polls while wave 0 writes the children)
             bool ok = false;
             clu4 r;
             for (int i = 0; i < kClPollLimit && !ok; ++i) {
@@ -589,11 +594,11 @@ static bool clusterPlacementOk(int gpad, hipStream_t s)
 }
 
 template <int H, int W, int CDYN_PAD, int CPAD>
-static int launchSimMzClusterT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
+static int launchSimMzClusterT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s, int pre_epoch)
 {
     MZ_LDS_ATTR((sim_kernel_mz_cluster<H, W, CDYN_PAD, CPAD>), lds);
     int gpad = (games + 7) / 8 * 8;
-    void* params[] = {(void*)&d_args, (void*)&sim0, (void*)&nsims, (void*)&host_start, (void*)&games, (void*)&gpad};
+    void* params[] = {(void*)&d_args, (void*)&sim0, (void*)&nsims, (void*)&host_start, (void*)&games, (void*)&gpad, (void*)&pre_epoch};
     // all 4 * gpad workgroups must be resident at once (they wait for each other): a cooperative launch guarantees it or fails
     const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<void*>(sim_kernel_mz_cluster<H, W, CDYN_PAD, CPAD>), dim3(kClMembers * gpad), dim3(512), params,
                                                     static_cast<unsigned>(lds), s);

@@ -15,6 +15,21 @@
 
 namespace mz {
 
+// Up to _S_threshold = 16 elements std::sort is __insertion_sort alone (bits/stl_algo.h __final_insertion_sort), a STABLE sort: element i ends up behind
+// the elements that come before it under comp and behind the equivalent ones it followed.  That position can be counted for every element independently —
+// what the device's wave-parallel sorts of <= 16 Gumbel candidates do (gumbel_body.h sortSmallStable); checked against the real std::sort by
+// tests/test_sort_emul.py.
+constexpr int kStdSortInsertionOnly = 16;
+template <class T, class Comp>
+MZ_HD int stableRankOf(const T* a, int n, int i, Comp comp)
+{
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        if (j != i) { rank += (j < i ? !comp(a[i], a[j]) : comp(a[j], a[i])) ? 1 : 0; }
+    }
+    return rank;
+}
+
 // A = random-access "array view" with T get(i) / void set(i, T) is overkill here: the candidates are a plain struct array.
 template <class T, class Comp>
 struct StdSortEmul {

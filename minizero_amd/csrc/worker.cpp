@@ -305,6 +305,17 @@ public:
     int envResetSeed(int g, int seed);
     int envRotateAction(int g, int action_id, int rotation) const;
     mz_worker_stats stats_{};
+    int getStats(mz_worker_stats* out)
+    {
+        *out = stats_;
+        for (auto& L : lanes_) {
+            unsigned hits = 0, evals = 0;
+            int rc = L->net->simPreStats(&hits, &evals);
+            if (rc) { return rc; }
+            out->pre_hits += hits; out->pre_evals += evals;
+        }
+        return MZ_OK;
+    }
     Net& net0() { return *lanes_[0]->net; }
 
 private:
@@ -346,7 +357,8 @@ private:
         PinBuf<float> h_noise;   // Dirichlet noise of the root children drawn ahead of the launch [game][A]
         DevBuf<float> d_noise;
         // GPU time of the simulation-kernel launches (stats: ms_forward): one pair of events per part of a move's launch (runCyclesSim)
-        static constexpr int kSimParts = 3;
+        static constexpr int kSimParts = 24; // (a Gumbel-round move of muzero_atari: one part per round that is evaluated ahead + the stretches between)
+        int pre_epoch = 0;        // serial number of the current move's pre-evaluated leaves (mz_sim_rounds), 0: none
         hipEvent_t ev0[kSimParts] = {}, ev1[kSimParts] = {};
         hipStream_t up_stream = nullptr; // uploads of the draws for a later part while an earlier part runs on `stream`
         hipEvent_t ev_up = nullptr;
@@ -438,6 +450,9 @@ private:
     bool root_host_pending_ = false; // ... whose outputs the next phase1 still has to turn into the root's children (host candidate lists)
     int syncGumbel(Lane& L, bool to_device);
     bool sim_mz_ = false;     // MuZero board game on sim_kernel_mz (no device rules needed: the leaves have no environment)
+    struct Round { int s0, R; };
+    std::vector<Round> rounds_; // mz_sim_rounds: the rounds of a move whose leaves are evaluated ahead (first simulation, size), from the Gumbel schedule of (n, m)
+    void planRounds();
     bool shared_net_ = false; // the network belongs to the caller (mz_worker_create_shared): load_model only renames, the caller reloads
     bool sim_kernel_ = false; // ... and whole runs of cycles are ONE launch of the per-game simulation kernel (sim.hip)
 };
@@ -568,6 +583,17 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         defer_info_ = !cfg_.mz_manual_step;
         sim_root_host_ = desc.type == 2;
         { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
+        if (dev_gumbel_ && desc.type == 2 && cfg_.mz_sim_rounds && cfg_.mz_sim_split) {
+            planRounds();
+            int covered = 0;
+            for (const Round& rd : rounds_) { covered += rd.R; }
+            for (auto& L : lanes_) {
+                L->net->sim_rounds_ = !rounds_.empty();
+                // every simulation of a move has its leaf evaluated ahead: what is left for the simulation kernel is the tree work of one wave per game, which one
+                // workgroup per game does with less overhead than a cluster of four (no command / result exchange, no cooperative launch): 616 -> 656 k leaf-evals/s
+                if (covered == n_) { L->net->sim_cluster_ = false; }
+            }
+        }
         const int fw = sim_root_host_ ? 1 : games_[0].env->featureWords(), LW = (A_ + 63) / 64;
         for (auto& L : lanes_) {
             if (!L->h_rootfeat.alloc(size_t(L->n) * fw) || !L->d_rootfeat.alloc(size_t(L->n) * fw) || !L->h_rootlegal.alloc(size_t(L->n) * LW) ||
@@ -583,6 +609,44 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         }
     }
     return MZ_OK;
+}
+
+// The visiting order of a Gumbel root is a function of the visit COUNTS alone (ref gumbel_zero.cpp:74-119: fewest visits first, halving when every candidate has
+// reached the budget): with m sampled children the simulations of a move fall into rounds in which every remaining candidate is visited once — m, m/2, ... —
+// e.g. n = 50, m = 16: 16, 8, 4, 4, 4, 2 x 7.  The rounds of >= kMinRound simulations are evaluated ahead (sim.hip sim_pre_kernel_mz); a root with fewer than m
+// children follows another schedule: its entries simply do not match and its simulations evaluate their own leaves.
+void Worker::planRounds()
+{
+    rounds_.clear();
+    const int kMinRound = std::max(1, cfg_.mz_sim_round_min);
+    const int n = cfg_.actor_num_simulation, m = cfg_.actor_gumbel_sample_size;
+    if (m < 2 || m > kGumbelMaxSample || A_ < m) { return; }
+    std::vector<int> cnt(m, 0);
+    int ncand = m, sample = m;
+    int budget = static_cast<int>(std::max(1.0, std::floor(n / (std::log2(m) * m))));
+    int s = 1;
+    while (s <= n) {
+        if (s > 1) { // the step before simulation s (gumbel_zero.cpp:104-118)
+            bool all = true;
+            for (int i = 0; i < ncand; ++i) { if (cnt[i] < budget) { all = false; break; } }
+            if (all) {
+                const int next_budget = static_cast<int>(std::floor(n / (std::log2(m) * sample / 2)));
+                if (next_budget > 0 && sample > 2) {
+                    sample /= 2;
+                    if (ncand > sample) { ncand = sample; } // (which ones survive does not matter here: their counts are equal)
+                    budget = cnt[0] + next_budget;
+                }
+            }
+        }
+        // a round: every candidate with the minimum count once
+        int mn = cnt[0];
+        for (int i = 1; i < ncand; ++i) { mn = std::min(mn, cnt[i]); }
+        int R = 0;
+        for (int i = 0; i < ncand; ++i) { if (cnt[i] == mn) { ++cnt[i]; ++R; } }
+        R = std::min(R, n - s + 1);
+        if (R >= kMinRound) { rounds_.push_back({s, R}); }
+        s += R;
+    }
 }
 
 int Worker::setupDeviceGumbel() // the constants of the device-side Gumbel step + its per-lane state buffers
@@ -1519,13 +1583,31 @@ int Worker::runCyclesSim(int n)
         // simulation, 102 400 per move on BASELINE configs[1]) are made while the second part runs.  Same draws in the same order: nothing a record
         // could show.  The parts are queued back to back on the lane's stream; the draws of a later part travel on a second stream.
         const bool az_draws = desc_.type == 0 && cfg_.actor_use_random_rotation_features;
-        int cuts[Lane::kSimParts + 1] = {0, batch, batch, batch}, parts = 1;
+        int cuts[Lane::kSimParts + 1], pre_R[Lane::kSimParts] = {0}, parts = 1;
+        for (int k = 0; k <= Lane::kSimParts; ++k) { cuts[k] = k == 0 ? 0 : batch; }
         if (cfg_.mz_sim_split && sim0 == 0 && batch > 1 && (noise_in_batch || az_draws)) {
             constexpr int kSecond = 16; // simulations of the middle part: 3 ms on BASELINE configs[1], three times what the draws of the rest take on this host
             cuts[parts++] = 1;
             static const long min_draws = getenv("MZ_SIM_SPLIT_MIN_DRAWS") ? atol(getenv("MZ_SIM_SPLIT_MIN_DRAWS")) : 32768; // (tests: 0 = three parts on small pools too)
             if (az_draws && batch > 1 + kSecond && long(batch - 1 - kSecond) * G_ >= min_draws) { cuts[parts++] = 1 + kSecond; }
             cuts[parts] = batch;
+        }
+        // Gumbel rounds (mz_sim_rounds, muzero_atari): the launch is cut at the rounds whose leaves are evaluated ahead — [evaluation of the round's leaves]
+        // [its simulations, which consume them in order] — with the stretches between them as ordinary parts; all queued back to back, no host step between
+        const bool use_rounds = root_on_device && !rounds_.empty() && sim0 == 1;
+        if (use_rounds) {
+            parts = 0;
+            int at = 0; // offset inside the batch
+            for (const Round& rd : rounds_) {
+                const int o = rd.s0 - sim0;
+                if (o < at || o + rd.R > batch || parts + 2 > Lane::kSimParts) { continue; }
+                if (o > at) { cuts[parts] = at; pre_R[parts] = 0; ++parts; }
+                cuts[parts] = o; pre_R[parts] = rd.R; ++parts;
+                at = o + rd.R;
+            }
+            if (at < batch || parts == 0) { cuts[parts] = at; pre_R[parts] = 0; ++parts; }
+            cuts[parts] = batch;
+            for (auto& L : lanes_) { L->pre_epoch = L->pre_epoch == 0x7fffffff ? 1 : L->pre_epoch + 1; }
         }
         int drawn = 1; // rows of the rotation table (= cycles of the batch) whose draws are made
         for (int part = 0; part < parts; ++part) {
@@ -1534,9 +1616,10 @@ int Worker::runCyclesSim(int n)
             for (auto& L : lanes_) {
                 // the first part's uploads go in front of its kernel on the lane's stream (nothing is running); later ones overlap the running part
                 hipStream_t us = part == 0 ? L->stream : L->up_stream;
-                if (desc_.type == 0 || part == 0) { MZ_HIP(hipMemcpyAsync(L->d_rot.p + size_t(c0) * L->n, L->h_rot.p + size_t(c0) * L->n, size_t(c1 - c0) * L->n, hipMemcpyHostToDevice, us)); }
-                if (noise_in_batch && (root_on_device ? part == 0 : (c0 <= 1 && 1 < c1))) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, us)); }
-                if (part > 0) {
+                bool uploaded = false;
+                if (desc_.type == 0 || part == 0) { MZ_HIP(hipMemcpyAsync(L->d_rot.p + size_t(c0) * L->n, L->h_rot.p + size_t(c0) * L->n, size_t(c1 - c0) * L->n, hipMemcpyHostToDevice, us)); uploaded = true; }
+                if (noise_in_batch && (root_on_device ? part == 0 : (c0 <= 1 && 1 < c1))) { MZ_HIP(hipMemcpyAsync(L->d_noise.p, L->h_noise.p, size_t(L->n) * A_ * sizeof(float), hipMemcpyHostToDevice, us)); uploaded = true; }
+                if (part > 0 && uploaded) {
                     MZ_HIP(hipEventRecord(L->ev_up, us));
                     MZ_HIP(hipStreamWaitEvent(L->stream, L->ev_up, 0));
                 }
@@ -1546,10 +1629,20 @@ int Worker::runCyclesSim(int n)
                 gv.state = L->d_gum.p;
                 const int noise_kind = cfg_.actor_use_dirichlet_noise ? 1 : 2;
                 const bool hg = host_gumbel && part == 0 && !root_on_device;
+                if (use_rounds) {
+                    // the first round needs the noisy logits before simulation 1 runs: the noise goes out as a launch of its own
+                    if (part == 0 && noise_in_batch) { int rcn = L->net->simRootNoiseMz(L->n); if (rcn) { return rcn; } }
+                    if (pre_R[part] > 0) {
+                        bool pre = false;
+                        int rcp = L->net->simPreEvalMz(L->n, L->pool.v_.max_depth, sim0 + c0, pre_R[part], L->pre_epoch, &pre);
+                        if (rcp) { return rcp; }
+                        if (pre) { ++stats_.sim_launches; }
+                    }
+                }
                 int rc = sim_mz_ ? L->net->simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
                                                       games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_reward.p, sim0 + c0, c1 - c0,
                                                       &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
-                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg)
+                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg, false, use_rounds ? L->pre_epoch : 0, use_rounds && noise_in_batch)
                                   : L->net->simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p + size_t(c0) * L->n, sim0 + c0, c1 - c0,
                                                      &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg);
@@ -1836,7 +1929,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
         MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
-        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
         // the Atari-shaped environments keep a window of screens sized from these three at creation (ref atari.cpp:87); records of a larger window
         // would miss frames, so they are fixed where observations are kept (board games: free to change, like the reference)
         if (games_[0].env->hasObservations()) { MZ_FIXED(zero_actor_intermediate_sequence_length) MZ_FIXED(learner_n_step_return) MZ_FIXED(learner_muzero_unrolling_step) }
@@ -1987,8 +2080,7 @@ int mz_worker_env_rotate_action(const mz_worker* w, int game, int action_id, int
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out)
 {
     if (!w || !out) { return MZ_ERR_ARG; }
-    *out = w->w.stats_;
-    return MZ_OK;
+    return w->w.getStats(out);
 }
 mz_net* mz_worker_net(mz_worker* w) { return w ? reinterpret_cast<mz_net*>(&w->w.net0()) : nullptr; }
 

@@ -39,6 +39,31 @@ int main()
             if (r2[i].action != m2[i].action) { printf("FAIL heap iter=%d n=%d at %d\n", iter, n, i); return 1; }
         }
     }
-    printf("OK %ld cases (%ld with ties)\n", cases, tie_cases);
+    // <= 16 elements: std::sort is the stable insertion sort, whose result the rank count of stableRankOf gives (the wave-parallel Gumbel sorts);
+    // the Gumbel comparators' shape: a primary key with many ties and a secondary key, as indices into key arrays
+    long small = 0;
+    for (int iter = 0; iter < 40000; ++iter) {
+        const int n = 1 + gen() % mz::kStdSortInsertionOnly;
+        const int levels = 1 + gen() % 4;
+        float cnt[16], lg[16];
+        for (int i = 0; i < 16; ++i) { cnt[i] = static_cast<float>(gen() % levels); lg[i] = static_cast<float>(gen() % 3); }
+        std::vector<int> ids(n);
+        for (int i = 0; i < n; ++i) { ids[i] = static_cast<int>(gen() % 16); } // (duplicates on purpose: equivalent elements that are not identical positions)
+        auto byCount = [&](int l, int r) { return cnt[l] < cnt[r] || (cnt[l] == cnt[r] && lg[l] > lg[r]); };
+        std::vector<int> ref = ids, mine(n);
+        // tag every element with its original position so that the permutation (not just the keys) is compared
+        std::vector<std::pair<int, int>> tagged(n), tref;
+        for (int i = 0; i < n; ++i) { tagged[i] = {ids[i], i}; }
+        tref = tagged;
+        auto byCountT = [&](const std::pair<int, int>& l, const std::pair<int, int>& r) { return byCount(l.first, r.first); };
+        std::sort(tref.begin(), tref.end(), byCountT);
+        std::vector<std::pair<int, int>> tm(n);
+        for (int i = 0; i < n; ++i) { tm[mz::stableRankOf(tagged.data(), n, i, byCountT)] = tagged[i]; }
+        for (int i = 0; i < n; ++i) {
+            if (tm[i] != tref[i]) { printf("FAIL small iter=%d n=%d at %d\n", iter, n, i); return 1; }
+        }
+        ++small;
+    }
+    printf("OK %ld cases (%ld with ties), %ld small stable cases\n", cases, tie_cases, small);
     return 0;
 }

@@ -355,6 +355,36 @@ def test_atari_cluster_pools_are_equivalent(mz, games):
     assert single == cluster
 
 
+@pytest.mark.parametrize("games,extra", [(5, ""), (13, ""), (64, ""), (64, ":mz_sim_cluster=false"), (16, ":mz_sim_round_min=2")])
+def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
+    """mz_sim_rounds (default): the leaves of a whole Gumbel round — the simulations between two halvings visit different root children — are evaluated side
+    by side ahead of the simulations, which then run in order and skip tower + heads when their leaf is the one evaluated for them (sim.hip
+    sim_pre_kernel_mz / simPreProbe).  Only where an evaluation runs changes: the records must be those of mz_sim_rounds=false, on clusters of four
+    workgroups per game and on one workgroup per game, and the counters must show that leaves were evaluated ahead and found."""
+    conf = ATARI_SMALL.replace("zero_num_parallel_games=5", f"zero_num_parallel_games={games}")
+    kw = dict(vh=ATARI_ARGS[10], dv=ATARI_ARGS[11], type_name=ATARI_ARGS[12])
+    d = mz.make_desc(*ATARI_ARGS[:10], **kw)
+
+    def run(more, chunks):
+        wk = mz.Worker(conf + extra + more + ":program_seed=17:nn_file_name=x.pt:zero_num_threads=2", d, mz.generate_weights(d, 4))
+        wk.command("start")
+        for c in chunks:
+            assert wk.run_cycles(c) == c
+        return wk.pop_lines(), wk.peek_records(games), wk.stats()
+
+    moves = 30 if games < 64 else 12
+    off, roff, soff = run(":mz_sim_rounds=false", [9] * moves)
+    on, ron, son = run("", [9] * moves)  # whole moves: every call takes the rounds path
+    assert soff["pre_evals"] == 0 and soff["pre_hits"] == 0
+    assert son["pre_evals"] >= games * 4 * (moves - 1) and 0 < son["pre_hits"] <= son["pre_evals"]
+    # round 1 (the root's children, visited once each) can never miss: at least those hits
+    assert son["pre_hits"] >= games * 4 * (moves - 1)
+    assert on == off and ron == roff and (len(on) >= 5 or games >= 64)
+    # a call that ends inside a move takes the ordinary path for the broken move: same records again
+    mixed, rmixed, _ = run("", [9, 4, 5, 9, 9 * (moves - 3)])
+    assert mixed == off and rmixed == roff
+
+
 def test_go_muzero_gumbel_execution_modes_are_equivalent(mz, oracle):
     """MuZero board game with a Gumbel root: device Gumbel step + noise on the logits inside sim_kernel_mz vs lock-step vs oracle."""
     conf = ("env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=12:zero_num_parallel_games=5:actor_use_dirichlet_noise=false:"

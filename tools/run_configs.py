@@ -64,6 +64,7 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     ach = (conv + heads) * sim_evals / (gpu_ms * 1e-3) / 1e12 if launches else None
     res = {"leaf_evals_per_sec": evals / dt, "ms_per_move": dt / moves * 1e3, "moves_per_sec": (s1["moves"] - s0["moves"]) / dt,
            "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "host_threads": threads if key != "c1" else 1,
+           "leaves_evaluated_ahead": s1.get("pre_evals", 0) - s0.get("pre_evals", 0), "simulations_that_found_their_leaf": s1.get("pre_hits", 0) - s0.get("pre_hits", 0),
            "config": mz.CONFIGS[key],
            "roofline": {"kernel": KERNEL[key], "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": (ach / F32_MFMA_PEAK_TFLOPS) if ach else None, "launches": launches,
