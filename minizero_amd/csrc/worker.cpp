@@ -221,6 +221,77 @@ private:
 
 struct Cand { int action; float policy, logit; };
 
+// One queued stdout line.  An Atari record's OBS tag (gzip + hex of ~6 MB per 200-move sequence: 30 ms of one CPU) is filled in by background threads
+// while the worker goes on playing; the line leaves the queue (mz_worker_pop_line) when it is complete, in the order the games finished.
+struct OutLine {
+    std::string text;
+    std::atomic<int> pending{0}; // 1: the OBS placeholder is still to be replaced
+    std::atomic<int> failed{0};
+};
+
+// Sleeping (not spinning) helper threads for those jobs: every game of a pool reaches its sequence boundary on the same move, i.e. 64 x 30 ms of
+// compression are due at once; done between two moves on all host threads they were 1.1 ms per move averaged over a run with 15 threads and 8.8 ms with
+// one (zero_num_threads=1, the budget of one rank of eight on a 16-CPU quota: C5 0.68 -> 0.24 M leaf-evals/s).  Here they overlap the following moves' kernels.
+class ObsCompressor {
+public:
+    explicit ObsCompressor(int n)
+    {
+        for (int t = 0; t < std::max(1, n); ++t) { threads_.emplace_back([this]() { loop(); }); }
+    }
+    ~ObsCompressor()
+    {
+        { std::lock_guard<std::mutex> l(mu_); quit_ = true; jobs_.clear(); } // (lines nobody popped go with the worker)
+        cv_.notify_all();
+        for (auto& t : threads_) { t.join(); }
+    }
+    void submit(OutLine* line, std::string&& raw, const char* placeholder, size_t placeholder_len)
+    {
+        line->pending.store(1, std::memory_order_relaxed);
+        {
+            // back-pressure: a host that cannot compress as fast as the GPU plays (one helper thread against 64 sequences of 6 MB per 200 moves) must not
+            // pile up raw observations without bound — the worker waits here, and is then exactly as fast as its compressor
+            std::unique_lock<std::mutex> l(mu_);
+            done_cv_.wait(l, [&]() { return jobs_.size() < kMaxQueued; });
+            jobs_.push_back(Job{line, std::move(raw), placeholder, placeholder_len});
+        }
+        cv_.notify_one();
+    }
+    void wait(const OutLine* line) // until the line is complete
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        done_cv_.wait(l, [&]() { return line->pending.load(std::memory_order_acquire) == 0; });
+    }
+
+private:
+    struct Job { OutLine* line; std::string raw; const char* ph; size_t ph_len; };
+    static constexpr size_t kMaxQueued = 192;
+    void loop()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [&]() { return quit_ || !jobs_.empty(); });
+                if (quit_) { return; }
+                j = std::move(jobs_.front());
+                jobs_.pop_front();
+            }
+            std::string hex;
+            const bool ok = compressToHex(reinterpret_cast<const uint8_t*>(j.raw.data()), j.raw.size(), &hex);
+            const size_t at = ok ? j.line->text.find(j.ph) : std::string::npos;
+            if (at == std::string::npos) { j.line->failed.store(1); }
+            else { j.line->text.replace(at, j.ph_len, hex); }
+            { std::lock_guard<std::mutex> l(mu_); j.line->pending.store(0, std::memory_order_release); }
+            done_cv_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::deque<Job> jobs_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    bool quit_ = false;
+};
+
 using ActionInfo = std::vector<std::pair<std::string, std::string>>;
 
 struct Game {
@@ -277,6 +348,7 @@ std::string escapeSGF(const std::string& s) // ref base_env.h:303-313
 
 class Worker {
 public:
+    ~Worker() { obs_.reset(); } // the compressor's threads write into queued lines: they end before anything else goes
     // shared != nullptr: the worker runs on the caller's network (BaseActor::setNetwork's shared_ptr, ref zero_actor.cpp:100-112) instead of its own copy
     int init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count, Net* shared = nullptr);
     int command(const std::string& line);
@@ -406,9 +478,7 @@ private:
     std::pair<int, int> trainingDataRange(const Game& gm) const;
     // obs_raw != nullptr: the OBS tag is left as a one-byte placeholder and the observation bytes are returned for finishObservations()
     std::string record(const Game& gm, const ActionInfo& extra, std::string* obs_raw = nullptr) const;
-    struct ObsJob { std::string* line; std::string raw; };
-    std::vector<ObsJob> obs_jobs_; // records waiting for their OBS tag (gzip + hex of megabytes: done on all host threads after the serial section)
-    int finishObservations();
+    std::unique_ptr<ObsCompressor> obs_; // created with the first record that carries observations
     ActionInfo actionInfo(int g, int child_player) const;
 
     WorkerConfig cfg_;
@@ -422,7 +492,7 @@ private:
     bool running_ = false, pending_ = false;
     int sims_done_ = 0; // root visit count of every game (lock-step: identical for all games)
     int sim_pre_ = 0, sim_post_ = 0; // its value before / after the expand+backup of the current cycle
-    std::deque<std::string> lines_;
+    std::deque<std::unique_ptr<OutLine>> lines_;
     std::vector<float> pending_weights_;
     // root statistics mirrors (valid after rootRead)
     std::vector<int> rr_nc_, rr_action_, rr_bsize_;
@@ -1083,23 +1153,6 @@ std::string Worker::record(const Game& gm, const ActionInfo& extra, std::string*
     return oss.str();
 }
 
-int Worker::finishObservations()
-{
-    if (obs_jobs_.empty()) { return MZ_OK; }
-    std::atomic<int> bad{0};
-    threads_->parallelFor(static_cast<int>(obs_jobs_.size()), [this, &bad](int k) {
-        ObsJob& j = obs_jobs_[k];
-        std::string hex;
-        if (!compressToHex(reinterpret_cast<const uint8_t*>(j.raw.data()), j.raw.size(), &hex)) { bad.fetch_add(1); return; }
-        const size_t at = j.line->find(kObsPlaceholder);
-        if (at == std::string::npos) { bad.fetch_add(1); return; }
-        j.line->replace(at, sizeof(kObsPlaceholder) - 1, hex);
-    });
-    obs_jobs_.clear();
-    if (bad.load()) { setError("worker: building the OBS tag of %d record(s) failed", bad.load()); return MZ_ERR_STATE; }
-    return MZ_OK;
-}
-
 std::pair<int, int> Worker::trainingDataRange(const Game& gm) const // ref actor_group.cpp:52-64
 {
     int game_length = static_cast<int>(gm.env->actionIds().size());
@@ -1129,8 +1182,13 @@ void Worker::outputGame(Game& gm) // ref actor_group.cpp:24-50
     if (!is_terminal) {
         for (int i = range.first; i <= range.second; ++i) { gm.action_info_history[i].clear(); gm.action_info_history[i].shrink_to_fit(); }
     }
-    lines_.push_back(oss.str());
-    if (gm.env->hasObservations()) { obs_jobs_.push_back(ObsJob{&lines_.back(), std::move(obs_raw)}); } // deque: references stay valid
+    lines_.push_back(std::make_unique<OutLine>());
+    lines_.back()->text = oss.str();
+    if (gm.env->hasObservations()) {
+        // (helpers: the host threads the configuration grants beyond the caller's, at least one, at most four — they sleep when there is nothing to compress)
+        if (!obs_) { obs_ = std::make_unique<ObsCompressor>(std::min(4, std::max(1, std::min(cfg_.zero_num_threads, usableCpus() - 1) - 1))); }
+        obs_->submit(lines_.back().get(), std::move(obs_raw), kObsPlaceholder, sizeof(kObsPlaceholder) - 1);
+    }
     if (is_terminal) { ++stats_.games; }
 }
 
@@ -1258,10 +1316,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
                 gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
             }
         }
-        const double tobs = nowMs();
-        if ((rc = finishObservations())) { return rc; }
         const double ts = nowMs();
-        trace_.add(10, ts - tobs);
         trace_.add(4, ts - t2);
         if (want_noise) {
             const size_t o = size_t(g0) * A_;
@@ -1709,7 +1764,10 @@ int Worker::runCycles(int n)
 int Worker::popLine(char* buf, int cap)
 {
     if (lines_.empty()) { return 0; }
-    const std::string& s = lines_.front();
+    OutLine& front = *lines_.front();
+    if (front.pending.load(std::memory_order_acquire) != 0 && obs_) { obs_->wait(&front); } // its OBS tag is still being compressed: lines leave in order, complete
+    if (front.failed.load()) { setError("worker: building the OBS tag of a record failed"); return MZ_ERR_STATE; }
+    const std::string& s = front.text;
     const int len = static_cast<int>(s.size());
     if (!buf) { return len; } // size query: the line stays queued
     if (cap <= len) { setError("pop_line: buffer of %d bytes too small for a %d-byte line", cap, len); return MZ_ERR_CAPACITY; }
@@ -1765,7 +1823,7 @@ int Worker::emitGame(int g) // ThreadSharedData::outputGame (ref actor_group.cpp
     if (g < 0 || g >= G_) { setError("emit_game: game %d out of range", g); return MZ_ERR_ARG; }
     flushDeferred();
     outputGame(games_[g]);
-    return finishObservations();
+    return MZ_OK;
 }
 
 int Worker::envQuery(int g, int what, float* out) const
