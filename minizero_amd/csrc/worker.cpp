@@ -429,7 +429,7 @@ private:
         PinBuf<float> h_noise;   // Dirichlet noise of the root children drawn ahead of the launch [game][A]
         DevBuf<float> d_noise;
         // GPU time of the simulation-kernel launches (stats: ms_forward): one pair of events per part of a move's launch (runCyclesSim)
-        static constexpr int kSimParts = 24; // (a Gumbel-round move of muzero_atari: one part per round that is evaluated ahead + the stretches between)
+        static constexpr int kSimParts = 24; // parts a launch can be cut into (a Gumbel-round move of muzero_atari: one part per round that is evaluated ahead + the stretches between)
         int pre_epoch = 0;        // serial number of the current move's pre-evaluated leaves (mz_sim_rounds), 0: none
         hipEvent_t ev0[kSimParts] = {}, ev1[kSimParts] = {};
         hipStream_t up_stream = nullptr; // uploads of the draws for a later part while an earlier part runs on `stream`
@@ -1679,7 +1679,8 @@ int Worker::runCyclesSim(int n)
                     MZ_HIP(hipStreamWaitEvent(L->stream, L->ev_up, 0));
                 }
                 bool launched = false;
-                MZ_HIP(hipEventRecord(L->ev0[part], L->stream));
+                // (one pair of events around all parts: an event between two dependent launches costs ~10 us of idle GPU each time — 12 of them per muzero_atari move)
+                if (part == 0) { MZ_HIP(hipEventRecord(L->ev0[0], L->stream)); }
                 GumbelView gv = gum_;
                 gv.state = L->d_gum.p;
                 const int noise_kind = cfg_.actor_use_dirichlet_noise ? 1 : 2;
@@ -1703,7 +1704,7 @@ int Worker::runCyclesSim(int n)
                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg);
                 if (rc) { return rc; }
                 if (!launched) { const std::string why = mz_last_error(); setError("worker: the simulation kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
-                MZ_HIP(hipEventRecord(L->ev1[part], L->stream));
+                if (part == parts - 1) { MZ_HIP(hipEventRecord(L->ev1[0], L->stream)); }
                 ++stats_.sim_launches;
             }
         }
@@ -1721,11 +1722,7 @@ int Worker::runCyclesSim(int n)
         for (auto& L : lanes_) {
             MZ_HIP(hipStreamSynchronize(L->stream));
             float ms = 0.0f;
-            for (int part = 0; part < parts; ++part) {
-                float msp = 0.0f;
-                MZ_HIP(hipEventElapsedTime(&msp, L->ev0[part], L->ev1[part]));
-                ms += msp;
-            }
+            MZ_HIP(hipEventElapsedTime(&ms, L->ev0[0], L->ev1[0]));
             ms_gpu = std::max(ms_gpu, ms);
         }
         stats_.ms_forward += ms_gpu;

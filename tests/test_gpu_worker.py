@@ -355,7 +355,7 @@ def test_atari_cluster_pools_are_equivalent(mz, games):
     assert single == cluster
 
 
-@pytest.mark.parametrize("games,extra", [(5, ""), (13, ""), (64, ""), (64, ":mz_sim_cluster=false"), (16, ":mz_sim_round_min=2")])
+@pytest.mark.parametrize("games,extra", [(5, ""), (13, ""), (64, ""), (64, ":mz_sim_cluster=false"), (16, ":mz_sim_round_min=4"), (64, ":mz_sim_round_min=4")])
 def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
     """mz_sim_rounds (default): the leaves of a whole Gumbel round — the simulations between two halvings visit different root children — are evaluated side
     by side ahead of the simulations, which then run in order and skip tower + heads when their leaf is the one evaluated for them (sim.hip
