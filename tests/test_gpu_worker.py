@@ -385,6 +385,29 @@ def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
     assert mixed == off and rmixed == roff
 
 
+@pytest.mark.parametrize("m,n", [(16, 50), (12, 50), (6, 33), (5, 20), (3, 7), (2, 9), (18, 40), (16, 16), (8, 100)])
+def test_atari_gumbel_rounds_other_shapes_match_the_oracle(mz, oracle, m, n):
+    """The rounds of other (n, m): m not a power of two (12 -> 6 -> 3: rounds of 12, 6, 3 ...), m = 18 > 16 (every root child sampled; the Gumbel step's
+    sorts then fall back to the one-lane replay of libstdc++'s introsort), n < m (the first round is cut short), n much larger than the schedule's
+    halvings.  Whole moves per call (the rounds path), records against the oracle and the leaves-found counter."""
+    conf = (ATARI_SMALL.replace("actor_num_simulation=8", f"actor_num_simulation={n}").replace("actor_gumbel_sample_size=4", f"actor_gumbel_sample_size={m}")
+            .replace("zero_num_parallel_games=5", "zero_num_parallel_games=6") + ":program_seed=23:nn_file_name=x.pt")
+    kw = dict(vh=ATARI_ARGS[10], dv=ATARI_ARGS[11], type_name=ATARI_ARGS[12])
+    d, od = mz.make_desc(*ATARI_ARGS[:10], **kw), oracle.make_desc(*ATARI_ARGS[:10], **kw)
+    w = mz.generate_weights(d, 5)
+    moves = 9
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles((n + 1) * moves)
+    wk = mz.Worker(conf + ":zero_num_threads=2", d, w)
+    wk.command("start")
+    for _ in range(moves):
+        assert wk.run_cycles(n + 1) == n + 1
+    st = wk.stats()
+    assert wk.pop_lines() == og.lines()
+    assert wk.peek_records(6) == og.peek_records(6)
+    assert st["pre_evals"] > 0 and st["pre_hits"] >= 6 * min(m, n) * (moves - 1)  # at least the first round of every move
+
+
 def test_go_muzero_gumbel_execution_modes_are_equivalent(mz, oracle):
     """MuZero board game with a Gumbel root: device Gumbel step + noise on the logits inside sim_kernel_mz vs lock-step vs oracle."""
     conf = ("env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=12:zero_num_parallel_games=5:actor_use_dirichlet_noise=false:"

@@ -13,9 +13,9 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 O=gpurun_out/refresh
 rm -rf $O; mkdir -p $O
-SHORT="--steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline"
+SHORT="--steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline --other-moves 0"
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-timeout 600 python bench.py --steps 20 --warmup 5 --precision bf16x3 --no-cpu-baseline > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err
+timeout 600 python bench.py --steps 20 --warmup 5 --precision bf16x3 --no-cpu-baseline --other-moves 0 > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py $SHORT > $O/bench_profiled.json 2> $O/stats.err
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
 # FETCH_SIZE takes 3 of the 4 TCC slots and WRITE_SIZE 2: one pass each (MI355X_MICROARCH.md, PMC section)
@@ -36,7 +36,8 @@ def load(d):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for f in glob.glob(f"{O}/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = "sim_kernel" if "sim_kernel" in r["Kernel_Name"] else r["Kernel_Name"].split("(")[0][-40:]
+            # (the simulation kernels of a config: sim_kernel / sim_kernel_mz / sim_kernel_mz_cluster and, with Gumbel rounds, sim_pre_kernel_mz)
+            k = "sim_kernel" if ("sim_kernel" in r["Kernel_Name"] or "sim_pre_kernel" in r["Kernel_Name"]) else r["Kernel_Name"].split("(")[0][-40:]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] in ("FETCH_SIZE", "GRBM_GUI_ACTIVE"): n[k] += 1
     return acc, n
@@ -61,6 +62,17 @@ for k, cyc in MOVES.items():
 PY
 timeout 900 python tools/run_configs.py --out $O/configs.json > $O/configs.log 2>&1
 MZ_SIM_PROF=1 timeout 200 python bench.py $SHORT 2>&1 | grep "sim prof" > $O/sim_prof.txt
+MZ_SIM_PROF=1 timeout 200 python tools/run_configs.py c5 --out $O/tmp.json 2>&1 | grep "sim prof" > $O/sim_prof_c5_rounds.txt
+MZ_SIM_PROF=1 timeout 200 python tools/run_configs.py c5 --conf mz_sim_rounds=false --out $O/tmp.json 2>&1 | grep "sim prof" > $O/sim_prof_c5_no_rounds.txt
+# host budget of one rank of eight on a 16-CPU quota (zero_num_threads=1) against the default, incl. 450-move runs of C5 that cross two sequence boundaries (OBS compression)
+timeout 600 python tools/run_configs.py c2 c3 c4 c5 --threads 1 --out $O/configs_threads1.json > $O/configs_threads1.log 2>&1
+timeout 300 python tools/run_configs.py c5 --moves 450 --threads 1 --out $O/c5_450moves_threads1.json > /dev/null 2>&1
+timeout 300 python tools/run_configs.py c5 --moves 450 --out $O/c5_450moves.json > /dev/null 2>&1
+timeout 300 python tools/run_configs.py c5 --conf mz_sim_rounds=false --out $O/c5_no_rounds.json > /dev/null 2>&1
+# kernel timeline of one C5 move (which launches, how long, the gaps between them)
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_c5 -- python tools/run_configs.py c5 --moves 20 --out $O/tmp.json > /dev/null 2>&1
+python tools/c5_move_timeline.py $(find $O/trace_c5 -name "*kernel_trace.csv" | head -1) > $O/c5_move_timeline.txt 2>&1
+rm -rf $O/trace_c5
 rm -rf $O/stats $O/stats_c* $O/pmc1a $O/pmc1b $O/pmc2 $O/pmcA_* $O/pmcB_* $O/pmcC_* $O/tmp.json
 ls -la $O | head -40; cat $O/pmc_sim.json; for k in c3 c4 c5; do cat $O/pmc_$k.json; done; python tools/kstats.py $O/kernel_stats.csv | head -6
 python - <<'PY'
