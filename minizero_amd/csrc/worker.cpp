@@ -1679,8 +1679,9 @@ int Worker::runCyclesSim(int n)
                     MZ_HIP(hipStreamWaitEvent(L->stream, L->ev_up, 0));
                 }
                 bool launched = false;
-                // (one pair of events around all parts: an event between two dependent launches costs ~10 us of idle GPU each time — 12 of them per muzero_atari move)
-                if (part == 0) { MZ_HIP(hipEventRecord(L->ev0[0], L->stream)); }
+                // Gumbel rounds: ONE pair of events around all parts — they are queued back to back without a host step, and an event between two dependent
+                // launches costs ~10 us of idle GPU (12 of them per muzero_atari move); otherwise one pair per part: the host's draws between two parts are not kernel time
+                if (!use_rounds || part == 0) { MZ_HIP(hipEventRecord(L->ev0[use_rounds ? 0 : part], L->stream)); }
                 GumbelView gv = gum_;
                 gv.state = L->d_gum.p;
                 const int noise_kind = cfg_.actor_use_dirichlet_noise ? 1 : 2;
@@ -1704,7 +1705,7 @@ int Worker::runCyclesSim(int n)
                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg);
                 if (rc) { return rc; }
                 if (!launched) { const std::string why = mz_last_error(); setError("worker: the simulation kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
-                if (part == parts - 1) { MZ_HIP(hipEventRecord(L->ev1[0], L->stream)); }
+                if (!use_rounds || part == parts - 1) { MZ_HIP(hipEventRecord(L->ev1[use_rounds ? 0 : part], L->stream)); }
                 ++stats_.sim_launches;
             }
         }
@@ -1722,7 +1723,11 @@ int Worker::runCyclesSim(int n)
         for (auto& L : lanes_) {
             MZ_HIP(hipStreamSynchronize(L->stream));
             float ms = 0.0f;
-            MZ_HIP(hipEventElapsedTime(&ms, L->ev0[0], L->ev1[0]));
+            for (int part = 0; part < (use_rounds ? 1 : parts); ++part) {
+                float msp = 0.0f;
+                MZ_HIP(hipEventElapsedTime(&msp, L->ev0[part], L->ev1[part]));
+                ms += msp;
+            }
             ms_gpu = std::max(ms_gpu, ms);
         }
         stats_.ms_forward += ms_gpu;
