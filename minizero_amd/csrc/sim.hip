@@ -100,7 +100,8 @@ struct SimArgs {
     unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
     // leaves evaluated AHEAD of their simulations (sim_pre_kernel_mz below): one entry per (game, slot of the simulation) of the current move
     int* pre_key;                     // [games][slots][4] = {parent's slab slot, action, epoch of the move, -}
-    float *pre_policy, *pre_logit;    // [games][slots][A]
+    float *pre_policy, *pre_logit;    // [games][slots][A]: the leaf's children in the reference's sort order (policy descending, zero_actor.cpp:241-243) ...
+    int* pre_action;                  // ... and their actions: the candidate list is built where the leaf was evaluated, not in the in-order part
     float *pre_value, *pre_reward;    // [games][slots], game scale
     unsigned* pre_stat;               // [0] simulations that found their leaf evaluated, [1] leaves evaluated ahead (tests / monitoring)
 };
@@ -499,7 +500,8 @@ __device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, in
 // given: the network outputs of this leaf come from the stand-alone kernels (the muzero_atari root: value / reward still in the transformed scale)
 // part 0: everything; part 1: the candidate list and the new children (needs the policy only); part 2: value / reward + backup (the cluster kernel runs
 // part 1 while the value and reward heads of the game's other workgroups are still busy)
-__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false, int part = 0)
+// presorted: the sorted candidate list already lies in a->cand_action / cand_policy / cand_logit (a leaf that was evaluated ahead, simPreProbe)
+__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false, int part = 0, bool presorted = false)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -508,7 +510,7 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
     part = __builtin_amdgcn_readfirstlane(part);
     const PoolView v = ldc(&a->pv);
     const int A = a->A, len = v.path_len[g], depth = len - 1;
-    if (part != 2) {
+    if (part != 2 && !presorted) {
         Cand* cs = reinterpret_cast<Cand*>(tiles);
         Cand* out = cs + A;
         if (k > 0 && k <= kCandCoopMax && a->cand_coop) {
@@ -575,11 +577,15 @@ __device__ __forceinline__ bool simPreProbe(CSimArgs* __restrict__ a, int epoch,
     const size_t e = size_t(g) * a->slots + slot;
     const int* key = a->pre_key + e * 4;
     const bool hit = __builtin_amdgcn_readfirstlane((key[2] == epoch && key[0] == src && key[1] == action) ? 1 : 0) != 0;
-    if (!hit) { return false; }
+    if (!hit) {
+        if (a->pre_stat && key[2] == epoch && lane == 0 && slot < 126) { atomicAdd(a->pre_stat + 2 + slot, 1u); } // (monitoring: which simulations of a move miss, MZ_SIM_PROF)
+        return false;
+    }
     const int A = a->A;
-    for (int i = lane; i < A; i += 64) {
-        a->policy[size_t(g) * A + i] = a->pre_policy[e * A + i];
-        a->logit[size_t(g) * A + i] = a->pre_logit[e * A + i];
+    for (int i = lane; i < A; i += 64) { // the sorted candidate list of a non-root leaf (all A actions: legality is only known at the root, zero_actor.cpp:238)
+        a->cand_action[size_t(g) * A + i] = a->pre_action[e * A + i];
+        a->cand_policy[size_t(g) * A + i] = a->pre_policy[e * A + i];
+        a->cand_logit[size_t(g) * A + i] = a->pre_logit[e * A + i];
     }
     if (lane == 0) {
         a->value[g] = a->pre_value[e];
@@ -718,12 +724,15 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
         __shared__ int s_cand_k;
-        if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
-        __syncthreads();
-        const int cand_k = s_cand_k;
-        if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
-        __syncthreads();
-        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k, given); }
+        int cand_k = a->A; // a leaf evaluated ahead brings its sorted candidate list along: all A actions (it is never the root)
+        if (!hit) {
+            if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
+            __syncthreads();
+            cand_k = s_cand_k;
+            if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
+            __syncthreads();
+        }
+        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k, given, 0, hit); }
         __syncthreads();
         if (prof && tid == 0 && !given) {
             const unsigned long long t4 = wall_clock64();
@@ -808,6 +817,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MZ_PRE_WPE,
     float* hd = a->hidden + e * size_t(hp.C) * hp.P;
     atariHeadsBody<256>(nullptr, xt, planeStride(H, W), W + 2, hp, a->pre_policy, a->pre_logit, a->pre_value, a->pre_reward, hd, 1, 1, static_cast<int>(e), tid, head_scratch);
     __syncthreads();
+    if (wave == 0) { // the leaf's candidate list in the reference's order (simMzCandGather + orderCandidates of a non-root leaf: all A actions), in place of the raw outputs
+        const int A = a->A;
+        Cand* cs = reinterpret_cast<Cand*>(tiles);
+        Cand* out = cs + A;
+        for (int i = lane; i < A; i += 64) { cs[i] = Cand{i, a->pre_policy[e * A + i], a->pre_logit[e * A + i]}; }
+        waveSync();
+        orderCandidates(cs, out, reinterpret_cast<int*>(out + A), A, lane, a->err);
+        waveSync();
+        for (int i = lane; i < A; i += 64) {
+            a->pre_action[e * A + i] = out[i].action;
+            a->pre_policy[e * A + i] = out[i].policy;
+            a->pre_logit[e * A + i] = out[i].logit;
+        }
+        waveSync();
+    }
     if (tid == 0) {
         int* key = a->pre_key + e * 4;
         key[0] = src; key[1] = action; key[2] = epoch; key[3] = 0;
@@ -1097,13 +1121,14 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     if (atari && gum) { // leaves evaluated ahead of their simulations (sim_pre_kernel_mz): one entry per (game, slot)
         const size_t ne = size_t(pool.v_.games) * slots, A = size_t(desc_.action_size);
         if (pre_key_.n != ne * 4) {
-            if (!pre_key_.alloc(ne * 4) || !pre_out_.alloc(ne * (2 * A + 2)) || !pre_stat_.alloc(2)) { setError("hipMalloc of the pre-evaluation entries failed"); return MZ_ERR_DEVICE; }
+            if (!pre_key_.alloc(ne * 4) || !pre_out_.alloc(ne * (3 * A + 2)) || !pre_stat_.alloc(128)) { setError("hipMalloc of the pre-evaluation entries failed"); return MZ_ERR_DEVICE; }
             MZ_HIP(hipMemset(pre_key_.p, 0, pre_key_.n * sizeof(int)));
-            MZ_HIP(hipMemset(pre_stat_.p, 0, 2 * sizeof(unsigned)));
+            MZ_HIP(hipMemset(pre_stat_.p, 0, 128 * sizeof(unsigned)));
         }
         a.pre_key = pre_key_.p;
         a.pre_policy = pre_out_.p; a.pre_logit = pre_out_.p + ne * A;
         a.pre_value = a.pre_logit + ne * A; a.pre_reward = a.pre_value + ne;
+        a.pre_action = reinterpret_cast<int*>(a.pre_reward + ne);
         a.pre_stat = pre_stat_.p;
     }
     a.no_spec = getenv("MZ_NO_SPEC") ? atoi(getenv("MZ_NO_SPEC")) : 0;
@@ -1210,9 +1235,14 @@ int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* 
 
 int Net::simPreStats(unsigned* hits, unsigned* evals)
 {
-    unsigned h[2] = {0, 0};
-    if (pre_stat_.n >= 2) { MZ_HIP(hipMemcpy(h, pre_stat_.p, sizeof(h), hipMemcpyDeviceToHost)); }
+    unsigned h[128] = {0};
+    if (pre_stat_.n >= 128) { MZ_HIP(hipMemcpy(h, pre_stat_.p, sizeof(h), hipMemcpyDeviceToHost)); }
     *hits = h[0]; *evals = h[1];
+    if (getenv("MZ_SIM_PROF") && h[1]) {
+        fprintf(stderr, "[mz sim prof] leaves evaluated ahead %u, found %u; misses by simulation of the move:", h[1], h[0]);
+        for (int i = 1; i < 126; ++i) { if (h[2 + i]) { fprintf(stderr, " %d:%u", i, h[2 + i]); } }
+        fprintf(stderr, "\n");
+    }
     return MZ_OK;
 }
 

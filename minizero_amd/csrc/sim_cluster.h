@@ -531,15 +531,18 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         // heads of the game's other workgroups are still at work (their 601-bin heads take three times as long as the policy head); the backup follows
         // when their results have arrived.
         MZ_HPROF(10);
-        if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
-        __syncthreads();
-        MZ_HPROF(11);
-        const int cand_k = s_cand_k;
-        if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
-        __syncthreads();
+        int cand_k = a->A; // (a leaf evaluated ahead brings its sorted candidate list along)
+        if (!hit) {
+            if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
+            __syncthreads();
+            MZ_HPROF(11);
+            cand_k = s_cand_k;
+            if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
+            __syncthreads();
+        }
         MZ_HPROF(12);
         if (wave == 0) {
-            simMzCandExpand(a, slot, g, lane, tiles, cand_k, false, 1);
+            simMzCandExpand(a, slot, g, lane, tiles, cand_k, false, 1, hit);
             // ... and so is the next simulation's Gumbel step (which candidate it starts from): the backup to come only adds a visit to the child on this path
             gumbel_ahead = a->use_gumbel && s + 1 < nsims && simGumbelAhead(a, slot + 1, g, lane, tiles);
         }
