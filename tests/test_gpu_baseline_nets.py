@@ -16,14 +16,14 @@ def _games(conf, games):
     return head + f"zero_num_parallel_games={games}" + (":" + tail.split(":", 1)[1] if ":" in tail else "")
 
 
-def _run(mz, oracle, key, games, chunks, extra="", seed=1, wseed=0, threads=2):
+def _run(mz, oracle, key, games, chunks, extra="", seed=1, wseed=0, threads=2, wextra=""):
     d, od = mz.DESCS[key](), getattr(oracle, "desc_" + key)()
     w = mz.generate_weights(d, wseed)
     conf = _games(mz.CONFIGS[key], games) + extra + f":program_seed={seed}:nn_file_name=/tmp/w/baseline_{key}_seed{wseed}.pt"
     total = sum(chunks)
     og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
     og.cycles(total)
-    wk = mz.Worker(conf + f":zero_num_threads={threads}", d, w)
+    wk = mz.Worker(conf + wextra + f":zero_num_threads={threads}", d, w)  # wextra: keys of the worker alone (execution modes)
     wk.command("start")
     for c in chunks:
         assert wk.run_cycles(c) == c
@@ -110,11 +110,20 @@ def test_c4_full_size_256_games_one_move(mz, oracle):
 
 
 @pytest.mark.slow
-def test_c5_full_size_64_games_cluster_octet_heads(mz, oracle):
-    """BASELINE configs[4]'s per-GPU shard at its own size AND on the 6-block x 64-channel muzero_atari network: 64 games = 256 workgroups in
-    clusters of four with the 601-bin heads of the eight games of an XCD computed together (sim_cluster.h octetHead — only pools of full
-    octets take that path), 2 moves + 5 cycles, sequence length as in the config (no line is due yet: records as they stand)."""
-    lines, recs, st = _run(mz, oracle, "c5", 64, [51 + 20, 51 - 20 + 5], threads=max(2, mz.usable_cpus() - 1))
+@pytest.mark.parametrize("mode", ["gumbel_rounds", "cluster_octet_heads"])
+def test_c5_full_size_64_games(mz, oracle, mode):
+    """BASELINE configs[4]'s per-GPU shard at its own size AND on the 6-block x 64-channel muzero_atari network, 2 moves + 5 cycles, sequence length as in
+    the config (no line is due yet: records as they stand), on both shipped paths:
+    gumbel_rounds (default): the leaves of every Gumbel round evaluated ahead (64 x 16 ... 64 x 2 workgroups per launch), consumed in order
+    by one workgroup per game — the first call is a whole move and takes that path, the counters say so;
+    cluster_octet_heads (mz_sim_rounds=false): 64 games = 256 workgroups in clusters of four with the 601-bin heads of the eight games of an
+    XCD computed together (sim_cluster.h octetHead: only pools of full octets take that path)."""
+    rounds = mode == "gumbel_rounds"
+    lines, recs, st = _run(mz, oracle, "c5", 64, [51, 20, 51 - 20 + 5], wextra="" if rounds else ":mz_sim_rounds=false", threads=max(2, mz.usable_cpus() - 1))
+    if rounds:
+        assert st["pre_evals"] >= 64 * 50 and st["pre_hits"] >= 64 * 40  # (the second move is cut by the calls: only its first round is evaluated ahead ... or none)
+    else:
+        assert st["pre_evals"] == 0
     assert st["moves"] == 128
     for r in recs:
         assert r.count(";B[") == 2 and r.count("P[") == 2

@@ -319,9 +319,12 @@ def test_atari_execution_modes_are_equivalent(mz):
     lockstep = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=false", ATARI_ARGS, [total], total)
     sim_whole = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true", ATARI_ARGS, [total], total)
     sim_chunks = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true", ATARI_ARGS, [1, 2, 5, 9, 3, 40, 10, 8], total)
-    # the default is the cluster mode (sim_cluster.h: four workgroups per game, tower split by output-channel tile, one 601-bin head per
-    # workgroup); mz_sim_cluster=false = one workgroup per game
+    # the default evaluates the leaves of whole Gumbel rounds ahead (a call that covers whole moves takes that path, a call that ends inside a
+    # move the ordinary one); mz_sim_rounds=false = the cluster mode (sim_cluster.h: four workgroups per game, tower split by output-channel tile, one
+    # 601-bin head per workgroup); mz_sim_cluster=false = one workgroup per game
     sim_single = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true:mz_sim_cluster=false", ATARI_ARGS, [3, 40, 9], total)
+    sim_cluster = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true:mz_sim_rounds=false", ATARI_ARGS, [1, 2, 5, 9, 3, 40, 10, 8], total)  # four workgroups per game, no rounds
+    assert lockstep == sim_cluster
     # mz_sim_split (default): the root is expanded on the device from the stand-alone kernels' outputs and simulations 1..n follow without a host
     # round trip (device-side Gumbel noise and first halving step); false = the root's candidate list, noise and first Gumbel step on the host
     sim_host_root = _lines_of(mz, ATARI_SMALL + ":mz_sim_kernel=true:mz_sim_split=false", ATARI_ARGS, [total], total)
@@ -349,10 +352,12 @@ def test_atari_cluster_pools_are_equivalent(mz, games):
         return wk.pop_lines()
 
     total = 9 * (40 if games < 64 else 24)
-    single = run(":mz_sim_cluster=false", [total])
-    cluster = run("", [5, 9, 100, total - 114])
+    single = run(":mz_sim_cluster=false:mz_sim_rounds=false", [total])
+    cluster = run(":mz_sim_rounds=false", [5, 9, 100, total - 114])  # (with Gumbel rounds the in-order part runs on one workgroup per game: §3.7)
+    rounds_on_clusters = run(":mz_sim_round_min=4", [total])         # rounds of >= 4 evaluated ahead, the rest on the cluster kernel (which then skips hits)
     assert len(single) >= 20
     assert single == cluster
+    assert single == rounds_on_clusters
 
 
 @pytest.mark.parametrize("games,extra", [(5, ""), (13, ""), (64, ""), (64, ":mz_sim_cluster=false"), (16, ":mz_sim_round_min=4"), (64, ":mz_sim_round_min=4")])
@@ -517,7 +522,8 @@ def test_cluster_member_going_missing_ends_in_an_error_not_a_hang(mz, monkeypatc
     kw = dict(vh=ATARI_ARGS[10], dv=ATARI_ARGS[11], type_name=ATARI_ARGS[12])
     d = mz.make_desc(*ATARI_ARGS[:10], **kw)
     conf = ATARI_SMALL.replace("zero_num_parallel_games=5", f"zero_num_parallel_games={games}")  # 64 games: the heads of an octet wait for each other too
-    wk = mz.Worker(conf + ":program_seed=11:nn_file_name=x.pt:zero_num_threads=2", d, mz.generate_weights(d, 3))
+    # (mz_sim_rounds=false: with the leaves of every Gumbel round evaluated ahead the in-order part runs on one workgroup per game, not on clusters)
+    wk = mz.Worker(conf + ":mz_sim_rounds=false:program_seed=11:nn_file_name=x.pt:zero_num_threads=2", d, mz.generate_weights(d, 3))
     wk.command("start")
     t0 = time.time()
     with pytest.raises(mz.MzError):
@@ -544,8 +550,10 @@ def test_atari_cluster_other_search_settings(mz, variant):
         conf = conf.replace("actor_mcts_value_rescale=true", "actor_mcts_value_rescale=false")
     total = (n + 1) * 50
     lockstep = _lines_of(mz, conf + ":mz_sim_kernel=false", ATARI_ARGS, [total], total)
-    cluster = _lines_of(mz, conf, ATARI_ARGS, [4, n + 1, 100, 7], total)
-    single = _lines_of(mz, conf + ":mz_sim_cluster=false", ATARI_ARGS, [total], total)
+    cluster = _lines_of(mz, conf + ":mz_sim_rounds=false", ATARI_ARGS, [4, n + 1, 100, 7], total)  # (the cluster kernel is what runs without Gumbel rounds)
+    single = _lines_of(mz, conf + ":mz_sim_cluster=false:mz_sim_rounds=false", ATARI_ARGS, [total], total)
+    default = _lines_of(mz, conf, ATARI_ARGS, [n + 1], total)  # whole moves per call: Gumbel variants take the rounds path
     assert len(lockstep) >= 8
     assert lockstep == cluster
     assert lockstep == single
+    assert lockstep == default
