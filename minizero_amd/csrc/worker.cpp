@@ -1797,6 +1797,10 @@ int Worker::actGame(int g, int action_id, int player) // BaseActor::act (ref bas
     if (!gm.env->act(action_id, player)) { return 0; }
     gm.action_info_history.resize(gm.env->actionIds().size());
     gm.action_info_history.back() = search_done_ ? held_[g].info : ActionInfo();
+    // getActionInfo() runs AFTER env_.act() (base_actor.cpp:24-28): P and V are the completed search's, R is the reward of the move just played
+    for (auto& kv : gm.action_info_history.back()) {
+        if (kv.first == "R") { std::ostringstream oss; oss << gm.env->reward(); kv.second = oss.str(); }
+    }
     ++stats_.moves;
     return 1;
 }

@@ -77,8 +77,13 @@ static int runNet(const char* file, const char* out, int B)
 
 // ActorGroup's handleSearchDone (ref actor_group.cpp:116-134) written against the per-actor surface, one actor
 // action id -> the strings BaseActor::act(const std::vector<std::string>&) takes (ref utils/sgf_loader.cpp:101-108 actionIDToBoardCoordinateString)
-static std::vector<std::string> actionStrings(const Action& a, int board_size)
+static std::vector<std::string> actionStrings(const Action& a, int board_size, bool atari)
 {
+    if (atari) { // ALE's action names without their PLAYER_A_ prefix (ref atari.cpp:9-22), mixed case on purpose
+        static const char* const names[18] = {"noop", "Fire", "UP", "right", "LEFT", "down", "upright", "UPLEFT", "downright", "DOWNLEFT", "upfire", "RIGHTFIRE", "leftfire",
+                                              "DOWNFIRE", "uprightfire", "UPLEFTFIRE", "downrightfire", "DOWNLEFTFIRE"};
+        return {std::string(1, env::playerToChar(a.getPlayer())), names[a.getActionID()]};
+    }
     std::string pos = "PASS";
     if (a.getActionID() < board_size * board_size) {
         const int x = a.getActionID() % board_size, y = a.getActionID() / board_size;
@@ -97,6 +102,7 @@ static int runActor(const std::string& conf, int moves, const char* feat_out)
     if (a->createSearch() != nullptr) { return 20; }
     if (net.use_count() < 2) { std::cerr << "setNetwork did not keep the caller's network" << std::endl; return 21; } // shared, not re-read
     const int board = net->getInputChannelHeight();
+    const bool atari = net->getNetworkTypeName() == "muzero_atari";
     std::vector<char> buf(1 << 22);
     for (int m = 0; m < moves; ++m) {
         if (m % 2 == 0) {
@@ -118,7 +124,7 @@ static int runActor(const std::string& conf, int moves, const char* feat_out)
             const Environment& env = static_cast<const actor::BaseActor&>(*a).getEnvironment();
             if (!env.isLegalAction(sa) || env.isLegalAction(Action(sa.getActionID(), sa.getPlayer() == env::Player::kPlayer1 ? env::Player::kPlayer2 : env::Player::kPlayer1))) { return 9; }
             // every third move goes through act(vector<string>) (ref base_actor.cpp:32-40), the others through act(Action)
-            if (m % 3 == 2 ? !a->act(actionStrings(sa, board)) : !a->act(sa)) { return 5; }
+            if (m % 3 == 2 ? !a->act(actionStrings(sa, board, atari)) : !a->act(sa)) { return 5; }
             if (a->act(std::vector<std::string>{"B", "?"})) { return 10; } // not an action: refused like an illegal move, nothing recorded
         }
         if (a->isResign() || a->isEnvTerminal()) {
@@ -150,7 +156,7 @@ static int runActor(const std::string& conf, int moves, const char* feat_out)
         fclose(f);
     }
     std::cerr << env.toString();
-    const env::Player other = env.getTurn() == env::Player::kPlayer1 ? env::Player::kPlayer2 : env::Player::kPlayer1;
+    const env::Player other = atari ? env::Player::kPlayer1 /* one player */ : (env.getTurn() == env::Player::kPlayer1 ? env::Player::kPlayer2 : env::Player::kPlayer1);
     env.setTurn(other);
     if (a->getEnvironment().getTurn() != other) { return 12; }
     env.reset(7); // Environment::reset(seed): a new game without a draw from the actor's generator

@@ -99,6 +99,10 @@ CASES = [
     ("othello gumbel", "env_game=othello:env_board_size=8:actor_num_simulation=16:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
      "actor_use_gumbel_noise=true:actor_gumbel_sample_size=8", ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65, 16, 1, "alphazero"), 130, 2),
     ("go muzero", "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=9", ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "muzero"), 12, 0),
+    # the Atari-shaped game through the per-actor surface: Gumbel rounds in manual stepping (think() = whole moves), act() by action NAME, 601-bin heads, OBS / L tags
+    ("atari gumbel muzero", "env_game=atari:nn_type_name=muzero:actor_num_simulation=8:actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:"
+     "actor_gumbel_sample_size=4:actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:actor_mcts_reward_discount=0.997:atari_init_q=true:"
+     "env_atari_episode_length=14", ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari"), 37, 2),
 ]
 
 
@@ -132,18 +136,24 @@ def test_actor_facade_against_the_oracle(mz, oracle, tmp_path, name, conf, dargs
     assert len(hist) == 1
     # getActionInfoHistory(): exactly the per-move tags of the record, move by move
     assert hist[0][len("HIST"):] == "".join(" ;" + tags for _, _, tags in played)
-    oe = oracle.OracleEnv(conf)
-    for colour, aid, _ in played:
-        assert oe.act(int(aid), 1 if colour == "B" else 2)
     envl = [l for l in out if l.startswith("ENV ")][0]
     kv = dict(t.split("=") for t in envl.split()[1:])
-    board = dargs[2]
-    rot_tab = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_rng_rotation_config.json")))["rotation"][str(board)]
-    assert int(kv["turn"]) == oe.turn() and int(kv["actions"]) == len(played) and int(kv["terminal"]) == int(oe.is_terminal())
-    assert int(kv["rot5"]) == rot_tab[3][5]  # getRotateAction(5, kRotation270): the reference's own table (pinned golden)
-    assert float(kv["reward"]) == oe.reward()
-    legal = [l for l in out if l.startswith("LEGAL")][0].split()[1:]
-    assert [int(a) for a in legal] == [int(a) for a in np.flatnonzero(oe.legal_mask())]
+    legal = [int(a) for a in [l for l in out if l.startswith("LEGAL")][0].split()[1:]]
     got = np.fromfile(feat_file, np.float32)
-    assert np.array_equal(got, oe.features(3).ravel())  # getFeatures(kRotation270)
+    board = dargs[2]
+    if dargs[12] == "muzero_atari":  # (the synthetic screens depend on the game's seed, which only the record carries: shapes and the rule "every action is legal")
+        assert int(kv["turn"]) == 1 and int(kv["actions"]) == len(played) and int(kv["terminal"]) == 0
+        assert int(kv["rot5"]) == 5  # the Atari environment has no rotations (ref atari.h:77-78)
+        assert legal == list(range(18)) and got.size == 32 * 96 * 96 and float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+        assert "OBS[1f8b08" in lines[0] and "SD[" in lines[0]  # finished episodes carry their observations (gzip member as hex) and their seed
+    else:
+        oe = oracle.OracleEnv(conf)
+        for colour, aid, _ in played:
+            assert oe.act(int(aid), 1 if colour == "B" else 2)
+        assert int(kv["turn"]) == oe.turn() and int(kv["actions"]) == len(played) and int(kv["terminal"]) == int(oe.is_terminal())
+        rot_tab = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_rng_rotation_config.json")))["rotation"][str(board)]
+        assert int(kv["rot5"]) == rot_tab[3][5]  # getRotateAction(5, kRotation270): the reference's own table (pinned golden)
+        assert float(kv["reward"]) == oe.reward()
+        assert legal == [int(a) for a in np.flatnonzero(oe.legal_mask())]
+        assert np.array_equal(got, oe.features(3).ravel())  # getFeatures(kRotation270)
     assert "model file name:" in p.stderr and "move number:" in p.stderr  # getSearchInfo()
