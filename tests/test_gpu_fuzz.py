@@ -55,3 +55,49 @@ def test_random_configuration_matches_oracle(mz, oracle, seed):
     lines, olines = wk.pop_lines(), og.lines()
     assert len(olines) >= 1, conf
     assert lines == olines, conf
+
+
+def _atari_case(seed):
+    rng = np.random.default_rng(7000 + seed)
+    gumbel = bool(rng.random() < 0.75)
+    n = int(rng.choice([4, 8, 13, 24, 50]))
+    m = int(rng.choice([2, 3, 4, 6, 8, 16]))
+    games = int(rng.choice([1, 3, 6, 9]))
+    ep = int(rng.integers(5, 14))
+    seq = int(rng.choice([0, 3, 5]))
+    conf = (f"env_game=atari:nn_type_name=muzero:actor_num_simulation={n}:zero_num_parallel_games={games}:env_atari_episode_length={ep}:"
+            f"actor_use_gumbel={'true' if gumbel else 'false'}:actor_use_gumbel_noise={'true' if gumbel else 'false'}:actor_gumbel_sample_size={m}:"
+            f"actor_use_dirichlet_noise={'false' if gumbel else 'true'}:actor_gumbel_sigma_scale_c={float(rng.choice([0.1, 1.0]))}:"
+            f"actor_mcts_value_rescale={'true' if rng.random() < 0.8 else 'false'}:actor_mcts_reward_discount={float(rng.choice([0.997, 1.0, 0.9]))}:"
+            f"atari_init_q={'true' if rng.random() < 0.8 else 'false'}:zero_actor_intermediate_sequence_length={seq}:learner_n_step_return={int(rng.integers(1, 4))}:"
+            f"learner_muzero_unrolling_step={int(rng.integers(1, 3))}:actor_select_action_by_count={'true' if rng.random() < 0.3 else 'false'}")
+    moves = 2 * ep + 3
+    # calls of whole moves (the Gumbel-round path) mixed with calls that end inside a move (the ordinary path)
+    chunks = [n + 1, n + 1, int(rng.integers(1, n + 1)), 2 * (n + 1), int(rng.integers(1, 3 * (n + 1)))] if rng.random() < 0.6 else [n + 1]
+    return conf, (n + 1) * moves, chunks, games, int(rng.integers(0, 50)), int(rng.integers(1, 1000))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_atari_configuration_matches_oracle(mz, oracle, seed):
+    """The same for the Atari-shaped game on the muzero_atari network (601-bin heads, value rescaling, discount, ATARI init-Q, intermediate sequences with
+    their OBS / L tags): Gumbel roots of random sample sizes take the Gumbel-round path (leaves of a round evaluated ahead) whenever a call covers whole moves."""
+    conf, cycles, chunks, games, wseed, pseed = _atari_case(seed)
+    dargs = ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18)
+    kw = dict(vh=32, dv=601, type_name="muzero_atari")
+    d, od = mz.make_desc(*dargs, **kw), oracle.make_desc(*dargs, **kw)
+    w = mz.generate_weights(d, wseed)
+    conf = f"{conf}:program_seed={pseed}:nn_file_name=/tmp/fuzz_atari_{wseed}.pt"
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles(cycles)
+    wk = mz.Worker(conf + ":zero_num_threads=2", d, w)
+    wk.command("start")
+    done, k = 0, 0
+    while done < cycles:
+        c = min(chunks[k % len(chunks)], cycles - done)
+        assert wk.run_cycles(c) == c
+        done += c
+        k += 1
+    lines, olines = wk.pop_lines(), og.lines()
+    assert len(olines) >= 1, conf
+    assert lines == olines, conf
+    assert wk.peek_records(games) == og.peek_records(games), conf
