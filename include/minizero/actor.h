@@ -10,8 +10,9 @@
 // What differs, and why (INTEGRATION.md §2 lists the same):
 //   * afterNNEvaluation(output) does not consume `output`: the evaluation happens on the device inside the library, one
 //     beforeNNEvaluation / afterNNEvaluation pair still = one simulation; getNNEvaluationBatchIndex() is 0 while one is in flight, -1 otherwise;
-//   * think() runs the whole search as one library call: actor_mcts_think_batch_size, actor_mcts_think_time_limit and the virtual loss of
-//     ZeroActor::step (ref zero_actor.cpp:36-49,128-157) are not honoured — the self-play path (ActorGroup) never uses them;
+//   * think() runs the search as library calls of whole launches: actor_mcts_think_time_limit IS honoured (the clock is looked at every 32 cycles and the
+//     decision is then taken from the simulations run so far, zero_actor.cpp:40-45), actor_mcts_think_batch_size and the virtual loss of ZeroActor::step
+//     (ref zero_actor.cpp:128-157) are not — the self-play path (ActorGroup) never uses them;
 //   * setNetwork(network) runs the actor ON the caller's network (mz_worker_create_shared): no second copy of the weights, a later
 //     network->loadModel(...) is what the next search uses;
 //   * getEnvironment() is an `Environment` over the library's rules engine with the members the actor's callers use (isTerminal, getTurn, setTurn,
@@ -23,6 +24,8 @@
 #pragma once
 #include "mzgpu_config.h"
 #include "network.h"
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -287,7 +290,16 @@ public:
     Action think(bool with_play = false, bool display_board = false) override // ref zero_actor.cpp:36-49
     {
         resetSearch();
-        while (!isSearchDone()) { step(); }
+        // actor_mcts_think_time_limit (seconds; 0 = none): the reference checks the clock after every step() = one batch of simulations; here a step is a chunk of
+        // cycles (one launch), and when the limit breaks the loop the decision is taken from the simulations run so far (zero_actor.cpp:40-45)
+        const std::string lim = config::mzgpuConfValue(config::mzgpuCollectConfiguration(), "actor_mcts_think_time_limit");
+        const double limit_ms = lim.empty() ? 0.0 : std::atof(lim.c_str()) * 1000.0;
+        const auto start = std::chrono::steady_clock::now();
+        while (!isSearchDone()) {
+            if (limit_ms > 0) { check(mz_worker_run_cycles(handle(), kThinkChunk)); } else { step(); }
+            if (limit_ms > 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count() >= limit_ms) { break; }
+        }
+        if (!isSearchDone()) { check(mz_worker_finish_search(handle())); }
         const Action a = getSearchAction();
         if (with_play) { act(a); }
         if (display_board) { std::cerr << env_.toString() << getSearchInfo() << std::endl; }
@@ -349,6 +361,7 @@ protected:
         check(mz_worker_run_cycles(handle(), cyclesPerMove() + 1));
     }
     int cyclesPerMove() const { return mz_worker_cycles_per_move(handle()); }
+    static constexpr int kThinkChunk = 32; // cycles between two looks at the clock when a think-time limit is set (>= 2: the root's expansion precedes any decision)
     uint64_t tree_node_size_;
     int cycles_in_search_ = 0;
     bool fresh_ = false; // the worker has just been created: its game is new

@@ -209,6 +209,9 @@ int mz_worker_search_done(const mz_worker* w);
 int mz_worker_search_action(const mz_worker* w, int game, int* action_id, int* player, int* is_resign);
 int mz_worker_act(mz_worker* w, int game, int action_id, int player);
 int mz_worker_reset_search(mz_worker* w);
+/* ZeroActor::think's early end (ref zero_actor.cpp:40-45: the time limit broke the loop, `if (!isSearchDone()) handleSearchDone()`): the decision from the
+ * simulations run so far; needs the root's expansion (>= 2 cycles of the search).  After it mz_worker_search_done() == 1 and the held action is valid. */
+int mz_worker_finish_search(mz_worker* w);
 int mz_worker_reset_game(mz_worker* w, int game);
 int mz_worker_emit_game(mz_worker* w, int game);
 int mz_worker_env_query(const mz_worker* w, int game, int what, float* out);

@@ -366,6 +366,7 @@ public:
     int searchAction(int g, int* action_id, int* player, int* resign) const;
     int actGame(int g, int action_id, int player);
     int resetSearchAll();
+    int finishSearch();
     int resetGameAt(int g);
     int emitGame(int g);
     int envQuery(int g, int what, float* out) const;
@@ -1817,6 +1818,30 @@ int Worker::resetSearchAll() // ZeroActor::resetSearch (ref zero_actor.cpp:29-34
     return resetAllSearches();
 }
 
+// ZeroActor::think's `if (!isSearchDone()) { handleSearchDone(); }` (ref zero_actor.cpp:40-45): the search stops where it stands — at least the root has to be
+// expanded — and the decision is taken from the simulations run so far (move decision, resign test, P / V strings: exactly what the complete search's last
+// cycle does, with fewer visits).  Per-actor stepping only.
+int Worker::finishSearch()
+{
+    if (!cfg_.mz_manual_step) { setError("finish_search: the worker plays on its own (mz_manual_step=false)"); return MZ_ERR_STATE; }
+    if (search_done_) { return MZ_OK; }
+    if (!pending_ || sims_done_ < 1) { setError("finish_search: the root has not been evaluated yet (run at least two cycles of the search first)"); return MZ_ERR_STATE; }
+    MZ_HIP(hipSetDevice(device_));
+    sim_pre_ = sims_done_;
+    sim_post_ = sims_done_ + 1;
+    const bool host_gumbel = dev_gumbel_;
+    for (auto& L : lanes_) {
+        int rc = MZ_OK;
+        MZ_HIP(hipStreamSynchronize(L->stream));
+        if (host_gumbel && (rc = syncGumbel(*L, false))) { return rc; }
+        if ((rc = phase1(*L, false, true, false))) { return rc; } // done = true: root statistics, decision, held action (manual stepping returns before the next selection)
+    }
+    search_done_ = true;
+    pending_ = false;
+    sims_done_ = 0;
+    return MZ_OK;
+}
+
 int Worker::resetGameAt(int g) // ZeroActor::reset without the search part (ref zero_actor.cpp:23-27, base_actor.cpp:8-13)
 {
     if (g < 0 || g >= G_) { setError("reset_game: game %d out of range", g); return MZ_ERR_ARG; }
@@ -2090,6 +2115,11 @@ int mz_worker_reset_search(mz_worker* w)
 {
     if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
     return w->w.resetSearchAll();
+}
+int mz_worker_finish_search(mz_worker* w)
+{
+    if (!w) { mz::setError("NULL worker"); return MZ_ERR_ARG; }
+    return w->w.finishSearch();
 }
 int mz_worker_reset_game(mz_worker* w, int game)
 {

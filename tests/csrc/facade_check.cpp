@@ -1,6 +1,7 @@
 // Test driver of the C++ facades (include/minizero/{network,actor,actor_group}.h): built by __graft_entry__.build() into tests/_bin/,
 // run on the GPU by tests/test_gpu_facade.py, which compares what it prints / writes with the ctypes path and with the oracle.
 //   facade_check net <weight file> <out.bin> <batch>     createNetwork -> pushBack* -> forward / initialInference / recurrentInference
+//   facade_check think <conf> <moves>                    think() under actor_mcts_think_time_limit: RECORD line
 //   facade_check actor <conf> <moves> [features.bin]     createNetwork + createActor + think()/act() loop, SelfPlay lines on stdout; every member of
 //                                                         BaseActor / Environment the facade declares is called at least once (HIST / ENV / LEGAL lines)
 #include "minizero/actor.h"
@@ -168,8 +169,26 @@ static int runActor(const std::string& conf, int moves, const char* feat_out)
     return 0;
 }
 
+// think() under actor_mcts_think_time_limit (ref zero_actor.cpp:36-49): every move is decided when the clock says so, from the simulations run until then
+static int runThink(const std::string& conf, int moves)
+{
+    config::mzgpuConfigurationString() = conf;
+    std::shared_ptr<network::Network> net = network::createNetwork(config::mzgpuConfValue(conf, "nn_file_name"), 0);
+    const int n = std::stoi(config::mzgpuConfValue(conf, "actor_num_simulation"));
+    std::shared_ptr<actor::BaseActor> a = actor::createActor(uint64_t(n + 1) * net->getActionSize(), net);
+    for (int m = 0; m < moves && !a->isEnvTerminal(); ++m) {
+        const Action act = a->think(false, false);
+        if (!a->isSearchDone()) { return 3; }
+        if (a->isResign()) { break; }
+        if (!a->act(act)) { return 4; }
+    }
+    std::cout << "RECORD " << a->getRecord() << std::endl;
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 4 && !strcmp(argv[1], "think")) { return runThink(argv[2], atoi(argv[3])); }
     if (argc >= 5 && !strcmp(argv[1], "net")) { return runNet(argv[2], argv[3], atoi(argv[4])); }
     if (argc >= 4 && !strcmp(argv[1], "actor")) { return runActor(argv[2], atoi(argv[3]), argc >= 5 ? argv[4] : nullptr); }
     std::cerr << "usage: facade_check net <file> <out> <batch> | actor <conf> <moves>" << std::endl;

@@ -157,3 +157,26 @@ def test_actor_facade_against_the_oracle(mz, oracle, tmp_path, name, conf, dargs
         assert legal == [int(a) for a in np.flatnonzero(oe.legal_mask())]
         assert np.array_equal(got, oe.features(3).ravel())  # getFeatures(kRotation270)
     assert "model file name:" in p.stderr and "move number:" in p.stderr  # getSearchInfo()
+
+
+@pytest.mark.parametrize("gumbel", [False, True])
+def test_think_time_limit_decides_from_the_simulations_run_so_far(mz, oracle, tmp_path, gumbel):
+    """actor_mcts_think_time_limit (ref zero_actor.cpp:36-49): think() looks at the clock after every step and, when the limit has passed, decides with
+    the simulations run so far.  With a limit of a microsecond every move stops after its first chunk of 32 cycles = the root + 31 simulations, so the
+    record must be exactly that of a 31-simulation search (the oracle with actor_num_simulation=31: same tree, same RNG stream) although 2000 are configured."""
+    dargs = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    kw = dict(vh=16, dv=1, type_name="alphazero")
+    d, od = mz.make_desc(*dargs[:10], **kw), oracle.make_desc(*dargs[:10], **kw)
+    w = mz.generate_weights(d, 2)
+    pt = _write(mz, tmp_path, d, w)
+    base = "env_game=go:env_board_size=9:zero_num_parallel_games=1:program_seed=5"
+    if gumbel:
+        base += ":actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:actor_gumbel_sample_size=8"
+    moves = 6
+    p = _run(["think", f"{base}:actor_num_simulation=2000:actor_mcts_think_time_limit=0.000001:nn_file_name={pt}", str(moves)])
+    rec = [l for l in p.stdout.strip().split("\n") if l.startswith("RECORD ")][0][len("RECORD "):]
+    assert rec.count(";B[") + rec.count(";W[") == moves and rec.count("]P[") == moves and rec.count("]V[") == moves
+    if not gumbel:  # (a Gumbel root's visiting schedule and policy string depend on the CONFIGURED number of simulations: only the shape of the record is checked there)
+        og = oracle.OracleGroup(f"{base}:actor_num_simulation=31:nn_file_name={pt}:zero_num_threads=1", od, w)
+        og.cycles(32 * moves + 1)
+        assert rec == og.peek_records(1)[0]
