@@ -578,7 +578,13 @@ __device__ __forceinline__ bool simPreProbe(CSimArgs* __restrict__ a, int epoch,
     const int* key = a->pre_key + e * 4;
     const bool hit = __builtin_amdgcn_readfirstlane((key[2] == epoch && key[0] == src && key[1] == action) ? 1 : 0) != 0;
     if (!hit) {
-        if (a->pre_stat && key[2] == epoch && lane == 0 && slot < 126) { atomicAdd(a->pre_stat + 2 + slot, 1u); } // (monitoring: which simulations of a move miss, MZ_SIM_PROF)
+        if (a->pre_stat && key[2] == epoch && lane == 0 && slot < 126) { // (monitoring: which simulations of a move miss, MZ_SIM_PROF)
+            atomicAdd(a->pre_stat + 2 + slot, 1u);
+#ifdef MZ_PRE_DEBUG
+            const unsigned k = atomicAdd(a->pre_stat + 128, 1u);
+            if (k < 40) { unsigned* d = a->pre_stat + 129 + k * 6; d[0] = slot; d[1] = key[0]; d[2] = key[1]; d[3] = src; d[4] = action; d[5] = g; }
+#endif
+        }
         return false;
     }
     const int A = a->A;
@@ -1121,9 +1127,9 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     if (atari && gum) { // leaves evaluated ahead of their simulations (sim_pre_kernel_mz): one entry per (game, slot)
         const size_t ne = size_t(pool.v_.games) * slots, A = size_t(desc_.action_size);
         if (pre_key_.n != ne * 4) {
-            if (!pre_key_.alloc(ne * 4) || !pre_out_.alloc(ne * (3 * A + 2)) || !pre_stat_.alloc(128)) { setError("hipMalloc of the pre-evaluation entries failed"); return MZ_ERR_DEVICE; }
+            if (!pre_key_.alloc(ne * 4) || !pre_out_.alloc(ne * (3 * A + 2)) || !pre_stat_.alloc(512)) { setError("hipMalloc of the pre-evaluation entries failed"); return MZ_ERR_DEVICE; }
             MZ_HIP(hipMemset(pre_key_.p, 0, pre_key_.n * sizeof(int)));
-            MZ_HIP(hipMemset(pre_stat_.p, 0, 128 * sizeof(unsigned)));
+            MZ_HIP(hipMemset(pre_stat_.p, 0, 512 * sizeof(unsigned)));
         }
         a.pre_key = pre_key_.p;
         a.pre_policy = pre_out_.p; a.pre_logit = pre_out_.p + ne * A;
@@ -1235,8 +1241,11 @@ int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* 
 
 int Net::simPreStats(unsigned* hits, unsigned* evals)
 {
-    unsigned h[128] = {0};
-    if (pre_stat_.n >= 128) { MZ_HIP(hipMemcpy(h, pre_stat_.p, sizeof(h), hipMemcpyDeviceToHost)); }
+    unsigned h[512] = {0};
+    if (pre_stat_.n >= 512) { MZ_HIP(hipMemcpy(h, pre_stat_.p, sizeof(h), hipMemcpyDeviceToHost)); }
+#ifdef MZ_PRE_DEBUG
+    for (unsigned k = 0; k < h[128] && k < 40; ++k) { const unsigned* d = h + 129 + k * 6; fprintf(stderr, "[miss] game %u sim %u: evaluated (slot %u, action %u), true leaf (slot %u, action %u)\n", d[5], d[0], d[1], d[2], d[3], d[4]); }
+#endif
     *hits = h[0]; *evals = h[1];
     if (getenv("MZ_SIM_PROF") && h[1]) {
         fprintf(stderr, "[mz sim prof] leaves evaluated ahead %u, found %u; misses by simulation of the move:", h[1], h[0]);
