@@ -149,12 +149,19 @@ constexpr int kSpecCap = 128;                                   // levels rememb
 constexpr int kSpecWay = 4 + 3 * kSpecCap;                      // words of one remembered path: [0] length, then node / first_child / num_children per level
 constexpr int kGw = 4, kLv = 64 / kGw;                          // lanes per predicted level (its first children) and levels per pass
 constexpr int kSpecWays = 16;                                   // remembered paths (one per recently walked root child)
-constexpr int kSpecWords = kSpecWays * kSpecWay + 8;            // the paths + [kSpecWays * kSpecWay] = the next one to replace; [+1] passes, [+3] walks that found their path, [+5] levels taken
+// Helper segments (selectSpecHelper): while wave 0 walks levels 1 .. 16 of a remembered path, waves 1 .. 3 evaluate levels 17 .. 32, 33 .. 48 and 49 .. 64 of the path the
+// PREVIOUS walk took, each into its own result block; wave 0 takes a block over when it arrives at the block's entry node with all 16 levels before it accepted.
+constexpr int kHelpSegs = 3;                                    // helper waves / segments of kLv levels behind the first
+constexpr int kHelpHdr = 16;                                    // [0] serial of the simulation the block belongs to, [2] entry node, [3] levels accepted, [4..9] header of the last chosen node + the node
+constexpr int kHelpSeg = kHelpHdr + 4 * kLv;                    // + per accepted level: chosen node, its action, first_child, num_children
+constexpr int kSpecHelp = kSpecWays * kSpecWay + 8;
+constexpr int kSpecWords = kSpecHelp + kHelpSegs * kHelpSeg;    // the paths + [kSpecWays * kSpecWay] = the next one to replace; [+1] passes, [+3] walks that found their path, [+5] levels taken, [+6] the way of the last walk, [+7] levels taken over from helpers; the helpers' blocks
 constexpr int kSpecNode = 4, kSpecFc = 4 + kSpecCap, kSpecNc = 4 + 2 * kSpecCap;
 struct SpecMem { LdsI32* w; LdsCFloat* bias; LdsCDbl* sqrt; }; // w == nullptr: no speculation
 
+// serial > 0: helper waves run selectSpecHelper(serial) beside this walk (the per-game simulation kernels): their blocks are taken over where they fit
 template <bool SPEC = false, class RcpPtr>
-__device__ __forceinline__ void selectBody(const PoolView& v, const int* __restrict__ start, int g, int lane, RcpPtr rcp, SpecMem sm = SpecMem{nullptr, nullptr, nullptr})
+__device__ __forceinline__ void selectBody(const PoolView& v, const int* __restrict__ start, int g, int lane, RcpPtr rcp, SpecMem sm = SpecMem{nullptr, nullptr, nullptr}, int serial = 0)
 {
     GNodeRec* recs = (GNodeRec*)(v.rec + size_t(g) * v.cap);
     // (generic pointers: the simulation kernel keeps the path of its game in LDS and points the view there)
@@ -180,6 +187,7 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
                 if (lane == 0) { sm.w[kSpecWays * kSpecWay] = way + 1; sm.w[way * kSpecWay] = 0; }
             }
             spec = sm.w + way * kSpecWay;
+            if (lane == 0) { sm.w[kSpecWays * kSpecWay + 6] = way; } // (the helpers of the NEXT walk follow this path)
         }
         if (spec && lane == 0 && d < kSpecCap) {
             spec[kSpecNode + d] = n;
@@ -238,6 +246,37 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
             if (SPEC && spec && node != 0 && !v.atari_init_q && !v.value_rescale) {
                 const int L0 = depth - 1;
                 const int plen = __builtin_amdgcn_readfirstlane(spec[0]);
+                // a helper wave has evaluated the 16 levels from this node on (selectSpecHelper): take its block over.  The block says "from entry node E, with the records
+                // as they are, the arg-max choices are c1, c2, ..." — every level validated against the records it loaded — so it holds whatever path it was found on
+                if (serial > 0 && L0 > kLv && (L0 - 1) % kLv == 0 && (L0 - 1) / kLv <= kHelpSegs) {
+                    LdsI32* h = sm.w + kSpecHelp + ((L0 - 1) / kLv - 1) * kHelpSeg;
+                    if (__builtin_amdgcn_readfirstlane(h[0]) == serial) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const int hadv = __builtin_amdgcn_readfirstlane(h[3]);
+                        if (__builtin_amdgcn_readfirstlane(h[2]) == node && hadv > 0 && depth + hadv <= max_depth) {
+                            if (lane < hadv) {
+                                const int ch = h[kHelpHdr + lane], ca = h[kHelpHdr + kLv + lane];
+                                path[depth + lane] = ch;
+                                pact[depth + lane] = ca;
+                                if (hact) { hact[depth + lane] = ca; }
+                                if (depth + lane < kSpecCap) {
+                                    spec[kSpecNode + depth + lane] = ch;
+                                    spec[kSpecFc + depth + lane] = h[kHelpHdr + 2 * kLv + lane];
+                                    spec[kSpecNc + depth + lane] = h[kHelpHdr + 3 * kLv + lane];
+                                }
+                            }
+                            cur.count = __int_as_float(__builtin_amdgcn_readfirstlane(h[4]));
+                            cur.first_child = __builtin_amdgcn_readfirstlane(h[5]);
+                            cur.num_children = __builtin_amdgcn_readfirstlane(h[6]);
+                            cur.action = __builtin_amdgcn_readfirstlane(h[7]);
+                            cur.players = __builtin_amdgcn_readfirstlane(h[8]);
+                            node = __builtin_amdgcn_readfirstlane(h[9]);
+                            depth += hadv;
+                            if (lane == 0) { sm.w[kSpecWays * kSpecWay + 7] += hadv; }
+                            continue;
+                        }
+                    }
+                }
                 if (L0 + 1 < plen && L0 + 1 < kSpecCap && __builtin_amdgcn_readfirstlane(spec[kSpecNode + L0]) == node) {
                     int K = plen - L0 < kSpecCap - L0 ? plen - L0 : kSpecCap - L0;
                     K = K < kLv ? K : kLv;
@@ -518,6 +557,108 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
         if (v.host_path_len) { v.host_path_len[g] = depth; }
         if (spec) { spec[0] = depth < kSpecCap ? depth : kSpecCap; }
     }
+}
+
+// One helper segment of the walk (wave `seg` = 1 .. kHelpSegs of the per-game simulation kernels, beside wave 0's selectBody): the kLv levels from level 1 + seg * kLv on of
+// the path the previous walk took, evaluated in one pass of the same arithmetic as selectBody's speculation pass — every level's children block and header are checked
+// against the records loaded here, the header of the segment's entry node comes from memory — into the segment's block.  Nothing but that block is written.
+template <class RcpPtr>
+__device__ __forceinline__ void selectSpecHelper(const PoolView& v, int g, int lane, int seg, int serial, RcpPtr rcp, SpecMem sm)
+{
+    if (!sm.w || v.atari_init_q || v.value_rescale || seg < 1 || seg > kHelpSegs) { return; }
+    LdsI32* out = sm.w + kSpecHelp + (seg - 1) * kHelpSeg;
+    const int way = __builtin_amdgcn_readfirstlane(sm.w[kSpecWays * kSpecWay + 6]) & (kSpecWays - 1);
+    LdsI32* spec = sm.w + way * kSpecWay;
+    const int plen = __builtin_amdgcn_readfirstlane(spec[0]);
+    const int L0 = 1 + seg * kLv, depth = L0 + 1; // the entry node's level / the path index of the first chosen node
+    const int max_depth = __builtin_amdgcn_readfirstlane(v.max_depth);
+    int adv = 0, n0 = -1;
+    int f_count = 0, f_fc = 0, f_nc = 0, f_act = 0, f_pl = 0, f_node = 0;
+    if (L0 + 1 < plen && L0 + 1 < kSpecCap) {
+        GNodeRec* recs = (GNodeRec*)(v.rec + size_t(g) * v.cap);
+        MZ_GLOBAL const float* bias_tab = (MZ_GLOBAL const float*)v.bias_tab;
+        MZ_GLOBAL const double* sqrt_tab = (MZ_GLOBAL const double*)v.sqrt_tab;
+        int K = plen - L0 < kSpecCap - L0 ? plen - L0 : kSpecCap - L0;
+        K = K < kLv ? K : kLv;
+        const int k = lane / kGw, j = lane % kGw, Lk = L0 + k, base8 = lane - j;
+        const bool inrange = k < K;
+        n0 = __builtin_amdgcn_readfirstlane(spec[kSpecNode + L0]);
+        const int nk = inrange ? spec[kSpecNode + Lk] : 0;
+        const int fck = inrange ? spec[kSpecFc + Lk] : 0;
+        const int nck = inrange ? spec[kSpecNc + Lk] : 0;
+        const int pfc = (inrange && k >= 1) ? spec[kSpecFc + Lk - 1] : 0; // the block the predicted node lives in
+        const int pnc = (inrange && k >= 1) ? spec[kSpecNc + Lk - 1] : 0;
+        const int nl = nck < kGw ? nck : kGw;
+        const bool ld = inrange && j < nl && fck >= 0 && fck + j < v.cap;
+        const NodeRec c = loadRec(recs + (ld ? fck + j : 0));
+        const NodeRec h0 = loadRec(recs + ((n0 >= 0 && n0 < v.cap) ? n0 : 0)); // the entry node's own record: its header is not among the records of a level before it
+        const int idx = nk - pfc;
+        const bool idx_ok = idx >= 0 && idx < kGw && idx < pnc;
+        const int srcl = idx_ok ? base8 - kGw + idx : lane;
+        float hcount = __shfl(c.count, srcl);
+        int hfc = __shfl(c.first_child, srcl), hnc = __shfl(c.num_children, srcl), hpl = __shfl(c.players, srcl);
+        if (k == 0) { hcount = h0.count; hfc = h0.first_child; hnc = h0.num_children; hpl = h0.players; }
+        bool okk = inrange && ld == (j < nl) && nck > 0 && n0 >= 0 && n0 < v.cap && (k == 0 || idx_ok) && hfc == fck && hnc == nck && hcount >= 1.0f;
+        int Nk = static_cast<int>(hcount - 1);
+        Nk = okk ? Nk : 0;
+        const float biask = sm.bias ? sm.bias[Nk] : bias_tab[Nk];
+        const double sqrtNk = sm.sqrt ? sm.sqrt[Nk] : sqrt_tab[Nk];
+        const unsigned visn = static_cast<unsigned>(hpl) >> 16;
+        const int nek = (visn == 0xFFFFu) ? nck : (nck < static_cast<int>(visn) + 1 ? nck : static_cast<int>(visn) + 1);
+        okk = okk && nek <= kGw;
+        const int cplk = (hpl >> 8) & 0xFF;
+        const bool has = okk && j < nek;
+        const RcpPtr rp = rcp + (has ? static_cast<int>(c.count) : 0);
+        bool tiny = false;
+        const LevelEval e = evalChild(v, c, cplk, biask, sqrtNk, rp[0], rp[1], &tiny);
+        const bool vis = has && c.count != 0.0f;
+        if (__ballot(vis && tiny) == 0) { // (a subnormal quotient needs the reference's division: left to the plain walk)
+            int mx = 0;
+#pragma unroll
+            for (int t = 1; t <= kGw; ++t) { if (__ballot(okk && nek >= t) != 0) { mx = t; } }
+            const float qm = vis ? e.q : 0.0f, vm1 = vis ? 1.0f : 0.0f;
+            float sum_of_win = 0.0f, sum = 0.0f;
+            for (int i = 0; i < mx; ++i) {
+                const float qi = __shfl(qm, base8 + i), vi = __shfl(vm1, base8 + i);
+                sum_of_win = sum_of_win + qi;
+                sum = sum + vi;
+            }
+            const float init_q = (sum_of_win - 1) / (sum + 1);
+            const float sc = e.score + (c.count == 0.0f ? init_q : e.q);
+            float bs = 0.0f, bp = 0.0f;
+            int bi = 0;
+            for (int i = 0; i < mx; ++i) {
+                const float si = __shfl(sc, base8 + i), pi = __shfl(c.policy, base8 + i);
+                if (i < nek && (i == 0 || better(si, pi, i, bs, bp, bi))) { bs = si; bp = pi; bi = i; }
+            }
+            const int chl = base8 + bi; // the lane that holds the level's chosen child
+            const float ch_count = __shfl(c.count, chl);
+            const int ch_fc = __shfl(c.first_child, chl), ch_nc = __shfl(c.num_children, chl), ch_act = __shfl(c.action, chl), ch_pl = __shfl(c.players, chl);
+            const int chosen = fck + bi;
+            const int prev_chosen = __shfl(chosen, lane >= kGw ? lane - kGw : lane), prev_nc = __shfl(ch_nc, lane >= kGw ? lane - kGw : lane);
+            const bool link = okk && (k == 0 || (prev_chosen == nk && prev_nc != 0)) && depth + k < max_depth;
+            const unsigned long long lm = __ballot(j == 0 && !link);
+            const int adv_all = lm ? static_cast<int>(__builtin_ctzll(lm)) / kGw : kLv;
+            adv = adv_all < K ? adv_all : K;
+            if (adv > 0) {
+                if (j == 0 && k < adv) {
+                    out[kHelpHdr + k] = chosen;
+                    out[kHelpHdr + kLv + k] = ch_act;
+                    out[kHelpHdr + 2 * kLv + k] = ch_fc;
+                    out[kHelpHdr + 3 * kLv + k] = ch_nc;
+                }
+                const int l = kGw * (adv - 1);
+                f_count = __builtin_amdgcn_readlane(__float_as_int(ch_count), l);
+                f_fc = laneI(ch_fc, l); f_nc = laneI(ch_nc, l); f_act = laneI(ch_act, l); f_pl = laneI(ch_pl, l); f_node = laneI(chosen, l);
+            }
+        }
+    }
+    if (lane == 0) {
+        out[2] = n0; out[3] = adv; out[4] = f_count; out[5] = f_fc; out[6] = f_nc; out[7] = f_act; out[8] = f_pl; out[9] = f_node;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { out[0] = serial; }
 }
 
 // `lds` = 2 * bound_cap words of LDS (value-bound multiset: keys then counts; only touched with value_rescale)

@@ -173,8 +173,9 @@ typedef __attribute__((address_space(3))) const double LdsCDouble;
 
 template <int CPL, int WPE, class RcpPtr>
 __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, RcpPtr rcp, SpecMem spec,
-                                           float* xchg, const uint64_t* seen_lds)
+                                           float* xchg, const uint64_t* seen_lds, int serial = 0)
 {
+    serial = __builtin_amdgcn_readfirstlane(serial);
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
     slot = __builtin_amdgcn_readfirstlane(slot);
@@ -187,7 +188,7 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
     waveSync();
     if (a->prof) { t0 = wall_clock64(); }
 #endif
-    selectBody<WPE == 2>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
+    selectBody<WPE == 2>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec, serial);
     waveSync();
     if (a->prof && lane == 0) {
         a->prof[size_t(g) * 8 + 5] += wall_clock64() - t0;
@@ -198,6 +199,18 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
     if constexpr (CPL == -1) { tttLeafBody(gv, pv, rot, slot, g, lane); } // CPL -1: TicTacToe, 0: Othello (go_body.h)
     else if constexpr (CPL == 0) { othLeafBody(gv, pv, rot, slot, g, lane); }
     else { goLeafBody<CPL, true>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles), seen_lds); } // planes: simLeafPlanes, all waves
+}
+
+// waves 1 .. 3 beside wave 0's walk: levels 17 .. 64 of the path the previous simulation took, 16 per wave (pool_body.h selectSpecHelper): a deep principal variation is
+// re-walked by almost every simulation, and the launch lasts as long as its deepest game
+template <class RcpPtr>
+__device__ __noinline__ void simSelectHelper(CSimArgs* __restrict__ a, int g, int lane, int seg, int serial, RcpPtr rcp, SpecMem spec)
+{
+    g = __builtin_amdgcn_readfirstlane(g);
+    seg = __builtin_amdgcn_readfirstlane(seg);
+    serial = __builtin_amdgcn_readfirstlane(serial);
+    const PoolView pv = ldc(&a->pv);
+    selectSpecHelper(pv, g, lane, seg, serial, rcp, spec);
 }
 
 // Go: the 18 feature planes of the leaf, two or three per wave (32 ballots over LDS words: 3.3 us on one wave)
@@ -413,6 +426,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         for (int i = tid; i < tab_n; i += 512) { sqrt_w[i] = a->pv.sqrt_tab[i]; bias_w[i] = a->pv.bias_tab[i]; }
         if (tid < kSpecWays) { spec_w[tid * kSpecWay] = 0; }
         if (tid < 8) { spec_w[kSpecWays * kSpecWay + tid] = 0; }
+        if (tid < kHelpSegs) { spec_w[kSpecHelp + tid * kHelpSeg] = 0; }
         __syncthreads();
         spec = SpecMem{(a->no_spec & 1) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
         xchg = reinterpret_cast<float*>(spec_w + kSpecWords) + path_words;
@@ -434,7 +448,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (wave == 0) {
             if (slot == 1 && a->root_noise) { simApplyRootNoise<WPE>(a, g, lane); }
             if (a->use_gumbel) { simGumbelStart<WPE>(a, slot, s == 0 && host_start != 0, g, lane, tiles); }
-            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec, xchg, seen_lds);
+            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec, xchg, seen_lds, (a->no_spec & 2) ? 0 : s + 1);
+        } else if (WPE == 2 && wave <= kHelpSegs && spec.w && !(a->no_spec & 2)) { // (MZ_NO_SPEC=2: helper segments off)
+            simSelectHelper(a, g, lane, wave, s + 1, rcp_lds, spec);
         }
         __syncthreads();
         if constexpr (CPL > 0) {
@@ -470,7 +486,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
             prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
         }
     }
-    if (prof && tid == 0 && spec_w) { prof[7] += (static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 1]) << 40) | (static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 5]) << 20) | spec_w[kSpecWays * kSpecWay + 3]; }
+    if (prof && tid == 0 && spec_w) {
+        prof[7] += (static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 1]) << 40) | (static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 5]) << 20) | spec_w[kSpecWays * kSpecWay + 3];
+        prof[6] += static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 7]) << 40; // levels taken over from the helper waves (the low bits hold the path lengths)
+    }
 }
 
 // ---- MuZero (board games; ref muzero_network.h:97-178, zero_actor.cpp:215-245): no leaf environment.  The leaf is evaluated from
@@ -557,15 +576,16 @@ __device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_s
 }
 
 __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
-                                         bool gumbel_done = false, bool noise_done = false)
+                                         bool gumbel_done = false, bool noise_done = false, int serial = 0)
 {
+    serial = __builtin_amdgcn_readfirstlane(serial);
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     slot = __builtin_amdgcn_readfirstlane(slot);
     g = __builtin_amdgcn_readfirstlane(g);
     if (slot == 1 && a->root_noise && !noise_done) { simApplyRootNoise<2>(a, g, lane); }
     if (a->use_gumbel && !gumbel_done) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
     const PoolView pv = ldc(&a->pv);
-    selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec);
+    selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec, serial);
 }
 
 // Leaves evaluated ahead (sim_pre_kernel_mz): does the entry of simulation `slot` hold THIS leaf — the same parent hidden state (slab slot `src`) and the
@@ -683,6 +703,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     for (int i = tid; i < tab_n; i += 512) { sqrt_w[i] = a->pv.sqrt_tab[i]; bias_w[i] = a->pv.bias_tab[i]; }
     if (tid < kSpecWays) { spec_w[tid * kSpecWay] = 0; }
     if (tid < 8) { spec_w[kSpecWays * kSpecWay + tid] = 0; }
+    if (tid < kHelpSegs) { spec_w[kSpecHelp + tid * kHelpSeg] = 0; }
     __syncthreads();
     SpecMem spec{((a->no_spec & 1) || a->atari) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
     float* head_scratch = reinterpret_cast<float*>(spec_w + kSpecWords);
@@ -695,7 +716,8 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         // host_start bit 1: the root's network outputs are given (policy / logit / value / reward arrays, hidden state in slab slot 0: the muzero_atari
         // root, whose 96x96 representation runs as stand-alone kernels) — simulation 0 is only its candidate list + expand + backup
         const bool given = slot == 0 && (host_start & 2) != 0;
-        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, false, (host_start & 4) != 0); }
+        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, false, (host_start & 4) != 0, (a->no_spec & 2) ? 0 : s + 1); }
+        else if (wave <= kHelpSegs && spec.w && !(a->no_spec & 2)) { simSelectHelper(a, g, lane, wave, s + 1, rcp_lds, spec); }
         __syncthreads();
         // was this leaf evaluated ahead (sim_pre_kernel_mz)?  Then the tower and the heads are skipped: outputs and hidden state are in place
         __shared__ int s_pre_hit;
@@ -943,7 +965,10 @@ void Net::dumpSimProf()
     }
     {
         double sel = 0, lev = 0, sims = 0, maxlev = 0;
-        for (size_t g = 0; g < G; ++g) { sel += double(h[g * 8 + 5]); lev += double(h[g * 8 + 6]); sims += double(h[g * 8 + 4]); maxlev = std::max(maxlev, double(h[g * 8 + 6]) / std::max(1.0, double(h[g * 8 + 4]))); }
+        double helped = 0;
+        const unsigned long long low = (1ull << 40) - 1;
+        for (size_t g = 0; g < G; ++g) { sel += double(h[g * 8 + 5]); lev += double(h[g * 8 + 6] & low); helped += double(h[g * 8 + 6] >> 40); sims += double(h[g * 8 + 4]); maxlev = std::max(maxlev, double(h[g * 8 + 6] & low) / std::max(1.0, double(h[g * 8 + 4]))); }
+        fprintf(stderr, "[mz sim prof] levels taken over from the helper waves: %.0f (%.1f %% of all levels)\n", helped, 100.0 * helped / std::max(1.0, lev));
         fprintf(stderr, "[mz sim prof] select alone avg %8.2f us, path length avg %.2f (deepest game avg %.2f) -> %.2f us per level\n", sel / std::max(1.0, sims) * 0.01,
                 lev / std::max(1.0, sims), maxlev, sel / std::max(1.0, lev) * 0.01);
     }
