@@ -381,6 +381,7 @@ public:
     int getStats(mz_worker_stats* out)
     {
         *out = stats_;
+        MZ_HIP(hipSetDevice(device_));
         for (auto& L : lanes_) {
             unsigned hits = 0, evals = 0;
             int rc = L->net->simPreStats(&hits, &evals);
