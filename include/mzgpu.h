@@ -239,6 +239,7 @@ typedef struct mz_worker_stats {
     uint64_t sim_cycles;   /* cycles that ran inside those launches */
     uint64_t pre_evals;    /* Gumbel rounds (mz_sim_rounds): leaves evaluated ahead of their simulations ... */
     uint64_t pre_hits;     /* ... and simulations that found their leaf among them (the rest evaluated their own) */
+    uint64_t pre_alt_hits; /* ... of which: the leaf was the simulation's SECOND expected one (mz_sim_round_alt) */
 } mz_worker_stats;
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out);
 mz_net* mz_worker_net(mz_worker* w);

@@ -66,6 +66,7 @@ struct WorkerConfig {
     bool mz_sim_split = true;   // a move's simulation-kernel launch in up to three parts, so that the host's noise / rotation draws overlap the parts already running
     bool mz_sim_rounds = true;  // muzero_atari with a Gumbel root: the leaves of a whole Gumbel round (the simulations between two halvings visit different root children)
                                 // are evaluated side by side ahead of the simulations that consume them in order (sim.hip sim_pre_kernel_mz); false: every simulation evaluates its own leaf
+    bool mz_sim_round_alt = true; // ... and, where a round leaves half of the CUs idle, a second expected leaf per simulation
     int mz_sim_round_min = 2;   // ... for the rounds of at least this many simulations (2 = every round of a 50-simulation, 16-sample search: 16, 8, 4, 4, 4, 2 x 7)
     bool mz_sim_cluster = true; // muzero_atari simulation kernel: four workgroups per game when 4 x games <= CUs (sim_cluster.h)
     bool mz_sim_kernel = true; // with mz_device_env: whole runs of cycles as one launch of the per-game simulation kernel (sim.hip)

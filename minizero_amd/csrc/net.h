@@ -100,7 +100,7 @@ public:
     // (the first round needs the noisy logits before simulation 1): the simLaunchMz calls after it pass noise_applied = true.
     int simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched);
     int simRootNoiseMz(int games);
-    int simPreStats(unsigned* hits, unsigned* evals);
+    int simPreStats(unsigned* hits, unsigned* evals, unsigned* alt_hits);
     bool hasSimKernelMz(int num_simulation = 0) const;
     int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat);
     int shiftExpandAtariFeatures(const uint8_t* d_prev, const uint8_t* d_newest, const uint8_t* d_meta, uint8_t* d_cur, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)
@@ -164,6 +164,7 @@ private:
     int sim_cluster_checked_ = 0; // pool size (padded) whose cluster placement has been probed
     bool coop_launch_ = false;
 public:
+    int sim_alt_base_ = 0;      // != 0: the slab has 2 x sim_alt_base_ slots per game, the upper half for the rounds' second expected leaves (sim.hip simPreProbe)
     bool sim_rounds_ = false;   // the worker evaluates Gumbel rounds ahead (simPreEvalMz): the cluster kernel then runs every game's 601-bin heads alone
     bool sim_octet_ = true;     // cluster mode: the 601-bin heads of the games that share an XCD are computed together (sim_cluster.h octetHead)
     bool sim_cluster_ = true;   // four workgroups per game when 4 x games <= CUs (muzero_atari instances); false: always one workgroup per game

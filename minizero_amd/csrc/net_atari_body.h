@@ -440,12 +440,14 @@ __device__ __forceinline__ void atariHeadsBody(const float* __restrict__ xg, con
         pf[i] = v > 0.0f ? v : 0.0f;
     }
     __syncthreads();
+    MZ_HPROF(8);
     for (int a = tid; a < A; a += NT2) {
         const float v = dotChain<16, true>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
         lgp[a] = v;
         logit[size_t(b) * A + a] = v;
     }
     __syncthreads();
+    MZ_HPROF(9);
     if (wave == 0) {
         float m = -3.4e38f;
         for (int a = lane; a < A; a += 64) { m = lgp[a] > m ? lgp[a] : m; }
@@ -457,6 +459,7 @@ __device__ __forceinline__ void atariHeadsBody(const float* __restrict__ xg, con
         for (int a = 0; a < A; ++a) { s += lgp[a]; }
         for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lgp[a] / s; }
     }
+    MZ_HPROF(10);
 }
 
 inline size_t atariHeadsSmemFloats(const AtariHeadParams& hp)

@@ -104,6 +104,7 @@ struct SimArgs {
     int* pre_action;                  // ... and their actions: the candidate list is built where the leaf was evaluated, not in the in-order part
     float *pre_value, *pre_reward;    // [games][slots], game scale
     unsigned* pre_stat;               // [0] simulations that found their leaf evaluated, [1] leaves evaluated ahead (tests / monitoring)
+    int alt_base;                     // != 0: slots alt_base + s hold a SECOND expected leaf of simulation s (sim_pre_kernel_mz, hypothesis 1)
 };
 
 // SimArgs never changes during a launch: the device functions read it through the CONSTANT address space, i.e. with scalar loads whose
@@ -589,23 +590,24 @@ __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, boo
 }
 
 // Leaves evaluated ahead (sim_pre_kernel_mz): does the entry of simulation `slot` hold THIS leaf — the same parent hidden state (slab slot `src`) and the
-// same action, written in this move (`epoch`)?  Then its hidden state already lies in slab slot `slot` and its network outputs are copied to the game's
-// arrays (one wave; A <= 64 per pass).  The simulation then runs exactly as if the kernel had evaluated the leaf itself: candidates, expand, backup.
-__device__ __forceinline__ bool simPreProbe(CSimArgs* __restrict__ a, int epoch, int g, int slot, int src, int action, int lane)
+// same action, written in this move (`epoch`)?  Then its network outputs are copied to the game's arrays (one wave; A <= 64 per pass) and the slab slot
+// that holds its hidden state is returned (`slot`, or alt_base + slot for the second expected leaf); -1: not evaluated ahead.  The simulation then runs
+// exactly as if the kernel had evaluated the leaf itself: candidates, expand (the node remembers the returned slot), backup.
+__device__ __forceinline__ int simPreProbe(CSimArgs* __restrict__ a, int epoch, int g, int slot, int src, int action, int lane)
 {
-    if (epoch == 0 || !a->pre_key) { return false; }
-    const size_t e = size_t(g) * a->slots + slot;
+    if (epoch == 0 || !a->pre_key) { return -1; }
+    size_t e = size_t(g) * a->slots + slot;
     const int* key = a->pre_key + e * 4;
-    const bool hit = __builtin_amdgcn_readfirstlane((key[2] == epoch && key[0] == src && key[1] == action) ? 1 : 0) != 0;
+    bool hit = __builtin_amdgcn_readfirstlane((key[2] == epoch && key[0] == src && key[1] == action) ? 1 : 0) != 0;
+    int eslot = slot;
+    if (!hit && a->alt_base) { // the second expected leaf of this simulation (entry and slab slot alt_base + slot)
+        const int* key2 = key + size_t(a->alt_base) * 4;
+        hit = __builtin_amdgcn_readfirstlane((key2[2] == epoch && key2[0] == src && key2[1] == action) ? 1 : 0) != 0;
+        if (hit) { e += a->alt_base; eslot += a->alt_base; if (a->pre_stat && lane == 0) { atomicAdd(a->pre_stat + 128, 1u); } }
+    }
     if (!hit) {
-        if (a->pre_stat && key[2] == epoch && lane == 0 && slot < 126) { // (monitoring: which simulations of a move miss, MZ_SIM_PROF)
-            atomicAdd(a->pre_stat + 2 + slot, 1u);
-#ifdef MZ_PRE_DEBUG
-            const unsigned k = atomicAdd(a->pre_stat + 128, 1u);
-            if (k < 40) { unsigned* d = a->pre_stat + 129 + k * 6; d[0] = slot; d[1] = key[0]; d[2] = key[1]; d[3] = src; d[4] = action; d[5] = g; }
-#endif
-        }
-        return false;
+        if (a->pre_stat && key[2] == epoch && lane == 0 && slot < 126) { atomicAdd(a->pre_stat + 2 + slot, 1u); } // (monitoring: which simulations of a move miss, MZ_SIM_PROF)
+        return -1;
     }
     const int A = a->A;
     for (int i = lane; i < A; i += 64) { // the sorted candidate list of a non-root leaf (all A actions: legality is only known at the root, zero_actor.cpp:238)
@@ -619,7 +621,7 @@ __device__ __forceinline__ bool simPreProbe(CSimArgs* __restrict__ a, int epoch,
         if (a->pre_stat) { atomicAdd(a->pre_stat, 1u); }
     }
     waveSync();
-    return true;
+    return eslot;
 }
 
 // scale_hidden_state (ref muzero_network.py:81-88) of the tower's output where it lies (padded planes in LDS), in place, and the rescaled state
@@ -726,12 +728,13 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             if (wave == 0) {
                 const int len = v.path_len[g];
                 const int* path = v.path + size_t(g) * v.max_depth;
-                const bool h = simPreProbe(a, pre_epoch, g, slot, v.hslot[size_t(g) * v.cap + path[len - 2]], v.path_action[size_t(g) * v.max_depth + len - 1], lane);
-                if (lane == 0) { s_pre_hit = h ? 1 : 0; }
+                const int h = simPreProbe(a, pre_epoch, g, slot, v.hslot[size_t(g) * v.cap + path[len - 2]], v.path_action[size_t(g) * v.max_depth + len - 1], lane);
+                if (lane == 0) { s_pre_hit = h; }
             }
             __syncthreads();
-            hit = s_pre_hit != 0;
+            hit = s_pre_hit >= 0;
         }
+        const int eslot = hit ? s_pre_hit : slot; // the slab slot of this leaf's hidden state
         if (prof) { t1 = wall_clock64(); }
         float* xt = nullptr;
         if (given || hit) {
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
             __syncthreads();
         }
-        if (wave == 0) { simMzCandExpand(a, slot, g, lane, tiles, cand_k, given, 0, hit); }
+        if (wave == 0) { simMzCandExpand(a, eslot, g, lane, tiles, cand_k, given, 0, hit); }
         __syncthreads();
         if (prof && tid == 0 && !given) {
             const unsigned long long t4 = wall_clock64();
@@ -792,11 +795,11 @@ __global__ __launch_bounds__(64) void sim_root_noise_kernel(const SimArgs* __res
 #define MZ_PRE_WPE 2 // (4 = two workgroups per CU, 128 VGPRs: measured 211 us per launch on average against 198 us — 50 spilled registers, and both towers want the same MFMA pipes)
 #endif
 template <int H, int W, int CDYN_PAD, int CPAD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MZ_PRE_WPE, 4))) void sim_pre_kernel_mz(const SimArgs* __restrict__ a_, int s0, int R, int epoch)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MZ_PRE_WPE, 4))) void sim_pre_kernel_mz(const SimArgs* __restrict__ a_, int s0, int R, int NH, int epoch)
 {
     CSimArgs* a = (CSimArgs*)a_;
     extern __shared__ __attribute__((aligned(16))) float tiles[];
-    const int g = blockIdx.x / R, r = blockIdx.x % R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x / (R * NH), q = blockIdx.x % (R * NH), r = q % R, hyp = q / R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int CM = CDYN_PAD > CPAD ? CDYN_PAD : CPAD;
     constexpr int kTileFloats = kTowerTiles * CM * planeStride(H, W);
     const AtariHeadParams hp = ldc(&a->ahp);
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MZ_PRE_WPE,
     int* st_l = ctl + 4;
     int* path_l = st_l + 4 + kGumbelMaxSample;
     float* head_scratch = reinterpret_cast<float*>(ctl + ((4 + 4 + kGumbelMaxSample + 2 * v.max_depth + 2 + 3) & ~3));
-    const int slot = s0 + r;
+    const int slot = s0 + r + (hyp ? a->alt_base : 0);
     if (wave == 0) {
         const int stride = 3 + kGumbelMaxSample;
         for (int i = lane; i < stride; i += 64) { st_l[i] = a->gum.state[size_t(g) * stride + i]; }
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MZ_PRE_WPE,
         waveSync();
         const size_t base = size_t(g) * v.cap;
         const int fc = v.rec[base].first_child, ncand = st_l[0];
-        bool ok = slot < a->slots && r < ncand && r < kGumbelMaxSample;
+        bool ok = slot < a->slots && s0 + r < (a->alt_base ? a->alt_base : a->slots) && r < ncand && r < kGumbelMaxSample;
         if (ok) { ok = v.rec[base + fc + st_l[3 + r]].count == v.rec[base + fc + st_l[3]].count; } // still in the round of candidate 0
         ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
         if (ok) {
@@ -827,9 +830,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MZ_PRE_WPE,
             selectBody<false>(pl, ctl + 3 - g, g, lane, v.rcp_tab);
             waveSync();
             const int len = path_l[2 * v.max_depth];
-            if (lane == 0) {
-                ctl[1] = v.hslot[base + path_l[len - 2]];
-                ctl[2] = path_l[v.max_depth + len - 1];
+            if (hyp == 0) {
+                if (lane == 0) {
+                    ctl[1] = v.hslot[base + path_l[len - 2]];
+                    ctl[2] = path_l[v.max_depth + len - 1];
+                }
+            } else {
+                // Hypothesis 1.  Where the true walk leaves the expected path it does so at the LAST choice between a visited child and an unvisited one
+                // (every miss traced on BASELINE configs[4] was of this kind: the backups of the round's earlier simulations move the value bounds, and the
+                // closest call of a walk is "once more into the child visited last, or the next sibling"): the walk stops one level earlier, at the
+                // grandparent of the expected leaf, and takes that node's first unvisited child.  Never the root: its child is the Gumbel step's choice.
+                ok = len >= 4;
+                if (ok) {
+                    const NodeRec z = v.rec[base + path_l[len - 3]];
+                    const unsigned visn = static_cast<unsigned>(z.players) >> 16; // the visited children of a node are a prefix of its sorted list
+                    ok = visn != 0xFFFFu && static_cast<int>(visn) < z.num_children;
+                    if (ok && lane == 0) {
+                        ctl[1] = v.hslot[base + path_l[len - 3]];
+                        ctl[2] = v.rec[base + z.first_child + visn].action;
+                    }
+                }
+                ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
             }
         }
         if (lane == 0) { ctl[0] = ok ? 1 : 0; }
@@ -881,10 +902,10 @@ static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, i
 }
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
-static int launchSimPreMzT(const SimArgs* d_args, int games, int s0, int R, int epoch, size_t lds, hipStream_t s)
+static int launchSimPreMzT(const SimArgs* d_args, int games, int s0, int R, int NH, int epoch, size_t lds, hipStream_t s)
 {
     MZ_LDS_ATTR((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD>), lds);
-    hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD>), dim3(games * R), dim3(512), lds, s, d_args, s0, R, epoch);
+    hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD>), dim3(games * R * NH), dim3(512), lds, s, d_args, s0, R, NH, epoch);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
@@ -921,7 +942,7 @@ void Net::dumpSimProf()
         unsigned long long h[16];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hp), sizeof(h)) == hipSuccess && h[15]) {
             fprintf(stderr, "[mz sim hprof] us per section of the heads (game 0, avg over %llu calls; board games: [1] tail wait, [5] setup, [6] conv1x1, [7] FCs, [8] FC2 / softmax):", h[15]);
-            for (int i = 1; i < 15; ++i) { if (i != 8) { fprintf(stderr, " [%d] %.2f", i, double(h[i]) / double(h[15]) * 0.01); } }
+            for (int i = 1; i < 15; ++i) { if (true) { fprintf(stderr, " [%d] %.2f", i, double(h[i]) / double(h[15]) * 0.01); } }
             fprintf(stderr, "\n");
         }
     }
@@ -1141,7 +1162,8 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.cand_policy = pool.d_cand_policy_.p; a.cand_logit = pool.d_cand_logit_.p; a.value_io = pool.d_value_.p; a.reward_io = pool.d_reward_.p;
     a.err = pool.errFlag();
     a.rcp_n = pool.rcpEntries();
-    a.hidden = d_hidden; a.slots = slots; a.root_feat = d_root_feat; a.root_legal = d_root_legal; a.root_turn = d_root_turn;
+    a.hidden = d_hidden; a.slots = slots;
+    a.alt_base = (atari && gum && sim_alt_base_ > 0 && 2 * sim_alt_base_ <= slots) ? sim_alt_base_ : 0; a.root_feat = d_root_feat; a.root_legal = d_root_legal; a.root_turn = d_root_turn;
     a.A = desc_.action_size; a.LW = (desc_.action_size + 63) / 64; a.num_players = num_players;
     a.root_noise = d_root_noise;
     a.noise_eps = noise_eps;
@@ -1257,23 +1279,22 @@ int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* 
     const size_t ctl_words = (4 + 4 + kGumbelMaxSample + 2 * size_t(max_depth) + 2 + 3) & ~size_t(3);
     const size_t lds = tile_bytes + ctl_words * sizeof(int) + atariHeadsSmemFloats(a.ahp) * sizeof(float);
     if (lds > 160 * 1024) { return MZ_OK; }
+    // the second expected leaf of every simulation rides along where the round leaves half of the CUs idle (the rounds of two on a pool of 64 games)
+    const int NH = (a.alt_base && 2 * games * R <= cu_count_ * (getenv("MZ_PRE_ALT_WAVES") ? atoi(getenv("MZ_PRE_ALT_WAVES")) : 1)) ? 2 : 1;
 #define MZ_SIM_PRE_LAUNCH(h, w, cin0, cdyn, cpad) \
-    if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimPreMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), games, s0, R, epoch, lds, stream_); }
+    if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimPreMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), games, s0, R, NH, epoch, lds, stream_); }
     MZ_SIM_MZ_CLUSTER_CASES(MZ_SIM_PRE_LAUNCH)
 #undef MZ_SIM_PRE_LAUNCH
     return MZ_OK;
 }
 
-int Net::simPreStats(unsigned* hits, unsigned* evals)
+int Net::simPreStats(unsigned* hits, unsigned* evals, unsigned* alt_hits)
 {
     unsigned h[512] = {0};
     if (pre_stat_.n >= 512) { MZ_HIP(hipMemcpy(h, pre_stat_.p, sizeof(h), hipMemcpyDeviceToHost)); }
-#ifdef MZ_PRE_DEBUG
-    for (unsigned k = 0; k < h[128] && k < 40; ++k) { const unsigned* d = h + 129 + k * 6; fprintf(stderr, "[miss] game %u sim %u: evaluated (slot %u, action %u), true leaf (slot %u, action %u)\n", d[5], d[0], d[1], d[2], d[3], d[4]); }
-#endif
-    *hits = h[0]; *evals = h[1];
+    *hits = h[0]; *evals = h[1]; *alt_hits = h[128];
     if (getenv("MZ_SIM_PROF") && h[1]) {
-        fprintf(stderr, "[mz sim prof] leaves evaluated ahead %u, found %u; misses by simulation of the move:", h[1], h[0]);
+        fprintf(stderr, "[mz sim prof] leaves evaluated ahead %u, found %u (%u of them the second expected leaf); misses by simulation of the move:", h[1], h[0], h[128]);
         for (int i = 1; i < 126; ++i) { if (h[2 + i]) { fprintf(stderr, " %d:%u", i, h[2 + i]); } }
         fprintf(stderr, "\n");
     }

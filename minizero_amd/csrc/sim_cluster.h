@@ -485,8 +485,10 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
                 const int* path = v.path + size_t(g) * v.max_depth;
                 const int src = v.hslot[size_t(g) * v.cap + path[len - 2]], action = v.path_action[size_t(g) * v.max_depth + len - 1];
                 // a leaf that was evaluated ahead (sim_pre_kernel_mz): its outputs are copied in, the whole cluster skips tower + heads
-                const bool hit = simPreProbe(a, pre_epoch, g, slot, src, action, lane);
+                const int hslot = simPreProbe(a, pre_epoch, g, slot, src, action, lane);
+                const bool hit = hslot >= 0;
                 if (lane == 0) {
+                    s_cmd[3] = hit ? hslot : slot; // (owner only) the slab slot of this leaf's hidden state
                     clu4 cmd;
                     cmd.x = unsigned(src);
                     cmd.y = unsigned(action);
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz_cluster(const SimArgs* __re
         }
         MZ_HPROF(12);
         if (wave == 0) {
-            simMzCandExpand(a, slot, g, lane, tiles, cand_k, false, 1, hit);
+            simMzCandExpand(a, s_cmd[3], g, lane, tiles, cand_k, false, 1, hit);
             // ... and so is the next simulation's Gumbel step (which candidate it starts from): the backup to come only adds a visit to the child on this path
             gumbel_ahead = a->use_gumbel && s + 1 < nsims && simGumbelAhead(a, slot + 1, g, lane, tiles);
         }

@@ -383,10 +383,10 @@ public:
         *out = stats_;
         MZ_HIP(hipSetDevice(device_));
         for (auto& L : lanes_) {
-            unsigned hits = 0, evals = 0;
-            int rc = L->net->simPreStats(&hits, &evals);
+            unsigned hits = 0, evals = 0, alt = 0;
+            int rc = L->net->simPreStats(&hits, &evals, &alt);
             if (rc) { return rc; }
-            out->pre_hits += hits; out->pre_evals += evals;
+            out->pre_hits += hits; out->pre_evals += evals; out->pre_alt_hits += alt;
         }
         return MZ_OK;
     }
@@ -523,6 +523,7 @@ private:
     int syncGumbel(Lane& L, bool to_device);
     bool sim_mz_ = false;     // MuZero board game on sim_kernel_mz (no device rules needed: the leaves have no environment)
     struct Round { int s0, R; };
+    int slab_slots_ = 0;        // hidden-state slots per game
     std::vector<Round> rounds_; // mz_sim_rounds: the rounds of a move whose leaves are evaluated ahead (first simulation, size), from the Gumbel schedule of (n, m)
     void planRounds();
     bool shared_net_ = false; // the network belongs to the caller (mz_worker_create_shared): load_model only renames, the caller reloads
@@ -591,7 +592,9 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         L->d_policy = {L->d_out.p, GA}; L->d_logit = {L->d_out.p + GA, GA}; L->d_value = {L->d_out.p + 2 * GA, Gn}; L->d_reward = {L->d_out.p + 2 * GA + Gn, Gn};
         MZ_HIP(hipMemset(L->d_out.p, 0, L->d_out.n * sizeof(float)));
         if (desc.type >= 1) {
-            WALLOC(L->d_hidden, Gn * (n_ + 1) * L->net->hiddenSize()); // hidden-state slab: one slot per expanded node
+            // hidden-state slab: one slot per expanded node; with Gumbel rounds on muzero_atari a second bank for the rounds' second expected leaves
+            slab_slots_ = (n_ + 1) * ((desc.type == 2 && cfg_.actor_use_gumbel && cfg_.mz_sim_rounds && cfg_.mz_sim_round_alt) ? 2 : 1);
+            WALLOC(L->d_hidden, Gn * slab_slots_ * L->net->hiddenSize());
             WALLOC(L->d_src_idx, Gn); WALLOC(L->d_dst_idx, Gn); WALLOC(L->d_action_ids, Gn);
         }
 #undef WALLOC
@@ -661,9 +664,10 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             for (const Round& rd : rounds_) { covered += rd.R; }
             for (auto& L : lanes_) {
                 L->net->sim_rounds_ = !rounds_.empty();
+                L->net->sim_alt_base_ = (!rounds_.empty() && slab_slots_ == 2 * (n_ + 1)) ? n_ + 1 : 0;
                 // every simulation of a move has its leaf evaluated ahead: what is left for the simulation kernel is the tree work of one wave per game, which one
                 // workgroup per game does with less overhead than a cluster of four (no command / result exchange, no cooperative launch): 616 -> 656 k leaf-evals/s
-                if (covered == n_) { L->net->sim_cluster_ = false; }
+                if (covered == n_ && !getenv("MZ_ROUNDS_CLUSTER")) { L->net->sim_cluster_ = false; }
             }
         }
         const int fw = sim_root_host_ ? 1 : games_[0].env->featureWords(), LW = (A_ + 63) / 64;
@@ -1458,12 +1462,12 @@ int Worker::phase2(Lane& L)
         } else {
             MZ_HIP(hipMemcpyAsync(L.d_feat.p, L.h_feat.p, size_t(L.n) * L.net->featSize() * sizeof(float), hipMemcpyHostToDevice, L.stream));
         }
-        if ((rc = L.pool.hiddenIndexAsync(n_ + 1, 0, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
+        if ((rc = L.pool.hiddenIndexAsync(slab_slots_, 0, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
         if ((rc = L.net->initial(L.d_feat.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_hidden.p, L.d_dst_idx.p))) { return rc; }
         MZ_HIP(hipMemsetAsync(L.d_reward.p, 0, L.n * sizeof(float), L.stream));
     } else {
         // device-resident MuZero step: parent hidden state gathered from the slab, action plane synthesised on device
-        if ((rc = L.pool.hiddenIndexAsync(n_ + 1, sims_done_, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
+        if ((rc = L.pool.hiddenIndexAsync(slab_slots_, sims_done_, L.d_src_idx.p, L.d_dst_idx.p, L.d_action_ids.p))) { return rc; }
         if ((rc = L.net->recurrent(L.d_hidden.p, L.d_src_idx.p, nullptr, L.d_action_ids.p, L.n, L.d_policy.p, L.d_logit.p, L.d_value.p, L.d_reward.p,
                                   L.d_hidden.p, L.d_dst_idx.p))) {
             return rc;
@@ -1611,7 +1615,7 @@ int Worker::runCyclesSim(int n)
                 GumbelView gv = gum_;
                 gv.state = L->d_gum.p;
                 bool launched = false;
-                int rc = L->net->simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p, games_[0].env->numPlayers(), L->d_policy.p,
+                int rc = L->net->simLaunchMz(L->pool, L->d_hidden.p, slab_slots_, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p, games_[0].env->numPlayers(), L->d_policy.p,
                                             L->d_logit.p, L->d_value.p, L->d_reward.p, 0, 1, &launched, noise_cfg ? L->d_noise.p : nullptr,
                                             cfg_.actor_dirichlet_noise_epsilon, cfg_.actor_use_dirichlet_noise ? 1 : 2, dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p,
                                             host_gumbel, true);
@@ -1698,7 +1702,7 @@ int Worker::runCyclesSim(int n)
                         if (pre) { ++stats_.sim_launches; }
                     }
                 }
-                int rc = sim_mz_ ? L->net->simLaunchMz(L->pool, L->d_hidden.p, n_ + 1, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
+                int rc = sim_mz_ ? L->net->simLaunchMz(L->pool, L->d_hidden.p, slab_slots_, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
                                                       games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_reward.p, sim0 + c0, c1 - c0,
                                                       &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
                                                       dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg, false, use_rounds ? L->pre_epoch : 0, use_rounds && noise_in_batch)
@@ -2019,7 +2023,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
         MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
-        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_sim_round_alt) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
         // the Atari-shaped environments keep a window of screens sized from these three at creation (ref atari.cpp:87); records of a larger window
         // would miss frames, so they are fixed where observations are kept (board games: free to change, like the reference)
         if (games_[0].env->hasObservations()) { MZ_FIXED(zero_actor_intermediate_sequence_length) MZ_FIXED(learner_n_step_return) MZ_FIXED(learner_muzero_unrolling_step) }

@@ -360,7 +360,8 @@ def test_atari_cluster_pools_are_equivalent(mz, games):
     assert single == rounds_on_clusters
 
 
-@pytest.mark.parametrize("games,extra", [(5, ""), (13, ""), (64, ""), (64, ":mz_sim_cluster=false"), (16, ":mz_sim_round_min=4"), (64, ":mz_sim_round_min=4")])
+@pytest.mark.parametrize("games,extra", [(5, ""), (13, ""), (64, ""), (64, ":mz_sim_cluster=false"), (16, ":mz_sim_round_min=4"), (64, ":mz_sim_round_min=4"),
+                                         (13, ":mz_sim_round_alt=false"), (64, ":mz_sim_round_alt=false")])
 def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
     """mz_sim_rounds (default): the leaves of a whole Gumbel round — the simulations between two halvings visit different root children — are evaluated side
     by side ahead of the simulations, which then run in order and skip tower + heads when their leaf is the one evaluated for them (sim.hip
@@ -390,7 +391,7 @@ def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
     assert mixed == off and rmixed == roff
 
 
-@pytest.mark.parametrize("m,n", [(16, 50), (12, 50), (6, 33), (5, 20), (3, 7), (2, 9), (18, 40), (16, 16), (8, 100)])
+@pytest.mark.parametrize("m,n", [(16, 50), (12, 50), (6, 33), (5, 20), (3, 7), (2, 9), (18, 40), (16, 16), (8, 100), (2, 60), (4, 90)])
 def test_atari_gumbel_rounds_other_shapes_match_the_oracle(mz, oracle, m, n):
     """The rounds of other (n, m): m not a power of two (12 -> 6 -> 3: rounds of 12, 6, 3 ...), m = 18 > 16 (every root child sampled; the Gumbel step's
     sorts then fall back to the one-lane replay of libstdc++'s introsort), n < m (the first round is cut short), n much larger than the schedule's
@@ -411,6 +412,11 @@ def test_atari_gumbel_rounds_other_shapes_match_the_oracle(mz, oracle, m, n):
     assert wk.pop_lines() == og.lines()
     assert wk.peek_records(6) == og.peek_records(6)
     assert st["pre_evals"] > 0 and st["pre_hits"] >= 6 * min(m, n) * (moves - 1)  # at least the first round of every move
+    # six games leave most CUs idle: every round also evaluates each simulation's SECOND expected leaf (mz_sim_round_alt, the walk stopping one level
+    # earlier); the deep searches of few root children do consume some of them — the node then remembers a slot of the slab's second bank
+    print(f"m={m} n={n}: evaluated ahead {st['pre_evals']}, found {st['pre_hits']}, second expected leaf {st['pre_alt_hits']}")
+    if (m, n) in ((4, 90), (8, 100)):
+        assert st["pre_alt_hits"] > 0
 
 
 def test_go_muzero_gumbel_execution_modes_are_equivalent(mz, oracle):
