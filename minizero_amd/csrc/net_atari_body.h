@@ -23,7 +23,7 @@ struct AtariHeadParams {
 // sequential f32 chain (dotChain: the weights of 16 steps are loaded ahead of the 16 dependent fmas); the 601 quotients of the
 // expectation are independent and computed by all threads, only the two index-ordered sums are serial.
 // s = ((x[0] + x[1]) + x[2]) + ... in index order, by ONE wave: lane l holds elements [l * VPL, (l + 1) * VPL) in registers and the running
-// sum is handed from lane to lane (v_readlane).  The same n - 1 dependent adds as a scalar loop, but without an LDS round trip per
+// sum is handed from lane to lane.  The same n - 1 dependent adds as a scalar loop, but without an LDS round trip per
 // element (one lane reading x[i] and adding, 601 times, cost 33 us per sum: the 601-bin heads have four such sums).
 template <int VPL>
 __device__ __forceinline__ float orderedSumWaveT(const float* x, int n, int vpl, int lane)
@@ -31,15 +31,18 @@ __device__ __forceinline__ float orderedSumWaveT(const float* x, int n, int vpl,
     float v[VPL]; // slots beyond the lane's elements hold +0: adding +0 never changes a sum that is not -0, and these sums never are
 #pragma unroll
     for (int k = 0; k < VPL; ++k) { const int i = lane * vpl + k; v[k] = (k < vpl && i < n) ? x[i] : 0.0f; }
-    float acc = 0.0f;
+    // Systolic: in every step each lane adds its elements to what its left neighbour held after the previous step (DPP wave_shr:1, lane 0 reads +0).
+    // Lane 0 is right after step 0 and stays right (same inputs every step), so lane l is right from step l on: after `lanes` steps the last lane
+    // holds the sum of all elements, added in index order.  The hand-over costs no instruction (the shift is folded into the first add of the
+    // step); handing the sum over with v_readlane cost a VALU -> SGPR -> VALU round trip per lane (3.9 us per 601-bin sum, 2.3 us this way).
+    float a = 0.0f;
     const int lanes = (n + vpl - 1) / vpl;
-    for (int l = 0; l < lanes; ++l) { // straight-line body: VPL dependent adds in every lane, lane l's result is the one that counts
-        float a = acc;
+    for (int l = 0; l < lanes; ++l) {
+        a = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
 #pragma unroll
         for (int k = 0; k < VPL; ++k) { a = a + v[k]; }
-        acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), l));
     }
-    return acc;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), lanes - 1));
 }
 __device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
 {
@@ -267,9 +270,14 @@ __device__ __forceinline__ void discreteTail(int size, bool active, float m, flo
 }
 
 // WIDE (one head per workgroup, sim_cluster.h): one hidden unit / two bins per thread, so that more waves have weight loads in flight
-template <int NT, bool WIDE = false>
+struct NoSideJob {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// side / side_mine: a job for the threads with side_mine set (whole waves that have no share of the first FC layer), run beside that layer
+template <int NT, bool WIDE = false, class Side = NoSideJob>
 __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool active, const float* xs, int C, int P, float* f, float* h1, float* lg, float* red,
-                             float* out, int t, float* ring = nullptr)
+                             float* out, int t, float* ring = nullptr, bool side_mine = false, Side side = Side())
 {
     // ring != nullptr (WIDE): FC layers whose shapes fit stream their weights through it (fcStream)
     const bool stream1 = WIDE && ring && NT == 512 && fcStream1Fits(d.hc * P, d.hidden, d.hidden);
@@ -277,7 +285,9 @@ __device__ __forceinline__ void discreteHead(const DiscreteParams& d, bool activ
     if (active) { discreteConv<NT>(d, xs, C, P, f, t); }
     __syncthreads();
     MZ_HPROF(1);
-    if (active) {
+    if (side_mine) {
+        side();
+    } else if (active) {
         const int n1 = d.hc * P;
         if (WIDE && stream1) {
             if constexpr (WIDE) {
@@ -369,6 +379,37 @@ __device__ __forceinline__ float invertValueDev(float value)
     return sign_value * (sq - 1);
 }
 
+// The policy head of one sample by ONE wave, without a workgroup barrier: conv1x1 + ReLU, fully connected layer, softmax (every sum the reference's
+// sequential chain).  atariHeadsBody runs it on a wave that has no share of the discrete heads' first FC layer, beside that layer.
+__device__ __forceinline__ void policyHeadWave(const AtariHeadParams& hp, const float* xs, float* pf, float* lgp, float* __restrict__ policy,
+                                               float* __restrict__ logit, int b, int lane)
+{
+    const int C = hp.C, P = hp.P, A = hp.A, PC = hp.PC;
+    for (int i = lane; i < PC * P; i += 64) {
+        const int j = i / P, p = i - j * P;
+        const float v = dotChain<16, true>(xs + p, P, hp.pconv_w + j * C, 1, C) + hp.pconv_b[j];
+        pf[i] = v > 0.0f ? v : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int a = lane; a < A; a += 64) {
+        const float v = dotChain<16, true>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
+        lgp[a] = v;
+        logit[size_t(b) * A + a] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float m = -3.4e38f;
+    for (int a = lane; a < A; a += 64) { m = lgp[a] > m ? lgp[a] : m; }
+    for (int o = 32; o > 0; o >>= 1) { const float m2 = __shfl_xor(m, o); m = m2 > m ? m2 : m; }
+    for (int a = lane; a < A; a += 64) { lgp[a] = mz_expf(lgp[a] - m); }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float s = 0.0f;
+    for (int a = 0; a < A; ++a) { s += lgp[a]; }
+    for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lgp[a] / s; }
+}
+
 // The heads of one sample, run by 2 * NTH threads (tid = 0 .. 2 * NTH - 1): x = the trunk's output, either [C][P] in global memory (xg) or
 // padded planes in LDS (xlds: channel stride xcs, row stride xpw, 1-pixel border).  `sm` = atariHeadsSmemFloats() floats of LDS scratch.
 // invert: value / reward are written in the game's scale (invertValueDev) instead of the transformed scale.
@@ -431,8 +472,13 @@ __device__ __forceinline__ void atariHeadsBody(const float* __restrict__ xg, con
     // half 1: value head on the rescaled state
     MZ_HPROF(0);
     float* out = half == 0 ? reward + b : value + b;
-    discreteHead<NTH>(half == 0 ? hp.reward : hp.value, half == 0 ? do_reward != 0 : true, half == 0 ? xr : xs, C, P, f, h1, lg, red, out, t);
+    // the policy head rides on the last wave of the value half while the first FC layers run (four hidden units per thread: the layer occupies the
+    // first hidmax / 4 threads of each half); 4.8 us of 40 per leaf on BASELINE configs[4] when it followed the discrete heads on all threads
+    const bool policy_beside = 4 * (NTH - 64) >= hidmax;
+    discreteHead<NTH>(half == 0 ? hp.reward : hp.value, half == 0 ? do_reward != 0 : true, half == 0 ? xr : xs, C, P, f, h1, lg, red, out, t, nullptr,
+                      policy_beside && tid >= NT2 - 64, [&]() { policyHeadWave(hp, xs, pf, lgp, policy, logit, b, lane); });
     if (invert && t == 0 && (half == 1 || do_reward)) { *out = invertValueDev(*out); }
+    if (policy_beside) { return; }
     // policy head (all threads; its barriers come after the discrete heads')
     for (int i = tid; i < PC * P; i += NT2) {
         const int j = i / P, p = i - j * P;
