@@ -103,7 +103,9 @@ inline size_t gumbelSmemBytes(int A) { return size_t(A) * (3 * sizeof(float) + s
 // bump >= 0: the step is computed AHEAD of the backup of the simulation in flight — that backup will add one visit to root child `bump` (the child on the
 // current path) and to nothing else this step reads, unless the candidates have all reached their budget (the halving ranks them by their means, which
 // the backup changes): then nothing is written and -1 comes back, and the step runs again after the backup (sim_cluster.h).
-__device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelView& gv, int sim_post, int g, int lane, float* smem, int bump = -1)
+// bump_cnt >= 0: the visit count of child `bump` BEFORE that backup, read by the caller while no backup was in flight (the step then runs beside the
+// backup on another wave, sim_kernel_mz: whatever the record of that child holds at the moment is not looked at)
+__device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelView& gv, int sim_post, int g, int lane, float* smem, int bump = -1, float bump_cnt = -1.0f)
 {
     const size_t base = size_t(g) * v.cap;
     const NodeRec root = v.rec[base];
@@ -120,7 +122,7 @@ __device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelVie
     float mx = 0.0f;
     for (int i = lane; i < nc; i += 64) {
         const NodeRec c = v.rec[base + fc + i];
-        cnt[i] = i == bump ? c.count + 1.0f : c.count;
+        cnt[i] = i == bump ? (bump_cnt >= 0.0f ? bump_cnt : c.count) + 1.0f : c.count;
         lg[i] = v.logit[base + fc + i];
         mx = c.count > mx ? c.count : mx;
         // score of gumbelSortByScore: logit + (c_visit + max count) * c_scale * normalized mean; the max count is added below

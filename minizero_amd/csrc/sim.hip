@@ -520,7 +520,7 @@ __device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, in
 // given: the network outputs of this leaf come from the stand-alone kernels (the muzero_atari root: value / reward still in the transformed scale)
 // part 0: everything; part 1: the candidate list and the new children (needs the policy only); part 2: value / reward + backup (the cluster kernel runs
 // part 1 while the value and reward heads of the game's other workgroups are still busy)
-// presorted: the sorted candidate list already lies in a->cand_action / cand_policy / cand_logit (a leaf that was evaluated ahead, simPreProbe)
+// presorted: a leaf that was evaluated ahead (simPreProbe) — `slot` is its entry, which holds the sorted candidate list
 __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false, int part = 0, bool presorted = false)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
@@ -556,12 +556,19 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
         }
     }
     waveSync();
-    expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, part);
+    MZ_LPROF(23);
+    if (presorted) { // the sorted candidate list of a leaf evaluated ahead lies in its entry (= its slab slot): all A actions (legality is only known at the root, zero_actor.cpp:238)
+        const size_t off = (size_t(g) * a->slots + slot - g) * A;
+        expandBackupBody(v, a->cand_count, a->pre_action + off, a->pre_policy + off, a->pre_logit + off, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, part);
+    } else {
+        expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, part);
+    }
+    MZ_LPROF(24);
 }
 
 // The Gumbel step of simulation `next_slot`, ahead of the backup of the simulation in flight (gumbel_body.h `bump`): true if a->start[g] and the state are
 // those the step after the backup would write.  The cluster kernel runs it on its owner while the other workgroups' value / reward heads are still busy.
-__device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_slot, int g, int lane, float* tiles)
+__device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_slot, int g, int lane, float* tiles, float bump_cnt = -1.0f)
 {
     g = __builtin_amdgcn_readfirstlane(g);
     next_slot = __builtin_amdgcn_readfirstlane(next_slot);
@@ -570,7 +577,7 @@ __device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_s
     const int len = pv.path_len[g];
     if (len < 2) { return false; }
     const int child = pv.path[size_t(g) * pv.max_depth + 1] - pv.rec[size_t(g) * pv.cap].first_child;
-    const int st = gumbelStepBody(pv, gum, next_slot, g, lane, tiles, child);
+    const int st = gumbelStepBody(pv, gum, next_slot, g, lane, tiles, child, bump_cnt);
     if (st >= 0 && lane == 0) { a->start[g] = st; }
     waveSync();
     return st >= 0;
@@ -583,14 +590,17 @@ __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, boo
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     slot = __builtin_amdgcn_readfirstlane(slot);
     g = __builtin_amdgcn_readfirstlane(g);
+    MZ_LPROF(0);
     if (slot == 1 && a->root_noise && !noise_done) { simApplyRootNoise<2>(a, g, lane); }
     if (a->use_gumbel && !gumbel_done) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
+    MZ_LPROF(20);
     const PoolView pv = ldc(&a->pv);
     selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec, serial);
+    MZ_LPROF(21);
 }
 
 // Leaves evaluated ahead (sim_pre_kernel_mz): does the entry of simulation `slot` hold THIS leaf — the same parent hidden state (slab slot `src`) and the
-// same action, written in this move (`epoch`)?  Then its network outputs are copied to the game's arrays (one wave; A <= 64 per pass) and the slab slot
+// same action, written in this move (`epoch`)?  Then its value and reward are copied to the game's arrays and the slab slot
 // that holds its hidden state is returned (`slot`, or alt_base + slot for the second expected leaf); -1: not evaluated ahead.  The simulation then runs
 // exactly as if the kernel had evaluated the leaf itself: candidates, expand (the node remembers the returned slot), backup.
 __device__ __forceinline__ int simPreProbe(CSimArgs* __restrict__ a, int epoch, int g, int slot, int src, int action, int lane)
@@ -609,13 +619,7 @@ __device__ __forceinline__ int simPreProbe(CSimArgs* __restrict__ a, int epoch, 
         if (a->pre_stat && key[2] == epoch && lane == 0 && slot < 126) { atomicAdd(a->pre_stat + 2 + slot, 1u); } // (monitoring: which simulations of a move miss, MZ_SIM_PROF)
         return -1;
     }
-    const int A = a->A;
-    for (int i = lane; i < A; i += 64) { // the sorted candidate list of a non-root leaf (all A actions: legality is only known at the root, zero_actor.cpp:238)
-        a->cand_action[size_t(g) * A + i] = a->pre_action[e * A + i];
-        a->cand_policy[size_t(g) * A + i] = a->pre_policy[e * A + i];
-        a->cand_logit[size_t(g) * A + i] = a->pre_logit[e * A + i];
-    }
-    if (lane == 0) {
+    if (lane == 0) { // (the entry's sorted candidate list is read where it lies: simMzCandExpand)
         a->value[g] = a->pre_value[e];
         a->reward[g] = a->pre_reward[e];
         if (a->pre_stat) { atomicAdd(a->pre_stat, 1u); }
@@ -718,9 +722,13 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         // host_start bit 1: the root's network outputs are given (policy / logit / value / reward arrays, hidden state in slab slot 0: the muzero_atari
         // root, whose 96x96 representation runs as stand-alone kernels) — simulation 0 is only its candidate list + expand + backup
         const bool given = slot == 0 && (host_start & 2) != 0;
-        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, false, (host_start & 4) != 0, (a->no_spec & 2) ? 0 : s + 1); }
+        // s_gum_ahead: this simulation's Gumbel step was computed beside the previous simulation's expand + backup (below)
+        __shared__ int s_gum_ahead;
+        __shared__ float s_bump_cnt;
+        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, s > 0 && s_gum_ahead != 0, (host_start & 4) != 0, (a->no_spec & 2) ? 0 : s + 1); }
         else if (wave <= kHelpSegs && spec.w && !(a->no_spec & 2)) { simSelectHelper(a, g, lane, wave, s + 1, rcp_lds, spec); }
         __syncthreads();
+        if (tid == 64) { s_gum_ahead = 0; } // (wave 1 sets it again below; wave 0 looked at it before the barrier)
         // was this leaf evaluated ahead (sim_pre_kernel_mz)?  Then the tower and the heads are skipped: outputs and hidden state are in place
         __shared__ int s_pre_hit;
         bool hit = false;
@@ -729,7 +737,11 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
                 const int len = v.path_len[g];
                 const int* path = v.path + size_t(g) * v.max_depth;
                 const int h = simPreProbe(a, pre_epoch, g, slot, v.hslot[size_t(g) * v.cap + path[len - 2]], v.path_action[size_t(g) * v.max_depth + len - 1], lane);
-                if (lane == 0) { s_pre_hit = h; }
+                if (lane == 0) {
+                    s_pre_hit = h;
+                    s_bump_cnt = v.rec[size_t(g) * v.cap + path[1]].count; // the root child on this path, before this simulation's backup
+                }
+                MZ_LPROF(22);
             }
             __syncthreads();
             hit = s_pre_hit >= 0;
@@ -764,6 +776,14 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             __syncthreads();
         }
         if (wave == 0) { simMzCandExpand(a, eslot, g, lane, tiles, cand_k, given, 0, hit); }
+        else if (wave == 1 && hit && a->use_gumbel && s + 1 < nsims) {
+            // The next simulation's Gumbel step beside this simulation's expand + backup (4.4 of 15.7 us per simulation on BASELINE configs[4]): that backup
+            // adds one visit to the root child on this path and changes nothing else the step reads — unless the candidates have all reached their
+            // budget (the halving ranks them by means): then the step says so and runs after the backup as always.  The heads' scratch is free: the
+            // leaf was evaluated ahead.
+            const bool done = simGumbelAhead(a, slot + 1, g, lane, head_scratch, s_bump_cnt);
+            if (lane == 0) { s_gum_ahead = done ? 1 : 0; }
+        }
         __syncthreads();
         if (prof && tid == 0 && !given) {
             const unsigned long long t4 = wall_clock64();
@@ -956,6 +976,7 @@ void Net::dumpSimProf()
                                   "cand.store", "expand", "backup", "expand+backup"};
             fprintf(stderr, "[mz sim lprof] us per section of the tree phases (game 0, avg over %llu simulations):", h[31]);
             for (int i = 1; i < 13; ++i) { if (h[i]) { fprintf(stderr, " %s %.2f", nm[i], double(h[i]) / double(h[31]) * 0.01); } }
+            for (int i = 15; i < 31; ++i) { if (h[i]) { fprintf(stderr, " [%d] %.2f", i, double(h[i]) / double(h[31]) * 0.01); } }
             fprintf(stderr, "\n");
         }
     }
