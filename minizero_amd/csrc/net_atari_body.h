@@ -475,8 +475,9 @@ __device__ __forceinline__ void atariHeadsBody(const float* __restrict__ xg, con
     // the policy head rides on the last wave of the value half while the first FC layers run (four hidden units per thread: the layer occupies the
     // first hidmax / 4 threads of each half); 4.8 us of 40 per leaf on BASELINE configs[4] when it followed the discrete heads on all threads
     const bool policy_beside = 4 * (NTH - 64) >= hidmax;
-    discreteHead<NTH>(half == 0 ? hp.reward : hp.value, half == 0 ? do_reward != 0 : true, half == 0 ? xr : xs, C, P, f, h1, lg, red, out, t, nullptr,
-                      policy_beside && tid >= NT2 - 64, [&]() { policyHeadWave(hp, xs, pf, lgp, policy, logit, b, lane); });
+    auto policy_job = [&]() { policyHeadWave(hp, xs, pf, lgp, policy, logit, b, lane); };
+    discreteHead<NTH, false, decltype(policy_job)>(half == 0 ? hp.reward : hp.value, half == 0 ? do_reward != 0 : true, half == 0 ? xr : xs, C, P, f, h1, lg, red,
+                                                        out, t, nullptr, policy_beside && tid >= NT2 - 64, policy_job);
     if (invert && t == 0 && (half == 1 || do_reward)) { *out = invertValueDev(*out); }
     if (policy_beside) { return; }
     // policy head (all threads; its barriers come after the discrete heads')

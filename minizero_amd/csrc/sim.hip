@@ -811,17 +811,23 @@ __global__ __launch_bounds__(64) void sim_root_noise_kernel(const SimArgs* __res
 // (parent slot, action, epoch).  Nothing of the search state is touched.  The simulation kernel then runs the R simulations IN ORDER as always — true
 // Gumbel step, true walk, expand, backup — and skips tower + heads whenever its leaf is the tagged one (simPreProbe); a walk that ends elsewhere
 // (the bounds moved, a halving fell differently) just evaluates its leaf itself.  Records cannot change: only WHERE an evaluation ran does.
-#ifndef MZ_PRE_WPE
-#define MZ_PRE_WPE 2 // (4 = two workgroups per CU, 128 VGPRs: measured 211 us per launch on average against 198 us — 50 spilled registers, and both towers want the same MFMA pipes)
-#endif
-template <int H, int W, int CDYN_PAD, int CPAD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MZ_PRE_WPE, 4))) void sim_pre_kernel_mz(const SimArgs* __restrict__ a_, int s0, int R, int NH, int epoch)
+// WPE = waves per SIMD the registers are budgeted for: 2 = one workgroup per CU (256 VGPRs; the rounds that leave CUs idle: latency counts), 4 = two
+// workgroups per CU (128 VGPRs; the rounds of more workgroups than CUs: one workgroup's walk, heads and layer boundaries fill behind the other's MFMAs).
+// Measured on BASELINE configs[4]: the round of 16 (1024 workgroups) 601 -> 535 us, the round of 8 286 -> 261 us — two workgroups on a CU take 1.85 x
+// the time of one: both stream the same 4.5 MB of weights through the CU's L1 and both towers want the same four MFMA pipes.  (The tower does not spill at
+// 128 registers — what spills, 39 registers, is in the heads' chains; leaving out the layer-to-layer weight prefetch or halving the heads' prefetch depth
+// changed nothing.)
+template <int H, int W, int CDYN_PAD, int CPAD, int WPE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, 4))) void sim_pre_kernel_mz(const SimArgs* __restrict__ a_, int s0, int R, int NH, int epoch)
 {
     CSimArgs* a = (CSimArgs*)a_;
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     const int g = blockIdx.x / (R * NH), q = blockIdx.x % (R * NH), r = q % R, hyp = q / R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int CM = CDYN_PAD > CPAD ? CDYN_PAD : CPAD;
-    constexpr int kTileFloats = kTowerTiles * CM * planeStride(H, W);
+    // (the tower's second tile only ever holds CPAD channels: what follows starts there — the tower's zero fill of 2 x CM channels runs over the control
+    // words and the heads' scratch, which are dead / not yet alive then — so that two workgroups fit the CU's 160 KB)
+    constexpr int kTileFloats = (CM + CPAD) * planeStride(H, W);
+    static_assert(kTowerTiles == 2, "layout of the tower tiles");
     const AtariHeadParams hp = ldc(&a->ahp);
     const PoolView v = ldc(&a->pv);
     // LDS: the tower tiles | [0] ok [1] parent slot [2] action [3] start node | Gumbel state copy | the walk's path | the heads' scratch (16-byte aligned)
@@ -922,10 +928,16 @@ static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, i
 }
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
-static int launchSimPreMzT(const SimArgs* d_args, int games, int s0, int R, int NH, int epoch, size_t lds, hipStream_t s)
+static int launchSimPreMzT(const SimArgs* d_args, int games, int s0, int R, int NH, int epoch, size_t lds, hipStream_t s, bool dense)
 {
-    MZ_LDS_ATTR((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD>), lds);
-    hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD>), dim3(games * R * NH), dim3(512), lds, s, d_args, s0, R, NH, epoch);
+    if (dense) {
+        MZ_LDS_ATTR((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 4>), lds);
+        hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 4>), dim3(games * R * NH), dim3(512), lds, s, d_args, s0, R, NH, epoch);
+        MZ_HIP(hipGetLastError());
+        return MZ_OK;
+    }
+    MZ_LDS_ATTR((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 2>), lds);
+    hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 2>), dim3(games * R * NH), dim3(512), lds, s, d_args, s0, R, NH, epoch);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
@@ -1295,15 +1307,17 @@ int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* 
     int cd = 0;
     if (!makeTowerArgs(dyn_, false, true, &t2, &cd)) { return MZ_OK; }
     const int c0 = C, cmax = std::max(cd, C);
-    const size_t tile_bytes = size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float);
+    const size_t tile_bytes = size_t(cmax + C) * planeStride(H, W) * sizeof(float);
     if (gumbelSmemBytes(a.A) > tile_bytes) { return MZ_OK; }
     const size_t ctl_words = (4 + 4 + kGumbelMaxSample + 2 * size_t(max_depth) + 2 + 3) & ~size_t(3);
     const size_t lds = tile_bytes + ctl_words * sizeof(int) + atariHeadsSmemFloats(a.ahp) * sizeof(float);
-    if (lds > 160 * 1024) { return MZ_OK; }
+    if (lds > 160 * 1024 || size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float) > lds) { return MZ_OK; }
     // the second expected leaf of every simulation rides along where the round leaves half of the CUs idle (the rounds of two on a pool of 64 games)
-    const int NH = (a.alt_base && 2 * games * R <= cu_count_ * (getenv("MZ_PRE_ALT_WAVES") ? atoi(getenv("MZ_PRE_ALT_WAVES")) : 1)) ? 2 : 1;
+    const int NH = (a.alt_base && 2 * games * R <= cu_count_) ? 2 : 1;
+    // more workgroups than CUs: two per CU (the 128-VGPR build of the kernel), if two fit the LDS
+    const bool dense = NH * games * R > cu_count_ && 2 * lds <= 160 * 1024 && !getenv("MZ_PRE_SPARSE");
 #define MZ_SIM_PRE_LAUNCH(h, w, cin0, cdyn, cpad) \
-    if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimPreMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), games, s0, R, NH, epoch, lds, stream_); }
+    if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimPreMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), games, s0, R, NH, epoch, lds, stream_, dense); }
     MZ_SIM_MZ_CLUSTER_CASES(MZ_SIM_PRE_LAUNCH)
 #undef MZ_SIM_PRE_LAUNCH
     return MZ_OK;
