@@ -816,7 +816,8 @@ __global__ __launch_bounds__(64) void sim_root_noise_kernel(const SimArgs* __res
 // Measured on BASELINE configs[4]: the round of 16 (1024 workgroups) 601 -> 535 us, the round of 8 286 -> 261 us — two workgroups on a CU take 1.85 x
 // the time of one: both stream the same 4.5 MB of weights through the CU's L1 and both towers want the same four MFMA pipes.  (The tower does not spill at
 // 128 registers — what spills, 39 registers, is in the heads' chains; leaving out the layer-to-layer weight prefetch or halving the heads' prefetch depth
-// changed nothing.)
+// changed nothing.  Starting the CU's second workgroup half a run time late, so that one's heads run beside the other's tower, changed nothing either:
+// the heads' vector instructions take issue slots from the MFMAs of the same SIMD.)
 template <int H, int W, int CDYN_PAD, int CPAD, int WPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, 4))) void sim_pre_kernel_mz(const SimArgs* __restrict__ a_, int s0, int R, int NH, int epoch)
 {
