@@ -496,11 +496,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
 // ---- MuZero (board games; ref muzero_network.h:97-178, zero_actor.cpp:215-245): no leaf environment.  The leaf is evaluated from
 // its parent's hidden state (slab slot `hslot[parent]`) and the move; its children are ALL actions (the root: the legal ones) in
 // the reference's sort order; the new hidden state is rescaled to [0, 1] per sample and written to the slab slot of this simulation.
-__device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, int lane, float* tiles, int* kshare)
+__device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, int lane, float* tiles, int* kshare, int* lds_path = nullptr)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
-    const PoolView v = ldc(&a->pv);
+    const PoolView v = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
     const int A = a->A, len = v.path_len[g], depth = len - 1;
     Cand* cs = reinterpret_cast<Cand*>(tiles);
     int k = 0;
@@ -521,14 +521,16 @@ __device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, in
 // part 0: everything; part 1: the candidate list and the new children (needs the policy only); part 2: value / reward + backup (the cluster kernel runs
 // part 1 while the value and reward heads of the game's other workgroups are still busy)
 // presorted: a leaf that was evaluated ahead (simPreProbe) — `slot` is its entry, which holds the sorted candidate list
-__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false, int part = 0, bool presorted = false)
+// lds_path: the simulation's path lives in LDS (simPathView) instead of the pool's arrays
+__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false, int part = 0, bool presorted = false,
+                                             int* lds_path = nullptr)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
     slot = __builtin_amdgcn_readfirstlane(slot);
     k = __builtin_amdgcn_readfirstlane(k);
     part = __builtin_amdgcn_readfirstlane(part);
-    const PoolView v = ldc(&a->pv);
+    const PoolView v = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
     const int A = a->A, len = v.path_len[g], depth = len - 1;
     if (part != 2 && !presorted) {
         Cand* cs = reinterpret_cast<Cand*>(tiles);
@@ -568,11 +570,11 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
 
 // The Gumbel step of simulation `next_slot`, ahead of the backup of the simulation in flight (gumbel_body.h `bump`): true if a->start[g] and the state are
 // those the step after the backup would write.  The cluster kernel runs it on its owner while the other workgroups' value / reward heads are still busy.
-__device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_slot, int g, int lane, float* tiles, float bump_cnt = -1.0f)
+__device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_slot, int g, int lane, float* tiles, float bump_cnt = -1.0f, int* lds_path = nullptr)
 {
     g = __builtin_amdgcn_readfirstlane(g);
     next_slot = __builtin_amdgcn_readfirstlane(next_slot);
-    const PoolView pv = ldc(&a->pv);
+    const PoolView pv = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
     const GumbelView gum = ldc(&a->gum);
     const int len = pv.path_len[g];
     if (len < 2) { return false; }
@@ -584,7 +586,7 @@ __device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_s
 }
 
 __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
-                                         bool gumbel_done = false, bool noise_done = false, int serial = 0)
+                                         bool gumbel_done = false, bool noise_done = false, int serial = 0, int* lds_path = nullptr)
 {
     serial = __builtin_amdgcn_readfirstlane(serial);
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
@@ -594,7 +596,7 @@ __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, boo
     if (slot == 1 && a->root_noise && !noise_done) { simApplyRootNoise<2>(a, g, lane); }
     if (a->use_gumbel && !gumbel_done) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
     MZ_LPROF(20);
-    const PoolView pv = ldc(&a->pv);
+    const PoolView pv = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
     selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec, serial);
     MZ_LPROF(21);
 }
@@ -713,7 +715,10 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     __syncthreads();
     SpecMem spec{((a->no_spec & 1) || a->atari) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
     float* head_scratch = reinterpret_cast<float*>(spec_w + kSpecWords);
-    const PoolView v = ldc(&a->pv);
+    // muzero_atari (no path speculation: its memory is free): the simulation's path stays in LDS — the walk writes it, the probe, expand, backup and the
+    // next Gumbel step read it — instead of going through the pool's arrays in global memory (a round trip each)
+    int* lds_path = (a->atari && 2 * a->pv.max_depth + 2 <= kSpecWords) ? spec_w : nullptr;
+    const PoolView v = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr; // MZ_SIM_PROF=1: [select, tower, heads, cand+expand] ticks + sims
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
@@ -725,7 +730,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         // s_gum_ahead: this simulation's Gumbel step was computed beside the previous simulation's expand + backup (below)
         __shared__ int s_gum_ahead;
         __shared__ float s_bump_cnt;
-        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, s > 0 && s_gum_ahead != 0, (host_start & 4) != 0, (a->no_spec & 2) ? 0 : s + 1); }
+        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, s > 0 && s_gum_ahead != 0, (host_start & 4) != 0, (a->no_spec & 2) ? 0 : s + 1, lds_path); }
         else if (wave <= kHelpSegs && spec.w && !(a->no_spec & 2)) { simSelectHelper(a, g, lane, wave, s + 1, rcp_lds, spec); }
         __syncthreads();
         if (tid == 64) { s_gum_ahead = 0; } // (wave 1 sets it again below; wave 0 looked at it before the barrier)
@@ -769,19 +774,19 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         __shared__ int s_cand_k;
         int cand_k = a->A; // a leaf evaluated ahead brings its sorted candidate list along: all A actions (it is never the root)
         if (!hit) {
-            if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k); }
+            if (wave == 0) { simMzCandGather(a, g, lane, tiles, &s_cand_k, lds_path); }
             __syncthreads();
             cand_k = s_cand_k;
             if (a->cand_coop) { simCandRank(a->A, cand_k, wave, lane, tiles); }
             __syncthreads();
         }
-        if (wave == 0) { simMzCandExpand(a, eslot, g, lane, tiles, cand_k, given, 0, hit); }
+        if (wave == 0) { simMzCandExpand(a, eslot, g, lane, tiles, cand_k, given, 0, hit, lds_path); }
         else if (wave == 1 && hit && a->use_gumbel && s + 1 < nsims) {
             // The next simulation's Gumbel step beside this simulation's expand + backup (4.4 of 15.7 us per simulation on BASELINE configs[4]): that backup
             // adds one visit to the root child on this path and changes nothing else the step reads — unless the candidates have all reached their
             // budget (the halving ranks them by means): then the step says so and runs after the backup as always.  The heads' scratch is free: the
             // leaf was evaluated ahead.
-            const bool done = simGumbelAhead(a, slot + 1, g, lane, head_scratch, s_bump_cnt);
+            const bool done = simGumbelAhead(a, slot + 1, g, lane, head_scratch, s_bump_cnt, lds_path);
             if (lane == 0) { s_gum_ahead = done ? 1 : 0; }
         }
         __syncthreads();
