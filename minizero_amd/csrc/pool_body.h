@@ -661,12 +661,18 @@ __device__ __forceinline__ void selectSpecHelper(const PoolView& v, int g, int l
     if (lane == 0) { out[0] = serial; }
 }
 
+// what expandBackupBody otherwise reads from the per-game staging arrays, for a caller that holds it in registers
+struct ExpandGiven {
+    int k, player;
+    float value, reward;
+};
+
 // `lds` = 2 * bound_cap words of LDS (value-bound multiset: keys then counts; only touched with value_rescale)
 __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* __restrict__ cand_count, const int* __restrict__ cand_action,
                                                  const float* __restrict__ cand_policy, const float* __restrict__ cand_logit,
                                                  const int* __restrict__ cand_player, const float* __restrict__ value_in,
                                                  const float* __restrict__ reward_in, int hslot, int* __restrict__ err, int g, int lane,
-                                                 float* __restrict__ lds, int part = 0)
+                                                 float* __restrict__ lds, int part = 0, const ExpandGiven* given = nullptr)
 {
     // part 0: expand, then backup (one wave).  The two touch different words of the tree (expand: the new children, the leaf's child block and
     // slot; backup: mean / count of the path's nodes and the parent's visited-prefix counter), so without value rescaling two waves can run
@@ -676,7 +682,7 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
     if (len <= 0) { return; }
     const int* path = v.path + size_t(g) * v.max_depth;
     const int leaf = path[len - 1];
-    const int k = part == 2 ? 0 : cand_count[g];
+    const int k = part == 2 ? 0 : (given ? given->k : cand_count[g]);
     // ---- expand (ref mcts.cpp:151-164, tree.h:71-77) ----
     if (k > 0) {
         const int fc = v.num_nodes[g];
@@ -684,7 +690,7 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
             if (lane == 0) { atomicExch(err, MZ_ERR_CAPACITY); }
             return;
         }
-        const int pl = cand_player[g];
+        const int pl = given ? given->player : cand_player[g];
         bool unsorted = false; // select's visited-prefix shortcut needs the priors in descending order (the actor always sorts them)
         for (int i = lane; i < k; i += 64) {
             const size_t n = base + fc + i, c = size_t(g) * v.A + i;
@@ -715,7 +721,7 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
         // The only leaf -> root dependence is `updated = r + gamma * updated`, which needs the rewards but not the means: the
         // path's records are loaded by 64 lanes at once (one memory round trip per 64 levels instead of one per level — the
         // deepest of the 256 paths sets the kernel time), the chain runs over registers, then every lane updates its own node.
-        const float val = value_in[g], rew = reward_in[g];
+        const float val = given ? given->value : value_in[g], rew = given ? given->reward : reward_in[g];
         if (lane == 0) {
             v.value[base + leaf] = val;
             v.rec[base + leaf].reward = rew;
@@ -754,8 +760,9 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
     float* bkey = lds;                                     // value-bound multiset, LDS copy
     int* bcnt = reinterpret_cast<int*>(lds + v.bound_cap);
     int bsize = v.bound_size[g];
-    for (int j = lane; j < bsize; j += 64) { bkey[j] = v.bound_key[size_t(g) * v.bound_cap + j]; bcnt[j] = v.bound_cnt[size_t(g) * v.bound_cap + j]; }
-    const float val = value_in[g], rew = reward_in[g];
+    // (all bound_cap entries, not only the bsize live ones: the loads then do not wait for bsize; the others are never looked at)
+    for (int j = lane; j < v.bound_cap; j += 64) { bkey[j] = v.bound_key[size_t(g) * v.bound_cap + j]; bcnt[j] = v.bound_cnt[size_t(g) * v.bound_cap + j]; }
+    const float val = given ? given->value : value_in[g], rew = given ? given->reward : reward_in[g];
     if (lane == 0) {
         v.value[base + leaf] = val;
         v.rec[base + leaf].reward = rew;

@@ -545,6 +545,17 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
             a->cand_logit[size_t(g) * A + i] = out[i].logit;
         }
     }
+    if (presorted && part == 0) {
+        // A leaf evaluated ahead: its sorted candidate list lies in its entry (= its slab slot) — all A actions (legality is only known at the root,
+        // zero_actor.cpp:238) — and its value and reward too; everything expand + backup need is loaded side by side, nothing goes through the game's arrays
+        const size_t e = size_t(g) * a->slots + slot, off = (e - g) * A;
+        const int rt = a->root_turn[g];
+        const ExpandGiven eg{k, (a->num_players == 2 && (depth & 1)) ? 3 - rt : rt, a->pre_value[e], a->atari ? a->pre_reward[e] : 0.0f};
+        MZ_LPROF(23);
+        expandBackupBody(v, a->cand_count, a->pre_action + off, a->pre_policy + off, a->pre_logit + off, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, 0, &eg);
+        MZ_LPROF(24);
+        return;
+    }
     if (lane == 0) {
         if (part != 2) {
             const int rt = a->root_turn[g];
@@ -559,7 +570,7 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
     }
     waveSync();
     MZ_LPROF(23);
-    if (presorted) { // the sorted candidate list of a leaf evaluated ahead lies in its entry (= its slab slot): all A actions (legality is only known at the root, zero_actor.cpp:238)
+    if (presorted) { // (cluster kernel, part 1: the children of a leaf evaluated ahead; part 2 takes value and reward from the game's arrays, simPreProbe put them there)
         const size_t off = (size_t(g) * a->slots + slot - g) * A;
         expandBackupBody(v, a->cand_count, a->pre_action + off, a->pre_policy + off, a->pre_logit + off, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, part);
     } else {
