@@ -7,6 +7,9 @@
 #ifndef MZ_LPROF
 #define MZ_LPROF(k) // experiment hook (sim.hip -DMZ_SIM_LPROF): time stamps inside the single-wave tree phases
 #endif
+#ifndef MZ_BPROF
+#define MZ_BPROF(role, k) // experiment hook (sim.hip -DMZ_SIM_BPROF): time stamps inside the part of the leaf that runs beside the heads
+#endif
 
 namespace mz {
 
@@ -19,7 +22,9 @@ __device__ __forceinline__ void waveSync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-inline size_t goLeafSmemBytes(const GoDevView& v, int max_depth) { return sizeof(uint64_t) * (size_t(v.Ppad) + max_depth + 4 + 18 * v.W) + size_t(v.Ppad) * (4 + 2 + 1); }
+// (+ behind the arrays of the body: two words handed from PART 1 to PART 2, and a copy of the 2 x P Zobrist keys for the kernels that keep the block for a whole launch)
+__host__ __device__ inline size_t goLeafKeyWord(int Ppad, int W, int max_depth) { return (sizeof(uint64_t) * (size_t(Ppad) + max_depth + 4 + 18 * W) + size_t(Ppad) * (4 + 2 + 1)) / sizeof(uint64_t) + 2; }
+inline size_t goLeafSmemBytes(const GoDevView& v, int max_depth) { return sizeof(uint64_t) * (goLeafKeyWord(v.Ppad, v.W, max_depth) + 2 * size_t(v.P)); }
 
 struct Cand { int action; float policy, logit; };
 struct CandGreater { __host__ __device__ bool operator()(const Cand& l, const Cand& r) const { return l.policy > r.policy; } };
@@ -41,7 +46,13 @@ __device__ inline uint64_t normH(uint64_t h) { return h ? h : 1; }
 __device__ inline int rotOf(const RotPack& r, int g) { return (r.w[g / 10] >> (3 * (g % 10))) & 7; }
 
 // position + legal mask + feature planes of the leaf selected for game `g` (one wave64; `smem` as sized by goLeafSmemBytes)
-template <int CPL, bool EXT_PLANES = false>
+// PART 0: everything.  PART 1 / 2 (the one-game-per-CU simulation kernel, whose `smem` block then outlives the tower): 1 = what the network needs — the
+// leaf's position (parent + move, stored to its slot), the history block of the planes, the player to move and the terminal flag; 2 = what only the
+// phases AFTER the network need — the path's hashes, the groups' liberties and key sums, the legal mask, the score of a terminal leaf — run by another
+// wave beside the heads: with SYNC it passes a workgroup barrier after the liberties and after the legal mask (the two barriers inside headsBody), and
+// TWO waves share the work — ROLE 0: liberties + key sums | barrier | legal mask of the even 64-point chunks | barrier | score; ROLE 1: the path's hashes |
+// barrier | legal mask of the odd chunks | barrier — so that each piece fits the interval of the heads it runs beside
+template <int CPL, bool EXT_PLANES = false, int PART = 0, bool SYNC = false, int ROLE = 0>
 // EXT_PLANES: the caller builds the feature planes itself from the history block this body leaves in `smem` (goPlanesPart, all waves)
 // seen_lds: optional LDS copy of the root's positional-superko table (GoRootSnapshot::seen; constant during a move) — the simulation kernel
 // makes one per launch so that the probes of every candidate point are LDS reads instead of dependent trips to L2
@@ -56,6 +67,9 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     int* libs = reinterpret_cast<int*>(cur + 2 * W);       // [Ppad] liberties of a group, by group id
     uint16_t* lab = reinterpret_cast<uint16_t*>(libs + Ppad); // [Ppad] group id per point
     uint8_t* col = reinterpret_cast<uint8_t*>(lab + Ppad);  // [Ppad] 0 empty, 1 black, 2 white, 3 off board
+    uint64_t* stash = reinterpret_cast<uint64_t*>(col + Ppad); // [2] PART 1 -> PART 2: the leaf's hash, its terminal flag (Ppad is a multiple of 64: aligned)
+    // the Zobrist keys: with PART 1 / 2 the caller keeps a copy behind the stash (LDS) — a key is on the walk's critical path at every move
+    const uint64_t* zkey = PART != 0 ? smem + goLeafKeyWord(Ppad, W, MD) : v.key;
 
     const int len = pv.path_len[g];
     const int* path = pv.path + size_t(g) * MD;
@@ -70,6 +84,36 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     int c[CPL], l[CPL];
     short nb[CPL][4];
     uint64_t sbw[CPL], sww[CPL];
+    uint64_t hash = 0;
+    int nmoves = 0, passes = 0;
+    int t = (depth & 1) ? 3 - root_turn : root_turn; // the player to move at the leaf
+    bool terminal = false;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int p = i * 64 + lane;
+        nb[i][0] = nb[i][1] = nb[i][2] = nb[i][3] = -1;
+        if (p < P) {
+            const int x = p % n, y = p / n;
+            if (y + 1 < n) { nb[i][0] = static_cast<short>(p + n); }
+            if (x + 1 < n) { nb[i][1] = static_cast<short>(p + 1); }
+            if (y > 0) { nb[i][2] = static_cast<short>(p - n); }
+            if (x > 0) { nb[i][3] = static_cast<short>(p - 1); }
+        }
+    }
+    if constexpr (PART == 2) { // the leaf as PART 1 left it in the block
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int p = i * 64 + lane;
+            c[i] = col[p];
+            l[i] = lab[p];
+            sbw[i] = cur[i];
+            sww[i] = cur[W + i];
+        }
+        hash = stash[0];
+        terminal = (stash[1] & 1) != 0;
+        t = static_cast<int>(stash[1] >> 1); // (no trip to the root's snapshot in global memory)
+    }
+    if constexpr (PART != 2) {
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int p = i * 64 + lane;
@@ -77,24 +121,17 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         sww[i] = v.stones[((sb + src) * 2 + 1) * W + i];
         c[i] = 3;
         l[i] = 0;
-        nb[i][0] = nb[i][1] = nb[i][2] = nb[i][3] = -1;
         if (p < P) {
             c[i] = ((sbw[i] >> lane) & 1) ? 1 : (((sww[i] >> lane) & 1) ? 2 : 0);
             l[i] = v.lab[(sb + src) * Ppad + p];
-            const int x = p % n, y = p / n;
-            if (y + 1 < n) { nb[i][0] = static_cast<short>(p + n); }
-            if (x + 1 < n) { nb[i][1] = static_cast<short>(p + 1); }
-            if (y > 0) { nb[i][2] = static_cast<short>(p - n); }
-            if (x > 0) { nb[i][3] = static_cast<short>(p - 1); }
         }
         col[p] = static_cast<uint8_t>(c[i]);
         lab[p] = static_cast<uint16_t>(l[i]);
     }
-    uint64_t hash = v.hash[sb + src];
-    int nmoves = v.meta[(sb + src) * 2], passes = v.meta[(sb + src) * 2 + 1];
+    hash = v.hash[sb + src];
+    nmoves = v.meta[(sb + src) * 2]; passes = v.meta[(sb + src) * 2 + 1];
     waveSync();
     MZ_LPROF(1); // parent slot loaded
-    const int t = (depth & 1) ? 3 - root_turn : root_turn; // the player to move at the leaf
 
     if (depth >= 1) { // leaf = parent + one move (ref go.cpp:132-190, observable effects only)
         const int a = pact[len - 1], m = 3 - t;
@@ -161,12 +198,12 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
                     if (c[i] == 3 - m && ((cap[0] && l[i] == en[0]) || (cap[1] && l[i] == en[1]) || (cap[2] && l[i] == en[2]) || (cap[3] && l[i] == en[3]))) {
                         c[i] = 0;
                         col[p] = 0;
-                        hx ^= v.key[size_t(2 - m) * P + p];
+                        hx ^= zkey[size_t(2 - m) * P + p];
                     }
                 }
                 hx = waveXor64(hx);
             }
-            hash ^= v.key[size_t(m - 1) * P + a] ^ hx;
+            hash ^= zkey[size_t(m - 1) * P + a] ^ hx;
             waveSync();
         }
 #pragma unroll
@@ -191,83 +228,13 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         if (lane == 0) { cur[i] = sbw[i]; cur[W + i] = sww[i]; }
     }
     MZ_LPROF(2); // move applied, slot stored
-    const bool terminal = passes >= 2 || nmoves > 2 * P; // ref go.cpp:246-257
-    // ---- hashes along the path (d = 1 .. depth; the root and everything before it is in the root's table) ----
-    for (int d = 1 + lane; d <= depth; d += 64) { ph[d - 1] = normH(d == depth ? hash : v.hash[sb + hs[path[d]]]); }
-    if (lane < 4) { ph[depth + lane] = 0; } // normH never returns 0: the padding matches no candidate
-    // ---- group liberties / key sums at the leaf ----
+    terminal = passes >= 2 || nmoves > 2 * P; // ref go.cpp:246-257
+    if (lane == 0) { stash[0] = hash; stash[1] = (terminal ? 1 : 0) | (static_cast<uint64_t>(t) << 1); }
+    if constexpr (PART == 1) { // (PART 2 counts the liberties on two waves: the counters are cleared here)
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { libs[i * 64 + lane] = 0; gh[i * 64 + lane] = 0; }
-    waveSync();
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        if (c[i] != 0) { continue; }
-        int seen_l[4], ns = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int q = nb[i][k];
-            if (q < 0 || col[q] == 0) { continue; }
-            const int lq = lab[q];
-            bool dup = false;
-            for (int j = 0; j < ns; ++j) { dup |= seen_l[j] == lq; }
-            if (!dup) { seen_l[ns++] = lq; atomicAdd(&libs[lq], 1); }
-        }
+        for (int i = 0; i < CPL; ++i) { libs[i * 64 + lane] = 0; gh[i * 64 + lane] = 0; }
     }
     waveSync();
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const int p = i * 64 + lane;
-        if (c[i] == 3 - t && libs[l[i]] == 1) { atomicXor(reinterpret_cast<unsigned long long*>(&gh[l[i]]), static_cast<unsigned long long>(v.key[size_t(2 - t) * P + p])); }
-    }
-    waveSync();
-    MZ_LPROF(3); // path hashes, liberties, key sums
-    // ---- legal mask for the player to move (ref go.cpp:208-244): not occupied, not suicide, not a positional-superko repeat ----
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        bool bit = false;
-        if (c[i] == 0 && !terminal) {
-            const int p = i * 64 + lane;
-            bool ok = false;
-            uint64_t nh = hash ^ v.turn_key ^ v.key[size_t(t - 1) * P + p];
-            int capl[4], ncap = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int q = nb[i][k];
-                if (q < 0) { continue; }
-                const int cq = col[q];
-                if (cq == 0) { ok = true; continue; }
-                const int lq = lab[q];
-                if (cq == t) {
-                    if (libs[lq] > 1) { ok = true; }
-                } else if (libs[lq] == 1) { // an enemy group in atari is captured: each group once
-                    bool dup = false;
-                    for (int j = 0; j < ncap; ++j) { dup |= capl[j] == lq; }
-                    if (!dup) { capl[ncap++] = lq; nh ^= gh[lq]; }
-                    ok = true;
-                }
-            }
-            if (ok) {
-                const uint64_t h = normH(nh);
-                bool rep = false;
-                const uint64_t* seen = seen_lds ? seen_lds : S.seen;
-                for (uint32_t s = static_cast<uint32_t>(h) & (kGoSeenCap - 1);; s = (s + 1) & (kGoSeenCap - 1)) {
-                    const uint64_t e = seen[s];
-                    if (e == 0) { break; }
-                    if (e == h) { rep = true; break; }
-                }
-                for (int d = 0; d < depth; d += 4) { // four hashes per step, no early exit: a deep path made this loop the longest part of the leaf
-                    const uint64_t a0 = ph[d], a1 = ph[d + 1], a2 = ph[d + 2], a3 = ph[d + 3];
-                    rep |= (a0 == h) | (a1 == h) | (a2 == h) | (a3 == h);
-                }
-                bit = !rep;
-            }
-        }
-        uint64_t w = __ballot(bit);
-        if (i == (P >> 6)) { w |= 1ull << (P & 63); } // pass is always legal
-        if (lane == 0) { v.legal[size_t(g) * v.LW + i] = w; }
-    }
-    if (v.LW > CPL && lane == 0) { v.legal[size_t(g) * v.LW + CPL] = (P >> 6) == CPL ? 1ull << (P & 63) : 0; } // P a multiple of 64
-    MZ_LPROF(4); // legal mask
     // ---- feature planes (ref go.cpp:280-308): planes 2k / 2k+1 = own / opponent stones k moves ago, 16 / 17 = black / white to move ----
     const int avail = root_hist_len + depth;
     for (int idx = lane; idx < 16 * W; idx += 64) {
@@ -305,6 +272,117 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         }
     }
     MZ_LPROF(5); // planes
+    if (lane == 0) {
+        v.leaf_player[g] = t;
+        v.terminal[g] = terminal ? 1 : 0;
+    }
+    } // PART != 2
+    if constexpr (PART == 1) { return; }
+    constexpr bool kShared = PART == 2 && SYNC; // two waves share PART 2 (ROLE)
+    MZ_BPROF(ROLE, 0);
+    // the legal mask of the 64-point chunks i with want(i) (ref go.cpp:208-244): not occupied, not suicide, not a positional-superko repeat
+    auto legalMask = [&](auto want) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            if (!want(i)) { continue; }
+            bool bit = false;
+            if (c[i] == 0 && !terminal) {
+                const int p = i * 64 + lane;
+                bool ok = false;
+                uint64_t nh = hash ^ v.turn_key ^ zkey[size_t(t - 1) * P + p];
+                int capl[4], ncap = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = nb[i][k];
+                    if (q < 0) { continue; }
+                    const int cq = col[q];
+                    if (cq == 0) { ok = true; continue; }
+                    const int lq = lab[q];
+                    if (cq == t) {
+                        if (libs[lq] > 1) { ok = true; }
+                    } else if (libs[lq] == 1) { // an enemy group in atari is captured: each group once
+                        bool dup = false;
+                        for (int j = 0; j < ncap; ++j) { dup |= capl[j] == lq; }
+                        if (!dup) { capl[ncap++] = lq; nh ^= gh[lq]; }
+                        ok = true;
+                    }
+                }
+                if (ok) {
+                    const uint64_t h = normH(nh);
+                    bool rep = false;
+                    const uint64_t* seen = seen_lds ? seen_lds : S.seen;
+                    for (uint32_t s = static_cast<uint32_t>(h) & (kGoSeenCap - 1);; s = (s + 1) & (kGoSeenCap - 1)) {
+                        const uint64_t e = seen[s];
+                        if (e == 0) { break; }
+                        if (e == h) { rep = true; break; }
+                    }
+                    for (int d = 0; d < depth; d += 4) { // four hashes per step, no early exit: a deep path made this loop the longest part of the leaf
+                        const uint64_t a0 = ph[d], a1 = ph[d + 1], a2 = ph[d + 2], a3 = ph[d + 3];
+                        rep |= (a0 == h) | (a1 == h) | (a2 == h) | (a3 == h);
+                    }
+                    bit = !rep;
+                }
+            }
+            uint64_t w = __ballot(bit);
+            if (i == (P >> 6)) { w |= 1ull << (P & 63); } // pass is always legal
+            if (lane == 0) { v.legal[size_t(g) * v.LW + i] = w; }
+        }
+    };
+    // Shared by two waves, the pieces are laid into the three intervals of the heads (conv1x1 | FCs | softmax + value: 2.2 / 2.9 / 2.2 us on BASELINE configs[1]):
+    //   ROLE 0: liberties of the even chunks              | barrier | key sums, legal mask of the even chunks | barrier | score of a terminal leaf, the leaf's scalars
+    //   ROLE 1: path hashes, liberties of the odd chunks  | barrier |                                        | barrier | legal mask of the odd chunks
+    // ---- hashes along the path (d = 1 .. depth; the root and everything before it is in the root's table) ----
+    if (!kShared || ROLE == 1) {
+        for (int d = 1 + lane; d <= depth; d += 64) { ph[d - 1] = normH(d == depth ? hash : v.hash[sb + hs[path[d]]]); }
+        if (lane < 4) { ph[depth + lane] = 0; } // normH never returns 0: the padding matches no candidate
+    }
+    // ---- group liberties / key sums at the leaf ----
+    if constexpr (!kShared) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { libs[i * 64 + lane] = 0; gh[i * 64 + lane] = 0; }
+        waveSync();
+    }
+    {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            if (kShared && (i & 1) != ROLE) { continue; }
+            if (c[i] != 0) { continue; }
+            int seen_l[4], ns = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = nb[i][k];
+                if (q < 0 || col[q] == 0) { continue; }
+                const int lq = lab[q];
+                bool dup = false;
+                for (int j = 0; j < ns; ++j) { dup |= seen_l[j] == lq; }
+                if (!dup) { seen_l[ns++] = lq; atomicAdd(&libs[lq], 1); }
+            }
+        }
+    }
+    waveSync();
+    MZ_BPROF(ROLE, 1);
+    if constexpr (SYNC) { __syncthreads(); }
+    MZ_BPROF(ROLE, 2);
+    if (!kShared || ROLE == 0) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int p = i * 64 + lane;
+            if (c[i] == 3 - t && libs[l[i]] == 1) { atomicXor(reinterpret_cast<unsigned long long*>(&gh[l[i]]), static_cast<unsigned long long>(zkey[size_t(2 - t) * P + p])); }
+        }
+        waveSync();
+        MZ_LPROF(3); // path hashes, liberties, key sums
+        if constexpr (kShared) { legalMask([](int i) { return (i & 1) == 0; }); }
+        else { legalMask([](int) { return true; }); }
+        if (v.LW > CPL && lane == 0) { v.legal[size_t(g) * v.LW + CPL] = (P >> 6) == CPL ? 1ull << (P & 63) : 0; } // P a multiple of 64
+        MZ_LPROF(4); // legal mask
+    }
+    MZ_BPROF(ROLE, 3);
+    if constexpr (SYNC) { __syncthreads(); }
+    MZ_BPROF(ROLE, 4);
+    if constexpr (kShared && ROLE == 1) {
+        legalMask([](int i) { return (i & 1) == 1; });
+        return;
+    }
     // ---- terminal: Tromp-Taylor area score + komi (ref go.cpp:259-278,703-723) ----
     float eval = 0.0f;
     if (terminal) {

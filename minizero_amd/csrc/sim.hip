@@ -49,6 +49,17 @@ __shared__ unsigned long long s_lp_prev;
         }                                                                                             \
     } while (0)
 #endif
+#ifdef MZ_SIM_BPROF // experiment: the part of the Go leaf that runs beside the heads (game 0): [role][0] entry -> start, [1] first piece, [2] wait at barrier 1, [3] legal mask, [4] wait at barrier 2
+__device__ unsigned long long g_bp[20];
+#define MZ_BPROF(role, k)                                                                              \
+    do {                                                                                               \
+        if (PART == 2 && (threadIdx.x & 63) == 0 && blockIdx.x == 0) {                                 \
+            const unsigned long long t_ = wall_clock64();                                              \
+            if ((k) == 0) { g_bp[16 + (role)] += 1; g_bp[18 + (role)] = t_; }                          \
+            else { g_bp[(role) * 8 + (k)] += t_ - g_bp[18 + (role)]; g_bp[18 + (role)] = t_; }        \
+        }                                                                                              \
+    } while (0)
+#endif
 #include "pool_body.h"
 #include "go_body.h"
 #include "gumbel_body.h"
@@ -174,7 +185,7 @@ typedef __attribute__((address_space(3))) const double LdsCDouble;
 
 template <int CPL, int WPE, class RcpPtr>
 __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, RcpPtr rcp, SpecMem spec,
-                                           float* xchg, const uint64_t* seen_lds, int serial = 0)
+                                           float* xchg, const uint64_t* seen_lds, int serial = 0, uint64_t* leaf_smem = nullptr)
 {
     serial = __builtin_amdgcn_readfirstlane(serial);
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
@@ -199,7 +210,25 @@ __device__ __noinline__ void simSelectLeaf(CSimArgs* __restrict__ a, int rot, in
     const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
     if constexpr (CPL == -1) { tttLeafBody(gv, pv, rot, slot, g, lane); } // CPL -1: TicTacToe, 0: Othello (go_body.h)
     else if constexpr (CPL == 0) { othLeafBody(gv, pv, rot, slot, g, lane); }
+    else if (leaf_smem) { goLeafBody<CPL, true, 1>(gv, pv, rot, slot, g, lane, leaf_smem, seen_lds); } // what the network needs; the rest beside the heads (simLeafRest)
     else { goLeafBody<CPL, true>(gv, pv, rot, slot, g, lane, reinterpret_cast<uint64_t*>(tiles), seen_lds); } // planes: simLeafPlanes, all waves
+}
+
+// Go, one game per CU: what only the phases after the network need of the leaf — path hashes, liberties, legal mask, a terminal leaf's score (go_body.h
+// goLeafBody PART 2) — on the workgroup's last two waves BESIDE the heads, in which those waves have no share.  They pass the two barriers headsBody passes.
+template <int CPL>
+__device__ __noinline__ void simLeafRest(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* xchg, const uint64_t* seen_lds, uint64_t* leaf_smem, int role)
+{
+    role = __builtin_amdgcn_readfirstlane(role);
+    g = __builtin_amdgcn_readfirstlane(g);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    rot = __builtin_amdgcn_readfirstlane(rot);
+    if constexpr (CPL > 0) {
+        const PoolView pv = simPathView(ldc(&a->pv), reinterpret_cast<int*>(xchg) - 2 * a->pv.max_depth - 2, g);
+        const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
+        if (role == 0) { goLeafBody<CPL, true, 2, true, 0>(gv, pv, rot, slot, g, lane, leaf_smem, seen_lds); }
+        else { goLeafBody<CPL, true, 2, true, 1>(gv, pv, rot, slot, g, lane, leaf_smem, seen_lds); }
+    }
 }
 
 // waves 1 .. 3 beside wave 0's walk: levels 17 .. 64 of the path the previous simulation took, 16 per wave (pool_body.h selectSpecHelper): a deep principal variation is
@@ -216,11 +245,11 @@ __device__ __noinline__ void simSelectHelper(CSimArgs* __restrict__ a, int g, in
 
 // Go: the 18 feature planes of the leaf, two or three per wave (32 ballots over LDS words: 3.3 us on one wave)
 template <int CPL>
-__device__ __forceinline__ void simLeafPlanes(CSimArgs* __restrict__ a, int rot, int g, int wave, int lane, float* tiles, float* xchg)
+__device__ __forceinline__ void simLeafPlanes(CSimArgs* __restrict__ a, int rot, int g, int wave, int lane, const uint64_t* leaf_smem, float* xchg)
 {
     if constexpr (CPL > 0) {
         const GoDevView gv = simLeafView(ldc(&a->gv), xchg, g);
-        goPlanesPart<CPL>(gv, a->pv.max_depth, rot, g, wave, 8, lane, reinterpret_cast<const uint64_t*>(tiles));
+        goPlanesPart<CPL>(gv, a->pv.max_depth, rot, g, wave, 8, lane, leaf_smem);
     }
 }
 
@@ -440,6 +469,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         __syncthreads();
         seen_lds = sw;
     }
+    // ... and behind it the leaf's scratch block, which then outlives the tower: the part of the leaf only the phases AFTER the network need (path
+    // hashes, liberties, legal mask: 4.4 of its 8.1 us on BASELINE configs[1]) runs on waves 6 and 7 beside the heads, in which those waves have no share
+    uint64_t* leaf_smem = nullptr;
+    if constexpr (CPL > 0 && WPE == 2) {
+        const HeadParams hp = ldc(&a->hp);
+        if (hp.VH <= 256 && (hp.PC + 1) * hp.P <= 384 && hp.A <= 384 && !(a->no_spec & 8)) { // (MZ_NO_SPEC=8: off)
+            leaf_smem = const_cast<uint64_t*>(seen_lds) + kGoSeenCap;
+            uint64_t* zk = leaf_smem + goLeafKeyWord(a->gv.Ppad, a->gv.W, a->pv.max_depth); // the block's copy of the Zobrist keys (go_body.h)
+            for (int i = tid; i < 2 * a->gv.P; i += 512) { zk[i] = a->gv.key[i]; }
+            __syncthreads();
+        }
+    }
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr;
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = position slot of its leaf
@@ -449,13 +490,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (wave == 0) {
             if (slot == 1 && a->root_noise) { simApplyRootNoise<WPE>(a, g, lane); }
             if (a->use_gumbel) { simGumbelStart<WPE>(a, slot, s == 0 && host_start != 0, g, lane, tiles); }
-            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec, xchg, seen_lds, (a->no_spec & 2) ? 0 : s + 1);
+            simSelectLeaf<CPL, WPE>(a, rot, slot, g, lane, tiles, rcp_lds, spec, xchg, seen_lds, (a->no_spec & 2) ? 0 : s + 1, leaf_smem);
         } else if (WPE == 2 && wave <= kHelpSegs && spec.w && !(a->no_spec & 2)) { // (MZ_NO_SPEC=2: helper segments off)
             simSelectHelper(a, g, lane, wave, s + 1, rcp_lds, spec);
         }
         __syncthreads();
         if constexpr (CPL > 0) {
-            simLeafPlanes<CPL>(a, rot, g, wave, lane, tiles, xchg);
+            simLeafPlanes<CPL>(a, rot, g, wave, lane, leaf_smem ? leaf_smem : reinterpret_cast<const uint64_t*>(tiles), xchg);
             __syncthreads();
         }
         if (prof) { t1 = wall_clock64(); }
@@ -465,6 +506,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
         if constexpr (WPE == 4) { simHeadsImpl<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
+        else if (leaf_smem && wave >= 6) { simLeafRest<CPL>(a, rot, slot, g, lane, xchg, seen_lds, leaf_smem, 7 - wave); }
         else { simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
@@ -986,6 +1028,17 @@ static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, in
 
 void Net::dumpSimProf()
 {
+#ifdef MZ_SIM_BPROF
+    {
+        unsigned long long h[20];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bp), sizeof(h)) == hipSuccess && h[16]) {
+            for (int r = 0; r < 2; ++r) {
+                fprintf(stderr, "[mz sim bprof] leaf part beside the heads, role %d (game 0, avg us over %llu calls): first piece %.2f, wait %.2f, legal mask %.2f, wait %.2f\n", r, h[16 + r],
+                        double(h[r * 8 + 1]) / double(h[16 + r]) * 0.01, double(h[r * 8 + 2]) / double(h[16 + r]) * 0.01, double(h[r * 8 + 3]) / double(h[16 + r]) * 0.01, double(h[r * 8 + 4]) / double(h[16 + r]) * 0.01);
+            }
+        }
+    }
+#endif
 #ifdef MZ_SIM_HPROF
     {
         unsigned long long h[16];
@@ -1132,7 +1185,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     const bool two_per_cu = !bf && H * W <= 64 && tile_bytes <= size_t(76) * 1024;
     const size_t lds = tile_bytes + size_t(a.rcp_n) * sizeof(double) +
                        (two_per_cu ? 0 : size_t(a.rcp_n) * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int)) + (simXchgWords(gv.A, gv.channels, gv.W32) + 2 + 2 * size_t(pool.v_.max_depth) + 2) * sizeof(float) +
-                       ((gv.kind == 0 && !two_per_cu) ? size_t(kGoSeenCap) * sizeof(uint64_t) : 0);
+                       ((gv.kind == 0 && !two_per_cu) ? size_t(kGoSeenCap) * sizeof(uint64_t) + ((goLeafSmemBytes(gv, pool.v_.max_depth) + 7) & ~size_t(7)) : 0);
     // the argument block is constant between weight reloads / re-allocations: upload it only when it changed
     static_assert(sizeof(SimArgs) % 4 == 0, "SimArgs is copied as words");
     if (sim_args_host_.size() != sizeof(SimArgs) || memcmp(sim_args_host_.data(), &a, sizeof(SimArgs)) != 0) {
