@@ -67,7 +67,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     int* libs = reinterpret_cast<int*>(cur + 2 * W);       // [Ppad] liberties of a group, by group id
     uint16_t* lab = reinterpret_cast<uint16_t*>(libs + Ppad); // [Ppad] group id per point
     uint8_t* col = reinterpret_cast<uint8_t*>(lab + Ppad);  // [Ppad] 0 empty, 1 black, 2 white, 3 off board
-    uint64_t* stash = reinterpret_cast<uint64_t*>(col + Ppad); // [2] PART 1 -> PART 2: the leaf's hash, its terminal flag (Ppad is a multiple of 64: aligned)
+    uint64_t* stash = reinterpret_cast<uint64_t*>(col + Ppad); // [2] PART 1 -> PART 2: the leaf's hash; terminal flag, player to move, move / pass counters (Ppad is a multiple of 64: aligned)
     // the Zobrist keys: with PART 1 / 2 the caller keeps a copy behind the stash (LDS) — a key is on the walk's critical path at every move
     const uint64_t* zkey = PART != 0 ? smem + goLeafKeyWord(Ppad, W, MD) : v.key;
 
@@ -111,7 +111,9 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
         }
         hash = stash[0];
         terminal = (stash[1] & 1) != 0;
-        t = static_cast<int>(stash[1] >> 1); // (no trip to the root's snapshot in global memory)
+        t = static_cast<int>((stash[1] >> 1) & 3); // (no trip to the root's snapshot in global memory)
+        passes = static_cast<int>((stash[1] >> 4) & 15);
+        nmoves = static_cast<int>(stash[1] >> 8);
     }
     if constexpr (PART != 2) {
 #pragma unroll
@@ -211,16 +213,20 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
             const int p = i * 64 + lane;
             sbw[i] = __ballot(c[i] == 1);
             sww[i] = __ballot(c[i] == 2);
-            if (lane == 0) {
-                v.stones[((sb + slot) * 2 + 0) * W + i] = sbw[i];
-                v.stones[((sb + slot) * 2 + 1) * W + i] = sww[i];
+            if constexpr (PART != 1) { // (PART 1 leaves the slot's store to PART 2: the next fence would wait for it)
+                if (lane == 0) {
+                    v.stones[((sb + slot) * 2 + 0) * W + i] = sbw[i];
+                    v.stones[((sb + slot) * 2 + 1) * W + i] = sww[i];
+                }
+                if (p < P) { v.lab[(sb + slot) * Ppad + p] = static_cast<uint16_t>(l[i]); }
             }
-            if (p < P) { v.lab[(sb + slot) * Ppad + p] = static_cast<uint16_t>(l[i]); }
         }
-        if (lane == 0) {
-            v.hash[sb + slot] = hash;
-            v.meta[(sb + slot) * 2] = nmoves;
-            v.meta[(sb + slot) * 2 + 1] = passes;
+        if constexpr (PART != 1) {
+            if (lane == 0) {
+                v.hash[sb + slot] = hash;
+                v.meta[(sb + slot) * 2] = nmoves;
+                v.meta[(sb + slot) * 2 + 1] = passes;
+            }
         }
     }
 #pragma unroll
@@ -229,7 +235,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     }
     MZ_LPROF(2); // move applied, slot stored
     terminal = passes >= 2 || nmoves > 2 * P; // ref go.cpp:246-257
-    if (lane == 0) { stash[0] = hash; stash[1] = (terminal ? 1 : 0) | (static_cast<uint64_t>(t) << 1); }
+    if (lane == 0) { stash[0] = hash; stash[1] = (terminal ? 1 : 0) | (static_cast<uint64_t>(t) << 1) | (static_cast<uint64_t>(passes) << 4) | (static_cast<uint64_t>(nmoves) << 8); }
     if constexpr (PART == 1) { // (PART 2 counts the liberties on two waves: the counters are cleared here)
 #pragma unroll
         for (int i = 0; i < CPL; ++i) { libs[i * 64 + lane] = 0; gh[i * 64 + lane] = 0; }
@@ -279,6 +285,7 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     } // PART != 2
     if constexpr (PART == 1) { return; }
     constexpr bool kShared = PART == 2 && SYNC; // two waves share PART 2 (ROLE)
+    static_assert(PART != 2 || SYNC, "PART 2 is the two-wave version (it also stores the leaf's slot)");
     MZ_BPROF(ROLE, 0);
     // the legal mask of the 64-point chunks i with want(i) (ref go.cpp:208-244): not occupied, not suicide, not a positional-superko repeat
     auto legalMask = [&](auto want) {
@@ -363,6 +370,24 @@ __device__ __forceinline__ void goLeafBody(const GoDevView& v, const PoolView& p
     MZ_BPROF(ROLE, 1);
     if constexpr (SYNC) { __syncthreads(); }
     MZ_BPROF(ROLE, 2);
+    if constexpr (kShared && ROLE == 1) { // the leaf's position into its slab slot (PART 1 left it out)
+        if (depth >= 1) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int p = i * 64 + lane;
+                if (lane == 0) {
+                    v.stones[((sb + slot) * 2 + 0) * W + i] = sbw[i];
+                    v.stones[((sb + slot) * 2 + 1) * W + i] = sww[i];
+                }
+                if (p < P) { v.lab[(sb + slot) * Ppad + p] = static_cast<uint16_t>(l[i]); }
+            }
+            if (lane == 0) {
+                v.hash[sb + slot] = hash;
+                v.meta[(sb + slot) * 2] = nmoves;
+                v.meta[(sb + slot) * 2 + 1] = passes;
+            }
+        }
+    }
     if (!kShared || ROLE == 0) {
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
