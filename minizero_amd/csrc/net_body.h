@@ -463,6 +463,8 @@ __device__ __forceinline__ void dotChain4(const float* __restrict__ x, const flo
 }
 
 // the body of heads_kernel for sample `b`, run by NT threads (a multiple of 64, >= 128); `sm` = (C*P + PC*P + P + VH + A + 16) floats of LDS
+// With xlds and without scale_hidden it passes exactly TWO workgroup barriers (after the conv1x1, after the FCs): the simulation kernel runs the second half
+// of the Go leaf beside it on waves that have no share of the heads (sim.hip simLeafRest / go_body.h goLeafBody PART 2), and those waves pass the same two.
 __device__ __forceinline__ void headsBody(const float* __restrict__ x, const HeadParams& hp, float* __restrict__ policy, float* __restrict__ logit,
                                           float* __restrict__ value, float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int scale_hidden,
                                           int b, int tid, int NT, float* __restrict__ sm, const float* __restrict__ xlds = nullptr, int xcs = 0,
