@@ -188,9 +188,11 @@ def _lines_of(mz, conf, desc_args, chunks, total):
 
 
 @pytest.mark.parametrize("noise", ["true", "false"])
-def test_go_execution_modes_are_equivalent(mz, noise):
+def test_go_execution_modes_are_equivalent(mz, monkeypatch, noise):
     """Host leaf environment (lock-step, host hops), device-resident lock-step kernels, and the per-game simulation kernel
-    (whole runs of cycles in one launch, batches cut at arbitrary run_cycles boundaries) must emit identical records."""
+    (whole runs of cycles in one launch, batches cut at arbitrary run_cycles boundaries) must emit identical records.  The simulation kernel runs the
+    leaf in two halves — what the network needs before the tower, the rest (path hashes, liberties, legal mask, the slot's store, a terminal leaf's
+    score) on two idle waves beside the heads (go_body.h goLeafBody PART 1 / 2) — or, with MZ_NO_SPEC=8, in one piece: both against the other modes."""
     conf = f"env_game=go:env_board_size=9:actor_num_simulation=12:zero_num_parallel_games=5:actor_use_dirichlet_noise={noise}"
     args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
     total = 13 * 200
@@ -198,10 +200,13 @@ def test_go_execution_modes_are_equivalent(mz, noise):
     resident = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=false", args, [7, 1, 30], total)
     sim_whole = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [total], total)
     sim_chunks = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [1, 2, 5, 13, 3, 40, 12, 14], total)
+    monkeypatch.setenv("MZ_NO_SPEC", "8")
+    sim_one_piece = _lines_of(mz, conf + ":mz_device_env=true:mz_sim_kernel=true", args, [total], total)
     assert len(host) >= 5
     assert host == resident
     assert host == sim_whole
     assert host == sim_chunks
+    assert host == sim_one_piece
 
 
 @pytest.mark.parametrize("variant", ["dirichlet", "no_noise", "gumbel", "muzero"])
