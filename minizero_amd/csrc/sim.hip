@@ -154,13 +154,15 @@ struct SimXchg { // word offsets inside the block for A actions
 inline size_t simXchgWords(int A, int channels, int W32) { return size_t(5) * (A + (A & 1)) + 12 + 16 + size_t(channels) * W32; }
 __device__ __forceinline__ int simXchgWordsDev(int A, int channels, int W32) { return 5 * (A + (A & 1)) + 12 + 16 + channels * W32; }
 
-// ... and so does the path of the simulation (node ids, moves, length): written by the walk, read by the leaf and by expand + backup
+// ... and so does the path of the simulation (node ids, moves, length): written by the walk, read by the leaf and by expand + backup; the word behind
+// them holds the game's node count for the launch (expand reads and advances it at every simulation: simNodeCountIn / simNodeCountOut)
 __device__ __forceinline__ PoolView simPathView(PoolView pv, int* lds_path, int g)
 {
     const size_t off = size_t(g) * pv.max_depth;
     pv.path = lds_path - off;
     pv.path_action = lds_path + pv.max_depth - off;
     pv.path_len = lds_path + 2 * pv.max_depth - g;
+    pv.num_nodes = lds_path + 2 * pv.max_depth + 1 - g;
     pv.host_path_len = nullptr;
     pv.host_path_action = nullptr;
     return pv;
@@ -482,6 +484,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         }
     }
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr;
+    int* const node_count = reinterpret_cast<int*>(xchg) - 1; // (the spare word of the path block: simPathView)
+    if (tid == 0) { *node_count = a->pv.num_nodes[g]; }
+    __syncthreads();
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = position slot of its leaf
         const int rot = rot_tab[size_t(s) * games + g];
@@ -529,6 +534,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
             prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
         }
     }
+    if (tid == 0) { a->pv.num_nodes[g] = *node_count; }
     if (prof && tid == 0 && spec_w) {
         prof[7] += (static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 1]) << 40) | (static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 5]) << 20) | spec_w[kSpecWays * kSpecWay + 3];
         prof[6] += static_cast<unsigned long long>(spec_w[kSpecWays * kSpecWay + 7]) << 40; // levels taken over from the helper waves (the low bits hold the path lengths)
@@ -772,6 +778,10 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     // next Gumbel step read it — instead of going through the pool's arrays in global memory (a round trip each)
     int* lds_path = (a->atari && 2 * a->pv.max_depth + 2 <= kSpecWords) ? spec_w : nullptr;
     const PoolView v = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
+    if (lds_path) { // (the game's node count for the launch: the word behind the path, simPathView)
+        if (tid == 0) { lds_path[2 * a->pv.max_depth + 1] = a->pv.num_nodes[g]; }
+        __syncthreads();
+    }
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr; // MZ_SIM_PROF=1: [select, tower, heads, cand+expand] ticks + sims
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
@@ -848,6 +858,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[3] += t4 - t3; prof[4] += 1;
         }
     }
+    if (lds_path && tid == 0) { a->pv.num_nodes[g] = lds_path[2 * a->pv.max_depth + 1]; }
 }
 
 
