@@ -1186,7 +1186,8 @@ void Worker::outputGame(Game& gm) // ref actor_group.cpp:24-50
         << record(gm, {{"DLEN", std::to_string(range.first) + "-" + std::to_string(range.second)}}, &obs_raw) << " "
         << "#";
     if (!is_terminal) {
-        for (int i = range.first; i <= range.second; ++i) { gm.action_info_history[i].clear(); gm.action_info_history[i].shrink_to_fit(); }
+        // (i < size: a resignation before the first move of an intermediate-sequence game has range 0-0 and an EMPTY history — the reference indexes it anyway)
+        for (int i = range.first; i <= range.second && i < static_cast<int>(gm.action_info_history.size()); ++i) { gm.action_info_history[i].clear(); gm.action_info_history[i].shrink_to_fit(); }
     }
     lines_.push_back(std::make_unique<OutLine>());
     lines_.back()->text = oss.str();

@@ -337,7 +337,9 @@ void Group::outputGame(ZeroActor& actor) // ref actor_group.cpp:24-50
         << actor.getRecord({{"DLEN", std::to_string(data_range.first) + "-" + std::to_string(data_range.second)}}) << " "
         << "#";
     if (!is_terminal) {
-        for (int i = data_range.first; i <= data_range.second; ++i) { actor.action_info_history_[i].clear(); }
+        // (a resignation before the first move of an intermediate-sequence game — game_length 0, range 0-0 — indexes an EMPTY history in the reference:
+        // undefined behaviour there, found by the fuzz sweep; the restatement and the worker skip what does not exist)
+        for (int i = data_range.first; i <= data_range.second && i < static_cast<int>(actor.action_info_history_.size()); ++i) { actor.action_info_history_[i].clear(); }
     }
     std::lock_guard<std::mutex> lock(out_mutex_);
     lines_.push_back(oss.str());

@@ -1,10 +1,19 @@
 """Randomised end-to-end parity: for seeded random search configurations (game, network type, PUCT / Gumbel root, noise, number of
 simulations and games, weights, program seed, chunking of run_cycles) the HIP worker in its default mode (per-game simulation kernels,
 device rules, path speculation) must emit exactly the `SelfPlay` lines of the CPU oracle.  Whole games, so every record is compared."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def _seeds(default_n, var):
+    """The seeds of a sweep: 0 .. default_n - 1, or `lo:hi` from the environment (an extended sweep: MZ_FUZZ_SEEDS=80:480 pytest tests/test_gpu_fuzz.py)."""
+    lo, hi = (int(x) for x in os.environ.get(var, f"0:{default_n}").split(":"))
+    return range(lo, hi)
+
 
 GAMES = {
     "go": ("env_game=go:env_board_size=9", ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82), 170),
@@ -35,7 +44,7 @@ def _case(seed):
     return conf, dargs, typ, cycles, chunks, int(rng.integers(0, 50)), int(rng.integers(1, 1000))
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", _seeds(80, "MZ_FUZZ_SEEDS"))
 def test_random_configuration_matches_oracle(mz, oracle, seed):
     conf, dargs, typ, cycles, chunks, wseed, pseed = _case(seed)
     kw = dict(vh=16, dv=1, type_name=typ)
@@ -77,7 +86,7 @@ def _atari_case(seed):
     return conf, (n + 1) * moves, chunks, games, int(rng.integers(0, 50)), int(rng.integers(1, 1000))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _seeds(24, "MZ_FUZZ_ATARI_SEEDS"))
 def test_random_atari_configuration_matches_oracle(mz, oracle, seed):
     """The same for the Atari-shaped game on the muzero_atari network (601-bin heads, value rescaling, discount, ATARI init-Q, intermediate sequences with
     their OBS / L tags): Gumbel roots of random sample sizes take the Gumbel-round path (leaves of a round evaluated ahead) whenever a call covers whole moves."""
