@@ -1264,7 +1264,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
         double t1 = t0, te = t0;
         int rc = MZ_OK;
         if (!resident_ && (!sim_mz_ || root_host_pending_)) { // resident / simulation kernel: candidates + expand + backup already ran on the device
-            root_host_pending_ = false;
+            // (root_host_pending_ is cleared by the caller when EVERY lane has had its turn: cleared here, the lanes behind the first kept unexpanded roots)
             if (use_signal_) { int rcw = L.pool.waitSignal(L.signal_seq); if (rcw) { return rcw; } }
             else { MZ_HIP(hipStreamSynchronize(L.stream)); } // network outputs of this lane
             t1 = nowMs();
@@ -1493,6 +1493,7 @@ int Worker::cycle()
         int rc = phase1(*L, root_expansion, done);
         if (rc) { return rc; }
     }
+    root_host_pending_ = false;
     if (done && cfg_.mz_manual_step) { search_done_ = true; stop_now_ = true; pending_ = false; sims_done_ = 0; return MZ_OK; }
     if (pending_) { sims_done_ = done ? 0 : sim_post_; }
     for (auto& L : lanes_) {
@@ -1588,6 +1589,7 @@ int Worker::runCyclesSim(int n)
             if (host_gumbel && (rc = syncGumbel(*L, true))) { return rc; }
             for (int j = 0; j < L->n; ++j) { L->h_rot.p[j] = static_cast<uint8_t>(games_[L->g0 + j].rot); }
         }
+        root_host_pending_ = false;
         if (done && cfg_.mz_manual_step) { search_done_ = true; pending_ = false; sims_done_ = 0; stats_.ms_total += nowMs() - t0; return i; }
         if (pending_) { sims_done_ = done ? 0 : sim_post_; }
         int sim0 = sims_done_;
@@ -1842,6 +1844,7 @@ int Worker::finishSearch()
         if (host_gumbel && (rc = syncGumbel(*L, false))) { return rc; }
         if ((rc = phase1(*L, false, true, false))) { return rc; } // done = true: root statistics, decision, held action (manual stepping returns before the next selection)
     }
+    root_host_pending_ = false;
     search_done_ = true;
     pending_ = false;
     sims_done_ = 0;

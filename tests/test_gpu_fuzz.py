@@ -41,19 +41,25 @@ def _case(seed):
         conf += ":nn_type_name=muzero"
     cycles = (n + 1) * (glen + 4)
     chunks = [int(x) for x in rng.integers(1, 3 * (n + 1), 5)]
-    return conf, dargs, typ, cycles, chunks, int(rng.integers(0, 50)), int(rng.integers(1, 1000))
+    wseed, pseed = int(rng.integers(0, 50)), int(rng.integers(1, 1000))
+    wextra = ""  # worker-only keys (drawn last: the earlier draws of a seed stay what they were)
+    if rng.random() < 0.3:
+        wextra += f":mz_pipeline_lanes={int(rng.choice([2, 3]))}"
+    if rng.random() < 0.3:
+        wextra += f":zero_num_threads={int(rng.choice([1, 4]))}"
+    return conf, dargs, typ, cycles, chunks, wseed, pseed, wextra
 
 
 @pytest.mark.parametrize("seed", _seeds(80, "MZ_FUZZ_SEEDS"))
 def test_random_configuration_matches_oracle(mz, oracle, seed):
-    conf, dargs, typ, cycles, chunks, wseed, pseed = _case(seed)
+    conf, dargs, typ, cycles, chunks, wseed, pseed, wextra = _case(seed)
     kw = dict(vh=16, dv=1, type_name=typ)
     d, od = mz.make_desc(*dargs, **kw), oracle.make_desc(*dargs, **kw)
     w = mz.generate_weights(d, wseed)
     conf = f"{conf}:program_seed={pseed}:nn_file_name=/tmp/fuzz_{wseed}.pt"
     og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
     og.cycles(cycles)
-    wk = mz.Worker(conf + ":zero_num_threads=2", d, w)
+    wk = mz.Worker(conf + ":zero_num_threads=2" + wextra, d, w)
     wk.command("start")
     done, k = 0, 0
     while done < cycles:
@@ -62,7 +68,7 @@ def test_random_configuration_matches_oracle(mz, oracle, seed):
         done += c
         k += 1
     lines, olines = wk.pop_lines(), og.lines()
-    assert lines == olines, conf
+    assert lines == olines, conf + wextra
     # the games still in progress too (an Othello game with many passes can outlast the cycle budget: then this is all the case compares)
     games = int(conf.split("zero_num_parallel_games=")[1].split(":")[0])
     assert wk.peek_records(games) == og.peek_records(games), conf
@@ -85,14 +91,20 @@ def _atari_case(seed):
     moves = 2 * ep + 3
     # calls of whole moves (the Gumbel-round path) mixed with calls that end inside a move (the ordinary path)
     chunks = [n + 1, n + 1, int(rng.integers(1, n + 1)), 2 * (n + 1), int(rng.integers(1, 3 * (n + 1)))] if rng.random() < 0.6 else [n + 1]
-    return conf, (n + 1) * moves, chunks, games, int(rng.integers(0, 50)), int(rng.integers(1, 1000))
+    wseed, pseed = int(rng.integers(0, 50)), int(rng.integers(1, 1000))
+    wextra = ""  # worker-only keys (drawn last: the earlier draws of a seed stay what they were): execution modes that must not change a record
+    for key, values, p in (("mz_pipeline_lanes", [2, 3], 0.2), ("zero_num_threads", [1, 4], 0.3), ("mz_sim_round_alt", ["false"], 0.2), ("mz_sim_rounds", ["false"], 0.15),
+                           ("mz_sim_cluster", ["false"], 0.2), ("mz_sim_round_min", [1, 4, 8], 0.2), ("mz_raw_observations", ["false"], 0.15)):
+        if rng.random() < p:
+            wextra += f":{key}={rng.choice(values)}"
+    return conf, (n + 1) * moves, chunks, games, wseed, pseed, wextra
 
 
 @pytest.mark.parametrize("seed", _seeds(24, "MZ_FUZZ_ATARI_SEEDS"))
 def test_random_atari_configuration_matches_oracle(mz, oracle, seed):
     """The same for the Atari-shaped game on the muzero_atari network (601-bin heads, value rescaling, discount, ATARI init-Q, intermediate sequences with
     their OBS / L tags): Gumbel roots of random sample sizes take the Gumbel-round path (leaves of a round evaluated ahead) whenever a call covers whole moves."""
-    conf, cycles, chunks, games, wseed, pseed = _atari_case(seed)
+    conf, cycles, chunks, games, wseed, pseed, wextra = _atari_case(seed)
     dargs = ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18)
     kw = dict(vh=32, dv=601, type_name="muzero_atari")
     d, od = mz.make_desc(*dargs, **kw), oracle.make_desc(*dargs, **kw)
@@ -100,7 +112,7 @@ def test_random_atari_configuration_matches_oracle(mz, oracle, seed):
     conf = f"{conf}:program_seed={pseed}:nn_file_name=/tmp/fuzz_atari_{wseed}.pt"
     og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
     og.cycles(cycles)
-    wk = mz.Worker(conf + ":zero_num_threads=2", d, w)
+    wk = mz.Worker(conf + ":zero_num_threads=2" + wextra, d, w)
     wk.command("start")
     done, k = 0, 0
     while done < cycles:
@@ -109,6 +121,7 @@ def test_random_atari_configuration_matches_oracle(mz, oracle, seed):
         done += c
         k += 1
     lines, olines = wk.pop_lines(), og.lines()
+    conf += wextra
     assert len(olines) >= 1, conf
     assert lines == olines, conf
     assert wk.peek_records(games) == og.peek_records(games), conf
