@@ -47,6 +47,10 @@ def _case(seed):
         wextra += f":mz_pipeline_lanes={int(rng.choice([2, 3]))}"
     if rng.random() < 0.3:
         wextra += f":zero_num_threads={int(rng.choice([1, 4]))}"
+    for key, values, p in (("mz_sim_kernel", ["false"], 0.12), ("mz_device_env", ["false"], 0.12), ("mz_sim_split", ["false"], 0.15), ("mz_zero_copy", [0, 1, 2], 0.15),
+                           ("mz_signal_wait", ["false"], 0.1)):
+        if rng.random() < p:
+            wextra += f":{key}={rng.choice(values)}"
     return conf, dargs, typ, cycles, chunks, wseed, pseed, wextra
 
 
