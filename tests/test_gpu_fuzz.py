@@ -51,6 +51,9 @@ def _case(seed):
                            ("mz_signal_wait", ["false"], 0.1)):
         if rng.random() < p:
             wextra += f":{key}={rng.choice(values)}"
+    if game != "go" and rng.random() < 0.1:  # a pool larger than the chip has CUs / than one workgroup per CU (short games only: the oracle plays them on the CPU)
+        big = int(rng.choice([40, 150, 300, 600]))
+        conf = conf.replace(f"zero_num_parallel_games={games}:", f"zero_num_parallel_games={big}:")
     return conf, dargs, typ, cycles, chunks, wseed, pseed, wextra
 
 
@@ -101,6 +104,14 @@ def _atari_case(seed):
                            ("mz_sim_cluster", ["false"], 0.2), ("mz_sim_round_min", [1, 4, 8], 0.2), ("mz_raw_observations", ["false"], 0.15)):
         if rng.random() < p:
             wextra += f":{key}={rng.choice(values)}"
+    if rng.random() < 0.1:  # a pool that does not fit the small-pool kernels: more games than a cluster launch takes, rounds of more workgroups than CUs
+        big = int(rng.choice([20, 33, 70]))
+        conf = conf.replace(f"zero_num_parallel_games={games}:", f"zero_num_parallel_games={big}:")
+        games = big
+        if n > 13:
+            conf = conf.replace(f"actor_num_simulation={n}:", "actor_num_simulation=13:")
+            n = 13
+            chunks = [n + 1, n + 1, 3, 2 * (n + 1), 17]
     return conf, (n + 1) * moves, chunks, games, wseed, pseed, wextra
 
 
