@@ -180,3 +180,40 @@ def test_think_time_limit_decides_from_the_simulations_run_so_far(mz, oracle, tm
         og = oracle.OracleGroup(f"{base}:actor_num_simulation=31:nn_file_name={pt}:zero_num_threads=1", od, w)
         og.cycles(32 * moves + 1)
         assert rec == og.peek_records(1)[0]
+
+
+def _facade_seeds():
+    lo, hi = (int(x) for x in os.environ.get("MZ_FUZZ_FACADE_SEEDS", "0:10").split(":"))
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("seed", _facade_seeds())
+def test_random_configuration_through_the_actor_facade(mz, oracle, tmp_path, seed):
+    """Seeded random search configurations (the generators of tests/test_gpu_fuzz.py, one game) played through createActor / think() / act() / getRecord() in
+    ActorGroup's handleSearchDone loop (tests/csrc/facade_check.cpp `actor`): every `SelfPlay` line and the record of the game in progress against the oracle's
+    one-actor group.  MZ_FUZZ_FACADE_SEEDS=lo:hi for longer sweeps."""
+    import re
+    import test_gpu_fuzz as F
+    rng = np.random.default_rng(9000 + seed)
+    if rng.random() < 0.3:
+        conf, cycles, _, games, wseed, pseed, _ = F._atari_case(int(rng.integers(0, 10000)))
+        dargs = ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari")
+    else:
+        conf, shape, typ, cycles, _, wseed, pseed, _ = F._case(int(rng.integers(0, 10000)))
+        dargs = shape + (16, 1, typ)
+    conf = re.sub(r"zero_num_parallel_games=\d+", "zero_num_parallel_games=1", conf)
+    conf = re.sub(r"zero_actor_intermediate_sequence_length=\d+", "zero_actor_intermediate_sequence_length=0", conf)  # (emitting sequences is ActorGroup's part, not the actor's)
+    n = int(conf.split("actor_num_simulation=")[1].split(":")[0])
+    moves = min(cycles // (n + 1), 40)
+    kw = dict(vh=dargs[10], dv=dargs[11], type_name=dargs[12])
+    d, od = mz.make_desc(*dargs[:10], **kw), oracle.make_desc(*dargs[:10], **kw)
+    w = mz.generate_weights(d, wseed)
+    pt = _write(mz, tmp_path, d, w)
+    conf = f"{conf}:program_seed={pseed}:nn_file_name={pt}"
+    p = _run(["actor", conf, str(moves), str(tmp_path / "features.bin")])
+    out = p.stdout.strip().split("\n")
+    lines, rec = [l for l in out if l.startswith("SelfPlay ")], [l for l in out if l.startswith("RECORD ")]
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles(moves * (n + 1) + 1)
+    assert lines == og.lines(), conf
+    assert len(rec) == 1 and rec[0][len("RECORD "):].replace("XX[tag]", "") == og.peek_records(1)[0], conf
