@@ -185,6 +185,24 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     };
     bload(bc, 0, 0);
     MZ_TPROF(0);
+    // A narrow layer (the stem of a board-game tower: 18-20 input planes = 5 k-groups per tap) has 480 cycles of MFMAs per tap and wave, less than an L2 round
+    // trip: double-buffered by tap it waits for its fragments at every tap (the stem of BASELINE configs[1]: 12.6 k cycles for 7.8 k of MFMAs).  Its nine taps
+    // are 45 registers: all of them are fetched up front, one round trip for the layer.
+    constexpr bool kAllTaps = CG * 9 <= 48;
+    float aall[kAllTaps ? 9 : 1][CG];
+    if constexpr (kAllTaps) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t == 0 && have_first) {
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) { aall[0][cg] = a_first[cg]; }
+            } else {
+                loadA(aall[t], t);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { tap(aall[t], t); }
+    } else {
     if (have_first) {
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) { a0[cg] = a_first[cg]; }
@@ -197,6 +215,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
         tap(a0, t);
         loadA(a0, t + 2);
         tap(a1, t + 1);
+    }
     }
     if (next_wp) { // the next layer's first tap (its block of this wave's oc-tile): in flight during the last tap, the epilogue and the barrier
         constexpr int CGN4 = CGN / 4;
@@ -221,7 +240,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
         for (int r = 0; r < 4; ++r) { skv[j][r] = sk[(ocb + r) * CS + pixdst[j]]; }
     }
     asm volatile("" ::: "memory");
-    tap(a0, 8);
+    if constexpr (kAllTaps) { tap(aall[8], 8); } else { tap(a0, 8); }
     MZ_TPROF(1);
     if (gout) { // stand-alone launch, last layer: NCHW to HBM
 #pragma unroll
@@ -273,6 +292,7 @@ __device__ __forceinline__ void towerRun(const float* __restrict__ params, const
                                                              ta.C, ta.OT, lane, ot, px, false, aS, nw, aA);
         have = nw != nullptr;
         __syncthreads();
+        MZ_TPROF(3);
     }
     float *x = T1, *tmp = T0;
 #pragma unroll 1
@@ -311,7 +331,8 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     float* T0 = tiles;
     float* T1 = tiles + CMAX * CS;
     // zero both tiles (borders and padding channels stay zero for the whole kernel), then the sample's planes into T0
-    for (int i = tid; i < kTowerTiles * CMAX * CS; i += 512) { tiles[i] = 0.0f; }
+    static_assert((kTowerTiles * CMAX * CS) % 4 == 0, "16-byte zero fill");
+    for (int i = tid; i < kTowerTiles * CMAX * CS / 4; i += 512) { reinterpret_cast<float4*>(tiles)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
     __syncthreads();
     float* Tin = ta.has_stem ? T0 : T1; // without a stem the input IS the first block's x
     if (hidden_src) {
