@@ -16,39 +16,51 @@
 
 namespace mz {
 
-template <int STRIDE, int CIN_PAD, int OT>
+// OT = oc-tiles of the layer, OTW = oc-tiles one workgroup computes (blockIdx.z takes the others): the late layers of the representation have few pixel tiles
+// (24x24: 6 per sample, 12x12: 2), and with all output channels in one workgroup a batch of 64 samples is 128-384 workgroups of 1152 dependent-rate MFMAs per
+// wave on 256 CUs — split by output channels they are 512-1536 workgroups of 288 (the patch is staged once per workgroup: its loads come from the L2)
+template <int STRIDE, int CIN_PAD, int OT, int OTW = OT>
 __global__ __launch_bounds__(256) void conv3x3_tiled(const float* __restrict__ in, int cin, int H, int W, const float* __restrict__ wp,
                                                      const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ out, int cout)
 {
     constexpr int TH = 8, TW = 16, PR = (TH - 1) * STRIDE + 3, PC = (TW - 1) * STRIDE + 3, PLANE = PR * PC, CG = CIN_PAD / 4;
-    constexpr int NGROUPS = 4 / OT, ROWS = TH / NGROUPS;
+    constexpr int NGROUPS = 4 / OTW, ROWS = TH / NGROUPS;
+    static_assert(OT % OTW == 0 && 4 % OTW == 0, "oc-tiles per workgroup");
     extern __shared__ __attribute__((aligned(16))) float xs[]; // [CIN_PAD][PR][PC]
     const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1, tiles_x = (Wo + TW - 1) / TW;
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
     const float* src = in + size_t(b) * cin * H * W;
-    // the patch, eight elements per thread at a time: their loads are issued together (one at a time, each iteration of the staging loop waited for its own
-    // trip to the L2 / HBM: conv1 of the 96x96 representation took 120 us per 64 samples, four fifths of it here)
-    constexpr int TOTAL = CIN_PAD * PLANE, U = 8;
-    for (int base = 0; base < TOTAL; base += 256 * U) {
-        float v[U];
+    // The patch: a thread keeps its POSITIONS of the patch plane (row, column, the bounds check and the source offset are computed once per position) and
+    // walks the channels, eight loads in flight at a time.  (One flat index per element — two divisions by PLANE and PC each — was more vector work than
+    // the layer's MFMAs: conv1 of the 96x96 representation 73 -> 5x us per 64 samples; before that, one load at a time, 120 us.)
+    constexpr int U = 8, NPOS = (PLANE + 255) / 256;
+    static_assert(CIN_PAD % U == 0, "channels are staged eight at a time");
+    const size_t HW = size_t(H) * W;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * 256 + tid;
-            const int c = idx / PLANE, rem = idx - c * PLANE, r = rem / PC, q = rem - r * PC;
-            const int iy = oy0 * STRIDE + r - 1, ix = ox0 * STRIDE + q - 1;
-            const bool ok = idx < TOTAL && c < cin && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const float x = src[ok ? (size_t(c) * H + iy) * W + ix : 0];
-            v[u] = ok ? x : 0.0f;
-        }
+    for (int k = 0; k < NPOS; ++k) {
+        const int pos = k * 256 + tid;
+        const int r = pos / PC, q = pos - r * PC;
+        const int iy = oy0 * STRIDE + r - 1, ix = ox0 * STRIDE + q - 1;
+        const bool inside = pos < PLANE && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float* p = src + (inside ? size_t(iy) * W + ix : 0);
+#pragma unroll 1
+        for (int c0 = 0; c0 < CIN_PAD; c0 += U) {
+            float v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * 256 + tid;
-            if (idx < TOTAL) { xs[idx] = v[u]; }
+            for (int u = 0; u < U; ++u) {
+                const bool ok = inside && c0 + u < cin;
+                const float x = p[ok ? size_t(c0 + u) * HW : 0];
+                v[u] = ok ? x : 0.0f;
+            }
+            if (pos < PLANE) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { xs[(c0 + u) * PLANE + pos] = v[u]; }
+            }
         }
     }
     __syncthreads();
-    const int ot = wave % OT, row0 = (wave / OT) * ROWS;
+    const int ot = static_cast<int>(blockIdx.z) * OTW + wave % OTW, row0 = (wave / OTW) * ROWS;
     f32x4 acc[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
@@ -125,24 +137,32 @@ __global__ __launch_bounds__(1024) void heads_atari_kernel(const float* __restri
 // host side
 // ---------------------------------------------------------------------------------------------
 template <int STRIDE, int CIN_PAD, int OT>
-static int launchTiledT(const ConvLayer& L, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s)
+static int launchTiledT(const ConvLayer& L, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s, int cus)
 {
     constexpr int PR = 7 * STRIDE + 3, PC = 15 * STRIDE + 3;
     constexpr size_t lds = size_t(CIN_PAD) * PR * PC * sizeof(float);
-    MZ_LDS_ATTR((conv3x3_tiled<STRIDE, CIN_PAD, OT>), lds);
     const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
-    const dim3 grid(((Wo + 15) / 16) * ((Ho + 7) / 8), B);
-    hipLaunchKernelGGL((conv3x3_tiled<STRIDE, CIN_PAD, OT>), grid, dim3(256), lds, s, in, L.cin, H, W, params + L.w_off, params + L.b_off, skip, out, L.cout);
+    const int tiles = ((Wo + 15) / 16) * ((Ho + 7) / 8);
+    // fewer than two workgroups per CU: one oc-tile per workgroup (blockIdx.z = the oc-tile).  Measured at batch 64: 12x12 37 -> 19 us and 41 -> 20 us, 24x24 52 -> 49
+    // and 64 -> 55 us; the stride-2 layer 48 -> 24 with its 72-KB patch per workgroup got slower (37 -> 48 us) and keeps all its oc-tiles together
+    if (OT > 1 && STRIDE == 1 && tiles * B < 2 * cus) {
+        MZ_LDS_ATTR((conv3x3_tiled<STRIDE, CIN_PAD, OT, 1>), lds);
+        hipLaunchKernelGGL((conv3x3_tiled<STRIDE, CIN_PAD, OT, 1>), dim3(tiles, B, OT), dim3(256), lds, s, in, L.cin, H, W, params + L.w_off, params + L.b_off, skip, out, L.cout);
+        MZ_HIP(hipGetLastError());
+        return MZ_OK;
+    }
+    MZ_LDS_ATTR((conv3x3_tiled<STRIDE, CIN_PAD, OT>), lds);
+    hipLaunchKernelGGL((conv3x3_tiled<STRIDE, CIN_PAD, OT>), dim3(tiles, B), dim3(256), lds, s, in, L.cin, H, W, params + L.w_off, params + L.b_off, skip, out, L.cout);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
 
 static int launchTiled(const ConvLayer& L, int stride, const float* params, const float* in, const float* skip, float* out, int B, int H, int W,
-                       hipStream_t s)
+                       hipStream_t s, int cus)
 {
     const int ot = L.cout_pad / 16;
 #define MZ_TILED_CASE(st, c, o) \
-    if (stride == st && L.cin_pad == c && ot == o) { return launchTiledT<st, c, o>(L, params, in, skip, out, B, H, W, s); }
+    if (stride == st && L.cin_pad == c && ot == o) { return launchTiledT<st, c, o>(L, params, in, skip, out, B, H, W, s, cus); }
     MZ_TILED_CASE(2, 32, 2) // conv1 32 -> 32 (C = 64)
     MZ_TILED_CASE(1, 32, 2) // residual block at C/2 = 32
     MZ_TILED_CASE(2, 32, 4) // conv2 32 -> 64
@@ -198,14 +218,14 @@ int Net::initialAtari(const float* d_feat, int B, float* d_policy, float* d_logi
     float *b0 = at_buf_[0].p, *b1 = at_buf_[1].p, *b2 = at_buf_[2].p;
     const float* P = params_.p;
     // ref muzero_atari_network.py:21-39
-    if ((rc = launchTiled(at_.conv1, 2, P, d_feat, nullptr, b0, B, H, W, stream_))) { return rc; }
+    if ((rc = launchTiled(at_.conv1, 2, P, d_feat, nullptr, b0, B, H, W, stream_, cu_count_))) { return rc; }
     H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
-    if ((rc = launchTiled(at_.rb1[0], 1, P, b0, nullptr, b1, B, H, W, stream_))) { return rc; }
-    if ((rc = launchTiled(at_.rb1[1], 1, P, b1, b0, b2, B, H, W, stream_))) { return rc; }
-    if ((rc = launchTiled(at_.conv2, 2, P, b2, nullptr, b0, B, H, W, stream_))) { return rc; }
+    if ((rc = launchTiled(at_.rb1[0], 1, P, b0, nullptr, b1, B, H, W, stream_, cu_count_))) { return rc; }
+    if ((rc = launchTiled(at_.rb1[1], 1, P, b1, b0, b2, B, H, W, stream_, cu_count_))) { return rc; }
+    if ((rc = launchTiled(at_.conv2, 2, P, b2, nullptr, b0, B, H, W, stream_, cu_count_))) { return rc; }
     H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
-    if ((rc = launchTiled(at_.rb2[0], 1, P, b0, nullptr, b1, B, H, W, stream_))) { return rc; }
-    if ((rc = launchTiled(at_.rb2[1], 1, P, b1, b0, b2, B, H, W, stream_))) { return rc; }
+    if ((rc = launchTiled(at_.rb2[0], 1, P, b0, nullptr, b1, B, H, W, stream_, cu_count_))) { return rc; }
+    if ((rc = launchTiled(at_.rb2[1], 1, P, b1, b0, b2, B, H, W, stream_, cu_count_))) { return rc; }
     auto pool = [&](const float* in, float* out) -> int {
         const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, total = B * C * Ho * Wo;
         hipLaunchKernelGGL(avgpool3s2_kernel, dim3((total + 255) / 256), dim3(256), 0, stream_, in, C, H, W, out, total);
@@ -214,8 +234,8 @@ int Net::initialAtari(const float* d_feat, int B, float* d_policy, float* d_logi
         return MZ_OK;
     };
     if ((rc = pool(b2, b0))) { return rc; }
-    if ((rc = launchTiled(at_.rb3[0], 1, P, b0, nullptr, b1, B, H, W, stream_))) { return rc; }
-    if ((rc = launchTiled(at_.rb3[1], 1, P, b1, b0, b2, B, H, W, stream_))) { return rc; }
+    if ((rc = launchTiled(at_.rb3[0], 1, P, b0, nullptr, b1, B, H, W, stream_, cu_count_))) { return rc; }
+    if ((rc = launchTiled(at_.rb3[1], 1, P, b1, b0, b2, B, H, W, stream_, cu_count_))) { return rc; }
     if ((rc = pool(b2, b0))) { return rc; }
     if (H != desc_.hidden_channel_height || W != desc_.hidden_channel_width) { setError("internal: representation output %dx%d", H, W); return MZ_ERR_ARG; }
     const float* x = b0;
