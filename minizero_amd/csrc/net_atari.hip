@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void conv3x3_tiled(const float* __restrict__ i
     // The patch: a thread keeps its POSITIONS of the patch plane (row, column, the bounds check and the source offset are computed once per position) and
     // walks the channels, eight loads in flight at a time.  (One flat index per element — two divisions by PLANE and PC each — was more vector work than
     // the layer's MFMAs: conv1 of the 96x96 representation 73 -> 5x us per 64 samples; before that, one load at a time, 120 us.)
-    constexpr int U = 8, NPOS = (PLANE + 255) / 256;
-    static_assert(CIN_PAD % U == 0, "channels are staged eight at a time");
+    constexpr int U = CIN_PAD < 32 ? CIN_PAD : 32, NPOS = (PLANE + 255) / 256; // loads in flight per thread: a batch of U is one trip to the L2 / HBM
+    static_assert(CIN_PAD % U == 0, "channels are staged U at a time");
     const size_t HW = size_t(H) * W;
 #pragma unroll
     for (int k = 0; k < NPOS; ++k) {
@@ -70,19 +70,30 @@ __global__ __launch_bounds__(256) void conv3x3_tiled(const float* __restrict__ i
     float a_cur[CG], a_nxt[CG];
 #pragma unroll
     for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = wl[size_t(cg) * wstep]; }
+    // B operand (one ds_read_b32 per MFMA): the values of k-group (t, cg + 1) are read BEFORE the MFMAs of group (t, cg) are issued, pinned with
+    // sched_barrier — left alone the scheduler puts every read in front of its MFMA and a wave issues one group per LDS round trip (net_body.h tower_layer)
+    float bc[ROWS];
+    auto bload = [&](float (&bv)[ROWS], int tapoff, int cg) {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { bv[j] = xs[lane_off + cg * 4 * PLANE + (row0 + j) * STRIDE * PC + tapoff]; }
+    };
+    bload(bc, 0, 0);
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
         const int tn = t < 8 ? t + 1 : 8;
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) { a_nxt[cg] = wl[(size_t(tn) * CG + cg) * wstep]; }
-        const int tapoff = (t / 3) * PC + (t % 3);
+        const int tapoff = (t / 3) * PC + (t % 3), tapoff_n = (tn / 3) * PC + (tn % 3);
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
+            float bn[ROWS];
+            if (cg + 1 < CG) { bload(bn, tapoff, cg + 1); } else { bload(bn, tapoff_n, 0); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) {
-                float bv = xs[lane_off + cg * 4 * PLANE + (row0 + j) * STRIDE * PC + tapoff];
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[cg], bv, acc[j], 0, 0, 0);
-            }
+            for (int j = 0; j < ROWS; ++j) { acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[cg], bc[j], acc[j], 0, 0, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { bc[j] = bn[j]; }
         }
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = a_nxt[cg]; }
