@@ -127,3 +127,11 @@ def test_c5_full_size_64_games(mz, oracle, mode):
     assert st["moves"] == 128
     for r in recs:
         assert r.count(";B[") == 2 and r.count("P[") == 2
+
+
+@pytest.mark.parametrize("key,games,chunks,lanes", [("c2", 9, [401 + 30, 60], 2), ("c3", 70, [17 * 4 + 5, 17 * 3], 3), ("c4", 9, [51 + 20, 51], 2), ("c5", 9, [51 * 2, 51 + 7, 51], 3)])
+def test_baseline_nets_on_several_pipeline_lanes(mz, oracle, key, games, chunks, lanes):
+    """The BASELINE networks with the pool cut into pipeline lanes (mz_pipeline_lanes: own device pool, network instance and stream per lane; uneven lanes),
+    calls that end inside a move and — C5 — right after a root cycle (the host-side root expansion of every lane): records against the oracle."""
+    extra = ":env_atari_episode_length=12:zero_actor_intermediate_sequence_length=5" if key == "c5" else ""
+    _run(mz, oracle, key, games, chunks, extra=extra, wextra=f":mz_pipeline_lanes={lanes}")
