@@ -760,16 +760,29 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
     float* bkey = lds;                                     // value-bound multiset, LDS copy
     int* bcnt = reinterpret_cast<int*>(lds + v.bound_cap);
     int bsize = v.bound_size[g];
-    // (all bound_cap entries, not only the bsize live ones: the loads then do not wait for bsize; the others are never looked at)
-    for (int j = lane; j < v.bound_cap; j += 64) { bkey[j] = v.bound_key[size_t(g) * v.bound_cap + j]; bcnt[j] = v.bound_cnt[size_t(g) * v.bound_cap + j]; }
-    const float val = given ? given->value : value_in[g], rew = given ? given->reward : reward_in[g];
-    if (lane == 0) {
-        v.value[base + leaf] = val;
-        v.rec[base + leaf].reward = rew;
-        if (len >= 2 && v.rec[base + leaf].count == 0.0f && (static_cast<unsigned>(v.rec[base + path[len - 2]].players) >> 16) != 0xFFFFu) {
-            v.rec[base + path[len - 2]].players += 1 << 16;
-        }
+    // Up to 64 entries (num_simulation <= 61: BASELINE configs[4] has 53) the multiset lives in REGISTERS, entry j in lane j: a key search is one ballot, an
+    // update a readlane and a predicated move — no LDS round trips and no fences between the steps of the chain (3.8 -> 1.x us per backup)
+    const bool in_regs = v.bound_cap <= 64;
+    float rkey = 0.0f;
+    int rcnt = 0;
+    if (in_regs) {
+        if (lane < v.bound_cap) { rkey = v.bound_key[size_t(g) * v.bound_cap + lane]; rcnt = v.bound_cnt[size_t(g) * v.bound_cap + lane]; }
+    } else {
+        // (all bound_cap entries, not only the bsize live ones: the loads then do not wait for bsize; the others are never looked at)
+        for (int j = lane; j < v.bound_cap; j += 64) { bkey[j] = v.bound_key[size_t(g) * v.bound_cap + j]; bcnt[j] = v.bound_cnt[size_t(g) * v.bound_cap + j]; }
     }
+    const float val = given ? given->value : value_in[g], rew = given ? given->reward : reward_in[g];
+    // The records of the path's nodes are fetched by 64 lanes at once (lane k = the k-th node from the leaf), together with the multiset: ONE round trip in front
+    // of the chain.  Nothing is stored to global memory before the chain is through — the chain's steps are separated by fences (the multiset lives in LDS, but a
+    // release fence also waits for every global store in flight: with the nodes' new mean / count stored inside the loop each level paid a store round trip,
+    // 3.9 us per backup on BASELINE configs[4]); lane k keeps the new statistics of its node and stores them at the end.
+    float pmean = 0.0f, pcnt = 0.0f, prew = 0.0f;
+    int ppl = 0;
+    if (lane < len) {
+        const NodeRec* pn = v.rec + base + path[len - 1 - lane];
+        pmean = pn->mean; pcnt = pn->count; prew = pn->reward; ppl = pn->players;
+    }
+    float my_mean = 0.0f, my_cnt = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -786,12 +799,6 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
-    // the records of the path's nodes are fetched by 64 lanes at once (lane k = the k-th node from the leaf) instead of one L2 round trip per level
-    float pmean = 0.0f, pcnt = 0.0f, prew = 0.0f;
-    if (lane < len) {
-        const NodeRec* pn = v.rec + base + path[len - 1 - lane];
-        pmean = pn->mean; pcnt = pn->count; prew = pn->reward;
-    }
     float updated = val;
     for (int i = len - 1; i >= 0; --i) {
         NodeRec* n = v.rec + base + path[i];
@@ -802,11 +809,35 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
         // MCTSNode::add(value, 1.0f) (ref mcts.cpp:20-28); count + 1 <= 0 cannot happen for count >= 0
         cnt += 1.0f;
         mean += 1.0f * (updated - mean) / cnt;
-        if (lane == 0) {
+        if (kk < 64) {
+            if (lane == kk) { my_mean = mean; my_cnt = cnt; }
+        } else if (lane == 0) { // (levels beyond the 64 the lanes hold)
             n->mean = mean;
             n->count = cnt;
         }
-        { // updateTreeValueBound(old, new) (ref mcts.cpp:219-228)
+        if (in_regs) { // updateTreeValueBound(old, new) (ref mcts.cpp:219-228) on the register copy: the same steps as below
+            const float new_mean = r + v.gamma * mean;
+            const unsigned long long mo = __ballot(lane < bsize && rkey == old_mean);
+            if (mo) {
+                const int jo = static_cast<int>(__builtin_ctzll(mo));
+                const int c = __builtin_amdgcn_readlane(rcnt, jo) - 1;
+                if (c == 0) {
+                    --bsize;
+                    const float lk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rkey), bsize));
+                    const int lc = __builtin_amdgcn_readlane(rcnt, bsize);
+                    if (lane == jo) { rkey = lk; rcnt = lc; }
+                } else if (lane == jo) {
+                    rcnt = c;
+                }
+            }
+            const unsigned long long mn = __ballot(lane < bsize && rkey == new_mean);
+            if (mn) {
+                if (lane == static_cast<int>(__builtin_ctzll(mn))) { ++rcnt; }
+            } else if (bsize < v.bound_cap) {
+                if (lane == bsize) { rkey = new_mean; rcnt = 1; }
+                ++bsize;
+            }
+        } else { // updateTreeValueBound(old, new) (ref mcts.cpp:219-228)
             const float new_mean = r + v.gamma * mean;
             const int jo = find(old_mean);
             if (jo >= 0) {
@@ -828,8 +859,25 @@ __device__ __forceinline__ void expandBackupBody(const PoolView& v, const int* _
         }
         updated = r + v.gamma * updated;
     }
+    if (lane < len && lane < 64) { // the nodes' new statistics; the leaf's value and reward; one more visited child of the leaf's parent (select's prefix)
+        NodeRec* n = v.rec + base + path[len - 1 - lane];
+        n->mean = my_mean;
+        n->count = my_cnt;
+        if (lane == 0) {
+            v.value[base + leaf] = val;
+            n->reward = rew;
+        }
+        if (lane == 1 && laneF(pcnt, 0) == 0.0f && (static_cast<unsigned>(ppl) >> 16) != 0xFFFFu) { n->players = ppl + (1 << 16); }
+    }
     {
         float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+        if (in_regs) {
+            if (lane < bsize) {
+                v.bound_key[size_t(g) * v.bound_cap + lane] = rkey;
+                v.bound_cnt[size_t(g) * v.bound_cap + lane] = rcnt;
+                lo = rkey; hi = rkey;
+            }
+        } else
         for (int j = lane; j < bsize; j += 64) {
             v.bound_key[size_t(g) * v.bound_cap + j] = bkey[j];
             v.bound_cnt[size_t(g) * v.bound_cap + j] = bcnt[j];
