@@ -105,10 +105,17 @@ inline size_t gumbelSmemBytes(int A) { return size_t(A) * (3 * sizeof(float) + s
 // the backup changes): then nothing is written and -1 comes back, and the step runs again after the backup (sim_cluster.h).
 // bump_cnt >= 0: the visit count of child `bump` BEFORE that backup, read by the caller while no backup was in flight (the step then runs beside the
 // backup on another wave, sim_kernel_mz: whatever the record of that child holds at the moment is not looked at)
-__device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelView& gv, int sim_post, int g, int lane, float* smem, int bump = -1, float bump_cnt = -1.0f)
+// kids != nullptr (only with bump >= 0): the caller keeps the root's first_child / num_children (kids[0], kids[1]) and its children's visit counts and logits
+// (kids + 2, kids + 2 + A: floats) up to date in LDS — the counts without the backup in flight — so the step ahead of a backup makes no trip to global memory: it
+// never looks at the children's means (a step that would, the halving, returns -1 first)
+__device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelView& gv, int sim_post, int g, int lane, float* smem, int bump = -1, float bump_cnt = -1.0f,
+                                              const int* kids = nullptr)
 {
     const size_t base = size_t(g) * v.cap;
-    const NodeRec root = v.rec[base];
+    const bool from_kids = kids != nullptr && bump >= 0 && sim_post != 1;
+    NodeRec root;
+    if (from_kids) { root.first_child = kids[0]; root.num_children = kids[1]; root.players = 0; }
+    else { root = v.rec[base]; }
     const int nc = root.num_children, fc = root.first_child, cplayer = (root.players >> 8) & 0xFF;
     float* cnt = smem;              // [nc]
     float* lg = cnt + v.A;          // [nc]
@@ -117,10 +124,19 @@ __device__ __forceinline__ int gumbelStepBody(const PoolView& v, const GumbelVie
     int* cand = idx + v.A;                           // [kGumbelMaxSample] the candidates, sorted in LDS
     int* stack = cand + kGumbelMaxSample;            // sort_emul range stack
     int* st = gv.state + size_t(g) * (3 + kGumbelMaxSample);
-    const int bsize = v.bound_size[g];
-    const float lo = v.bound_lo[g], hi = v.bound_hi[g];
     float mx = 0.0f;
-    for (int i = lane; i < nc; i += 64) {
+    if (from_kids) {
+        const float* kc = reinterpret_cast<const float*>(kids + 2);
+        for (int i = lane; i < nc; i += 64) {
+            cnt[i] = i == bump ? kc[i] + 1.0f : kc[i];
+            lg[i] = kc[v.A + i];
+            score[i] = 0.0f;
+            idx[i] = i;
+        }
+    }
+    const int bsize = from_kids ? 0 : v.bound_size[g];
+    const float lo = from_kids ? 0.0f : v.bound_lo[g], hi = from_kids ? 0.0f : v.bound_hi[g];
+    for (int i = lane; i < nc && !from_kids; i += 64) {
         const NodeRec c = v.rec[base + fc + i];
         cnt[i] = i == bump ? (bump_cnt >= 0.0f ? bump_cnt : c.count) + 1.0f : c.count;
         lg[i] = v.logit[base + fc + i];

@@ -359,15 +359,21 @@ __device__ __noinline__ void simApplyRootNoise(CSimArgs* __restrict__ a, int g, 
 
 // Gumbel: sequential halving + the root child the next simulation starts from (slot >= 1); the first simulation of a launch takes the
 // start node the host computed when it ran this step itself (it does at every launch boundary, reading the state back first)
+// state_lds: the game's Gumbel state lives in LDS for the launch (sim_kernel_mz) instead of the pool's array
 template <int WPE>
-__device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles)
+__device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, int* state_lds = nullptr)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
     slot = __builtin_amdgcn_readfirstlane(slot);
     if (host_start && slot >= 1) { return; } // a->start[g] was uploaded by the host
     int st = 0;
-    if (slot >= 1 && !host_start) { const PoolView pv = ldc(&a->pv); const GumbelView gum = ldc(&a->gum); st = gumbelStepBody(pv, gum, slot, g, lane, tiles); }
+    if (slot >= 1 && !host_start) {
+        const PoolView pv = ldc(&a->pv);
+        GumbelView gum = ldc(&a->gum);
+        if (state_lds) { gum.state = state_lds - size_t(g) * (3 + kGumbelMaxSample); }
+        st = gumbelStepBody(pv, gum, slot, g, lane, tiles);
+    }
     if (lane == 0) { a->start[g] = st; }
     waveSync();
 }
@@ -629,23 +635,25 @@ __device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot,
 
 // The Gumbel step of simulation `next_slot`, ahead of the backup of the simulation in flight (gumbel_body.h `bump`): true if a->start[g] and the state are
 // those the step after the backup would write.  The cluster kernel runs it on its owner while the other workgroups' value / reward heads are still busy.
-__device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_slot, int g, int lane, float* tiles, float bump_cnt = -1.0f, int* lds_path = nullptr)
+__device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_slot, int g, int lane, float* tiles, float bump_cnt = -1.0f, int* lds_path = nullptr,
+                                            int* state_lds = nullptr, const int* kids = nullptr)
 {
     g = __builtin_amdgcn_readfirstlane(g);
     next_slot = __builtin_amdgcn_readfirstlane(next_slot);
     const PoolView pv = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
-    const GumbelView gum = ldc(&a->gum);
+    GumbelView gum = ldc(&a->gum);
+    if (state_lds) { gum.state = state_lds - size_t(g) * (3 + kGumbelMaxSample); }
     const int len = pv.path_len[g];
     if (len < 2) { return false; }
-    const int child = pv.path[size_t(g) * pv.max_depth + 1] - pv.rec[size_t(g) * pv.cap].first_child;
-    const int st = gumbelStepBody(pv, gum, next_slot, g, lane, tiles, child, bump_cnt);
+    const int child = pv.path[size_t(g) * pv.max_depth + 1] - (kids ? kids[0] : pv.rec[size_t(g) * pv.cap].first_child);
+    const int st = gumbelStepBody(pv, gum, next_slot, g, lane, tiles, child, bump_cnt, kids);
     if (st >= 0 && lane == 0) { a->start[g] = st; }
     waveSync();
     return st >= 0;
 }
 
 __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
-                                         bool gumbel_done = false, bool noise_done = false, int serial = 0, int* lds_path = nullptr)
+                                         bool gumbel_done = false, bool noise_done = false, int serial = 0, int* lds_path = nullptr, int* state_lds = nullptr)
 {
     serial = __builtin_amdgcn_readfirstlane(serial);
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
@@ -653,7 +661,7 @@ __device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, boo
     g = __builtin_amdgcn_readfirstlane(g);
     MZ_LPROF(0);
     if (slot == 1 && a->root_noise && !noise_done) { simApplyRootNoise<2>(a, g, lane); }
-    if (a->use_gumbel && !gumbel_done) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles); }
+    if (a->use_gumbel && !gumbel_done) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles, state_lds); }
     MZ_LPROF(20);
     const PoolView pv = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
     selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec, serial);
@@ -778,8 +786,26 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     // next Gumbel step read it — instead of going through the pool's arrays in global memory (a round trip each)
     int* lds_path = (a->atari && 2 * a->pv.max_depth + 2 <= kSpecWords) ? spec_w : nullptr;
     const PoolView v = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
+    // ... and behind them the Gumbel root's state and what its step reads of the root's children (first_child, num_children, visit counts, logits): the step
+    // that runs beside a simulation's expand + backup (below) then makes no trip to global memory (6.5 -> ~2 us: it had become the longer of the two)
+    int* gum_state = nullptr;
+    int* gum_kids = nullptr;
+    if (lds_path && a->use_gumbel && sim0 >= 1 && 2 * a->pv.max_depth + 2 + (3 + kGumbelMaxSample) + 2 + 2 * a->A <= kSpecWords) {
+        gum_state = lds_path + 2 * a->pv.max_depth + 2;
+        gum_kids = gum_state + 3 + kGumbelMaxSample;
+    }
     if (lds_path) { // (the game's node count for the launch: the word behind the path, simPathView)
         if (tid == 0) { lds_path[2 * a->pv.max_depth + 1] = a->pv.num_nodes[g]; }
+        if (gum_state) {
+            const NodeRec root = a->pv.rec[size_t(g) * a->pv.cap];
+            if (tid < 3 + kGumbelMaxSample) { gum_state[tid] = a->gum.state[size_t(g) * (3 + kGumbelMaxSample) + tid]; }
+            if (tid == 64) { gum_kids[0] = root.first_child; gum_kids[1] = root.num_children; }
+            float* kc = reinterpret_cast<float*>(gum_kids + 2);
+            for (int i = tid; i < root.num_children && i < a->A; i += 512) {
+                kc[i] = a->pv.rec[size_t(g) * a->pv.cap + root.first_child + i].count;
+                kc[a->A + i] = a->pv.logit[size_t(g) * a->pv.cap + root.first_child + i];
+            }
+        }
         __syncthreads();
     }
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr; // MZ_SIM_PROF=1: [select, tower, heads, cand+expand] ticks + sims
@@ -793,7 +819,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         // s_gum_ahead: this simulation's Gumbel step was computed beside the previous simulation's expand + backup (below)
         __shared__ int s_gum_ahead;
         __shared__ float s_bump_cnt;
-        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, s > 0 && s_gum_ahead != 0, (host_start & 4) != 0, (a->no_spec & 2) ? 0 : s + 1, lds_path); }
+        if (wave == 0) { simMzSelect(a, slot, s == 0 && (host_start & 1) != 0, g, lane, tiles, rcp_lds, spec, s > 0 && s_gum_ahead != 0, (host_start & 4) != 0, (a->no_spec & 2) ? 0 : s + 1, lds_path, gum_state); }
         else if (wave <= kHelpSegs && spec.w && !(a->no_spec & 2)) { simSelectHelper(a, g, lane, wave, s + 1, rcp_lds, spec); }
         __syncthreads();
         if (tid == 64) { s_gum_ahead = 0; } // (wave 1 sets it again below; wave 0 looked at it before the barrier)
@@ -849,8 +875,12 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             // adds one visit to the root child on this path and changes nothing else the step reads — unless the candidates have all reached their
             // budget (the halving ranks them by means): then the step says so and runs after the backup as always.  The heads' scratch is free: the
             // leaf was evaluated ahead.
-            const bool done = simGumbelAhead(a, slot + 1, g, lane, head_scratch, s_bump_cnt, lds_path);
+            const bool done = simGumbelAhead(a, slot + 1, g, lane, head_scratch, s_bump_cnt, lds_path, gum_state, gum_kids);
             if (lane == 0) { s_gum_ahead = done ? 1 : 0; }
+        }
+        if (gum_kids && tid == 64 && slot >= 1 && !given) { // this simulation's visit to the root child on its path, in the launch's copy of the counts (after the step ahead read them)
+            const int child = v.path[size_t(g) * v.max_depth + 1] - gum_kids[0];
+            if (child >= 0 && child < a->A) { reinterpret_cast<float*>(gum_kids + 2)[child] += 1.0f; }
         }
         __syncthreads();
         if (prof && tid == 0 && !given) {
@@ -859,6 +889,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         }
     }
     if (lds_path && tid == 0) { a->pv.num_nodes[g] = lds_path[2 * a->pv.max_depth + 1]; }
+    if (gum_state && tid < 3 + kGumbelMaxSample) { a->gum.state[size_t(g) * (3 + kGumbelMaxSample) + tid] = gum_state[tid]; }
 }
 
 
