@@ -22,39 +22,7 @@ struct AtariHeadParams {
 // side by side on the two halves.  Both halves pass the same barriers; `active` = false: barriers only.  Every sum is the reference's
 // sequential f32 chain (dotChain: the weights of 16 steps are loaded ahead of the 16 dependent fmas); the 601 quotients of the
 // expectation are independent and computed by all threads, only the two index-ordered sums are serial.
-// s = ((x[0] + x[1]) + x[2]) + ... in index order, by ONE wave: lane l holds elements [l * VPL, (l + 1) * VPL) in registers and the running
-// sum is handed from lane to lane.  The same n - 1 dependent adds as a scalar loop, but without an LDS round trip per
-// element (one lane reading x[i] and adding, 601 times, cost 33 us per sum: the 601-bin heads have four such sums).
-template <int VPL>
-__device__ __forceinline__ float orderedSumWaveT(const float* x, int n, int vpl, int lane)
-{
-    float v[VPL]; // slots beyond the lane's elements hold +0: adding +0 never changes a sum that is not -0, and these sums never are
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) { const int i = lane * vpl + k; v[k] = (k < vpl && i < n) ? x[i] : 0.0f; }
-    // Systolic: in every step each lane adds its elements to what its left neighbour held after the previous step (DPP wave_shr:1, lane 0 reads +0).
-    // Lane 0 is right after step 0 and stays right (same inputs every step), so lane l is right from step l on: after `lanes` steps the last lane
-    // holds the sum of all elements, added in index order.  The hand-over costs no instruction (the shift is folded into the first add of the
-    // step); handing the sum over with v_readlane cost a VALU -> SGPR -> VALU round trip per lane (3.9 us per 601-bin sum, 2.3 us this way).
-    float a = 0.0f;
-    const int lanes = (n + vpl - 1) / vpl;
-    for (int l = 0; l < lanes; ++l) {
-        a = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
-#pragma unroll
-        for (int k = 0; k < VPL; ++k) { a = a + v[k]; }
-    }
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), lanes - 1));
-}
-__device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
-{
-    const int vpl = (n + 63) / 64;
-    if (vpl <= 4) { return orderedSumWaveT<4>(x, n, vpl, lane); }
-    if (vpl <= 10) { return orderedSumWaveT<10>(x, n, vpl, lane); } // 601 bins
-    if (vpl <= 16) { return orderedSumWaveT<16>(x, n, vpl, lane); }
-    float s = 0.0f; // not reached by the supported head sizes: plain loop
-    for (int i = 0; i < n; ++i) { s += x[i]; }
-    return s;
-}
-
+// (orderedSumWave: the index-ordered sum of an LDS vector by one wave, is in net_body.h)
 // A slice of a fully connected layer with the weights STREAMED through LDS (sim_cluster.h: a 601-bin head alone on its CU, or a column slice of
 // it for four games of an octet).  Chain k of thread t: acc[k] = the ordered f32 chain over i < n of xk[k][i] * W[i][col0 + uk[k]] (weights
 // wT[n][ws] in global memory, uk[k] < seg; xk[k] = an LDS vector, 16-byte aligned).  ALL NT threads fetch chunk c + D - 1 (R rows x seg columns,

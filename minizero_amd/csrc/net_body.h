@@ -483,6 +483,39 @@ __device__ __forceinline__ void dotChain4(const float* __restrict__ x, const flo
     for (int k = 0; k < 4; ++k) { acc[k] = (k + sh < 4) ? r[(k + sh) & 3] : 0.0f; } // component k + sh of the clamped load is output o + k
 }
 
+// s = ((x[0] + x[1]) + x[2]) + ... in index order, by ONE wave: lane l holds elements [l * VPL, (l + 1) * VPL) in registers and the running
+// sum is handed from lane to lane.  The same n - 1 dependent adds as a scalar loop, but without an LDS round trip per
+// element (one lane reading x[i] and adding, 601 times, cost 33 us per sum: the 601-bin heads have four such sums).
+template <int VPL>
+__device__ __forceinline__ float orderedSumWaveT(const float* x, int n, int vpl, int lane)
+{
+    float v[VPL]; // slots beyond the lane's elements hold +0: adding +0 never changes a sum that is not -0, and these sums never are
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) { const int i = lane * vpl + k; v[k] = (k < vpl && i < n) ? x[i] : 0.0f; }
+    // Systolic: in every step each lane adds its elements to what its left neighbour held after the previous step (DPP wave_shr:1, lane 0 reads +0).
+    // Lane 0 is right after step 0 and stays right (same inputs every step), so lane l is right from step l on: after `lanes` steps the last lane
+    // holds the sum of all elements, added in index order.  The hand-over costs no instruction (the shift is folded into the first add of the
+    // step); handing the sum over with v_readlane cost a VALU -> SGPR -> VALU round trip per lane (3.9 us per 601-bin sum, 2.3 us this way).
+    float a = 0.0f;
+    const int lanes = (n + vpl - 1) / vpl;
+    for (int l = 0; l < lanes; ++l) {
+        a = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { a = a + v[k]; }
+    }
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), lanes - 1));
+}
+__device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
+{
+    const int vpl = (n + 63) / 64;
+    if (vpl <= 4) { return orderedSumWaveT<4>(x, n, vpl, lane); }
+    if (vpl <= 10) { return orderedSumWaveT<10>(x, n, vpl, lane); } // 601 bins
+    if (vpl <= 16) { return orderedSumWaveT<16>(x, n, vpl, lane); }
+    float s = 0.0f; // not reached by the supported head sizes: plain loop
+    for (int i = 0; i < n; ++i) { s += x[i]; }
+    return s;
+}
+
 // the body of heads_kernel for sample `b`, run by NT threads (a multiple of 64, >= 128); `sm` = (C*P + PC*P + P + VH + A + 16) floats of LDS
 // With xlds and without scale_hidden it passes exactly TWO workgroup barriers (after the conv1x1, after the FCs): the simulation kernel runs the second half
 // of the Go leaf beside it on waves that have no share of the heads (sim.hip simLeafRest / go_body.h goLeafBody PART 2), and those waves pass the same two.
@@ -581,8 +614,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
         for (int a = lane; a < A; a += 64) { lg[a] = mz_expf(lg[a] - m); }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float s = 0.0f;
-        for (int a = 0; a < A; ++a) { s += lg[a]; } // index-order sum, every lane redundantly (LDS broadcast)
+        const float s = orderedSumWave(lg, A, lane); // index-order sum (the lanes hand it on: 82 dependent adds of one lane each behind an LDS read cost 1 us of the tail's 2.2)
         for (int a = lane; a < A; a += 64) { policy[size_t(b) * A + a] = lg[a] / s; }
         MZ_HPROF(8);
     }
