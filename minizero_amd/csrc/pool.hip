@@ -346,10 +346,17 @@ int Pool::rootRead(int* num_children, int* action, float* count, float* mean, fl
 {
     MZ_HIP(hipSetDevice(device_));
     const size_t G = v_.games, GA = G * v_.A;
-    hipLaunchKernelGGL(root_read_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, d_rr_f_.p, d_rr_i_.p);
-    MZ_HIP(hipGetLastError());
-    MZ_HIP(hipMemcpyAsync(h_rr_f_.p, d_rr_f_.p, (7 * GA + 5 * G) * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    MZ_HIP(hipMemcpyAsync(h_rr_i_.p, d_rr_i_.p, (G + GA + G) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    // A small pool's statistics (64 Atari games: 37 KB) are written by the kernel straight into the pinned host buffers — a kernel and one wait instead of a
+    // kernel, two copies and a wait on the host's critical path between two moves; a large pool's (256 Go games: 0.7 MB) take the copy engine
+    if ((8 * GA + 7 * G) * sizeof(float) <= size_t(128) * 1024) {
+        hipLaunchKernelGGL(root_read_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, h_rr_f_.p, h_rr_i_.p);
+        MZ_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(root_read_kernel, dim3(v_.games), dim3(64), 0, stream_, v_, d_rr_f_.p, d_rr_i_.p);
+        MZ_HIP(hipGetLastError());
+        MZ_HIP(hipMemcpyAsync(h_rr_f_.p, d_rr_f_.p, (7 * GA + 5 * G) * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        MZ_HIP(hipMemcpyAsync(h_rr_i_.p, d_rr_i_.p, (G + GA + G) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    }
     MZ_HIP(hipStreamSynchronize(stream_));
     const float* f = h_rr_f_.p;
     const int* iv = h_rr_i_.p;
