@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of two builds of libmzgpu.so (ab/old.so, ab/new.so — not tracked): alternates them over `tools/run_configs.py <args>`.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-cp minizero_amd/libmzgpu.so ab/keep.so
+mkdir -p ab && cp minizero_amd/libmzgpu.so ab/keep.so
 for i in 1 2 3; do
   for v in old new; do
     cp ab/$v.so minizero_amd/libmzgpu.so
