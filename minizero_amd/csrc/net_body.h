@@ -369,7 +369,16 @@ __device__ __forceinline__ float* towerBody(const float* __restrict__ in, const 
     if (ot < ta.OT && half == 0) {
         towerRun<H, W, CIN0_PAD, CPAD, TM::PT0, (TM::kCorner && TM::PT1 == 0), NTW>(params, ta, T0, T1, gout, lane, ot, 0);
     } else if (ot < ta.OT && TM::PT1 > 0) {
-        if constexpr (TM::PT1 > 0) { towerRun<H, W, CIN0_PAD, CPAD, TM::PT1, TM::kCorner, NTW>(params, ta, T0, T1, gout, lane, ot, TM::PT0); }
+        if constexpr (TM::PT1 > 0) {
+            // The two waves of a SIMD share its MFMA pipe.  The wave with FEWER pixel tiles has fewer independent accumulator chains (a dependent MFMA issues every
+            // 57 cycles, the pipe takes one every 32): it cannot fill the pipe alone, its partner can.  Left to the arbiter the partner finished first and this wave
+            // ran its last ~35 MFMAs of every layer alone at the dependent rate (tools/tower_prof: 9x9, waves 0-3 done at 25.2 k cycles, waves 4-7 at 26.3 k, the pipe's
+            // 784 MFMAs are 25.1 k).  With the higher priority it is served whenever it can issue, and the partner fills everything else.  (Measured: the order
+            // flips — waves 4-7 done at 24.4 k, waves 0-3 at 25.2 k on average over the 13 layers — but the later of the two is where it was: 0.2-0.5 % per move.)
+            if constexpr (TM::PT1 < TM::PT0 || TM::kCorner) { __builtin_amdgcn_s_setprio(2); }
+            towerRun<H, W, CIN0_PAD, CPAD, TM::PT1, TM::kCorner, NTW>(params, ta, T0, T1, gout, lane, ot, TM::PT0);
+            if constexpr (TM::PT1 < TM::PT0 || TM::kCorner) { __builtin_amdgcn_s_setprio(0); }
+        }
     } else {
         towerIdle(ta);
     }
