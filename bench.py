@@ -88,6 +88,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-moves", type=int, default=30, help="timed moves of the short C3 / C4 / C5 legs after the headline (0 = skip; N=1 only)")
     ap.add_argument("--extra-conf", default="", help="extra k=v:k=v keys (profiling variants only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the barriers / reductions / weight broadcast (nccl = RCCL; gloo: the world > 1 path on a box with fewer "
+                         "GPUs than ranks, with --device-map)")
+    ap.add_argument("--device-map", default=os.environ.get("MZ_BENCH_DEVICE_MAP", ""),
+                    help="TEST HOOK: comma-separated physical device of every local rank, e.g. 0,0 = two ranks on GPU 0 (needs --backend gloo: RCCL refuses "
+                         "two ranks on one device); default: local rank r drives device r")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="arithmetic of the residual tower: f32 (default, the headline: bit-exact against the oracle) or the opt-in bf16x3 "
                          "(split-bf16 operands on the 16-bit MFMA, outputs within 1e-3, records not bit-identical) — reported as its own line")
@@ -104,8 +110,17 @@ def main():
     from minizero_amd.dist import Group, shard_seed
     if not torch.cuda.is_available() or mz.device_count() < 1:
         raise SystemExit("bench.py needs a GPU (libmzgpu has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    grp = Group("nccl")  # RCCL over xGMI; only used for the weight broadcast, barriers and the final reductions
+    device = local_rank
+    if args.device_map:
+        dm = [int(t) for t in args.device_map.split(",")]
+        if len(dm) != world or any(o < 0 or o >= mz.device_count() for o in dm):
+            raise SystemExit(f"--device-map {args.device_map}: need {world} ordinals below {mz.device_count()}")
+        if args.backend == "nccl" and len(set(dm)) != len(dm):
+            raise SystemExit("--device-map puts two ranks on one device: use --backend gloo (RCCL needs one device per rank)")
+        device = dm[local_rank]
+    torch.cuda.set_device(device)
+    # RCCL over xGMI (or gloo, test hook above); only used for the weight broadcast, barriers and the final reductions
+    grp = Group(args.backend, device=torch.device("cuda", device) if args.backend == "nccl" else None)
 
     cores = os.cpu_count() or 1
     usable = mz.usable_cpus()  # affinity mask capped by the cgroup CPU quota: spinning past the quota gets the container throttled
@@ -117,7 +132,7 @@ def main():
     desc = mz.DESCS["c2"]()
     # the optional synchronous weight broadcast (load_model fan-out): rank 0's blob is the one every rank loads
     weights = grp.broadcast_weights(mz.generate_weights(desc, 0))
-    worker = mz.Worker(conf, desc, weights, device=local_rank)
+    worker = mz.Worker(conf, desc, weights, device=device)
     worker.command("start")
 
     cpm = N_SIM + 1  # cycles per move
@@ -140,17 +155,25 @@ def main():
         worker.pop_lines()
         grp.barrier()
         tg = time.perf_counter()
+        lines = []
         for _ in range(args.game_moves):
             assert worker.run_cycles(cpm) == cpm
+            lines += worker.pop_lines(wait=False)  # the `-mode sp` loop pops what is complete between two moves (include/minizero/actor_group.h)
         grp.barrier()
         g_dt = time.perf_counter() - tg
         s2 = worker.stats()
-        lines = worker.pop_lines()
+        lines += worker.pop_lines()
         finished = sum(1 for l in lines if l.startswith("SelfPlay true "))
         assert finished == s2["games"] - s1["games"]
         g_dt = float(grp.reduce([g_dt], "max")[0])
         g_games, g_moves, g_evals = grp.reduce([finished, s2["moves"] - s1["moves"], s2["leaf_evals"] - s1["leaf_evals"]], "sum")
 
+    # what every rank ran with (device, seed, CPU range, first record): gathered as a sum of one-hot rows, printed by rank 0
+    import zlib
+    row = [0.0] * (5 * world)
+    row[5 * rank:5 * rank + 5] = [float(device), float(shard_seed(1, rank)), float(local_rank * threads if args.pin else -1), float(threads),
+                                  float(zlib.crc32(worker.peek_records(1)[0].encode()))]
+    per_rank = grp.reduce(row, "sum")
     if rank == 0:
         evals = args.games * cpm * args.steps * world
         value = evals / dt
@@ -197,7 +220,9 @@ def main():
                        "step": "one move of every game = 401 lock-step cycles = games x 401 leaf evaluations per GPU, per-move host work included",
                        "games_per_gpu": args.games, "actor_num_simulation": N_SIM, "leaf_evals_per_step": args.games * cpm * world,
                        "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_cores": cores, "host_cpus_usable": usable,
-                       "sharding": f"{world} x independent actor pools, no data-path collective"},
+                       "sharding": f"{world} x independent actor pools, no data-path collective", "backend": args.backend,
+                       "ranks": [{"rank": r, "device": int(per_rank[5 * r]), "program_seed": int(per_rank[5 * r + 1]), "cpu_base": int(per_rank[5 * r + 2]),
+                                  "host_threads": int(per_rank[5 * r + 3]), "first_record_crc32": int(per_rank[5 * r + 4])} for r in range(world)]},
             "moves_per_sec": moves / dt, "games_finished_in_timed_region": games_done,
             "games_per_sec": (g_games / g_dt) if g_dt > 0 else None,
             "games_leg": {"moves_per_game_slot": args.game_moves, "seconds": g_dt, "games_finished": g_games, "moves": g_moves,

@@ -10,7 +10,7 @@
 // What differs, and why (INTEGRATION.md §2 lists the same):
 //   * afterNNEvaluation(output) does not consume `output`: the evaluation happens on the device inside the library, one
 //     beforeNNEvaluation / afterNNEvaluation pair still = one simulation; getNNEvaluationBatchIndex() is 0 while one is in flight, -1 otherwise;
-//   * think() runs the search as library calls of whole launches: actor_mcts_think_time_limit IS honoured (the clock is looked at every 32 cycles and the
+//   * think() runs the search as library calls of whole launches: actor_mcts_think_time_limit IS honoured (the clock is looked at between library calls of 1-64 cycles, a quarter of what still fits the limit, and the
 //     decision is then taken from the simulations run so far, zero_actor.cpp:40-45), actor_mcts_think_batch_size and the virtual loss of ZeroActor::step
 //     (ref zero_actor.cpp:128-157) are not — the self-play path (ActorGroup) never uses them;
 //   * setNetwork(network) runs the actor ON the caller's network (mz_worker_create_shared): no second copy of the weights, a later
@@ -220,8 +220,12 @@ public:
     inline const Environment& getEnvironment() const { return env_; }
     inline const int getNNEvaluationBatchIndex() const { return nn_evaluation_batch_id_; }
     // ref base_actor.h:33-34: per move its (key, value) pairs (P, V, R; L for the Atari-shaped game).  A snapshot of the library's history,
-    // refreshed by every call (the reference hands out its own member; writes into the returned vector do not reach the library)
-    inline const std::vector<std::vector<std::pair<std::string, std::string>>>& getActionInfoHistory() const
+    // refreshed by every call.  The reference hands out its own member as a non-const reference (base_actor.h:33): code written against it
+    // (`auto& h = actor->getActionInfoHistory(); h[i].clear();`) compiles here too, but writes into the snapshot do not reach the library's history —
+    // the library clears the entries a record has emitted itself (actor_group.cpp:40-46)
+    inline std::vector<std::vector<std::pair<std::string, std::string>>>& getActionInfoHistory() { return refreshActionInfoHistory(); }
+    inline const std::vector<std::vector<std::pair<std::string, std::string>>>& getActionInfoHistory() const { return refreshActionInfoHistory(); }
+    inline std::vector<std::vector<std::pair<std::string, std::string>>>& refreshActionInfoHistory() const
     {
         const int need = mz_worker_action_info_history(handle(), 0, nullptr, 0);
         check(need);
@@ -295,11 +299,29 @@ public:
         const std::string lim = config::mzgpuConfValue(config::mzgpuCollectConfiguration(), "actor_mcts_think_time_limit");
         const double limit_ms = lim.empty() ? 0.0 : std::atof(lim.c_str()) * 1000.0;
         const auto start = std::chrono::steady_clock::now();
+        auto elapsed = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count(); };
+        // Granularity of the limit: the clock is looked at between two library calls.  The first call runs kThinkFirst cycles (the root's expansion precedes any
+        // decision), every later one a quarter of the cycles that still fit the limit at the rate measured so far (1 .. kThinkChunk): the search ends within
+        // about a quarter of the remaining time of the limit, never a fixed 32 cycles late.
+        int chunk = kThinkFirst, cycles_run = 0;
         while (!isSearchDone()) {
-            if (limit_ms > 0) { check(mz_worker_run_cycles(handle(), kThinkChunk)); } else { step(); }
-            if (limit_ms > 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count() >= limit_ms) { break; }
+            if (limit_ms > 0) {
+                const int ran = mz_worker_run_cycles(handle(), chunk);
+                check(ran);
+                cycles_run += ran;
+                const double ms = elapsed();
+                if (ms >= limit_ms) { break; }
+                const double per_cycle = ms / (cycles_run > 0 ? cycles_run : 1);
+                const double fit = per_cycle > 0 ? (limit_ms - ms) / per_cycle : kThinkChunk;
+                chunk = fit / 4 < 1 ? 1 : (fit / 4 > kThinkChunk ? kThinkChunk : static_cast<int>(fit / 4));
+            } else {
+                step();
+            }
         }
-        if (!isSearchDone()) { check(mz_worker_finish_search(handle())); }
+        if (!isSearchDone()) {
+            // (a root that is not expanded yet — the limit fell inside the first two cycles — gets them: a decision needs the root's children)
+            if (mz_worker_finish_search(handle()) == MZ_ERR_STATE) { check(mz_worker_run_cycles(handle(), 2)); if (!isSearchDone()) { check(mz_worker_finish_search(handle())); } }
+        }
         const Action a = getSearchAction();
         if (with_play) { act(a); }
         if (display_board) { std::cerr << env_.toString() << getSearchInfo() << std::endl; }
@@ -361,7 +383,8 @@ protected:
         check(mz_worker_run_cycles(handle(), cyclesPerMove() + 1));
     }
     int cyclesPerMove() const { return mz_worker_cycles_per_move(handle()); }
-    static constexpr int kThinkChunk = 32; // cycles between two looks at the clock when a think-time limit is set (>= 2: the root's expansion precedes any decision)
+    static constexpr int kThinkFirst = 2;  // cycles of the first call under a think-time limit (the root's expansion precedes any decision)
+    static constexpr int kThinkChunk = 64; // ... and the most cycles between two looks at the clock
     uint64_t tree_node_size_;
     int cycles_in_search_ = 0;
     bool fresh_ = false; // the worker has just been created: its game is new

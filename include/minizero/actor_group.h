@@ -61,16 +61,20 @@ protected:
         if (visible < 1) { std::cerr << "ActorGroup: no GPU visible (libmzgpu has no CPU path)" << std::endl; exit(0); }
         auto number = [&](const char* key, int def) { const std::string v = config::mzgpuConfValue(conf_, key); return v.empty() ? def : std::stoi(v); };
         const int total_games = number("zero_num_parallel_games", 32), seed = number("program_seed", 0), threads = number("zero_num_threads", 4);
-        // MZ_DEVICE_MAP=0,0 (test hook): logical device g -> physical ordinal map[g], so that the multi-device logic below (game split i % G,
-        // seed + g, one host thread per device, the shared stdout mutex) runs with G > 1 on a one-GPU box: tests/test_gpu_protocol.py
+        // MZ_DEVICE_MAP=0,0 — TEST HOOK, never set it in production: logical device g -> physical ordinal map[g], so that the multi-device
+        // logic below (game split i % G, seed + g, one host thread per device, the shared stdout mutex) runs with G > 1 on a one-GPU box
+        // (tests/test_gpu_protocol.py).  Workers that share a physical GPU are each sized as if they had it to themselves.  Tokens are decimal ordinals only.
         std::vector<int> map;
         if (const char* m = getenv("MZ_DEVICE_MAP")) {
             std::istringstream iss(m);
             for (std::string tok; std::getline(iss, tok, ',');) {
-                const int o = tok.empty() ? -1 : atoi(tok.c_str());
-                if (o < 0 || o >= visible) { std::cerr << "ActorGroup: MZ_DEVICE_MAP names device " << tok << ", " << visible << " visible" << std::endl; exit(0); }
+                const bool digits = !tok.empty() && tok.size() <= 4 && tok.find_first_not_of("0123456789") == std::string::npos;
+                const int o = digits ? std::stoi(tok) : -1;
+                if (o < 0 || o >= visible) { std::cerr << "ActorGroup: MZ_DEVICE_MAP token '" << tok << "' is not a device ordinal (" << visible << " visible)" << std::endl; exit(0); }
                 map.push_back(o);
             }
+            if (map.empty()) { std::cerr << "ActorGroup: MZ_DEVICE_MAP is set but names no device" << std::endl; exit(0); }
+            std::cerr << "[mzgpu] MZ_DEVICE_MAP=" << m << " (test hook): " << map.size() << " logical device(s)" << std::endl;
         }
         const int ndev = map.empty() ? visible : static_cast<int>(map.size());
         const int G = gpu_id_ >= 0 ? 1 : std::max(1, std::min(ndev, total_games));
@@ -137,12 +141,19 @@ protected:
             const std::string prefix = command.substr(0, command.find(' '));
             const int rc = mz_worker_command(d.worker, command.c_str()); // the worker applies zero_actor_ignored_command itself
             if (rc < 0) { std::cerr << mz_last_error() << std::endl; exit(0); }
-            if (rc == 1) { return false; } // quit
+            if (rc == 1) { drainGames(d); return false; } // quit
             if (isIgnored(prefix)) { continue; }
             if (prefix == "start") { d.running = true; }
-            if (prefix == "stop") { d.running = false; }
+            if (prefix == "stop") { d.running = false; drainGames(d); }
         }
         return true;
+    }
+
+    // stop / quit: records whose OBS tag is still being compressed are waited for (between two moves flushGames takes what is complete and moves on)
+    void drainGames(Device& d)
+    {
+        if (mz_worker_wait_lines(d.worker) < 0) { std::cerr << mz_last_error() << std::endl; exit(0); }
+        flushGames(d);
     }
 
     void flushGames(Device& d)
@@ -153,6 +164,7 @@ protected:
             // zero_actor_intermediate_sequence_length=0; a line that does not fit must never block the lines behind it
             const int need = mz_worker_pop_line(d.worker, nullptr, 0);
             if (need == 0) { break; }
+            if (need == MZ_ERR_STATE) { std::cerr << mz_last_error() << std::endl; continue; } // one record lost its OBS tag: dropped and reported, the queue keeps draining
             if (need > 0 && static_cast<size_t>(need) >= buf.size()) { buf.resize(static_cast<size_t>(need) + 1); }
             const int n = need < 0 ? need : mz_worker_pop_line(d.worker, buf.data(), static_cast<int>(buf.size()));
             if (n < 0) { std::cerr << mz_last_error() << std::endl; exit(0); }

@@ -187,8 +187,13 @@ int mz_worker_run_cycles(mz_worker* w, int n);
 int mz_worker_cycles_per_move(const mz_worker* w);
 /* next pending stdout line ("SelfPlay ... #", ref actor_group.cpp:24-50); returns its length, 0 if none.  buf == NULL: the length of the
  * next line without popping it (Atari records carry their observations as hex and can be tens of megabytes); a buffer that is too small
- * gives MZ_ERR_CAPACITY and leaves the line queued.  mz_worker_peek_record / mz_worker_record answer buf == NULL the same way. */
+ * gives MZ_ERR_CAPACITY and leaves the line queued.  mz_worker_peek_record / mz_worker_record answer buf == NULL the same way.
+ * NEVER blocks: lines leave in the order the games finished, and while the front line's OBS tag (Atari: gzip + hex of megabytes, done by sleeping
+ * helper threads beside the following moves) is not complete the answer is 0 = none yet.  A line whose compression failed is dropped and reported
+ * once (MZ_ERR_STATE); the lines behind it keep draining. */
 int mz_worker_pop_line(mz_worker* w, char* buf, int cap);
+/* blocks until every queued line is complete (stop / quit / the end of a run: after it mz_worker_pop_line drains the queue); returns the number of queued lines */
+int mz_worker_wait_lines(mz_worker* w);
 /* test / monitoring access: the record of game `game` as it stands, unfinished games included (BaseActor::getRecord with no extra
  * tags, ref actor/base_actor.cpp:39-57); returns its length.  Does not disturb the search. */
 int mz_worker_peek_record(mz_worker* w, int game, char* buf, int cap);
@@ -240,6 +245,7 @@ typedef struct mz_worker_stats {
     uint64_t pre_evals;    /* Gumbel rounds (mz_sim_rounds): leaves evaluated ahead of their simulations ... */
     uint64_t pre_hits;     /* ... and simulations that found their leaf among them (the rest evaluated their own) */
     uint64_t pre_alt_hits; /* ... of which: the leaf was the simulation's SECOND expected one (mz_sim_round_alt) */
+    uint64_t pre_launches; /* launches (counted in sim_launches too) that evaluated the leaves of a Gumbel round ahead (sim_pre_kernel_mz) */
 } mz_worker_stats;
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out);
 mz_net* mz_worker_net(mz_worker* w);

@@ -55,6 +55,14 @@ struct GoDevView;
 struct GumbelView;
 class Pool;
 
+// What ONE worker wants of the MuZero simulation kernels (several workers may run on one Net — mz_worker_create_shared — so these are launch arguments,
+// not state of the network): four workgroups per game where the pool leaves CUs idle, Gumbel rounds evaluated ahead, the slab's second bank
+struct SimMzMode {
+    bool cluster = true;  // false: always one workgroup per game
+    bool rounds = false;  // the worker evaluates Gumbel rounds ahead (simPreEvalMz): the cluster kernel then runs every game's 601-bin heads alone
+    int alt_base = 0;     // != 0: the slab has 2 x alt_base slots per game, the upper half for the rounds' second expected leaves (sim.hip simPreProbe)
+};
+
 class Net {
 public:
     Net() = default;
@@ -93,7 +101,7 @@ public:
     int simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                     int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
                     const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given = false,
-                    int pre_epoch = 0, bool noise_applied = false);
+                    int pre_epoch = 0, bool noise_applied = false, const SimMzMode& mode = SimMzMode());
     // Gumbel rounds (sim.hip sim_pre_kernel_mz, muzero_atari): the leaves the next R simulations of every game are expected to reach, evaluated side by
     // side into the entries of simulations s0 .. s0 + R - 1, tagged with `epoch` (a per-move serial number, != 0); the following simLaunchMz calls of the
     // move pass the same pre_epoch and consume the entries that turn out to be their leaves.  simRootNoiseMz applies the root noise as a launch of its own
@@ -101,6 +109,9 @@ public:
     int simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched);
     int simRootNoiseMz(int games);
     int simPreStats(unsigned* hits, unsigned* evals, unsigned* alt_hits);
+    // serial numbers of the moves whose leaves are evaluated ahead come from the NETWORK: the entries (pre_key_ / pre_out_) belong to it, and two workers on one
+    // network that both counted from 1 would take each other's stale entries for their own (same parent slot, same action, same number)
+    int nextPreEpoch() { pre_epoch_counter_ = pre_epoch_counter_ == 0x7fffffff ? 1 : pre_epoch_counter_ + 1; return pre_epoch_counter_; }
     bool hasSimKernelMz(int num_simulation = 0) const;
     int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat);
     int shiftExpandAtariFeatures(const uint8_t* d_prev, const uint8_t* d_newest, const uint8_t* d_meta, uint8_t* d_cur, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)
@@ -164,10 +175,9 @@ private:
     int sim_cluster_checked_ = 0; // pool size (padded) whose cluster placement has been probed
     bool coop_launch_ = false;
 public:
-    int sim_alt_base_ = 0;      // != 0: the slab has 2 x sim_alt_base_ slots per game, the upper half for the rounds' second expected leaves (sim.hip simPreProbe)
-    bool sim_rounds_ = false;   // the worker evaluates Gumbel rounds ahead (simPreEvalMz): the cluster kernel then runs every game's 601-bin heads alone
+    int pre_epoch_counter_ = 0;
     bool sim_octet_ = true;     // cluster mode: the 601-bin heads of the games that share an XCD are computed together (sim_cluster.h octetHead)
-    bool sim_cluster_ = true;   // four workgroups per game when 4 x games <= CUs (muzero_atari instances); false: always one workgroup per game
+    bool sim_cluster_ = true;   // the device can run four workgroups per game (muzero_atari instances; MZ_SIM_CLUSTER=0, a failed placement probe or a refused cooperative launch clear it)
     bool use_fused_ = true;     // fused persistent tower kernel (same arithmetic as the per-layer kernels)
 };
 

@@ -1274,7 +1274,7 @@ bool Net::hasSimKernelMz(int num_simulation) const
 int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_root_feat, const unsigned long long* d_root_legal, const int* d_root_turn,
                      int num_players, float* d_policy, float* d_logit, float* d_value, float* d_reward, int sim0, int nsims, bool* launched,
                      const float* d_root_noise, float noise_eps, int noise_kind, const GumbelView* gum, int* d_start, bool host_start, bool root_given,
-                     int pre_epoch, bool noise_applied)
+                     int pre_epoch, bool noise_applied, const SimMzMode& mode)
 {
     *launched = false;
     const bool atari = desc_.type == 2;
@@ -1308,7 +1308,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.err = pool.errFlag();
     a.rcp_n = pool.rcpEntries();
     a.hidden = d_hidden; a.slots = slots;
-    a.alt_base = (atari && gum && sim_alt_base_ > 0 && 2 * sim_alt_base_ <= slots) ? sim_alt_base_ : 0; a.root_feat = d_root_feat; a.root_legal = d_root_legal; a.root_turn = d_root_turn;
+    a.alt_base = (atari && gum && mode.alt_base > 0 && 2 * mode.alt_base <= slots) ? mode.alt_base : 0; a.root_feat = d_root_feat; a.root_legal = d_root_legal; a.root_turn = d_root_turn;
     a.A = desc_.action_size; a.LW = (desc_.action_size + 63) / 64; a.num_players = num_players;
     a.root_noise = d_root_noise;
     a.noise_eps = noise_eps;
@@ -1349,7 +1349,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     if (lds > 160 * 1024) { return MZ_OK; }
     // cluster mode (sim_cluster.h): four workgroups per game when the pool leaves three quarters of the CUs idle (muzero_atari instances only)
     const int gpad = (pool.v_.games + 7) / 8 * 8;
-    bool cluster = atari && sim_cluster_ && H * W <= 36 && kClMembers * gpad <= cu_count_ && coop_launch_;
+    bool cluster = atari && sim_cluster_ && mode.cluster && H * W <= 36 && kClMembers * gpad <= cu_count_ && coop_launch_;
     if (cluster && sim_cluster_checked_ != gpad) { // once per pool size: do the members of a cluster share an XCD on this device?
         if (clusterPlacementOk(gpad, stream_)) { sim_cluster_checked_ = gpad; }
         else { sim_cluster_ = false; cluster = false; } // one workgroup per game (same records)
@@ -1363,7 +1363,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
         const int n1 = std::max(dv.hc, dr.hc) * a.ahp.P, hidm = std::max(dv.hidden, dr.hidden), sizem = std::max(dv.size, dr.size);
         const size_t ow = octetWords(n1, hidm, sizem);
         // (leaves evaluated ahead make the games of an octet skip tower + heads independently of each other: every game runs its heads alone then)
-        const bool octet = sim_octet_ && !sim_rounds_ && pool.v_.games >= 64 && size_t(4) * (up4i(n1) + up4i(hidm)) * sizeof(float) <= tile_bytes &&
+        const bool octet = sim_octet_ && !mode.rounds && pool.v_.games >= 64 && size_t(4) * (up4i(n1) + up4i(hidm)) * sizeof(float) <= tile_bytes &&
                            octetHeadFits(dv, a.ahp.P) && octetHeadFits(dr, a.ahp.P);
         const size_t total_words = size_t(pool.v_.games) * words + (octet ? 16 * ow : 0);
         if (!sim_cluster_mem_.ensure(total_words * sizeof(unsigned))) { setError("hipMalloc of the cluster exchange blocks failed"); return MZ_ERR_DEVICE; }

@@ -360,6 +360,7 @@ public:
     int runCycles(int n);
     int cyclesPerMove() const { return n_ + 1; }
     int popLine(char* buf, int cap);
+    int waitLines();
     int peekRecord(int game, char* buf, int cap, const char* const* keys = nullptr, const char* const* values = nullptr, int ntags = 0);
     // per-actor stepping (mz_manual_step=true): BaseActor / ZeroActor surface (ref actor/base_actor.h:16-55, zero_actor.h:24-70)
     bool searchDone() const { return search_done_; }
@@ -526,6 +527,7 @@ private:
     int slab_slots_ = 0;        // hidden-state slots per game
     std::vector<Round> rounds_; // mz_sim_rounds: the rounds of a move whose leaves are evaluated ahead (first simulation, size), from the Gumbel schedule of (n, m)
     void planRounds();
+    SimMzMode sim_mode_;      // this worker's choice of MuZero simulation kernels (launch arguments: the network may be shared with other workers)
     bool shared_net_ = false; // the network belongs to the caller (mz_worker_create_shared): load_model only renames, the caller reloads
     bool sim_kernel_ = false; // ... and whole runs of cycles are ONE launch of the per-game simulation kernel (sim.hip)
 };
@@ -573,7 +575,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         if (cfg_.mz_nn_precision != "f32" && cfg_.mz_nn_precision != "bf16x3") { setError("mz_nn_precision '%s' unknown (f32 | bf16x3)", cfg_.mz_nn_precision.c_str()); return MZ_ERR_ARG; }
         // (a shared network keeps the precision its owner chose with mz_net_set_precision)
         if (!shared && (rc = L->net->setPrecision(cfg_.mz_nn_precision == "bf16x3" ? 1 : 0))) { return rc; }
-        if (!cfg_.mz_sim_cluster || nl > 1) { L->net->sim_cluster_ = false; } // two lanes = two concurrent cooperative launches: not with clusters that wait for each other
+        if (!cfg_.mz_sim_cluster || nl > 1) { sim_mode_.cluster = false; } // two lanes = two concurrent cooperative launches: not with clusters that wait for each other
         L->stream = L->net->stream_;
         // ref actor_group.cpp:183: tree_node_size = (n + 1) * action_size; tree.h:66: 1 + tree_node_size nodes
         rc = L->pool.init(device, L->n, 1 + (n_ + 1) * A_, A_, sc, L->stream);
@@ -662,13 +664,11 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
             planRounds();
             int covered = 0;
             for (const Round& rd : rounds_) { covered += rd.R; }
-            for (auto& L : lanes_) {
-                L->net->sim_rounds_ = !rounds_.empty();
-                L->net->sim_alt_base_ = (!rounds_.empty() && slab_slots_ == 2 * (n_ + 1)) ? n_ + 1 : 0;
-                // every simulation of a move has its leaf evaluated ahead: what is left for the simulation kernel is the tree work of one wave per game, which one
-                // workgroup per game does with less overhead than a cluster of four (no command / result exchange, no cooperative launch): 616 -> 656 k leaf-evals/s
-                if (covered == n_ && !getenv("MZ_ROUNDS_CLUSTER")) { L->net->sim_cluster_ = false; }
-            }
+            sim_mode_.rounds = !rounds_.empty();
+            sim_mode_.alt_base = (!rounds_.empty() && slab_slots_ == 2 * (n_ + 1)) ? n_ + 1 : 0;
+            // every simulation of a move has its leaf evaluated ahead: what is left for the simulation kernel is the tree work of one wave per game, which one
+            // workgroup per game does with less overhead than a cluster of four (no command / result exchange, no cooperative launch): 616 -> 656 k leaf-evals/s
+            if (covered == n_ && !getenv("MZ_ROUNDS_CLUSTER")) { sim_mode_.cluster = false; }
         }
         const int fw = sim_root_host_ ? 1 : games_[0].env->featureWords(), LW = (A_ + 63) / 64;
         for (auto& L : lanes_) {
@@ -1192,8 +1192,8 @@ void Worker::outputGame(Game& gm) // ref actor_group.cpp:24-50
     lines_.push_back(std::make_unique<OutLine>());
     lines_.back()->text = oss.str();
     if (gm.env->hasObservations()) {
-        // (helpers: the host threads the configuration grants beyond the caller's, at least one, at most four — they sleep when there is nothing to compress)
-        if (!obs_) { obs_ = std::make_unique<ObsCompressor>(std::min(4, std::max(1, std::min(cfg_.zero_num_threads, usableCpus() - 1) - 1))); }
+        // (helpers: the host threads the configuration grants beyond the caller's, at least one — they sleep when there is nothing to compress)
+        if (!obs_) { obs_ = std::make_unique<ObsCompressor>(std::max(1, std::min(cfg_.zero_num_threads, usableCpus() - 1) - 1)); }
         obs_->submit(lines_.back().get(), std::move(obs_raw), kObsPlaceholder, sizeof(kObsPlaceholder) - 1);
     }
     if (is_terminal) { ++stats_.games; }
@@ -1621,7 +1621,7 @@ int Worker::runCyclesSim(int n)
                 int rc = L->net->simLaunchMz(L->pool, L->d_hidden.p, slab_slots_, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p, games_[0].env->numPlayers(), L->d_policy.p,
                                             L->d_logit.p, L->d_value.p, L->d_reward.p, 0, 1, &launched, noise_cfg ? L->d_noise.p : nullptr,
                                             cfg_.actor_dirichlet_noise_epsilon, cfg_.actor_use_dirichlet_noise ? 1 : 2, dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p,
-                                            host_gumbel, true);
+                                            host_gumbel, true, 0, false, sim_mode_);
                 if (rc) { return rc; }
                 if (!launched) { const std::string why = mz_last_error(); setError("worker: the root expansion kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
             }
@@ -1671,7 +1671,7 @@ int Worker::runCyclesSim(int n)
             }
             if (at < batch || parts == 0) { cuts[parts] = at; pre_R[parts] = 0; ++parts; }
             cuts[parts] = batch;
-            for (auto& L : lanes_) { L->pre_epoch = L->pre_epoch == 0x7fffffff ? 1 : L->pre_epoch + 1; }
+            for (auto& L : lanes_) { L->pre_epoch = L->net->nextPreEpoch(); }
         }
         int drawn = 1; // rows of the rotation table (= cycles of the batch) whose draws are made
         for (int part = 0; part < parts; ++part) {
@@ -1702,13 +1702,13 @@ int Worker::runCyclesSim(int n)
                         bool pre = false;
                         int rcp = L->net->simPreEvalMz(L->n, L->pool.v_.max_depth, sim0 + c0, pre_R[part], L->pre_epoch, &pre);
                         if (rcp) { return rcp; }
-                        if (pre) { ++stats_.sim_launches; }
+                        if (pre) { ++stats_.sim_launches; ++stats_.pre_launches; }
                     }
                 }
                 int rc = sim_mz_ ? L->net->simLaunchMz(L->pool, L->d_hidden.p, slab_slots_, L->d_rootfeat.p, L->d_rootlegal.p, L->d_rootturn.p,
                                                       games_[0].env->numPlayers(), L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_reward.p, sim0 + c0, c1 - c0,
                                                       &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
-                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg, false, use_rounds ? L->pre_epoch : 0, use_rounds && noise_in_batch)
+                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg, false, use_rounds ? L->pre_epoch : 0, use_rounds && noise_in_batch, sim_mode_)
                                   : L->net->simLaunch(L->pool, L->godev.v_, L->d_policy.p, L->d_logit.p, L->d_value.p, L->d_rot.p + size_t(c0) * L->n, sim0 + c0, c1 - c0,
                                                      &launched, noise_in_batch ? L->d_noise.p : nullptr, cfg_.actor_dirichlet_noise_epsilon, noise_kind,
                                                      dev_gumbel_ ? &gv : nullptr, L->pool.d_start_.p, hg);
@@ -1776,8 +1776,14 @@ int Worker::popLine(char* buf, int cap)
 {
     if (lines_.empty()) { return 0; }
     OutLine& front = *lines_.front();
-    if (front.pending.load(std::memory_order_acquire) != 0 && obs_) { obs_->wait(&front); } // its OBS tag is still being compressed: lines leave in order, complete
-    if (front.failed.load()) { setError("worker: building the OBS tag of a record failed"); return MZ_ERR_STATE; }
+    // Lines leave in order, complete.  A front line whose OBS tag is still being compressed is "none yet" (0), for the pop and for the size query: the caller
+    // launches its next move instead of sleeping here (mz_worker_wait_lines is the call that blocks, for stop / quit / the end of a test)
+    if (front.pending.load(std::memory_order_acquire) != 0) { return 0; }
+    if (front.failed.load()) { // reported once: the line goes, the records behind it keep draining
+        lines_.pop_front();
+        setError("worker: building the OBS tag of a record failed (the record is dropped)");
+        return MZ_ERR_STATE;
+    }
     const std::string& s = front.text;
     const int len = static_cast<int>(s.size());
     if (!buf) { return len; } // size query: the line stays queued
@@ -1786,6 +1792,12 @@ int Worker::popLine(char* buf, int cap)
     buf[len] = 0;
     lines_.pop_front();
     return len;
+}
+
+int Worker::waitLines() // until every queued line is complete; the number of queued lines
+{
+    if (obs_) { for (auto& l : lines_) { if (l->pending.load(std::memory_order_acquire) != 0) { obs_->wait(l.get()); } } }
+    return static_cast<int>(lines_.size());
 }
 
 int Worker::searchAction(int g, int* action_id, int* player, int* resign) const
@@ -2098,6 +2110,11 @@ int mz_worker_pop_line(mz_worker* w, char* buf, int cap)
 {
     if (!w) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
     return w->w.popLine(buf, cap);
+}
+int mz_worker_wait_lines(mz_worker* w)
+{
+    if (!w) { mz::setError("NULL argument"); return MZ_ERR_ARG; }
+    return w->w.waitLines();
 }
 int mz_worker_peek_record(mz_worker* w, int game, char* buf, int cap)
 {

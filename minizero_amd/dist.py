@@ -32,12 +32,14 @@ class Group:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             kw = {}
             if backend == "nccl":
-                kw["device_id"] = torch.device("cuda", self.local_rank)
+                kw["device_id"] = device if device is not None else torch.device("cuda", self.local_rank)
             dist.init_process_group(backend, **kw)
         self.backend = backend
 
     def _dev(self):
-        return self.device if self.device is not None else ("cuda" if self.backend == "nccl" else "cpu")
+        if self.backend != "nccl":
+            return "cpu"  # gloo reduces host tensors (the GPU work of the ranks is still fenced by barrier()'s synchronize)
+        return self.device if self.device is not None else "cuda"
 
     def broadcast_weights(self, weights, src=0):
         """load_model fan-out: rank `src` holds the parsed blob; one flat f32 broadcast (<= 6.1 MB)."""
@@ -48,11 +50,12 @@ class Group:
         return t.cpu().numpy()
 
     def barrier(self):
-        if self._dev() != "cpu":
+        gpu = self.torch.cuda.is_available()
+        if gpu:
             self.torch.cuda.synchronize()
         if self.world > 1:
             self.dist.barrier()
-        if self._dev() != "cpu":
+        if gpu:
             self.torch.cuda.synchronize()
 
     def reduce(self, values, op="sum"):

@@ -35,7 +35,7 @@ class WorkerStats(C.Structure):
     _fields_ = [("cycles", C.c_uint64), ("leaf_evals", C.c_uint64), ("moves", C.c_uint64), ("games", C.c_uint64),
                 ("ms_select", C.c_double), ("ms_env", C.c_double), ("ms_forward", C.c_double), ("ms_expand", C.c_double),
                 ("ms_move", C.c_double), ("ms_total", C.c_double), ("sim_launches", C.c_uint64), ("sim_cycles", C.c_uint64),
-                ("pre_evals", C.c_uint64), ("pre_hits", C.c_uint64), ("pre_alt_hits", C.c_uint64)]
+                ("pre_evals", C.c_uint64), ("pre_hits", C.c_uint64), ("pre_alt_hits", C.c_uint64), ("pre_launches", C.c_uint64)]
 
 
 NET_TYPES = {"alphazero": 0, "muzero": 1, "muzero_atari": 2}
@@ -123,6 +123,7 @@ def load():
         L.mz_worker_cycles_per_move.argtypes = [vp]
         L.mz_net_read_weight_file.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mz_worker_pop_line.argtypes = [vp, C.c_char_p, C.c_int]
+        L.mz_worker_wait_lines.argtypes = [vp]
         L.mz_worker_get_stats.argtypes = [vp, C.POINTER(WorkerStats)]
         L.mz_worker_peek_record.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         L.mz_worker_net.restype = vp
@@ -408,7 +409,11 @@ class Worker:
     def cycles_per_move(self):
         return _check(self.L, self.L.mz_worker_cycles_per_move(self.h))
 
-    def pop_lines(self):
+    def pop_lines(self, wait=True):
+        """Every finished record.  wait=False: only those that are complete right now (mz_worker_pop_line never blocks: an Atari record whose OBS tag
+        is still being compressed, and everything behind it, stays queued) — what a driver does between two moves."""
+        if wait:
+            _check(self.L, self.L.mz_worker_wait_lines(self.h))
         out = []
         buf = C.create_string_buffer(1 << 20)
         while True:

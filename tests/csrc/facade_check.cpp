@@ -130,6 +130,7 @@ static int runActor(const std::string& conf, int moves, const char* feat_out)
         }
         if (a->isResign() || a->isEnvTerminal()) {
             if (mz_worker_emit_game(a->handle(), 0) != MZ_OK) { return 6; }
+            if (mz_worker_wait_lines(a->handle()) < 0) { return 7; } // (an Atari record's OBS tag is compressed in the background: pop_line never blocks)
             while (mz_worker_pop_line(a->handle(), buf.data(), static_cast<int>(buf.size())) > 0) { std::cout << buf.data() << std::endl; }
             a->reset();
         }
@@ -186,8 +187,46 @@ static int runThink(const std::string& conf, int moves)
     return 0;
 }
 
+// Two actors on ONE network (the reference's normal pattern: many actors per Network, actor_group.cpp:179-187), different seeds, moves interleaved: the leaves one
+// actor evaluated ahead (Gumbel rounds: entries that belong to the network) must never be taken for the other's.  Prints both records.
+static int runTwoActors(const std::string& conf, int seed_a, int seed_b, int moves)
+{
+    const std::string file = config::mzgpuConfValue(conf, "nn_file_name");
+    std::shared_ptr<network::Network> net = network::createNetwork(file, 0);
+    const int n = std::stoi(config::mzgpuConfValue(conf, "actor_num_simulation"));
+    std::shared_ptr<actor::BaseActor> actors[2];
+    const int seeds[2] = {seed_a, seed_b};
+    for (int k = 0; k < 2; ++k) {
+        config::mzgpuConfigurationString() = conf + ":program_seed=" + std::to_string(seeds[k]);
+        actors[k] = actor::createActor(uint64_t(n + 1) * net->getActionSize(), net);
+    }
+    if (net.use_count() < 3) { return 21; }
+    std::vector<char> buf(1 << 22);
+    for (int m = 0; m < moves; ++m) {
+        for (int k = 0; k < 2; ++k) {
+            auto& a = actors[k];
+            a->think(false, false);
+            if (!a->isResign() && !a->act(a->getSearchAction())) { return 5; }
+            if (a->isResign() || a->isEnvTerminal()) {
+                if (mz_worker_emit_game(a->handle(), 0) != MZ_OK) { return 6; }
+                if (mz_worker_wait_lines(a->handle()) < 0) { return 7; }
+                while (mz_worker_pop_line(a->handle(), buf.data(), static_cast<int>(buf.size())) > 0) { std::cout << "LINE" << k << " " << buf.data() << std::endl; }
+                a->reset();
+            }
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        std::cout << "RECORD" << k << " " << actors[k]->getRecord() << std::endl;
+        mz_worker_stats st{};
+        if (mz_worker_get_stats(actors[k]->handle(), &st) != MZ_OK) { return 8; }
+        std::cout << "STATS" << k << " pre_evals=" << st.pre_evals << " pre_hits=" << st.pre_hits << std::endl;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 6 && !strcmp(argv[1], "two")) { return runTwoActors(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5])); }
     if (argc >= 4 && !strcmp(argv[1], "think")) { return runThink(argv[2], atoi(argv[3])); }
     if (argc >= 5 && !strcmp(argv[1], "net")) { return runNet(argv[2], argv[3], atoi(argv[4])); }
     if (argc >= 4 && !strcmp(argv[1], "actor")) { return runActor(argv[2], atoi(argv[3]), argc >= 5 ? argv[4] : nullptr); }

@@ -162,8 +162,9 @@ def test_actor_facade_against_the_oracle(mz, oracle, tmp_path, name, conf, dargs
 @pytest.mark.parametrize("gumbel", [False, True])
 def test_think_time_limit_decides_from_the_simulations_run_so_far(mz, oracle, tmp_path, gumbel):
     """actor_mcts_think_time_limit (ref zero_actor.cpp:36-49): think() looks at the clock after every step and, when the limit has passed, decides with
-    the simulations run so far.  With a limit of a microsecond every move stops after its first chunk of 32 cycles = the root + 31 simulations, so the
-    record must be exactly that of a 31-simulation search (the oracle with actor_num_simulation=31: same tree, same RNG stream) although 2000 are configured."""
+    the simulations run so far.  With a limit of a microsecond every move stops after its first library call of 2 cycles = the root + 1 simulation
+    (include/minizero/actor.h kThinkFirst), so the record must be exactly that of a 1-simulation search (the oracle with actor_num_simulation=1: same tree,
+    same RNG stream) although 2000 are configured."""
     dargs = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
     kw = dict(vh=16, dv=1, type_name="alphazero")
     d, od = mz.make_desc(*dargs[:10], **kw), oracle.make_desc(*dargs[:10], **kw)
@@ -177,9 +178,51 @@ def test_think_time_limit_decides_from_the_simulations_run_so_far(mz, oracle, tm
     rec = [l for l in p.stdout.strip().split("\n") if l.startswith("RECORD ")][0][len("RECORD "):]
     assert rec.count(";B[") + rec.count(";W[") == moves and rec.count("]P[") == moves and rec.count("]V[") == moves
     if not gumbel:  # (a Gumbel root's visiting schedule and policy string depend on the CONFIGURED number of simulations: only the shape of the record is checked there)
-        og = oracle.OracleGroup(f"{base}:actor_num_simulation=31:nn_file_name={pt}:zero_num_threads=1", od, w)
-        og.cycles(32 * moves + 1)
+        og = oracle.OracleGroup(f"{base}:actor_num_simulation=1:nn_file_name={pt}:zero_num_threads=1", od, w)
+        og.cycles(2 * moves + 1)
         assert rec == og.peek_records(1)[0]
+
+
+def test_think_time_limit_ends_a_long_search_on_time(mz, tmp_path):
+    """The granularity of the limit: the clock is looked at between library calls of a quarter of the cycles that still fit (not every 32 cycles), so a search
+    configured far beyond the limit ends within a fraction of it: 12 moves of a 100 000-simulation search under 50 ms each."""
+    import time
+    dargs = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero")
+    d = mz.make_desc(*dargs[:10], vh=16, dv=1, type_name="alphazero")
+    pt = _write(mz, tmp_path, d, mz.generate_weights(d, 2))
+    conf = f"env_game=go:env_board_size=9:zero_num_parallel_games=1:program_seed=5:actor_num_simulation=3000:actor_mcts_think_time_limit=0.05:nn_file_name={pt}"
+    t0 = time.perf_counter()
+    p = _run(["think", conf, "12"])
+    dt = time.perf_counter() - t0
+    rec = [l for l in p.stdout.strip().split("\n") if l.startswith("RECORD ")][0]
+    assert rec.count("]P[") == 12
+    assert dt < 12 * 0.05 * 2 + 20  # (process start, network load and context creation are in dt: the bound only catches a search that ignores its limit)
+
+
+def test_two_actors_on_one_network_do_not_take_each_others_leaves(mz, oracle, tmp_path):
+    """setNetwork(shared_ptr<Network>) puts several actors on ONE network (ref actor_group.cpp:179-187).  The leaves a Gumbel round evaluates ahead live in
+    entries of the network, tagged with a per-move serial number — which therefore comes from the network: two actors that both counted their moves from 1 took
+    each other's stale entries (same parent slot, same action, same number) for their own.  Two muzero_atari actors, different seeds, moves interleaved: each
+    record equals the oracle's one-actor group of its seed, and the rounds were really on (leaves evaluated ahead and found)."""
+    dargs = ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari")
+    kw = dict(vh=32, dv=601, type_name="muzero_atari")
+    d, od = mz.make_desc(*dargs[:10], **kw), oracle.make_desc(*dargs[:10], **kw)
+    w = mz.generate_weights(d, 4)
+    pt = _write(mz, tmp_path, d, w)
+    conf = ("env_game=atari:nn_type_name=muzero:actor_num_simulation=20:actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:"
+            "actor_gumbel_sample_size=4:actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:actor_mcts_reward_discount=0.997:atari_init_q=true:"
+            f"env_atari_episode_length=30:zero_num_parallel_games=1:nn_file_name={pt}")
+    moves, seeds = 24, (3, 4)
+    p = _run(["two", conf, str(seeds[0]), str(seeds[1]), str(moves)])
+    out = p.stdout.strip().split("\n")
+    for k, seed in enumerate(seeds):
+        og = oracle.OracleGroup(f"{conf}:program_seed={seed}:zero_num_threads=1", od, w)
+        og.cycles(moves * 21 + 1)
+        rec = [l for l in out if l.startswith(f"RECORD{k} ")][0][len(f"RECORD{k} "):]
+        assert rec == og.peek_records(1)[0], f"actor {k}"
+        assert [l[len(f"LINE{k} "):] for l in out if l.startswith(f"LINE{k} ")] == og.lines(), f"actor {k}"
+        st = dict(t.split("=") for t in [l for l in out if l.startswith(f"STATS{k} ")][0].split()[1:])
+        assert int(st["pre_evals"]) > 0 and int(st["pre_hits"]) > 0
 
 
 def _facade_seeds():

@@ -15,7 +15,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 MOVES = {"c1": 400, "c2": 4, "c3": 40, "c4": 20, "c5": 40}
 WARM = {"c5": 14}  # moves before the timed region (default 3: the first synchronisation of the third move takes 8 ms once): the Atari-shaped worker's first moves pay one-off host allocations
 KERNEL = {"c1": "sim_kernel<3,3,4,16,-1>", "c2": "sim_kernel<9,9,20,64,2>", "c3": "sim_kernel<8,8,4,64,0>", "c4": "sim_kernel_mz<9,9,20,68,64>",
-          "c5": "sim_kernel_mz_cluster<6,6,84,64> (4 workgroups per game; MZ_SIM_CLUSTER=0: sim_kernel_mz<6,6,64,84,64>)"}
+          "c5": "sim_pre_kernel_mz<6,6,84,64,2|4> (the leaves of a Gumbel round evaluated side by side) + sim_kernel_mz<6,6,64,84,64> (the simulations in order); "
+                "mz_sim_rounds=false: sim_kernel_mz_cluster<6,6,84,64>"}
 
 
 def flops_per_leaf_eval(d):
@@ -52,8 +53,10 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     wk.run_cycles((WARM.get(key, 3) if warm is None else warm) * (n + 1))
     s0 = wk.stats()
     t0 = time.perf_counter()
+    popped = 0
     for _ in range(moves):
         wk.run_cycles(n + 1)
+        popped += len(wk.pop_lines(wait=False))  # like the `-mode sp` loop (include/minizero/actor_group.h): the records that are complete leave between two moves
     dt = time.perf_counter() - t0
     s1 = wk.stats()
     evals = s1["leaf_evals"] - s0["leaf_evals"]
@@ -63,11 +66,13 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     sim_evals = (s1["sim_cycles"] - s0["sim_cycles"]) * games
     ach = (conv + heads) * sim_evals / (gpu_ms * 1e-3) / 1e12 if launches else None
     res = {"leaf_evals_per_sec": evals / dt, "ms_per_move": dt / moves * 1e3, "moves_per_sec": (s1["moves"] - s0["moves"]) / dt,
-           "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "host_threads": threads if key != "c1" else 1,
+           "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "records_popped_between_moves": popped, "host_threads": threads if key != "c1" else 1,
            "leaves_evaluated_ahead": s1.get("pre_evals", 0) - s0.get("pre_evals", 0), "simulations_that_found_their_leaf": s1.get("pre_hits", 0) - s0.get("pre_hits", 0),
            "config": mz.CONFIGS[key],
            "roofline": {"kernel": KERNEL[key], "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": (ach / F32_MFMA_PEAK_TFLOPS) if ach else None, "launches": launches,
+                        "launches_by_kernel": ({"sim_pre_kernel_mz": s1.get("pre_launches", 0) - s0.get("pre_launches", 0),
+                                                "sim_kernel_mz": launches - (s1.get("pre_launches", 0) - s0.get("pre_launches", 0))} if s1.get("pre_launches", 0) > s0.get("pre_launches", 0) else None),
                         "avg_launch_ms": gpu_ms / launches if launches else None, "flops_per_leaf_eval": conv + heads,
                         "conv3x3_flops_per_leaf_eval": conv, "leaf_evals_in_launches": sim_evals,
                         "wall_frac": (conv + heads) * evals / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
