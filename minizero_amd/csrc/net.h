@@ -107,8 +107,13 @@ public:
     // move pass the same pre_epoch and consume the entries that turn out to be their leaves.  simRootNoiseMz applies the root noise as a launch of its own
     // (the first round needs the noisy logits before simulation 1): the simLaunchMz calls after it pass noise_applied = true.
     int simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched);
+    // the same evaluation as a pipeline of batched kernels (sim_rounds.hip: walks | trunks of several leaves per workgroup | the heads' FC layers as MFMA GEMMs over
+    // all leaves | per-leaf tails); the entries it writes are bit-identical.  *launched = false: no instance for this network (use simPreEvalMz)
+    int simPreEvalBatchMz(int games, int max_depth, int s0, int R, int epoch, bool* launched, int force_nl = 0, bool want_alt = false); // force_nl: leaves per trunk workgroup (0 = by the pool size)
+    bool hasPreBatch() const;
     int simRootNoiseMz(int games);
     int simPreStats(unsigned* hits, unsigned* evals, unsigned* alt_hits);
+    int simPreCountersAsync(unsigned* h_pinned);
     // serial numbers of the moves whose leaves are evaluated ahead come from the NETWORK: the entries (pre_key_ / pre_out_) belong to it, and two workers on one
     // network that both counted from 1 would take each other's stale entries for their own (same parent slot, same action, same number)
     int nextPreEpoch() { pre_epoch_counter_ = pre_epoch_counter_ == 0x7fffffff ? 1 : pre_epoch_counter_ + 1; return pre_epoch_counter_; }
@@ -171,6 +176,7 @@ private:
     DevBuf<int> pre_key_;          // leaves evaluated ahead: keys [games][slots][4], outputs [policy | logit | value | reward], counters
     DevBuf<float> pre_out_;
     DevBuf<unsigned> pre_stat_;
+    DevBuf<char> pre_ctl_, pre_f_, pre_h1_, pre_lg_; // batched round evaluation (sim_rounds.hip): leaf table, FC1 inputs, hidden units, bins
     int cu_count_ = 0;
     int sim_cluster_checked_ = 0; // pool size (padded) whose cluster placement has been probed
     bool coop_launch_ = false;

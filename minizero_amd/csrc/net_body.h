@@ -119,13 +119,15 @@ __device__ __forceinline__ PixSet<NT> makePixSet(int lane, int tile0)
 
 // XOUT (cluster mode of the simulation kernel, sim_cluster.h): the oc-tile's outputs also go to `xout` ([16][P] floats in global memory, tagged with
 // `xsign` in the sign bit), from where the other workgroups of the game's cluster fetch them
-template <int H, int W, int CG, int NT, int CGN, bool CORNER, bool NTW = false, bool XOUT = false>
-__device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
+// (the geometry of the LDS planes as template arguments: CS = plane stride, PW = row stride of the padded plane, DUMP = a spare float of every plane that lanes of
+// padding columns write, P = pixels per sample in `gout` — the board kernels pass those of one padded H x W board, sim_rounds.hip those of several boards
+// stacked in one plane)
+template <int CS, int PW, int DUMP, int P, int CG, int NT, int CGN, bool CORNER, bool NTW = false, bool XOUT = false>
+__device__ __forceinline__ void tower_layer_geo(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
                                             float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
                                             int lane, int ot, const PixSet<NT>& px, bool have_first, float (&a_first)[CG],
                                             const float* __restrict__ next_wp, float (&a_next)[CGN], float* __restrict__ xout = nullptr, unsigned xsign = 0)
 {
-    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
     const int (&pixoff)[NT] = px.off;
     const int (&pixdst)[NT] = px.dst;
     const int (&pixq)[NT] = px.q;
@@ -259,7 +261,7 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float* dstp = tout + ocb * CS + pixdst[j];
-            float* dump = tout + ocb * CS + (H + 2) * (W + 2);
+            float* dump = tout + ocb * CS + DUMP;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[j][r] + biasv[r];
@@ -276,19 +278,28 @@ __device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const
     MZ_TPROF(2);
 }
 
+template <int H, int W, int CG, int NT, int CGN, bool CORNER, bool NTW = false, bool XOUT = false>
+__device__ __forceinline__ void tower_layer(const float* __restrict__ tin, const float* __restrict__ tskip, float* __restrict__ tout,
+                                            float* __restrict__ gout, const float* __restrict__ wp, const float* __restrict__ bias, int cout, int OT,
+                                            int lane, int ot, const PixSet<NT>& px, bool have_first, float (&a_first)[CG],
+                                            const float* __restrict__ next_wp, float (&a_next)[CGN], float* __restrict__ xout = nullptr, unsigned xsign = 0)
+{
+    tower_layer_geo<planeStride(H, W), W + 2, (H + 2) * (W + 2), H * W, CG, NT, CGN, CORNER, NTW, XOUT>(tin, tskip, tout, gout, wp, bias, cout, OT, lane, ot, px, have_first,
+                                                                                                       a_first, next_wp, a_next, xout, xsign);
+}
+
 // the layer sequence of one wave: oc-tile `ot` x the NT pixel tiles from `tile0` (CORNER: the last of them is the corner tile); T0 = the
 // temporary (holds the stem's input on entry), T1 = x.  Every wave of the workgroup passes the same number of barriers (towerIdle).
-template <int H, int W, int CIN0_PAD, int CPAD, int NT, bool CORNER, bool NTW = false>
-__device__ __forceinline__ void towerRun(const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ T0, float* __restrict__ T1,
-                                         float* __restrict__ gout, int lane, int ot, int tile0)
+template <int CS, int PW, int DUMP, int P, int CIN0_PAD, int CPAD, int NT, bool CORNER, bool NTW = false>
+__device__ __forceinline__ void towerRunPx(const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ T0, float* __restrict__ T1,
+                                           float* __restrict__ gout, int lane, int ot, const PixSet<NT>& px)
 {
-    const PixSet<NT> px = makePixSet<H, W, NT>(lane, tile0);
     // tap-0 A-fragments of the next layer travel from layer to layer in registers
     float aS[CIN0_PAD / 4], aA[CPAD / 4], aB[CPAD / 4];
     bool have = false;
     if (ta.has_stem) { // stem: T0 -> T1
         const float* nw = ta.nlayers > 1 ? params + ta.w_off[1] : nullptr;
-        tower_layer<H, W, CIN0_PAD / 4, NT, CPAD / 4, CORNER, NTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0],
+        tower_layer_geo<CS, PW, DUMP, P, CIN0_PAD / 4, NT, CPAD / 4, CORNER, NTW>(T0, nullptr, T1, ta.nlayers == 1 ? gout : nullptr, params + ta.w_off[0], params + ta.b_off[0],
                                                              ta.C, ta.OT, lane, ot, px, false, aS, nw, aA);
         have = nw != nullptr;
         __syncthreads();
@@ -298,7 +309,7 @@ __device__ __forceinline__ void towerRun(const float* __restrict__ params, const
 #pragma unroll 1
     for (int l = ta.has_stem; l < ta.nlayers; ++l) { // residual blocks: tmp = relu(conv1(x)); x = relu(conv2(tmp) + x) — one code copy for both convs
         const bool second = ((l - ta.has_stem) & 1) != 0, last = l + 1 == ta.nlayers;
-        tower_layer<H, W, CPAD / 4, NT, CPAD / 4, CORNER, NTW>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, last ? gout : nullptr,
+        tower_layer_geo<CS, PW, DUMP, P, CPAD / 4, NT, CPAD / 4, CORNER, NTW>(second ? tmp : x, second ? x : nullptr, second ? x : tmp, last ? gout : nullptr,
                                                          params + ta.w_off[l], params + ta.b_off[l], ta.C, ta.OT, lane, ot, px, have, aA,
                                                          last ? nullptr : params + ta.w_off[l + 1], aB);
 #pragma unroll
@@ -307,6 +318,14 @@ __device__ __forceinline__ void towerRun(const float* __restrict__ params, const
         __syncthreads();
         MZ_TPROF(3);
     }
+}
+
+template <int H, int W, int CIN0_PAD, int CPAD, int NT, bool CORNER, bool NTW = false>
+__device__ __forceinline__ void towerRun(const float* __restrict__ params, const TowerArgs& ta, float* __restrict__ T0, float* __restrict__ T1,
+                                         float* __restrict__ gout, int lane, int ot, int tile0)
+{
+    const PixSet<NT> px = makePixSet<H, W, NT>(lane, tile0);
+    towerRunPx<planeStride(H, W), W + 2, (H + 2) * (W + 2), H * W, CIN0_PAD, CPAD, NT, CORNER, NTW>(params, ta, T0, T1, gout, lane, ot, px);
 }
 
 // waves without tiles (oc-tiles beyond the network's width, boards of a single pixel tile) only keep the barrier count

@@ -63,6 +63,7 @@ __device__ unsigned long long g_bp[20];
 #include "pool_body.h"
 #include "go_body.h"
 #include "gumbel_body.h"
+#include "sim_args.h"
 #include <algorithm>
 #include <type_traits>
 #include <cstring>
@@ -71,71 +72,6 @@ __device__ unsigned long long g_bp[20];
 
 namespace mz {
 
-struct SimArgs {
-    PoolView pv;
-    GoDevView gv;
-    TowerArgs ta;
-    HeadParams hp;
-    const float* params;
-    float* act;                       // [games][C][P] tower output (input of the heads)
-    float *policy, *logit, *value;    // heads outputs
-    int *cand_count, *cand_action, *cand_player;
-    float *cand_policy, *cand_logit, *value_io, *reward_io;
-    int* err;
-    int rcp_n;                        // entries of pv.rcp_tab
-    // MuZero (sim_kernel_mz): dynamics trunk, hidden-state slab, root planes / legal mask / player from the host engine
-    TowerArgs ta_dyn;
-    float* hidden;                    // [games][slots][C * P]
-    const unsigned* root_feat;        // [games][cin * ceil(P / 32)] bit-packed planes of the root position
-    const unsigned long long* root_legal; // [games][LW] legal mask of the root position
-    const int* root_turn;             // [games] player to move at the root
-    int slots, A, LW, num_players;
-    const float* root_noise;          // [games][A] noise of the root children (host RNG), applied before simulation 1; nullptr: none
-    float noise_eps;
-    int noise_kind;                   // 1: Dirichlet on the priors, 2: Gumbel on the logits (ref zero_actor.cpp:194-213)
-    int use_gumbel;                   // Gumbel root logic (sequential halving + start node) between simulations
-    GumbelView gum;
-    int* start;                       // [games] start node of the next selection (written by the Gumbel step or by the host)
-    // muzero_atari (sim_kernel_mz, simulations >= 1; the 96x96 representation of the root runs as stand-alone kernels)
-    int atari, action_planes;
-    AtariHeadParams ahp;
-    float* reward;                    // [games] reward head output (game scale)
-    int no_spec;                      // MZ_NO_SPEC=1: path speculation of the walk off (experiments)
-    int cand_coop;                    // the candidate rank sort is shared by the 8 waves (its scratch fits the tower tiles)
-    // opt-in bf16x3 tower (net_bf16_body.h): fragments + layer table; used by the BF instantiations of sim_kernel
-    const uint4* wfrag;
-    TowerArgsBf16 tb;
-    unsigned* cluster;                // cluster mode (sim_cluster.h): per-game exchange block of `cluster_words` words; nullptr: one workgroup per game
-    int cluster_words, oct_words;
-    unsigned* cluster_oct;            // cluster mode: the blocks of the octet-wide 601-bin heads ([8 octets][2 heads][oct_words]); nullptr: per-game heads
-    unsigned long long* prof;         // optional (MZ_SIM_PROF=1): per game, 100-MHz ticks spent in [select+leaf, tower, heads, cand+expand] + sims
-    // leaves evaluated AHEAD of their simulations (sim_pre_kernel_mz below): one entry per (game, slot of the simulation) of the current move
-    int* pre_key;                     // [games][slots][4] = {parent's slab slot, action, epoch of the move, -}
-    float *pre_policy, *pre_logit;    // [games][slots][A]: the leaf's children in the reference's sort order (policy descending, zero_actor.cpp:241-243) ...
-    int* pre_action;                  // ... and their actions: the candidate list is built where the leaf was evaluated, not in the in-order part
-    float *pre_value, *pre_reward;    // [games][slots], game scale
-    unsigned* pre_stat;               // [0] simulations that found their leaf evaluated, [1] leaves evaluated ahead (tests / monitoring)
-    int alt_base;                     // != 0: slots alt_base + s hold a SECOND expected leaf of simulation s (sim_pre_kernel_mz, hypothesis 1)
-};
-
-// SimArgs never changes during a launch: the device functions read it through the CONSTANT address space, i.e. with scalar loads whose
-// results are wave-uniform and can be kept / re-used across stores.  Through a generic pointer every field was a flat load (divergent for
-// the compiler, since a flat address may be private memory: the whole selection loop was compiled with exec-mask control flow) that had
-// to be repeated after every store — the PUCT walk waited for such a reload on every level.
-typedef __attribute__((address_space(4))) const SimArgs CSimArgs;
-template <class T>
-__device__ __forceinline__ T ldc(__attribute__((address_space(4))) const T* p) // by-value copy of a sub-structure (SGPRs after SROA)
-{
-    static_assert(sizeof(T) % 4 == 0 && std::is_trivially_copyable<T>::value, "word-copied");
-    typedef __attribute__((address_space(4))) const unsigned CU;
-    CU* s = (CU*)p;
-    unsigned w[sizeof(T) / 4];
-#pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 4; ++i) { w[i] = s[i]; }
-    T t;
-    __builtin_memcpy(&t, w, sizeof(T));
-    return t;
-}
 
 // The heads' outputs and the candidate list of a simulation never leave the CU: they are handed from phase to phase through a small LDS
 // block instead of global memory (each hand-over was a store + a dependent load through L2).  The bodies index their arrays with the
@@ -154,19 +90,6 @@ struct SimXchg { // word offsets inside the block for A actions
 inline size_t simXchgWords(int A, int channels, int W32) { return size_t(5) * (A + (A & 1)) + 12 + 16 + size_t(channels) * W32; }
 __device__ __forceinline__ int simXchgWordsDev(int A, int channels, int W32) { return 5 * (A + (A & 1)) + 12 + 16 + channels * W32; }
 
-// ... and so does the path of the simulation (node ids, moves, length): written by the walk, read by the leaf and by expand + backup; the word behind
-// them holds the game's node count for the launch (expand reads and advances it at every simulation: simNodeCountIn / simNodeCountOut)
-__device__ __forceinline__ PoolView simPathView(PoolView pv, int* lds_path, int g)
-{
-    const size_t off = size_t(g) * pv.max_depth;
-    pv.path = lds_path - off;
-    pv.path_action = lds_path + pv.max_depth - off;
-    pv.path_len = lds_path + 2 * pv.max_depth - g;
-    pv.num_nodes = lds_path + 2 * pv.max_depth + 1 - g;
-    pv.host_path_len = nullptr;
-    pv.host_path_action = nullptr;
-    return pv;
-}
 
 // the leaf's outputs (planes, legal mask, player, terminal flag, result) go to the next phases through the hand-over block too
 __device__ __forceinline__ GoDevView simLeafView(GoDevView gv, float* xchg, int g)
@@ -682,7 +605,7 @@ __device__ __forceinline__ int simPreProbe(CSimArgs* __restrict__ a, int epoch, 
     if (!hit && a->alt_base) { // the second expected leaf of this simulation (entry and slab slot alt_base + slot)
         const int* key2 = key + size_t(a->alt_base) * 4;
         hit = __builtin_amdgcn_readfirstlane((key2[2] == epoch && key2[0] == src && key2[1] == action) ? 1 : 0) != 0;
-        if (hit) { e += a->alt_base; eslot += a->alt_base; if (a->pre_stat && lane == 0) { atomicAdd(a->pre_stat + 128, 1u); } }
+        if (hit) { e += a->alt_base; eslot += a->alt_base; if (a->pre_stat && lane == 0) { atomicAdd(a->pre_stat + 128, 1u); if (slot < 126) { atomicAdd(a->pre_stat + 256 + slot, 1u); } } } // ([256 + s]: by simulation, Worker::adaptRounds)
     }
     if (!hit) {
         if (a->pre_stat && key[2] == epoch && lane == 0 && slot < 126) { atomicAdd(a->pre_stat + 2 + slot, 1u); } // (monitoring: which simulations of a move miss, MZ_SIM_PROF)
@@ -1432,6 +1355,15 @@ int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* 
     if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimPreMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), games, s0, R, NH, epoch, lds, stream_, dense); }
     MZ_SIM_MZ_CLUSTER_CASES(MZ_SIM_PRE_LAUNCH)
 #undef MZ_SIM_PRE_LAUNCH
+    return MZ_OK;
+}
+
+// the counters of the leaves evaluated ahead (512 words: [0] found, [1] evaluated, [2 + s] misses of simulation s, [128] second expected leaves used, [256 + s] ... by
+// simulation) into a pinned host buffer, queued behind the move's launches on the network's stream
+int Net::simPreCountersAsync(unsigned* h_pinned)
+{
+    if (pre_stat_.n < 512) { return MZ_OK; }
+    MZ_HIP(hipMemcpyAsync(h_pinned, pre_stat_.p, 512 * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
     return MZ_OK;
 }
 

@@ -428,6 +428,7 @@ private:
         PinBuf<uint32_t> h_rootfeat; DevBuf<uint32_t> d_rootfeat;
         PinBuf<unsigned long long> h_rootlegal; DevBuf<unsigned long long> d_rootlegal;
         PinBuf<int> h_rootturn; DevBuf<int> d_rootturn;
+        PinBuf<unsigned> h_prestat;           // Gumbel rounds: the network's counters of leaves evaluated ahead, copied behind every move's launches (adaptRounds)
         PinBuf<int> h_gum; DevBuf<int> d_gum; // Gumbel state of every game (gumbel.h): the device runs the halving between simulations
         PinBuf<float> h_noise;   // Dirichlet noise of the root children drawn ahead of the launch [game][A]
         DevBuf<float> d_noise;
@@ -523,7 +524,9 @@ private:
     bool root_host_pending_ = false; // ... whose outputs the next phase1 still has to turn into the root's children (host candidate lists)
     int syncGumbel(Lane& L, bool to_device);
     bool sim_mz_ = false;     // MuZero board game on sim_kernel_mz (no device rules needed: the leaves have no environment)
-    struct Round { int s0, R; };
+    struct Round { int s0, R; float p_event = 0.0f; bool alt = false; }; // p_event: share of the recent moves in which a simulation of the round missed its leaf / took the second one
+    std::vector<unsigned> prestat_prev_; // the counters as of the previous move (summed over the lanes)
+    void adaptRounds();
     int slab_slots_ = 0;        // hidden-state slots per game
     std::vector<Round> rounds_; // mz_sim_rounds: the rounds of a move whose leaves are evaluated ahead (first simulation, size), from the Gumbel schedule of (n, m)
     void planRounds();
@@ -662,6 +665,10 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
         if (dev_gumbel_ && desc.type == 2 && cfg_.mz_sim_rounds && cfg_.mz_sim_split) {
             planRounds();
+            for (auto& L : lanes_) {
+                if (!L->h_prestat.alloc(512)) { setError("worker: allocation failed (round counters)"); return MZ_ERR_DEVICE; }
+                memset(L->h_prestat.p, 0, 512 * sizeof(unsigned));
+            }
             int covered = 0;
             for (const Round& rd : rounds_) { covered += rd.R; }
             sim_mode_.rounds = !rounds_.empty();
@@ -723,6 +730,31 @@ void Worker::planRounds()
         if (R >= kMinRound) { rounds_.push_back({s, R}); }
         s += R;
     }
+}
+
+// A simulation that does not find its leaf evaluated ahead evaluates it itself, on ONE CU, while the round's launch — every other game of the pool — waits: one
+// miss costs the move a whole evaluation's latency (150 us on BASELINE configs[4], where the second round of four misses in almost every move: the earlier
+// simulations of the round move the value bounds, and the fourth visit of a root child is where a close arg-max flips).  A second expected leaf per simulation
+// (mz_sim_round_alt) removes those misses but doubles the round's evaluations, so the rounds that do not fit the chip twice get it only while they keep needing it:
+// per round, the share of recent moves in which one of its simulations missed (alt off) or took its second leaf (alt on), with hysteresis.  Which leaves are
+// evaluated ahead never changes a record (sim.hip simPreProbe); the batched pipeline (sim_rounds.hip) evaluates the doubled round with two leaves per workgroup.
+void Worker::adaptRounds()
+{
+    if (!cfg_.mz_sim_round_alt || !cfg_.mz_sim_round_batch || sim_mode_.alt_base == 0) { return; }
+    unsigned now[512] = {0};
+    for (auto& L : lanes_) {
+        if (!L->h_prestat.p) { return; }
+        for (int i = 0; i < 512; ++i) { now[i] += L->h_prestat.p[i]; }
+    }
+    if (prestat_prev_.size() == 512) {
+        for (Round& rd : rounds_) {
+            bool ev = false;
+            for (int s = rd.s0; s < rd.s0 + rd.R && s < 126; ++s) { ev = ev || now[2 + s] != prestat_prev_[2 + s] || now[256 + s] != prestat_prev_[256 + s]; }
+            rd.p_event = 0.875f * rd.p_event + (ev ? 0.125f : 0.0f);
+            if (rd.p_event > 0.5f) { rd.alt = true; } else if (rd.p_event < 0.25f) { rd.alt = false; }
+        }
+    }
+    prestat_prev_.assign(now, now + 512);
 }
 
 int Worker::setupDeviceGumbel() // the constants of the device-side Gumbel step + its per-lane state buffers
@@ -1648,6 +1680,7 @@ int Worker::runCyclesSim(int n)
         // could show.  The parts are queued back to back on the lane's stream; the draws of a later part travel on a second stream.
         const bool az_draws = desc_.type == 0 && cfg_.actor_use_random_rotation_features;
         int cuts[Lane::kSimParts + 1], pre_R[Lane::kSimParts] = {0}, parts = 1;
+        bool pre_alt[Lane::kSimParts] = {false};
         for (int k = 0; k <= Lane::kSimParts; ++k) { cuts[k] = k == 0 ? 0 : batch; }
         if (cfg_.mz_sim_split && sim0 == 0 && batch > 1 && (noise_in_batch || az_draws)) {
             constexpr int kSecond = 16; // simulations of the middle part: 3 ms on BASELINE configs[1], three times what the draws of the rest take on this host
@@ -1666,7 +1699,7 @@ int Worker::runCyclesSim(int n)
                 const int o = rd.s0 - sim0;
                 if (o < at || o + rd.R > batch || parts + 2 > Lane::kSimParts) { continue; }
                 if (o > at) { cuts[parts] = at; pre_R[parts] = 0; ++parts; }
-                cuts[parts] = o; pre_R[parts] = rd.R; ++parts;
+                cuts[parts] = o; pre_R[parts] = rd.R; pre_alt[parts] = rd.alt; ++parts;
                 at = o + rd.R;
             }
             if (at < batch || parts == 0) { cuts[parts] = at; pre_R[parts] = 0; ++parts; }
@@ -1700,7 +1733,12 @@ int Worker::runCyclesSim(int n)
                     if (part == 0 && noise_in_batch) { int rcn = L->net->simRootNoiseMz(L->n); if (rcn) { return rcn; } }
                     if (pre_R[part] > 0) {
                         bool pre = false;
-                        int rcp = L->net->simPreEvalMz(L->n, L->pool.v_.max_depth, sim0 + c0, pre_R[part], L->pre_epoch, &pre);
+                        int rcp = MZ_OK;
+                        if (cfg_.mz_sim_round_batch) {
+                            rcp = L->net->simPreEvalBatchMz(L->n, L->pool.v_.max_depth, sim0 + c0, pre_R[part], L->pre_epoch, &pre, cfg_.mz_sim_round_leaves, pre_alt[part]);
+                            if (pre) { ++stats_.pre_batch_launches; }
+                        }
+                        if (!rcp && !pre) { rcp = L->net->simPreEvalMz(L->n, L->pool.v_.max_depth, sim0 + c0, pre_R[part], L->pre_epoch, &pre); }
                         if (rcp) { return rcp; }
                         if (pre) { ++stats_.sim_launches; ++stats_.pre_launches; }
                     }
@@ -1715,6 +1753,7 @@ int Worker::runCyclesSim(int n)
                 if (rc) { return rc; }
                 if (!launched) { const std::string why = mz_last_error(); setError("worker: the simulation kernel was not launched (%s)", why.c_str()); return MZ_ERR_STATE; }
                 if (!use_rounds || part == parts - 1) { MZ_HIP(hipEventRecord(L->ev1[use_rounds ? 0 : part], L->stream)); }
+                if (use_rounds && part == parts - 1 && L->h_prestat.p) { int rcc = L->net->simPreCountersAsync(L->h_prestat.p); if (rcc) { return rcc; } }
                 ++stats_.sim_launches;
             }
         }
@@ -1740,6 +1779,7 @@ int Worker::runCyclesSim(int n)
             ms_gpu = std::max(ms_gpu, ms);
         }
         stats_.ms_forward += ms_gpu;
+        if (use_rounds) { adaptRounds(); }
         stats_.ms_total += nowMs() - t0;
         trace_.add(18, nowMs() - twait);
     }
@@ -2039,7 +2079,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
         MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
-        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_sim_round_alt) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_sim_round_alt) MZ_FIXED(mz_sim_round_batch) MZ_FIXED(mz_sim_round_leaves) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
         // the Atari-shaped environments keep a window of screens sized from these three at creation (ref atari.cpp:87); records of a larger window
         // would miss frames, so they are fixed where observations are kept (board games: free to change, like the reference)
         if (games_[0].env->hasObservations()) { MZ_FIXED(zero_actor_intermediate_sequence_length) MZ_FIXED(learner_n_step_return) MZ_FIXED(learner_muzero_unrolling_step) }

@@ -110,16 +110,19 @@ def test_c4_full_size_256_games_one_move(mz, oracle):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("mode", ["gumbel_rounds", "cluster_octet_heads"])
+@pytest.mark.parametrize("mode", ["gumbel_rounds", "gumbel_rounds_one_workgroup_per_leaf", "cluster_octet_heads"])
 def test_c5_full_size_64_games(mz, oracle, mode):
     """BASELINE configs[4]'s per-GPU shard at its own size AND on the 6-block x 64-channel muzero_atari network, 2 moves + 5 cycles, sequence length as in
     the config (no line is due yet: records as they stand), on both shipped paths:
-    gumbel_rounds (default): the leaves of every Gumbel round evaluated ahead (64 x 16 ... 64 x 2 workgroups per launch), consumed in order
-    by one workgroup per game — the first call is a whole move and takes that path, the counters say so;
+    gumbel_rounds (default): the leaves of every Gumbel round evaluated ahead by the batched pipeline of sim_rounds.hip (walks, trunks of
+    4 / 2 / 1 leaves per workgroup, the FC layers of the 601-bin heads as MFMA GEMMs over all leaves, per-leaf tails), consumed in order by one workgroup
+    per game — the first call is a whole move and takes that path, the counters say so;
+    gumbel_rounds_one_workgroup_per_leaf (mz_sim_round_batch=false): the same rounds with one workgroup per leaf doing everything (sim.hip sim_pre_kernel_mz);
     cluster_octet_heads (mz_sim_rounds=false): 64 games = 256 workgroups in clusters of four with the 601-bin heads of the eight games of an
     XCD computed together (sim_cluster.h octetHead: only pools of full octets take that path)."""
-    rounds = mode == "gumbel_rounds"
-    lines, recs, st = _run(mz, oracle, "c5", 64, [51, 20, 51 - 20 + 5], wextra="" if rounds else ":mz_sim_rounds=false", threads=max(2, mz.usable_cpus() - 1))
+    rounds = mode != "cluster_octet_heads"
+    wextra = "" if mode == "gumbel_rounds" else ":mz_sim_round_batch=false" if rounds else ":mz_sim_rounds=false"
+    lines, recs, st = _run(mz, oracle, "c5", 64, [51, 20, 51 - 20 + 5], wextra=wextra, threads=max(2, mz.usable_cpus() - 1))
     if rounds:
         assert st["pre_evals"] >= 64 * 50 and st["pre_hits"] >= 64 * 40  # (the second move is cut by the calls: only its first round is evaluated ahead ... or none)
     else:

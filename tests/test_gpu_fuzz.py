@@ -112,6 +112,10 @@ def _atari_case(seed):
             conf = conf.replace(f"actor_num_simulation={n}:", "actor_num_simulation=13:")
             n = 13
             chunks = [n + 1, n + 1, 3, 2 * (n + 1), 17]
+    # (round 4, drawn after everything else) how the rounds' leaves are evaluated: the batched pipeline with 1 / 2 / 4 leaves per trunk workgroup, or one workgroup per leaf
+    for key, values, p in (("mz_sim_round_batch", ["false"], 0.2), ("mz_sim_round_leaves", [1, 2, 4], 0.5)):
+        if rng.random() < p:
+            wextra += f":{key}={rng.choice(values)}"
     return conf, (n + 1) * moves, chunks, games, wseed, pseed, wextra
 
 

@@ -366,12 +366,16 @@ def test_atari_cluster_pools_are_equivalent(mz, games):
 
 
 @pytest.mark.parametrize("games,extra", [(5, ""), (13, ""), (64, ""), (64, ":mz_sim_cluster=false"), (16, ":mz_sim_round_min=4"), (64, ":mz_sim_round_min=4"),
-                                         (13, ":mz_sim_round_alt=false"), (64, ":mz_sim_round_alt=false")])
+                                         (13, ":mz_sim_round_alt=false"), (64, ":mz_sim_round_alt=false"), (13, ":mz_sim_round_batch=false"),
+                                         (64, ":mz_sim_round_batch=false"), (13, ":mz_sim_round_leaves=4"), (64, ":mz_sim_round_leaves=2"), (64, ":mz_sim_round_leaves=4"),
+                                         (7, ":mz_sim_round_leaves=2:mz_sim_round_alt=false"), (5, ":mz_sim_round_leaves=1"), (64, ":mz_sim_round_leaves=1")])
 def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
     """mz_sim_rounds (default): the leaves of a whole Gumbel round — the simulations between two halvings visit different root children — are evaluated side
     by side ahead of the simulations, which then run in order and skip tower + heads when their leaf is the one evaluated for them (sim.hip
     sim_pre_kernel_mz / simPreProbe).  Only where an evaluation runs changes: the records must be those of mz_sim_rounds=false, on clusters of four
-    workgroups per game and on one workgroup per game, and the counters must show that leaves were evaluated ahead and found."""
+    workgroups per game and on one workgroup per game, and the counters must show that leaves were evaluated ahead and found.
+    The evaluation itself is the batched pipeline of sim_rounds.hip by default (mz_sim_round_leaves = leaves per trunk workgroup, forced here so that small pools
+    exercise the stacked-board trunks and the 64-sample FC tiles too) or one workgroup per leaf (mz_sim_round_batch=false): the same entries."""
     conf = ATARI_SMALL.replace("zero_num_parallel_games=5", f"zero_num_parallel_games={games}")
     kw = dict(vh=ATARI_ARGS[10], dv=ATARI_ARGS[11], type_name=ATARI_ARGS[12])
     d = mz.make_desc(*ATARI_ARGS[:10], **kw)
@@ -390,6 +394,8 @@ def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
     assert son["pre_evals"] >= games * 4 * (moves - 1) and 0 < son["pre_hits"] <= son["pre_evals"]
     # round 1 (the root's children, visited once each) can never miss: at least those hits
     assert son["pre_hits"] >= games * 4 * (moves - 1)
+    # the batched pipeline takes the rounds whose leaves outnumber the CUs (none in these pools) or every round when the leaves per workgroup are forced
+    assert (son["pre_batch_launches"] > 0) == ("mz_sim_round_leaves" in extra) and son["pre_batch_launches"] <= son["pre_launches"]
     assert on == off and ron == roff and (len(on) >= 5 or games >= 64)
     # a call that ends inside a move takes the ordinary path for the broken move: same records again
     mixed, rmixed, _ = run("", [9, 4, 5, 9, 9 * (moves - 3)])

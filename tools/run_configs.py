@@ -15,8 +15,9 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 MOVES = {"c1": 400, "c2": 4, "c3": 40, "c4": 20, "c5": 40}
 WARM = {"c5": 14}  # moves before the timed region (default 3: the first synchronisation of the third move takes 8 ms once): the Atari-shaped worker's first moves pay one-off host allocations
 KERNEL = {"c1": "sim_kernel<3,3,4,16,-1>", "c2": "sim_kernel<9,9,20,64,2>", "c3": "sim_kernel<8,8,4,64,0>", "c4": "sim_kernel_mz<9,9,20,68,64>",
-          "c5": "sim_pre_kernel_mz<6,6,84,64,2|4> (the leaves of a Gumbel round evaluated side by side) + sim_kernel_mz<6,6,64,84,64> (the simulations in order); "
-                "mz_sim_rounds=false: sim_kernel_mz_cluster<6,6,84,64>"}
+          "c5": "the leaves of a Gumbel round evaluated side by side: pre_walk_kernel + pre_tower_kernel<6,6,84,64,4|2|1> + pre_fc_kernel x 2 + pre_tail_kernel "
+                "(sim_rounds.hip; mz_sim_round_batch=false: sim_pre_kernel_mz<6,6,84,64,2|4>), then sim_kernel_mz<6,6,64,84,64> (the simulations in order); "
+                "launches_by_kernel has the counts; mz_sim_rounds=false: sim_kernel_mz_cluster<6,6,84,64>"}
 
 
 def flops_per_leaf_eval(d):
@@ -36,6 +37,20 @@ def flops_per_leaf_eval(d):
     else:
         heads += 2.0 * (P * C * 1 + P * d.num_value_hidden_channels + d.num_value_hidden_channels)
     return conv, heads
+
+
+def _by_kernel(s0, s1, launches):
+    """Gumbel rounds (C5): how many launches of which kernel the `launches` rounds + simulation stretches were (worker stats)."""
+    pre = s1.get("pre_launches", 0) - s0.get("pre_launches", 0)
+    if pre <= 0:
+        return None
+    batch = s1.get("pre_batch_launches", 0) - s0.get("pre_batch_launches", 0)
+    out = {"sim_kernel_mz": launches - pre}
+    if pre - batch:
+        out["sim_pre_kernel_mz"] = pre - batch
+    if batch:
+        out.update({"pre_walk_kernel": batch, "pre_tower_kernel": batch, "pre_fc_kernel": 2 * batch, "pre_tail_kernel": batch})
+    return out
 
 
 def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
@@ -71,8 +86,7 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
            "config": mz.CONFIGS[key],
            "roofline": {"kernel": KERNEL[key], "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": (ach / F32_MFMA_PEAK_TFLOPS) if ach else None, "launches": launches,
-                        "launches_by_kernel": ({"sim_pre_kernel_mz": s1.get("pre_launches", 0) - s0.get("pre_launches", 0),
-                                                "sim_kernel_mz": launches - (s1.get("pre_launches", 0) - s0.get("pre_launches", 0))} if s1.get("pre_launches", 0) > s0.get("pre_launches", 0) else None),
+                        "launches_by_kernel": _by_kernel(s0, s1, launches),
                         "avg_launch_ms": gpu_ms / launches if launches else None, "flops_per_leaf_eval": conv + heads,
                         "conv3x3_flops_per_leaf_eval": conv, "leaf_evals_in_launches": sim_evals,
                         "wall_frac": (conv + heads) * evals / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
