@@ -126,7 +126,9 @@ def main():
     usable = mz.usable_cpus()  # affinity mask capped by the cgroup CPU quota: spinning past the quota gets the container throttled
     threads = args.threads or max(1, min(32, usable // max(1, world) - 1))  # spin-wait pool incl. the calling thread
     base_conf = mz.CONFIGS["c2"].replace("zero_num_parallel_games=256", f"zero_num_parallel_games={args.games}")
-    conf = (f"{base_conf}:zero_num_threads={threads}:mz_pipeline_lanes={args.lanes}:mz_zero_copy={args.zero_copy}:mz_cpu_base={local_rank * threads if args.pin else -1}:program_seed={shard_seed(1, rank)}:"
+    # mz_rng_streams=0: one generator per slave thread, as the reference has them with zero_num_threads = T (actor_group.cpp:66-70), so that the RNG-ordered host
+    # section of a move runs on the pool's threads; rank r's generators are program_seed + r * T + t: no two ranks share one
+    conf = (f"{base_conf}:zero_num_threads={threads}:mz_rng_streams=0:mz_pipeline_lanes={args.lanes}:mz_zero_copy={args.zero_copy}:mz_cpu_base={local_rank * threads if args.pin else -1}:program_seed={shard_seed(1, rank, threads)}:"
             "nn_file_name=synthetic_go_6bx64_seed0.pt" + (":" + args.extra_conf if args.extra_conf else "") +
             (":mz_nn_precision=bf16x3" if args.precision == "bf16x3" else ""))
     desc = mz.DESCS["c2"]()
@@ -171,7 +173,7 @@ def main():
     # what every rank ran with (device, seed, CPU range, first record): gathered as a sum of one-hot rows, printed by rank 0
     import zlib
     row = [0.0] * (5 * world)
-    row[5 * rank:5 * rank + 5] = [float(device), float(shard_seed(1, rank)), float(local_rank * threads if args.pin else -1), float(threads),
+    row[5 * rank:5 * rank + 5] = [float(device), float(shard_seed(1, rank, threads)), float(local_rank * threads if args.pin else -1), float(threads),
                                   float(zlib.crc32(worker.peek_records(1)[0].encode()))]
     per_rank = grp.reduce(row, "sum")
     if rank == 0:

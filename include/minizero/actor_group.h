@@ -83,8 +83,11 @@ protected:
             Device& d = devices_[g];
             d.gpu = gpu_id_ >= 0 ? gpu_id_ : (map.empty() ? g : map[g]);
             d.games = (total_games - g + G - 1) / G; // |{i < total : i % G == g}| (ref actor_group.cpp:185)
-            const std::string conf = conf_ + ":zero_num_parallel_games=" + std::to_string(d.games) + ":program_seed=" + std::to_string(seed + g) +
-                                     ":zero_num_threads=" + std::to_string(std::max(1, threads / G));
+            // worker g's generators: mz_rng_streams = S of them (default 1; 0 = one per slave thread of this worker), seeded program_seed + g * S + t — over all
+            // devices the ids 0 .. G * S - 1 of the reference's slave threads (actor_group.cpp:66-70), each used once
+            const int per_worker = std::max(1, threads / G), streams_key = number("mz_rng_streams", 1), S = std::max(1, streams_key == 0 ? per_worker : streams_key);
+            const std::string conf = conf_ + ":zero_num_parallel_games=" + std::to_string(d.games) + ":program_seed=" + std::to_string(seed + g * S) +
+                                     ":zero_num_threads=" + std::to_string(per_worker);
             d.worker = mz_worker_create(d.gpu, conf.c_str(), nullptr, nullptr, 0); // reads nn_file_name itself
             if (!d.worker) { std::cerr << mz_last_error() << std::endl; exit(0); }
         }

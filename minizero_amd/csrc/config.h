@@ -33,6 +33,7 @@ struct WorkerConfig {
     float actor_gumbel_sigma_scale_c = 1;
     float actor_resign_threshold = -0.9f;
     int zero_num_threads = 4;
+    int mz_rng_streams = 1;     // worker-only: host RNG streams; 1 = slave thread 0's generator for every game (deterministic contract), 0 = one per slave thread (zero_num_threads, ref actor_group.cpp:66-70), games in contiguous blocks
     int zero_num_parallel_games = 32;
     float zero_disable_resign_ratio = 0.1;
     int zero_actor_intermediate_sequence_length = 0;

@@ -457,7 +457,8 @@ private:
     int phase2(Lane& L);
     int phase2Resident(Lane& L);
     int runCyclesSim(int n);
-    void drawCycle(int batch, bool noise_cycle);
+    void drawCycles(int b0, int b1, int noise_row);
+    void drawStream(int t, int b0, int b1, int noise_row);
     int uploadRoots(Lane& L);
     int setupDeviceGumbel();
     int cycle();
@@ -492,7 +493,19 @@ private:
     int lane_size_ = 1;
     std::unique_ptr<ThreadPool> threads_;
     std::vector<Game> games_;
-    Rng main_rng_, rng_;
+    Rng main_rng_;
+    // The slave threads' generators (ref actor_group.cpp:66-70: thread id seeds program_seed + id).  mz_rng_streams = 1 (default): every game draws from the
+    // generator of slave thread 0 — the deterministic contract, and one of the schedules the reference's first-come-first-served hand-out of actors to threads
+    // (actor_group.cpp:18-22) can produce.  mz_rng_streams = 0: as many generators as the reference has, zero_num_threads = T, the games statically partitioned
+    // over them in contiguous blocks (streamOf) — another of those schedules (mz_rng_streams = S > 1: S generators whatever zero_num_threads says).  Every draw of game g comes from rngOf(g) in the reference's per-actor order; draws of different
+    // streams are independent, so the long runs of draws (root noise, rotations: drawCycles) are made by the streams side by side on the pool's threads.
+    std::vector<Rng> rngs_;
+    int streams_ = 1;
+    // the pool's size: zero_num_threads, never more than the CPUs we may burn
+    int hostThreads() const { return std::max(1, std::min(cfg_.zero_num_threads, usableCpus() - 1)); }
+    int streamOf(int g) const { return static_cast<int>(static_cast<long long>(g) * streams_ / G_); }
+    Rng& rngOf(int g) { return rngs_[streamOf(g)]; }
+    std::vector<std::vector<float>> stream_noise_;   // per stream: scratch of a noise draw
     bool running_ = false, pending_ = false;
     int sims_done_ = 0; // root visit count of every game (lock-step: identical for all games)
     int sim_pre_ = 0, sim_post_ = 0; // its value before / after the expand+backup of the current cycle
@@ -510,6 +523,19 @@ private:
     bool feat_bits_ = false; // AlphaZero leaves travel host->device as bit-packed planes (all board-game planes are 0/1)
     bool resident_ = false;  // the whole cycle runs on the device (go_dev.hip): the host only does the RNG-ordered per-move logic
     struct DeferredInfo { int g, mover; size_t index; };
+    // what the per-move host logic of one RNG stream's games leaves for the pool: with several streams (mz_rng_streams) the streams' blocks of games run side by
+    // side on the pool's threads and their results are merged in stream order = game order (serialSection)
+    struct StreamSink {
+        uint64_t moves = 0, games = 0;
+        std::vector<DeferredInfo> deferred;
+        struct Line { std::unique_ptr<OutLine> line; std::string obs_raw; bool has_obs = false; };
+        std::vector<Line> lines;
+    };
+    std::vector<StreamSink> sinks_;
+    static thread_local StreamSink* tl_sink_; // the sink of the stream this thread is working for (nullptr: write through)
+    void queueLine(std::unique_ptr<OutLine> line, std::string&& obs_raw, bool has_obs);
+    void serialSection(Lane& L, bool want_noise, bool done, bool az);
+    void serialGame(int g, bool want_noise, bool done, bool az, std::vector<float>& noise);
     std::vector<float> noise_scratch_;
     std::vector<DeferredInfo> deferred_; // record strings of the last move, built while the next launch runs
     bool defer_info_ = false;
@@ -606,7 +632,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         lanes_.push_back(std::move(L));
     }
     // the pool spins: never more spinners than CPUs the container may use, minus one for the HIP runtime's helper threads
-    threads_ = std::make_unique<ThreadPool>(std::max(1, std::min(cfg_.zero_num_threads, usableCpus() - 1)), cfg_.mz_cpu_base);
+    threads_ = std::make_unique<ThreadPool>(hostThreads(), cfg_.mz_cpu_base);
     const size_t GA = size_t(G_) * A_;
     rr_nc_.resize(G_); rr_action_.resize(GA); rr_bsize_.resize(G_);
     for (auto* v : {&rr_count_, &rr_mean_, &rr_policy_, &rr_logit_, &rr_noise_, &rr_value_, &rr_reward_}) { v->resize(GA); }
@@ -832,7 +858,10 @@ int Worker::createActors()
         g.action_info_history.clear();
         g.enable_resign = (main_rng_.randReal() < cfg_.zero_disable_resign_ratio ? false : true);
     }
-    rng_.seed(cfg_.program_auto_seed ? static_cast<int>(std::random_device()()) : cfg_.program_seed + 0);
+    streams_ = std::max(1, cfg_.mz_rng_streams == 0 ? cfg_.zero_num_threads : cfg_.mz_rng_streams);
+    rngs_.assign(streams_, Rng());
+    for (int t = 0; t < streams_; ++t) { rngs_[t].seed(cfg_.program_auto_seed ? static_cast<int>(std::random_device()()) : cfg_.program_seed + t); }
+    stream_noise_.assign(streams_, {});
     sims_done_ = 0;
     pending_ = false;
     return resetAllSearches();
@@ -993,7 +1022,7 @@ int Worker::selectChildBySoftmaxCount(int g, float temperature, float value_thre
         const float mean = normalizedMean(rr_reward_[off + i], rr_mean_[off + i], rr_count_[off + i], child_player, g);
         if (mean < best_mean - value_threshold) { continue; }
         sum += count;
-        float rand = rng_.randReal(sum);
+        float rand = rngOf(g).randReal(sum);
         if (selected == -1 || rand < count) { selected = i; }
     }
     return selected;
@@ -1221,14 +1250,22 @@ void Worker::outputGame(Game& gm) // ref actor_group.cpp:24-50
         // (i < size: a resignation before the first move of an intermediate-sequence game has range 0-0 and an EMPTY history — the reference indexes it anyway)
         for (int i = range.first; i <= range.second && i < static_cast<int>(gm.action_info_history.size()); ++i) { gm.action_info_history[i].clear(); gm.action_info_history[i].shrink_to_fit(); }
     }
-    lines_.push_back(std::make_unique<OutLine>());
-    lines_.back()->text = oss.str();
-    if (gm.env->hasObservations()) {
+    auto line = std::make_unique<OutLine>();
+    line->text = oss.str();
+    const bool has_obs = gm.env->hasObservations();
+    if (is_terminal) { if (tl_sink_) { ++tl_sink_->games; } else { ++stats_.games; } }
+    if (tl_sink_) { tl_sink_->lines.push_back({std::move(line), std::move(obs_raw), has_obs}); }
+    else { queueLine(std::move(line), std::move(obs_raw), has_obs); }
+}
+
+void Worker::queueLine(std::unique_ptr<OutLine> line, std::string&& obs_raw, bool has_obs)
+{
+    lines_.push_back(std::move(line));
+    if (has_obs) {
         // (helpers: the host threads the configuration grants beyond the caller's, at least one — they sleep when there is nothing to compress)
-        if (!obs_) { obs_ = std::make_unique<ObsCompressor>(std::max(1, std::min(cfg_.zero_num_threads, usableCpus() - 1) - 1)); }
+        if (!obs_) { obs_ = std::make_unique<ObsCompressor>(std::max(1, hostThreads() - 1)); }
         obs_->submit(lines_.back().get(), std::move(obs_raw), kObsPlaceholder, sizeof(kObsPlaceholder) - 1);
     }
-    if (is_terminal) { ++stats_.games; }
 }
 
 void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor.cpp:22-30
@@ -1254,7 +1291,7 @@ void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor
             acted = true;
         }
     }
-    ++stats_.moves;
+    if (tl_sink_) { ++tl_sink_->moves; } else { ++stats_.moves; }
     const bool is_endgame = (resign || gm.env->isTerminal());
     const int game_length = static_cast<int>(gm.env->actionIds().size());
     const int seq = cfg_.zero_actor_intermediate_sequence_length;
@@ -1263,12 +1300,12 @@ void Worker::handleSearchDone(int g) // ref actor_group.cpp:116-134 + base_actor
     if (acted) {
         // the P/V/R strings of this move (no RNG involved) are only needed when the game is printed: for every other game they are
         // built after the next launch has been queued, off the critical path (the root statistics stay valid until the next root read)
-        if (defer_info_ && !is_endgame && !intermediate) { deferred_.push_back({g, mover, gm.action_info_history.size() - 1}); }
+        if (defer_info_ && !is_endgame && !intermediate) { (tl_sink_ ? tl_sink_->deferred : deferred_).push_back({g, mover, gm.action_info_history.size() - 1}); }
         else { gm.action_info_history.back() = actionInfo(g, mover); }
     }
     if (is_endgame) {
         outputGame(gm);
-        resetGame(gm, rng_);
+        resetGame(gm, rngOf(g));
     } else if (intermediate) {
         outputGame(gm);
     }
@@ -1282,6 +1319,71 @@ void Worker::flushDeferred()
         games_[d.g].action_info_history[d.index] = actionInfo(d.g, d.mover);
     });
     deferred_.clear();
+}
+
+thread_local Worker::StreamSink* Worker::tl_sink_ = nullptr;
+
+// the per-move host logic of one game, in the reference's order: [root noise][move decision + Gumbel bookkeeping + act / record / reset][rotation]
+void Worker::serialGame(int g, bool want_noise, bool done, bool az, std::vector<float>& noise)
+{
+    Game& gm = games_[g];
+    const size_t off = size_t(g) * A_;
+    if (want_noise) { // ref zero_actor.cpp:194-213
+        const int k = rr_nc_[g];
+        if (cfg_.actor_use_dirichlet_noise) {
+            const float epsilon = cfg_.actor_dirichlet_noise_epsilon;
+            rngOf(g).dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise);
+            for (int i = 0; i < k; ++i) {
+                rr_noise_[off + i] = noise[i];
+                rr_policy_[off + i] = (1 - epsilon) * rr_policy_[off + i] + epsilon * noise[i];
+            }
+        } else {
+            rngOf(g).gumbel(k, noise);
+            for (int i = 0; i < k; ++i) {
+                rr_noise_[off + i] = noise[i];
+                rr_logit_[off + i] = rr_logit_[off + i] + noise[i];
+            }
+        }
+        memcpy(noise_policy_.data() + off, rr_policy_.data() + off, k * sizeof(float));
+        memcpy(noise_logit_.data() + off, rr_logit_.data() + off, k * sizeof(float));
+        memcpy(noise_noise_.data() + off, rr_noise_.data() + off, k * sizeof(float));
+    }
+    if (done) { gm.selected = decideAction(g); }                  // zero_actor.cpp:96 handleSearchDone()
+    if (cfg_.actor_use_gumbel) { gumbelSequentialHalving(g); }     // zero_actor.cpp:97
+    if (done) { handleSearchDone(g); }                             // actor_group.cpp:92
+    if (az && !(done && cfg_.mz_manual_step)) { // beforeNNEvaluation: the rotation draw (zero_actor.cpp:56)
+        gm.rot = cfg_.actor_use_random_rotation_features ? rngOf(g).randInt() % 8 : 0;
+    }
+}
+
+// One stream: strictly serial, in actor index order (the deterministic contract).  Several streams (mz_rng_streams): every stream's block of games in index
+// order on one thread of the pool, the blocks side by side; what they produce for the pool (finished records, counters, deferred record strings) is merged in
+// stream order, which is game order — the lines leave exactly as the serial loop would have queued them.
+void Worker::serialSection(Lane& L, bool want_noise, bool done, bool az)
+{
+    const int g0 = L.g0, g1 = L.g0 + L.n;
+    if (streams_ == 1) {
+        std::vector<float>& noise = stream_noise_[0];
+        for (int g = g0; g < g1; ++g) { serialGame(g, want_noise, done, az, noise); }
+        return;
+    }
+    sinks_.resize(streams_);
+    threads_->parallelFor(streams_, [this, g0, g1, want_noise, done, az](int t) {
+        const int gs = std::max(g0, static_cast<int>((static_cast<long long>(t) * G_ + streams_ - 1) / streams_));
+        const int ge = std::min(g1, static_cast<int>((static_cast<long long>(t + 1) * G_ + streams_ - 1) / streams_));
+        if (gs >= ge) { return; }
+        tl_sink_ = &sinks_[t];
+        for (int g = gs; g < ge; ++g) { serialGame(g, want_noise, done, az, stream_noise_[t]); }
+        tl_sink_ = nullptr;
+    });
+    for (StreamSink& s : sinks_) {
+        stats_.moves += s.moves; stats_.games += s.games;
+        s.moves = s.games = 0;
+        deferred_.insert(deferred_.end(), s.deferred.begin(), s.deferred.end());
+        s.deferred.clear();
+        for (auto& l : s.lines) { queueLine(std::move(l.line), std::move(l.obs_raw), l.has_obs); }
+        s.lines.clear();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1323,38 +1425,8 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
         const double t2 = nowMs();
         stats_.ms_expand += t2 - t1;
         trace_.add(3, t2 - te);
-        // ---- strictly serial, RNG-ordered section (actor index order) ----
-        std::vector<float> noise;
-        for (int g = g0; g < g1; ++g) {
-            Game& gm = games_[g];
-            const size_t off = size_t(g) * A_;
-            if (want_noise) { // ref zero_actor.cpp:194-213
-                const int k = rr_nc_[g];
-                if (cfg_.actor_use_dirichlet_noise) {
-                    const float epsilon = cfg_.actor_dirichlet_noise_epsilon;
-                    rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise);
-                    for (int i = 0; i < k; ++i) {
-                        rr_noise_[off + i] = noise[i];
-                        rr_policy_[off + i] = (1 - epsilon) * rr_policy_[off + i] + epsilon * noise[i];
-                    }
-                } else {
-                    rng_.gumbel(k, noise);
-                    for (int i = 0; i < k; ++i) {
-                        rr_noise_[off + i] = noise[i];
-                        rr_logit_[off + i] = rr_logit_[off + i] + noise[i];
-                    }
-                }
-                memcpy(noise_policy_.data() + off, rr_policy_.data() + off, k * sizeof(float));
-                memcpy(noise_logit_.data() + off, rr_logit_.data() + off, k * sizeof(float));
-                memcpy(noise_noise_.data() + off, rr_noise_.data() + off, k * sizeof(float));
-            }
-            if (done) { gm.selected = decideAction(g); }                  // zero_actor.cpp:96 handleSearchDone()
-            if (cfg_.actor_use_gumbel) { gumbelSequentialHalving(g); }     // zero_actor.cpp:97
-            if (done) { handleSearchDone(g); }                             // actor_group.cpp:92
-            if (az && !(done && cfg_.mz_manual_step)) { // beforeNNEvaluation: the rotation draw (zero_actor.cpp:56)
-                gm.rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0;
-            }
-        }
+        // ---- the RNG-ordered section: actor index order within every RNG stream ----
+        serialSection(L, want_noise, done, az);
         const double ts = nowMs();
         trace_.add(4, ts - t2);
         if (want_noise) {
@@ -1378,7 +1450,7 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
         trace_.add(5, t0 - ts);
     } else {
         for (int g = g0; g < g1; ++g) {
-            if (az) { games_[g].rot = cfg_.actor_use_random_rotation_features ? rng_.randInt() % 8 : 0; }
+            if (az) { games_[g].rot = cfg_.actor_use_random_rotation_features ? rngOf(g).randInt() % 8 : 0; }
         }
     }
     // ---- selection of the next simulation ----
@@ -1567,33 +1639,57 @@ int Worker::syncGumbel(Lane& L, bool to_device)
     return MZ_OK;
 }
 
-// The RNG draws of one cycle that joins a launch (its own function: the hot loop of a 400-simulation move — 102 400 rotation draws and 20 k gamma
-// draws per move on BASELINE configs[1] — must not depend on the inlining decisions inside runCyclesSim, which cost 1.4 ms per move once)
-__attribute__((noinline, aligned(64))) void Worker::drawCycle(int batch, bool noise_cycle)
+// The RNG draws of the cycles [b0, b1) that join a launch: row b of the lanes' rotation tables (AlphaZero: one draw per game and cycle, zero_actor.cpp:56) and — cycle
+// `noise_row` — the root noise of every game (its length is the number of legal moves, which the host engine knows; zero_actor.cpp:194-213).  Per stream the
+// order is the reference's: cycle-major, actor-minor, [noise][rotation] per actor.  One stream (mz_rng_streams = 1, the deterministic contract): the calling
+// thread; T streams: each is a contiguous block of games with its own generator, so the blocks are drawn side by side on the pool's threads (the 20 k gamma
+// draws of 256 roots: 0.9 ms on one thread).  (Its own function: the hot loop of a 400-simulation move — 102 400 rotation draws per move on BASELINE
+// configs[1] — must not depend on the inlining decisions inside runCyclesSim, which cost 1.4 ms per move once.)
+__attribute__((noinline, aligned(64))) void Worker::drawStream(int t, int b0, int b1, int noise_row)
 {
     const bool az = desc_.type == 0, rotate = cfg_.actor_use_random_rotation_features;
-    for (auto& L : lanes_) {
-        uint8_t* rot_row = L->h_rot.p + size_t(batch) * L->n;
-        if (!noise_cycle) { // a plain cycle only fills its row of the rotation table (Game::rot is drawn again by the next phase1 before anybody reads it)
-            if (az) { for (int j = 0; j < L->n; ++j) { rot_row[j] = rotate ? static_cast<uint8_t>(rng_.randInt() % 8) : 0; } }
-            continue;
-        }
-        for (int j = 0; j < L->n; ++j) {
-            Game& gm = games_[L->g0 + j];
-            if (noise_cycle) {
+    // the games of stream t: [gs, ge) (streamOf is monotone)
+    int gs = 0, ge = G_;
+    if (streams_ > 1) {
+        gs = static_cast<int>((static_cast<long long>(t) * G_ + streams_ - 1) / streams_);
+        ge = static_cast<int>((static_cast<long long>(t + 1) * G_ + streams_ - 1) / streams_);
+    }
+    if (gs >= ge) { return; }
+    Rng& rng = rngs_[t];
+    std::vector<float>& scratch = stream_noise_[t];
+    for (int b = b0; b < b1; ++b) {
+        const bool noise_cycle = b == noise_row;
+        if (!noise_cycle && !az) { continue; } // MuZero draws nothing in a plain cycle
+        for (auto& L : lanes_) {
+            const int j0 = std::max(gs, L->g0) - L->g0, j1 = std::min(ge, L->g0 + L->n) - L->g0;
+            if (j0 >= j1) { continue; }
+            uint8_t* rot_row = L->h_rot.p + size_t(b) * L->n;
+            if (!noise_cycle) { // a plain cycle only fills its row of the rotation table (Game::rot is drawn again by the next phase1 before anybody reads it)
+                for (int j = j0; j < j1; ++j) { rot_row[j] = rotate ? static_cast<uint8_t>(rng.randInt() % 8) : 0; }
+                continue;
+            }
+            for (int j = j0; j < j1; ++j) {
+                Game& gm = games_[L->g0 + j];
                 gm.env->legalMask(gm.legal.data());
                 int k = 0;
                 for (int a = 0; a < A_; ++a) { k += gm.legal[a] != 0; }
-                if (cfg_.actor_use_dirichlet_noise) { rng_.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, noise_scratch_); }
-                else { rng_.gumbel(k, noise_scratch_); }
-                memcpy(L->h_noise.p + size_t(j) * A_, noise_scratch_.data(), size_t(k) * sizeof(float));
-            }
-            if (az) { // AlphaZero: the only draw of a plain cycle (zero_actor.cpp:56); MuZero draws nothing
-                gm.rot = rotate ? rng_.randInt() % 8 : 0;
-                rot_row[j] = static_cast<uint8_t>(gm.rot);
+                if (cfg_.actor_use_dirichlet_noise) { rng.dirichlet(cfg_.actor_dirichlet_noise_alpha, k, scratch); }
+                else { rng.gumbel(k, scratch); }
+                memcpy(L->h_noise.p + size_t(j) * A_, scratch.data(), size_t(k) * sizeof(float));
+                if (az) { // AlphaZero: the only draw of a plain cycle (zero_actor.cpp:56); MuZero draws nothing
+                    gm.rot = rotate ? rng.randInt() % 8 : 0;
+                    rot_row[j] = static_cast<uint8_t>(gm.rot);
+                }
             }
         }
     }
+}
+
+void Worker::drawCycles(int b0, int b1, int noise_row)
+{
+    if (b0 >= b1) { return; }
+    if (streams_ == 1) { drawStream(0, b0, b1, noise_row); return; }
+    threads_->parallelFor(streams_, [this, b0, b1, noise_row](int t) { drawStream(t, b0, b1, noise_row); });
 }
 
 // Device-resident cycles in batches: the host part of a cycle (per-move logic in RNG order, rotation draws) runs exactly as in
@@ -1673,7 +1769,7 @@ int Worker::runCyclesSim(int n)
         while (i + batch < n && sim0 + batch < n_ + 1 && !(sim0 + batch == 1 && noise_cfg && !device_noise)) { ++batch; }
         // (root_on_device: the launch starts AT simulation 1, its noise is drawn right here)
         const bool noise_in_batch = noise_cfg && ((sim0 == 0 && batch > 1) || root_on_device);
-        if (root_on_device && noise_cfg) { drawCycle(0, true); }
+        if (root_on_device && noise_cfg) { drawCycles(0, 1, 0); }
         // The launch goes out in up to three parts (mz_sim_split): simulation 0 needs no draw of this loop (its rotation was drawn in phase1), so it
         // runs while the host draws the root noise; a few simulations later the rest follows, whose rotation draws (AlphaZero: one per game and
         // simulation, 102 400 per move on BASELINE configs[1]) are made while the second part runs.  Same draws in the same order: nothing a record
@@ -1709,7 +1805,7 @@ int Worker::runCyclesSim(int n)
         int drawn = 1; // rows of the rotation table (= cycles of the batch) whose draws are made
         for (int part = 0; part < parts; ++part) {
             const int c0 = cuts[part], c1 = cuts[part + 1];
-            for (; drawn < c1; ++drawn) { drawCycle(drawn, drawn == 1 && noise_in_batch && !root_on_device); }
+            if (drawn < c1) { drawCycles(drawn, c1, (noise_in_batch && !root_on_device) ? 1 : -1); drawn = c1; }
             for (auto& L : lanes_) {
                 // the first part's uploads go in front of its kernel on the lane's stream (nothing is running); later ones overlap the running part
                 hipStream_t us = part == 0 ? L->stream : L->up_stream;
@@ -1906,7 +2002,7 @@ int Worker::finishSearch()
 int Worker::resetGameAt(int g) // ZeroActor::reset without the search part (ref zero_actor.cpp:23-27, base_actor.cpp:8-13)
 {
     if (g < 0 || g >= G_) { setError("reset_game: game %d out of range", g); return MZ_ERR_ARG; }
-    resetGame(games_[g], rng_);
+    resetGame(games_[g], rngOf(g));
     return MZ_OK;
 }
 
@@ -2078,7 +2174,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(actor_mcts_value_rescale) MZ_FIXED(actor_mcts_value_flipping_player) MZ_FIXED(actor_use_gumbel) MZ_FIXED(actor_gumbel_sample_size)
         MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
-        MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
+        MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_rng_streams) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
         MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_sim_round_alt) MZ_FIXED(mz_sim_round_batch) MZ_FIXED(mz_sim_round_leaves) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
         // the Atari-shaped environments keep a window of screens sized from these three at creation (ref atari.cpp:87); records of a larger window
         // would miss frames, so they are fixed where observations are kept (board games: free to change, like the reference)

@@ -11,9 +11,10 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def shard_seed(program_seed, rank):
-    """ref actor_group.cpp:66-70: thread/worker `id` seeds its generator with program_seed + id"""
-    return program_seed + rank
+def shard_seed(program_seed, rank, streams=1):
+    """ref actor_group.cpp:66-70: slave thread `id` seeds its generator with program_seed + id.  A rank with `streams` generators (mz_rng_streams) owns the ids
+    rank * streams .. rank * streams + streams - 1, so the generators of a node are program_seed + 0 .. program_seed + ranks * streams - 1, each used once."""
+    return program_seed + rank * max(1, streams)
 
 
 def games_for_rank(total_games, rank, world):

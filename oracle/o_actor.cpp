@@ -283,6 +283,7 @@ std::vector<NetOutput> NetQueue::run()
 // ---------------------------------------------------------------------------------------------
 // Group — ref actor/actor_group.cpp (one slave thread == the deterministic contract)
 // ---------------------------------------------------------------------------------------------
+thread_local int Group::cur_thread_ = -1;
 Group::Group(const Config& cfg, const NetDesc& nd, const float* raw, size_t nraw) : cfg_(cfg), nd_(nd)
 {
     net_ = Net::create(nd, raw, nraw);
@@ -298,15 +299,22 @@ Group::Group(const Config& cfg, const NetDesc& nd, const float* raw, size_t nraw
     // ref actor_group.cpp:66-70: slave thread 0 seeds ITS generator with program_seed + 0
     slave_rng_.seed(cfg_.program_seed + 0);
     for (auto& a : actors_) { a->rng_ = &slave_rng_; a->mcts_.rng_ = &slave_rng_; a->env_->rng_ = &slave_rng_; }
-    // throughput mode (NOT the deterministic contract): T slave threads, thread t seeds program_seed + t (actor_group.cpp:66-70).
-    // The reference hands actors to threads first-come-first-served (:18-22); here actor i belongs to thread i % T.
+    // T slave threads (oracle_throughput_threads = the reference's zero_num_threads > 1): thread t seeds ITS generator with program_seed + t (actor_group.cpp:66-70).
+    // The reference hands actors to threads first-come-first-served (:18-22, utils/paralleler.h) — a race: which thread's generator an actor draws from differs
+    // from run to run.  Here the partition is STATIC, one of the schedules that race can produce: actor i belongs to thread i * T / B (contiguous blocks, every
+    // thread takes its actors in index order), and the lines of a cycle are emitted in thread order = actor order.  The worker's host section follows the same
+    // partition (worker.cpp streamOf), so records stay comparable for every T.
     if (cfg_.oracle_throughput_threads > 1) {
-        for (int t = 0; t < cfg_.oracle_throughput_threads; ++t) {
+        const size_t T = static_cast<size_t>(cfg_.oracle_throughput_threads), B = actors_.size();
+        for (size_t t = 0; t < T; ++t) {
             thread_rngs_.emplace_back(std::make_unique<Random>());
-            thread_rngs_.back()->seed(cfg_.program_seed + t);
+            thread_rngs_.back()->seed(cfg_.program_seed + static_cast<int>(t));
         }
-        for (size_t i = 0; i < actors_.size(); ++i) {
-            Random* r = thread_rngs_[i % thread_rngs_.size()].get();
+        thread_lines_.resize(T);
+        thread_of_.resize(B);
+        for (size_t i = 0; i < B; ++i) {
+            thread_of_[i] = static_cast<int>(i * T / B);
+            Random* r = thread_rngs_[thread_of_[i]].get();
             actors_[i]->rng_ = r; actors_[i]->mcts_.rng_ = r; actors_[i]->env_->rng_ = r;
         }
     }
@@ -342,7 +350,8 @@ void Group::outputGame(ZeroActor& actor) // ref actor_group.cpp:24-50
         for (int i = data_range.first; i <= data_range.second && i < static_cast<int>(actor.action_info_history_.size()); ++i) { actor.action_info_history_[i].clear(); }
     }
     std::lock_guard<std::mutex> lock(out_mutex_);
-    lines_.push_back(oss.str());
+    if (cur_thread_ >= 0) { thread_lines_[cur_thread_].push_back(oss.str()); } // (T threads: merged in thread order at the end of the cycle)
+    else { lines_.push_back(oss.str()); }
     if (is_terminal) { ++games_; }
 }
 
@@ -364,13 +373,15 @@ void Group::handleSearchDone(int actor_id) // ref actor_group.cpp:116-134
 
 void Group::cycle() // ref actor_group.cpp:81-114 (one CPU phase + one GPU phase)
 {
-    if (!thread_rngs_.empty()) { // throughput mode: the CPU phase on T threads; batch slots are assigned up front in actor order
+    if (!thread_rngs_.empty()) { // T slave threads with a static partition (constructor); batch slots are assigned up front in actor order
         const int T = static_cast<int>(thread_rngs_.size()), B = static_cast<int>(actors_.size());
         std::vector<std::thread> th;
         q_.reserveSlots(B, nd_);
         for (int t = 0; t < T; ++t) {
-            th.emplace_back([this, t, T, B]() {
-                for (int i = t; i < B; i += T) {
+            th.emplace_back([this, t, B]() {
+                cur_thread_ = t;
+                for (int i = 0; i < B; ++i) {
+                    if (thread_of_[i] != t) { continue; }
                     ZeroActor& actor = *actors_[i];
                     const int out_id = actor.nn_evaluation_batch_id_;
                     if (out_id >= 0) {
@@ -380,9 +391,11 @@ void Group::cycle() // ref actor_group.cpp:81-114 (one CPU phase + one GPU phase
                     actor.slot_override_ = i;
                     actor.beforeNNEvaluation();
                 }
+                cur_thread_ = -1;
             });
         }
         for (auto& t : th) { t.join(); }
+        for (auto& tl : thread_lines_) { for (auto& l : tl) { lines_.push_back(std::move(l)); } tl.clear(); }
         outputs_ = q_.run();
         ++cycles_;
         return;

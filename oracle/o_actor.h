@@ -50,7 +50,10 @@ public:
     std::unique_ptr<Net> net_;
     NetQueue q_;
     Random main_rng_, slave_rng_;
-    std::vector<std::unique_ptr<Random>> thread_rngs_; // oracle_throughput_threads > 1: one generator per slave thread (seed + id), throughput mode
+    std::vector<std::unique_ptr<Random>> thread_rngs_; // oracle_throughput_threads > 1: one generator per slave thread (seed + id), static partition of the actors
+    std::vector<int> thread_of_;                       // ... actor -> thread
+    std::vector<std::vector<std::string>> thread_lines_; // ... the lines a thread produced in the current cycle
+    static thread_local int cur_thread_;
     std::vector<std::unique_ptr<ZeroActor>> actors_;
     std::vector<NetOutput> outputs_;
     std::vector<std::string> lines_, trace_lines_;

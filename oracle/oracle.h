@@ -87,7 +87,7 @@ struct Config {
     // environment/environment.h:5-110) and the ATARI init-Q rule with it (actor/mcts.cpp:211-216).
     std::string env_game = "tictactoe";
     bool atari_init_q = false;
-    int oracle_throughput_threads = 0; // oracle-only: >1 runs the CPU phase on T threads (bench cpu_baseline; NOT the deterministic contract)
+    int oracle_throughput_threads = 0; // oracle-only: T > 1 = the reference with zero_num_threads = T slave threads, actors statically partitioned (o_actor.cpp Group)
     std::string env_atari_name = "ms_pacman";
     int env_atari_episode_length = 1000; // synthetic Atari-shaped env: steps per episode
 

@@ -59,7 +59,7 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     d = mz.DESCS[key]()
     if threads is None:
         threads = max(1, mz.usable_cpus() - 1)
-    conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_cpu_base=0{extra_conf}"
+    conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_rng_streams=0:mz_cpu_base=0{extra_conf}"
     n = int(mz.CONFIGS[key].split("actor_num_simulation=")[1].split(":")[0])
     games = int(mz.CONFIGS[key].split("zero_num_parallel_games=")[1].split(":")[0])
     wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
