@@ -247,6 +247,7 @@ typedef struct mz_worker_stats {
     uint64_t pre_alt_hits; /* ... of which: the leaf was the simulation's SECOND expected one (mz_sim_round_alt) */
     uint64_t pre_launches; /* rounds (counted in sim_launches too) whose leaves were evaluated ahead (sim_pre_kernel_mz, or the pipeline of sim_rounds.hip) */
     uint64_t pre_batch_launches; /* ... of which: by the batched pipeline (mz_sim_round_batch; walks | trunks | FC GEMMs | tails = 5 kernel launches each) */
+    uint64_t pre_pair_launches;  /* ... of which: on pairs of workgroups per leaf (mz_sim_round_pairs, sim_pre_pair_kernel_mz; counted per network) */
 } mz_worker_stats;
 int mz_worker_get_stats(mz_worker* w, mz_worker_stats* out);
 mz_net* mz_worker_net(mz_worker* w);

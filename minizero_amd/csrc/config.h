@@ -69,6 +69,7 @@ struct WorkerConfig {
                                 // are evaluated side by side ahead of the simulations that consume them in order (sim.hip sim_pre_kernel_mz); false: every simulation evaluates its own leaf
     bool mz_sim_round_alt = true; // ... and, where a round leaves half of the CUs idle, a second expected leaf per simulation
     bool mz_sim_round_batch = true; // ... by the batched pipeline of sim_rounds.hip (false: one workgroup per leaf, sim.hip sim_pre_kernel_mz; same entries)
+    bool mz_sim_round_pairs = true; // ... and a round that leaves half of the CUs idle and does not use its second leaves runs every trunk on two workgroups (sim.hip sim_pre_pair_kernel_mz)
     int mz_sim_round_leaves = 0;    // ... with this many leaves per trunk workgroup (1, 2, 4; 0 = as many as keep every CU busy)
     int mz_sim_round_min = 2;   // ... for the rounds of at least this many simulations (2 = every round of a 50-simulation, 16-sample search: 16, 8, 4, 4, 4, 2 x 7)
     bool mz_sim_cluster = true; // muzero_atari simulation kernel: four workgroups per game when 4 x games <= CUs (sim_cluster.h)

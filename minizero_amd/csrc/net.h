@@ -106,11 +106,16 @@ public:
     // side into the entries of simulations s0 .. s0 + R - 1, tagged with `epoch` (a per-move serial number, != 0); the following simLaunchMz calls of the
     // move pass the same pre_epoch and consume the entries that turn out to be their leaves.  simRootNoiseMz applies the root noise as a launch of its own
     // (the first round needs the noisy logits before simulation 1): the simLaunchMz calls after it pass noise_applied = true.
-    int simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched);
+    // want_alt: the round's second expected leaves too (where they fit the chip beside the first); pairs: without them, two workgroups per leaf where those fit
+    // (sim.hip sim_pre_pair_kernel_mz)
+    int simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched, bool want_alt = true, bool pairs = false);
     // the same evaluation as a pipeline of batched kernels (sim_rounds.hip: walks | trunks of several leaves per workgroup | the heads' FC layers as MFMA GEMMs over
     // all leaves | per-leaf tails); the entries it writes are bit-identical.  *launched = false: no instance for this network (use simPreEvalMz)
     int simPreEvalBatchMz(int games, int max_depth, int s0, int R, int epoch, bool* launched, int force_nl = 0, bool want_alt = false); // force_nl: leaves per trunk workgroup (0 = by the pool size)
     bool hasPreBatch() const;
+    bool pairsAvailable() const { return pair_ok_; }
+    void pairTrouble() { pair_ok_ = false; } // a pair launch met a partner that never showed up (pre_stat[129]): one workgroup per leaf from here on
+    int cuCount() const { return cu_count_; }
     int simRootNoiseMz(int games);
     int simPreStats(unsigned* hits, unsigned* evals, unsigned* alt_hits);
     int simPreCountersAsync(unsigned* h_pinned);
@@ -176,6 +181,12 @@ private:
     DevBuf<int> pre_key_;          // leaves evaluated ahead: keys [games][slots][4], outputs [policy | logit | value | reward], counters
     DevBuf<float> pre_out_;
     DevBuf<unsigned> pre_stat_;
+    DevBuf<char> pre_pair_mem_;    // exchange blocks of the leaves evaluated by pairs of workgroups (sim.hip sim_pre_pair_kernel_mz)
+    bool pair_ok_ = true;          // ... cleared when a placement probe or a cooperative launch says no
+    int pair_checked_ = 0, pair_lpad_ = 0, pair_set_ = 0, pair_clean_ = 0; // launch shape probed / allocated for, the set the next launch uses, its blocks known to be zero
+public:
+    unsigned long long pre_pair_launches_ = 0;
+private:
     DevBuf<char> pre_ctl_, pre_f_, pre_h1_, pre_lg_; // batched round evaluation (sim_rounds.hip): leaf table, FC1 inputs, hidden units, bins
     int cu_count_ = 0;
     int sim_cluster_checked_ = 0; // pool size (padded) whose cluster placement has been probed

@@ -942,6 +942,132 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, 4))) v
 #include "sim_cluster.h"
 namespace mz {
 
+// ---- a round's leaves on PAIRS of workgroups (muzero_atari rounds that leave half of the CUs idle and do not need their second expected leaves) --------------
+// One leaf's latency is what such a round costs, and 93 of its 140 us are the trunk on ONE CU.  Two workgroups per leaf (cooperative launch; ids b and
+// b + pad8(leaves): congruent mod 8 = the same XCD, checked through XCC_ID) split every layer by output-channel tile — member m computes oc-tiles 2 m, 2 m + 1,
+// six of its waves one pixel tile each — and swap their halves through the XCD's L2 after every layer (sim_cluster.h clExchange: self-validating words, the
+// phase in the sign bit).  Same k-ordered chain per output: the entries are bit-identical to sim_pre_kernel_mz's.  Both members run the walk (same inputs,
+// same result); member 0 runs the heads and writes the entry.  xbuf: per leaf clusterWords(C, P) words, cleared by the host before the launch.
+template <int H, int W, int CDYN_PAD, int CPAD>
+__global__ __launch_bounds__(512) void sim_pre_pair_kernel_mz(const SimArgs* __restrict__ a_, int s0, int R, int leaves, int lpad, int epoch, unsigned* __restrict__ xbuf, int xwords, int set)
+{
+    CSimArgs* a = (CSimArgs*)a_;
+    extern __shared__ __attribute__((aligned(16))) float tiles[];
+    const int member = blockIdx.x / lpad, leaf = blockIdx.x % lpad;
+    if (leaf >= leaves) { return; }
+    const int g = leaf / R, r = leaf % R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The exchange blocks come in two sets: this launch uses `set` (all zero: "never written") and clears the leaf's block of the OTHER set — whose last users, the
+    // previous pair launch on this stream, are done — for the next launch: no memset between two rounds.  (16-byte sc1 stores: they must be in the L2 / memory
+    // before the next launch's loads, which bypass the vector cache.)
+    {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4* other = reinterpret_cast<u4*>(xbuf + (size_t(1 - set) * lpad + leaf) * xwords);
+        const int half = xwords / 4 / 2;
+        for (int i = member * half + tid; i < (member == 0 ? half : xwords / 4); i += 512) { __builtin_nontemporal_store(u4{0u, 0u, 0u, 0u}, other + i); }
+    }
+    constexpr int CM = CDYN_PAD > CPAD ? CDYN_PAD : CPAD;
+    constexpr int kTileFloats = kTowerTiles * CM * planeStride(H, W); // (towerBodyCluster zeroes two full tiles)
+    const AtariHeadParams hp = ldc(&a->ahp);
+    const PoolView v = ldc(&a->pv);
+    __shared__ int s_abort;
+    __shared__ int s_ctl[4];
+    int* st_l = reinterpret_cast<int*>(tiles + kTileFloats);
+    int* path_l = st_l + 4 + kGumbelMaxSample;
+    float* head_scratch = reinterpret_cast<float*>(st_l + ((4 + kGumbelMaxSample + 2 * v.max_depth + 2 + 3) & ~3));
+    const int slot = s0 + r;
+    if (tid == 0) { s_abort = 0; }
+    if (wave == 0) { // (sim_pre_kernel_mz, hypothesis 0: the Gumbel step on a private copy, the walk below candidate r)
+        const int stride = 3 + kGumbelMaxSample;
+        for (int i = lane; i < stride; i += 64) { st_l[i] = a->gum.state[size_t(g) * stride + i]; }
+        waveSync();
+        GumbelView gl = ldc(&a->gum);
+        gl.state = st_l - size_t(g) * stride;
+        (void)gumbelStepBody(v, gl, s0, g, lane, tiles);
+        waveSync();
+        const size_t base = size_t(g) * v.cap;
+        const int fc = v.rec[base].first_child, ncand = st_l[0];
+        bool ok = slot < a->slots && slot < (a->alt_base ? a->alt_base : a->slots) && r < ncand && r < kGumbelMaxSample;
+        if (ok) { ok = v.rec[base + fc + st_l[3 + r]].count == v.rec[base + fc + st_l[3]].count; }
+        ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
+        if (ok) {
+            if (lane == 0) { s_ctl[3] = fc + st_l[3 + r]; }
+            waveSync();
+            const PoolView pl = simPathView(v, path_l, g);
+            selectBody<false>(pl, s_ctl + 3 - g, g, lane, v.rcp_tab);
+            waveSync();
+            const int len = path_l[2 * v.max_depth];
+            if (lane == 0) {
+                s_ctl[1] = v.hslot[base + path_l[len - 2]];
+                s_ctl[2] = path_l[v.max_depth + len - 1];
+            }
+        }
+        if (lane == 0) { s_ctl[0] = ok ? 1 : 0; }
+    }
+    __syncthreads();
+    if (s_ctl[0] == 0) { return; } // (both members: same state, same walk)
+    const int src = s_ctl[1], action = s_ctl[2];
+    ClusterCtx c;
+    c.cm = xbuf + (size_t(set) * lpad + leaf) * xwords;
+    // (a partner that does not show up — two pair launches of different workers squeezed onto one GPU — is not an error: the leaf stays unevaluated, its simulation
+    // evaluates it itself, and the counter tells the host to stop using pairs: Net::pairTrouble)
+    int* trouble = reinterpret_cast<int*>(a->pre_stat + 129);
+    c.member = member; c.C = hp.C; c.P = hp.P; c.OT = a->ta_dyn.OT; c.xseq = 0; c.abort_lds = &s_abort; c.err = trouble;
+    c.mine0 = member * 32 * c.P; c.mine1 = c.mine0 + 32 * c.P;
+    c.NJ = 0; c.j = 0; c.oseq = 0; c.om = nullptr; c.convw = nullptr;
+    if (tid == 0) { // the two members must share an XCD (one L2), else the exchanges would read stale data
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        __hip_atomic_store(c.cm + kClXcc + member, (id & 15u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        clDrain();
+        __hip_atomic_fetch_add(c.cm + kClXcc + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = clWaitGE(c.cm + kClXcc + 4, 2u);
+        for (int m = 0; ok && m < 2; ++m) { ok = clLoadU(c.cm + kClXcc + m) == (id & 15u) + 1u; }
+        if (!ok) { s_abort = 1; atomicExch(trouble, 92); }
+    }
+    __syncthreads();
+    if (s_abort) { return; }
+    const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(hp.C) * hp.P;
+    float* xt = towerBodyCluster<H, W, CDYN_PAD, CPAD, 2>(a->params, *(const TowerArgs*)&a->ta_dyn, tid, tiles, hsrc, action, a->action_planes, c);
+    if (!xt || member != 0) { return; }
+    __syncthreads();
+    const size_t e = size_t(g) * a->slots + slot;
+    float* hd = a->hidden + e * size_t(hp.C) * hp.P;
+    atariHeadsBody<256>(nullptr, xt, planeStride(H, W), W + 2, hp, a->pre_policy, a->pre_logit, a->pre_value, a->pre_reward, hd, 1, 1, static_cast<int>(e), tid, head_scratch);
+    __syncthreads();
+    if (wave == 0) { // the leaf's candidate list in the reference's order, in place of the raw outputs (sim_pre_kernel_mz)
+        const int A = a->A;
+        Cand* cs = reinterpret_cast<Cand*>(tiles);
+        Cand* out = cs + A;
+        for (int i = lane; i < A; i += 64) { cs[i] = Cand{i, a->pre_policy[e * A + i], a->pre_logit[e * A + i]}; }
+        waveSync();
+        orderCandidates(cs, out, reinterpret_cast<int*>(out + A), A, lane, a->err);
+        waveSync();
+        for (int i = lane; i < A; i += 64) {
+            a->pre_action[e * A + i] = out[i].action;
+            a->pre_policy[e * A + i] = out[i].policy;
+            a->pre_logit[e * A + i] = out[i].logit;
+        }
+        waveSync();
+    }
+    if (tid == 0) {
+        int* key = a->pre_key + e * 4;
+        key[0] = src; key[1] = action; key[2] = epoch; key[3] = 0;
+        if (a->pre_stat) { atomicAdd(a->pre_stat + 1, 1u); }
+    }
+}
+
+template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
+static int launchSimPrePairMzT(const SimArgs* d_args, int leaves, int lpad, int s0, int R, int epoch, unsigned* xbuf, int xwords, int set, size_t lds, hipStream_t s)
+{
+    MZ_LDS_ATTR((sim_pre_pair_kernel_mz<H, W, CDYN_PAD, CPAD>), lds);
+    // An ordinary launch: at most as many workgroups as CUs, on a stream whose previous kernel has ended, are all resident at once; a cooperative launch would
+    // promise it but costs ~25 us of idle GPU around the kernel (12 of them per move took 0.76 -> 0.69 M leaf-evals/s off the cluster kernel), more than the
+    // pairs gain.  Should the GPU be shared and a partner stay out, the waits are bounded and the leaf is simply left to its simulation (kernel comment).
+    hipLaunchKernelGGL((sim_pre_pair_kernel_mz<H, W, CDYN_PAD, CPAD>), dim3(2 * lpad), dim3(512), lds, s, d_args, s0, R, leaves, lpad, epoch, xbuf, xwords, set);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
 static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, int host_start, size_t lds, hipStream_t s, int pre_epoch)
 {
@@ -1331,7 +1457,7 @@ int Net::simRootNoiseMz(int games)
 }
 
 // sim_pre_kernel_mz for the R simulations s0 .. s0 + R - 1 of every game (muzero_atari with a Gumbel root); *launched = false: no instance / no entries
-int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched)
+int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched, bool want_alt, bool pairs)
 {
     *launched = false;
     if (desc_.type != 2 || R < 1 || epoch == 0 || pre_key_.n == 0 || sim_args_host_.size() != sizeof(SimArgs)) { return MZ_OK; }
@@ -1347,8 +1473,38 @@ int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* 
     const size_t ctl_words = (4 + 4 + kGumbelMaxSample + 2 * size_t(max_depth) + 2 + 3) & ~size_t(3);
     const size_t lds = tile_bytes + ctl_words * sizeof(int) + atariHeadsSmemFloats(a.ahp) * sizeof(float);
     if (lds > 160 * 1024 || size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float) > lds) { return MZ_OK; }
-    // the second expected leaf of every simulation rides along where the round leaves half of the CUs idle (the rounds of two on a pool of 64 games)
-    const int NH = (a.alt_base && 2 * games * R <= cu_count_) ? 2 : 1;
+    // the second expected leaf of every simulation rides along where the round leaves half of the CUs idle (the rounds of two on a pool of 64 games) and the
+    // worker wants it (Worker::adaptRounds: while the round's simulations keep needing it); without it the idle half of the chip shortens the trunks instead
+    const int NH = (a.alt_base && 2 * games * R <= cu_count_ && want_alt) ? 2 : 1;
+    if (NH == 1 && pairs && pair_ok_ && 2 * ((games * R + 7) / 8 * 8) <= cu_count_ && H * W <= 36) {
+        const int leaves = games * R, lpad = (leaves + 7) / 8 * 8;
+        if (pair_checked_ != lpad) { // once per launch shape: do workgroups b and b + lpad share an XCD on this device?
+            if (clusterPlacementOk(lpad, stream_, 2)) { pair_checked_ = lpad; } else { pair_ok_ = false; }
+        }
+        const size_t words = (clusterWords(C, H * W) + 7) & ~size_t(7);
+        const size_t pair_lds = size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float) + (ctl_words + 4) * sizeof(int) + atariHeadsSmemFloats(a.ahp) * sizeof(float);
+        if (pair_ok_ && pair_lds <= size_t(160) * 1024) {
+            // two sets of blocks; a launch finds its set cleared by the launch before it (the kernel clears the other set's blocks of ITS leaves), by the
+            // allocation, or — when it has more leaves than that launch had — by a memset
+            if (pair_lpad_ != lpad || pre_pair_mem_.n < size_t(2) * lpad * words * sizeof(unsigned)) {
+                if (!pre_pair_mem_.ensure(size_t(2) * lpad * words * sizeof(unsigned))) { setError("hipMalloc of the pair exchange blocks failed"); return MZ_ERR_DEVICE; }
+                MZ_HIP(hipMemsetAsync(pre_pair_mem_.p, 0, size_t(2) * lpad * words * sizeof(unsigned), stream_));
+                pair_lpad_ = lpad; pair_set_ = 0; pair_clean_ = lpad;
+            } else if (pair_clean_ < leaves) {
+                MZ_HIP(hipMemsetAsync(pre_pair_mem_.p + size_t(pair_set_) * lpad * words * sizeof(unsigned), 0, size_t(lpad) * words * sizeof(unsigned), stream_));
+            }
+#define MZ_SIM_PAIR_LAUNCH(h, w, cin0, cdyn, cpad) \
+            if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { \
+                const int rcp = launchSimPrePairMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), leaves, lpad, s0, R, epoch, reinterpret_cast<unsigned*>(pre_pair_mem_.p), static_cast<int>(words), pair_set_, pair_lds, stream_); \
+                if (rcp) { return rcp; } \
+                pair_set_ ^= 1; pair_clean_ = leaves; /* the set the NEXT launch uses: cleared for this launch's leaves */ \
+                *launched = true; ++pre_pair_launches_; \
+                return MZ_OK; \
+            }
+            MZ_SIM_MZ_CLUSTER_CASES(MZ_SIM_PAIR_LAUNCH)
+#undef MZ_SIM_PAIR_LAUNCH
+        }
+    }
     // more workgroups than CUs: two per CU (the 128-VGPR build of the kernel), if two fit the LDS
     const bool dense = NH * games * R > cu_count_ && 2 * lds <= 160 * 1024 && !getenv("MZ_PRE_SPARSE");
 #define MZ_SIM_PRE_LAUNCH(h, w, cin0, cdyn, cpad) \
@@ -1375,6 +1531,8 @@ int Net::simPreStats(unsigned* hits, unsigned* evals, unsigned* alt_hits)
     if (getenv("MZ_SIM_PROF") && h[1]) {
         fprintf(stderr, "[mz sim prof] leaves evaluated ahead %u, found %u (%u of them the second expected leaf); misses by simulation of the move:", h[1], h[0], h[128]);
         for (int i = 1; i < 126; ++i) { if (h[2 + i]) { fprintf(stderr, " %d:%u", i, h[2 + i]); } }
+        fprintf(stderr, "; second expected leaves used by simulation:");
+        for (int i = 1; i < 126; ++i) { if (h[256 + i]) { fprintf(stderr, " %d:%u", i, h[256 + i]); } }
         fprintf(stderr, "\n");
     }
     return MZ_OK;

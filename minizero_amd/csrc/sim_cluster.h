@@ -275,7 +275,9 @@ __device__ __forceinline__ bool towerRunCluster(const float* __restrict__ params
 
 // dynamics trunk of one simulation on a cluster: every member fills its own copy of the input (parent hidden state + action planes), computes its
 // oc-tile of every layer and ends with the complete output x in its LDS tile T1.  nullptr: aborted.
-template <int H, int W, int CDYN_PAD, int CPAD>
+// MEMBERS = 4: member m computes oc-tile m, one pixel tile per wave; MEMBERS = 2 (the pairs of sim_pre_pair_kernel_mz): member m computes oc-tiles 2 m and
+// 2 m + 1, wave w the pixel tile w % PT of oc-tile 2 m + w / PT
+template <int H, int W, int CDYN_PAD, int CPAD, int MEMBERS = 4>
 __device__ __forceinline__ float* towerBodyCluster(const float* __restrict__ params, const TowerArgs& ta, int tid, float* __restrict__ tiles,
                                                    const float* __restrict__ hidden_src, int action, int action_planes, ClusterCtx& c)
 {
@@ -307,8 +309,15 @@ __device__ __forceinline__ float* towerBodyCluster(const float* __restrict__ par
         }
     } else if (tid == 0 && action >= 0 && action < P) { Tin[CH * CS + (action / W + 1) * PW + (action % W) + 1] = 1.0f; }
     __syncthreads();
-    const bool work = c.member < ta.OT && wave < TM::PT;
-    if (!towerRunCluster<H, W, CDYN_PAD, CPAD, false>(params, ta, T0, T1, lane, tid, work ? c.member : -1, wave, c)) { return nullptr; }
+    if constexpr (MEMBERS == 2) {
+        static_assert(2 * TM::PT <= 8, "pairs: two oc-tiles x PT pixel tiles on the 8 waves");
+        const int ot = 2 * c.member + wave / TM::PT;
+        const bool work = wave < 2 * TM::PT && ot < ta.OT;
+        if (!towerRunCluster<H, W, CDYN_PAD, CPAD, false>(params, ta, T0, T1, lane, tid, work ? ot : -1, wave % TM::PT, c)) { return nullptr; }
+    } else {
+        const bool work = c.member < ta.OT && wave < TM::PT;
+        if (!towerRunCluster<H, W, CDYN_PAD, CPAD, false>(params, ta, T0, T1, lane, tid, work ? c.member : -1, wave, c)) { return nullptr; }
+    }
     return T1;
 }
 
@@ -584,9 +593,9 @@ __global__ void xcc_probe_kernel(unsigned* out)
 }
 // true if workgroups whose ids differ by a multiple of `gpad` share an XCD, i.e. if the members of a cluster will (checked once per network before the
 // first cluster launch; the kernel checks again and refuses to run otherwise)
-static bool clusterPlacementOk(int gpad, hipStream_t s)
+static bool clusterPlacementOk(int gpad, hipStream_t s, int members = kClMembers)
 {
-    const int n = kClMembers * gpad;
+    const int n = members * gpad;
     unsigned* d = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&d), size_t(n) * sizeof(unsigned)) != hipSuccess) { return false; }
     std::vector<unsigned> h(n, 99u);

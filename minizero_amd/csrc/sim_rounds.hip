@@ -448,7 +448,7 @@ int Net::simPreEvalBatchMz(int games, int max_depth, int s0, int R, int epoch, b
         if ((rc = launchPreFc<2, 16, false>(r2, v2, NS, ldo, stream_))) { return rc; }
     } else {
         if ((rc = launchPreFc<1, 51, true>(r1, v1, NS, 0, stream_))) { return rc; }
-        if ((rc = launchPreFc<1, 32, false>(r2, v2, NS, ldo, stream_))) { return rc; }
+        if ((rc = launchPreFc<1, 16, false>(r2, v2, NS, ldo, stream_))) { return rc; }
     }
     {
         const size_t lds = (2 * size_t((size + 3) & ~3) + ((hp.C * hp.P + 3) & ~3) + ((hp.PC * hp.P + 3) & ~3) + 3 * size_t((a.A + 3) & ~3)) * sizeof(float) + azCandSmemBytes(a.A);

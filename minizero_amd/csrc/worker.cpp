@@ -388,6 +388,7 @@ public:
             int rc = L->net->simPreStats(&hits, &evals, &alt);
             if (rc) { return rc; }
             out->pre_hits += hits; out->pre_evals += evals; out->pre_alt_hits += alt;
+            out->pre_pair_launches += L->net->pre_pair_launches_;
         }
         return MZ_OK;
     }
@@ -553,6 +554,7 @@ private:
     struct Round { int s0, R; float p_event = 0.0f; bool alt = false; }; // p_event: share of the recent moves in which a simulation of the round missed its leaf / took the second one
     std::vector<unsigned> prestat_prev_; // the counters as of the previous move (summed over the lanes)
     void adaptRounds();
+    bool pairsUsable() { return cfg_.mz_sim_round_pairs && lanes_.size() == 1 && net0().pairsAvailable(); } // two workgroups per leaf (sim.hip sim_pre_pair_kernel_mz)
     int slab_slots_ = 0;        // hidden-state slots per game
     std::vector<Round> rounds_; // mz_sim_rounds: the rounds of a move whose leaves are evaluated ahead (first simulation, size), from the Gumbel schedule of (n, m)
     void planRounds();
@@ -753,7 +755,7 @@ void Worker::planRounds()
         int R = 0;
         for (int i = 0; i < ncand; ++i) { if (cnt[i] == mn) { ++cnt[i]; ++R; } }
         R = std::min(R, n - s + 1);
-        if (R >= kMinRound) { rounds_.push_back({s, R}); }
+        if (R >= kMinRound) { rounds_.push_back({s, R}); rounds_.back().alt = !lanes_.empty() && 2 * G_ * R <= net0().cuCount(); } // (the second leaves from the first move on where they fit: adaptRounds takes them away where they are not used)
         s += R;
     }
 }
@@ -766,18 +768,25 @@ void Worker::planRounds()
 // evaluated ahead never changes a record (sim.hip simPreProbe); the batched pipeline (sim_rounds.hip) evaluates the doubled round with two leaves per workgroup.
 void Worker::adaptRounds()
 {
-    if (!cfg_.mz_sim_round_alt || !cfg_.mz_sim_round_batch || sim_mode_.alt_base == 0) { return; }
+    if (!cfg_.mz_sim_round_alt || sim_mode_.alt_base == 0) { return; }
     unsigned now[512] = {0};
     for (auto& L : lanes_) {
         if (!L->h_prestat.p) { return; }
         for (int i = 0; i < 512; ++i) { now[i] += L->h_prestat.p[i]; }
     }
+    if (now[129] != 0) { for (auto& L : lanes_) { L->net->pairTrouble(); } } // (sim_pre_pair_kernel_mz: a partner workgroup stayed out — the GPU is shared)
     if (prestat_prev_.size() == 512) {
+        const int cus = net0().cuCount();
         for (Round& rd : rounds_) {
             bool ev = false;
             for (int s = rd.s0; s < rd.s0 + rd.R && s < 126; ++s) { ev = ev || now[2 + s] != prestat_prev_[2 + s] || now[256 + s] != prestat_prev_[256 + s]; }
             rd.p_event = 0.875f * rd.p_event + (ev ? 0.125f : 0.0f);
-            if (rd.p_event > 0.5f) { rd.alt = true; } else if (rd.p_event < 0.25f) { rd.alt = false; }
+            // what the second leaves cost the round (us on BASELINE configs[4]) against a miss's 150 us: a round that fits the chip twice gives up its pairs of
+            // workgroups per leaf (~30; nothing where pairs are not available: always on), a larger one doubles its evaluations (~80, batched pipeline only)
+            const bool small = 2 * G_ * rd.R <= cus;
+            if (!small && !cfg_.mz_sim_round_batch) { rd.alt = false; continue; }
+            const float cost = small ? (pairsUsable() ? 30.0f : 0.0f) : 80.0f;
+            if (rd.p_event * 150.0f > 1.3f * cost || cost == 0.0f) { rd.alt = true; } else if (rd.p_event * 150.0f < 0.6f * cost) { rd.alt = false; }
         }
     }
     prestat_prev_.assign(now, now + 512);
@@ -1834,7 +1843,7 @@ int Worker::runCyclesSim(int n)
                             rcp = L->net->simPreEvalBatchMz(L->n, L->pool.v_.max_depth, sim0 + c0, pre_R[part], L->pre_epoch, &pre, cfg_.mz_sim_round_leaves, pre_alt[part]);
                             if (pre) { ++stats_.pre_batch_launches; }
                         }
-                        if (!rcp && !pre) { rcp = L->net->simPreEvalMz(L->n, L->pool.v_.max_depth, sim0 + c0, pre_R[part], L->pre_epoch, &pre); }
+                        if (!rcp && !pre) { rcp = L->net->simPreEvalMz(L->n, L->pool.v_.max_depth, sim0 + c0, pre_R[part], L->pre_epoch, &pre, pre_alt[part] || !pairsUsable(), pairsUsable()); }
                         if (rcp) { return rcp; }
                         if (pre) { ++stats_.sim_launches; ++stats_.pre_launches; }
                     }
@@ -2175,7 +2184,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
         MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_rng_streams) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
-        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_sim_round_alt) MZ_FIXED(mz_sim_round_batch) MZ_FIXED(mz_sim_round_leaves) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_sim_round_alt) MZ_FIXED(mz_sim_round_batch) MZ_FIXED(mz_sim_round_pairs) MZ_FIXED(mz_sim_round_leaves) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
         // the Atari-shaped environments keep a window of screens sized from these three at creation (ref atari.cpp:87); records of a larger window
         // would miss frames, so they are fixed where observations are kept (board games: free to change, like the reference)
         if (games_[0].env->hasObservations()) { MZ_FIXED(zero_actor_intermediate_sequence_length) MZ_FIXED(learner_n_step_return) MZ_FIXED(learner_muzero_unrolling_step) }

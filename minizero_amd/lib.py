@@ -36,7 +36,7 @@ class WorkerStats(C.Structure):
                 ("ms_select", C.c_double), ("ms_env", C.c_double), ("ms_forward", C.c_double), ("ms_expand", C.c_double),
                 ("ms_move", C.c_double), ("ms_total", C.c_double), ("sim_launches", C.c_uint64), ("sim_cycles", C.c_uint64),
                 ("pre_evals", C.c_uint64), ("pre_hits", C.c_uint64), ("pre_alt_hits", C.c_uint64), ("pre_launches", C.c_uint64),
-                ("pre_batch_launches", C.c_uint64)]
+                ("pre_batch_launches", C.c_uint64), ("pre_pair_launches", C.c_uint64)]
 
 
 NET_TYPES = {"alphazero": 0, "muzero": 1, "muzero_atari": 2}

@@ -368,7 +368,7 @@ def test_atari_cluster_pools_are_equivalent(mz, games):
 @pytest.mark.parametrize("games,extra", [(5, ""), (13, ""), (64, ""), (64, ":mz_sim_cluster=false"), (16, ":mz_sim_round_min=4"), (64, ":mz_sim_round_min=4"),
                                          (13, ":mz_sim_round_alt=false"), (64, ":mz_sim_round_alt=false"), (13, ":mz_sim_round_batch=false"),
                                          (64, ":mz_sim_round_batch=false"), (13, ":mz_sim_round_leaves=4"), (64, ":mz_sim_round_leaves=2"), (64, ":mz_sim_round_leaves=4"),
-                                         (7, ":mz_sim_round_leaves=2:mz_sim_round_alt=false"), (5, ":mz_sim_round_leaves=1"), (64, ":mz_sim_round_leaves=1")])
+                                         (7, ":mz_sim_round_leaves=2:mz_sim_round_alt=false"), (5, ":mz_sim_round_leaves=1"), (64, ":mz_sim_round_leaves=1"), (13, ":mz_sim_round_pairs=false"), (30, "")])
 def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
     """mz_sim_rounds (default): the leaves of a whole Gumbel round — the simulations between two halvings visit different root children — are evaluated side
     by side ahead of the simulations, which then run in order and skip tower + heads when their leaf is the one evaluated for them (sim.hip
@@ -394,6 +394,12 @@ def test_atari_gumbel_rounds_are_equivalent(mz, games, extra):
     assert son["pre_evals"] >= games * 4 * (moves - 1) and 0 < son["pre_hits"] <= son["pre_evals"]
     # round 1 (the root's children, visited once each) can never miss: at least those hits
     assert son["pre_hits"] >= games * 4 * (moves - 1)
+    # rounds that fit the chip twice and stop using their second expected leaves run every trunk on a PAIR of workgroups (sim_pre_pair_kernel_mz) — from the
+    # second move on, when the worker has seen a move's counters; not with the pipeline forced, and not where the key switches them off
+    if "mz_sim_round_leaves" not in extra and "mz_sim_round_alt=false" not in extra and "mz_sim_round_pairs=false" not in extra and 2 * (-(-games * 4 // 8) * 8) <= 256:
+        assert son["pre_pair_launches"] > 0, son
+    if "mz_sim_round_pairs=false" in extra:
+        assert son["pre_pair_launches"] == 0
     # the batched pipeline takes the rounds whose leaves outnumber the CUs (none in these pools) or every round when the leaves per workgroup are forced
     assert (son["pre_batch_launches"] > 0) == ("mz_sim_round_leaves" in extra) and son["pre_batch_launches"] <= son["pre_launches"]
     assert on == off and ron == roff and (len(on) >= 5 or games >= 64)
@@ -415,7 +421,9 @@ def test_atari_gumbel_rounds_other_shapes_match_the_oracle(mz, oracle, m, n):
     moves = 9
     og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
     og.cycles((n + 1) * moves)
-    wk = mz.Worker(conf + ":zero_num_threads=2", d, w)
+    # (the deep searches below check that second expected leaves are consumed: without the pairs of workgroups per leaf a round that fits the chip twice always
+    # evaluates them; with pairs — the default — it only does while the worker sees them used, Worker::adaptRounds)
+    wk = mz.Worker(conf + ":zero_num_threads=2" + (":mz_sim_round_pairs=false" if (m, n) in ((4, 90), (8, 100)) else ""), d, w)
     wk.command("start")
     for _ in range(moves):
         assert wk.run_cycles(n + 1) == n + 1
