@@ -36,8 +36,10 @@ def load(d):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for f in glob.glob(f"{O}/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            # (the simulation kernels of a config: sim_kernel / sim_kernel_mz / sim_kernel_mz_cluster and, with Gumbel rounds, sim_pre_kernel_mz)
-            k = "sim_kernel" if ("sim_kernel" in r["Kernel_Name"] or "sim_pre_kernel" in r["Kernel_Name"]) else r["Kernel_Name"].split("(")[0][-40:]
+            # (the simulation kernels of a config: sim_kernel / sim_kernel_mz / sim_kernel_mz_cluster and, with Gumbel rounds, the kernels that evaluate a round's leaves
+            # ahead: sim_pre_kernel_mz, sim_pre_pair_kernel_mz, the batched pipeline pre_walk / pre_tower / pre_fc / pre_tail of sim_rounds.hip)
+            kn = r["Kernel_Name"]
+            k = "sim_kernel" if any(t in kn for t in ("sim_kernel", "sim_pre_kernel", "sim_pre_pair_kernel", "pre_walk_kernel", "pre_tower_kernel", "pre_fc_kernel", "pre_tail_kernel")) else kn.split("(")[0][-40:]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] in ("FETCH_SIZE", "GRBM_GUI_ACTIVE"): n[k] += 1
     return acc, n
@@ -69,6 +71,10 @@ timeout 600 python tools/run_configs.py c2 c3 c4 c5 --threads 1 --out $O/configs
 timeout 300 python tools/run_configs.py c5 --moves 450 --threads 1 --out $O/c5_450moves_threads1.json > /dev/null 2>&1
 timeout 300 python tools/run_configs.py c5 --moves 450 --out $O/c5_450moves.json > /dev/null 2>&1
 timeout 300 python tools/run_configs.py c5 --conf mz_sim_rounds=false --out $O/c5_no_rounds.json > /dev/null 2>&1
+# round 4: what each piece of the rounds' evaluation is worth on the same box (one workgroup per leaf everywhere = round 3's path; no pairs; no adaptive second leaves)
+timeout 300 python tools/run_configs.py c5 --conf mz_sim_round_batch=false:mz_sim_round_pairs=false --out $O/c5_round3_path.json > /dev/null 2>&1
+timeout 300 python tools/run_configs.py c5 --conf mz_sim_round_pairs=false --out $O/c5_no_pairs.json > /dev/null 2>&1
+timeout 600 python tools/run_configs.py c2 c3 c4 c5 --conf mz_rng_streams=1 --out $O/configs_one_rng_stream.json > /dev/null 2>&1
 # kernel timeline of one C5 move (which launches, how long, the gaps between them)
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_c5 -- python tools/run_configs.py c5 --moves 20 --out $O/tmp.json > /dev/null 2>&1
 python tools/c5_move_timeline.py $(find $O/trace_c5 -name "*kernel_trace.csv" | head -1) > $O/c5_move_timeline.txt 2>&1

@@ -16,7 +16,8 @@ MOVES = {"c1": 400, "c2": 4, "c3": 40, "c4": 20, "c5": 40}
 WARM = {"c5": 14}  # moves before the timed region (default 3: the first synchronisation of the third move takes 8 ms once): the Atari-shaped worker's first moves pay one-off host allocations
 KERNEL = {"c1": "sim_kernel<3,3,4,16,-1>", "c2": "sim_kernel<9,9,20,64,2>", "c3": "sim_kernel<8,8,4,64,0>", "c4": "sim_kernel_mz<9,9,20,68,64>",
           "c5": "the leaves of a Gumbel round evaluated side by side: pre_walk_kernel + pre_tower_kernel<6,6,84,64,4|2|1> + pre_fc_kernel x 2 + pre_tail_kernel "
-                "(sim_rounds.hip; mz_sim_round_batch=false: sim_pre_kernel_mz<6,6,84,64,2|4>), then sim_kernel_mz<6,6,64,84,64> (the simulations in order); "
+                "(sim_rounds.hip: the rounds whose leaves outnumber the CUs), sim_pre_pair_kernel_mz<6,6,84,64> (two workgroups per leaf: the rounds that fit the chip twice and do not "
+                "use their second expected leaves) or sim_pre_kernel_mz<6,6,84,64,2> (one workgroup per leaf), then sim_kernel_mz<6,6,64,84,64> (the simulations in order); "
                 "launches_by_kernel has the counts; mz_sim_rounds=false: sim_kernel_mz_cluster<6,6,84,64>"}
 
 
@@ -45,9 +46,12 @@ def _by_kernel(s0, s1, launches):
     if pre <= 0:
         return None
     batch = s1.get("pre_batch_launches", 0) - s0.get("pre_batch_launches", 0)
+    pairs = s1.get("pre_pair_launches", 0) - s0.get("pre_pair_launches", 0)
     out = {"sim_kernel_mz": launches - pre}
-    if pre - batch:
-        out["sim_pre_kernel_mz"] = pre - batch
+    if pre - batch - pairs:
+        out["sim_pre_kernel_mz"] = pre - batch - pairs
+    if pairs:
+        out["sim_pre_pair_kernel_mz"] = pairs
     if batch:
         out.update({"pre_walk_kernel": batch, "pre_tower_kernel": batch, "pre_fc_kernel": 2 * batch, "pre_tail_kernel": batch})
     return out
