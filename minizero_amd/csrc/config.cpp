@@ -24,7 +24,7 @@ const Key kKeys[] = {
     K(zero_disable_resign_ratio, T_FLOAT), K(zero_actor_intermediate_sequence_length, T_INT), K(zero_actor_ignored_command, T_STRING),
     K(learner_muzero_unrolling_step, T_INT), K(learner_n_step_return, T_INT), K(zero_num_games_per_iteration, T_INT), K(zero_replay_buffer, T_INT),
     K(learner_use_per, T_BOOL), K(learner_per_alpha, T_FLOAT), K(learner_per_init_beta, T_FLOAT), K(learner_batch_size, T_INT), K(nn_file_name, T_STRING), K(nn_type_name, T_STRING),
-    K(env_board_size, T_INT), K(env_go_komi, T_FLOAT), K(env_go_ko_rule, T_STRING), K(env_game, T_STRING), K(atari_init_q, T_BOOL), K(mz_pipeline_lanes, T_INT), K(mz_rng_streams, T_INT), K(mz_zero_copy, T_INT), K(mz_cpu_base, T_INT), K(mz_signal_wait, T_BOOL), K(mz_device_env, T_BOOL), K(mz_raw_observations, T_BOOL), K(mz_sim_kernel, T_BOOL), K(mz_sim_cluster, T_BOOL), K(mz_sim_split, T_BOOL), K(mz_sim_rounds, T_BOOL), K(mz_sim_round_min, T_INT), K(mz_sim_round_alt, T_BOOL), K(mz_sim_round_batch, T_BOOL), K(mz_sim_round_pairs, T_BOOL), K(mz_sim_round_leaves, T_INT), K(mz_manual_step, T_BOOL), K(mz_nn_precision, T_STRING), K(env_atari_name, T_STRING), K(env_atari_episode_length, T_INT),
+    K(env_board_size, T_INT), K(env_go_komi, T_FLOAT), K(env_go_ko_rule, T_STRING), K(env_game, T_STRING), K(atari_init_q, T_BOOL), K(mz_pipeline_lanes, T_INT), K(mz_rng_streams, T_INT), K(mz_zero_copy, T_INT), K(mz_cpu_base, T_INT), K(mz_signal_wait, T_BOOL), K(mz_device_env, T_BOOL), K(mz_raw_observations, T_BOOL), K(mz_sim_kernel, T_BOOL), K(mz_sim_cluster, T_BOOL), K(mz_sim_split, T_BOOL), K(mz_sim_rounds, T_BOOL), K(mz_sim_round_min, T_INT), K(mz_sim_round_alt, T_BOOL), K(mz_sim_round_batch, T_BOOL), K(mz_sim_rounds_board, T_BOOL), K(mz_sim_round_pairs, T_BOOL), K(mz_sim_round_leaves, T_INT), K(mz_manual_step, T_BOOL), K(mz_nn_precision, T_STRING), K(env_atari_name, T_STRING), K(env_atari_episode_length, T_INT),
 };
 #undef K
 

@@ -68,6 +68,7 @@ struct WorkerConfig {
     bool mz_sim_rounds = true;  // muzero_atari with a Gumbel root: the leaves of a whole Gumbel round (the simulations between two halvings visit different root children)
                                 // are evaluated side by side ahead of the simulations that consume them in order (sim.hip sim_pre_kernel_mz); false: every simulation evaluates its own leaf
     bool mz_sim_round_alt = true; // ... and, where a round leaves half of the CUs idle, a second expected leaf per simulation
+    bool mz_sim_rounds_board = true; // ... and for MuZero board games with a Gumbel root (one workgroup per leaf; pays where the pool leaves CUs idle)
     bool mz_sim_round_batch = true; // ... by the batched pipeline of sim_rounds.hip (false: one workgroup per leaf, sim.hip sim_pre_kernel_mz; same entries)
     bool mz_sim_round_pairs = true; // ... and a round that leaves half of the CUs idle and does not use its second leaves runs every trunk on two workgroups (sim.hip sim_pre_pair_kernel_mz)
     int mz_sim_round_leaves = 0;    // ... with this many leaves per trunk workgroup (1, 2, 4; 0 = as many as keep every CU busy)

@@ -909,12 +909,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, 4))) v
     if (ctl[0] == 0) { return; }
     const int src = ctl[1], action = ctl[2];
     __syncthreads(); // (the tower zeroes the tiles: the Gumbel scratch in them is done with)
-    const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(hp.C) * hp.P;
+    const size_t hsize = size_t(a->hp.C) * a->hp.P; // (the slab's geometry: both network types keep it in hp)
+    const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * hsize;
     float* xt = towerBody<H, W, CDYN_PAD, CPAD, (H * W <= 36)>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action, a->action_planes);
     __syncthreads();
     const size_t e = size_t(g) * a->slots + slot;
-    float* hd = a->hidden + e * size_t(hp.C) * hp.P;
-    atariHeadsBody<256>(nullptr, xt, planeStride(H, W), W + 2, hp, a->pre_policy, a->pre_logit, a->pre_value, a->pre_reward, hd, 1, 1, static_cast<int>(e), tid, head_scratch);
+    float* hd = a->hidden + e * hsize;
+    if (a->atari) {
+        atariHeadsBody<256>(nullptr, xt, planeStride(H, W), W + 2, hp, a->pre_policy, a->pre_logit, a->pre_value, a->pre_reward, hd, 1, 1, static_cast<int>(e), tid, head_scratch);
+    } else { // MuZero board games (round 4): rescale in place + slab store, policy and value heads exactly as sim_kernel_mz's simMzHeads computes them; no reward head
+        const HeadParams bhp = ldc(&a->hp);
+        rescaleTile<H, W>(xt, bhp.C, hd, tid, tiles); // tile 0 (the blocks' temporary) is free: its first words hold the reduction scratch
+        headsBody(nullptr, bhp, a->pre_policy, a->pre_logit, a->pre_value, nullptr, nullptr, 0, static_cast<int>(e), tid, 512, tiles, xt, planeStride(H, W), W + 2);
+        if (tid == 0) { a->pre_reward[e] = 0.0f; }
+    }
     __syncthreads();
     if (wave == 0) { // the leaf's candidate list in the reference's order (simMzCandGather + orderCandidates of a non-root leaf: all A actions), in place of the raw outputs
         const int A = a->A;
@@ -1080,11 +1088,13 @@ static int launchSimMzT(const SimArgs* d_args, int games, int sim0, int nsims, i
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
 static int launchSimPreMzT(const SimArgs* d_args, int games, int s0, int R, int NH, int epoch, size_t lds, hipStream_t s, bool dense)
 {
-    if (dense) {
-        MZ_LDS_ATTR((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 4>), lds);
-        hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 4>), dim3(games * R * NH), dim3(512), lds, s, d_args, s0, R, NH, epoch);
-        MZ_HIP(hipGetLastError());
-        return MZ_OK;
+    if constexpr (H * W <= 36) {
+        if (dense) {
+            MZ_LDS_ATTR((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 4>), lds);
+            hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 4>), dim3(games * R * NH), dim3(512), lds, s, d_args, s0, R, NH, epoch);
+            MZ_HIP(hipGetLastError());
+            return MZ_OK;
+        }
     }
     MZ_LDS_ATTR((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 2>), lds);
     hipLaunchKernelGGL((sim_pre_kernel_mz<H, W, CDYN_PAD, CPAD, 2>), dim3(games * R * NH), dim3(512), lds, s, d_args, s0, R, NH, epoch);
@@ -1100,6 +1110,9 @@ static int launchSimPreMzT(const SimArgs* d_args, int games, int s0, int R, int 
 #define MZ_SIM_MZ_CLUSTER_CASES(X) /* the instances that also exist as four-workgroup clusters */ \
     X(6, 6, 64, 84, 64) \
     X(6, 6, 32, 52, 32)
+#define MZ_SIM_MZ_BOARD_PRE_CASES(X) /* MuZero board games whose Gumbel rounds are evaluated ahead (sim_pre_kernel_mz, one workgroup per leaf) */ \
+    X(9, 9, 20, 68, 64) \
+    X(9, 9, 20, 12, 8)
 
 template <int H, int W, int CIN0_PAD, int CPAD, int CPL, bool BF = false>
 static int launchSimT(const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, size_t lds, hipStream_t s)
@@ -1348,6 +1361,8 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     } else {
         makeHeadParams(&a.hp);
         a.action_planes = 1;
+        // (with Gumbel rounds the next simulation's Gumbel step runs beside expand + backup of a leaf that was evaluated ahead, in the block the muzero_atari heads use)
+        if (gum && mode.rounds) { head_floats = (gumbelSmemBytes(desc_.action_size) + 3) / 4; }
     }
     a.pv = pool.v_;
     a.params = params_.p;
@@ -1365,7 +1380,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.use_gumbel = gum ? 1 : 0;
     if (gum) { a.gum = *gum; }
     a.start = d_start;
-    if (atari && gum) { // leaves evaluated ahead of their simulations (sim_pre_kernel_mz): one entry per (game, slot)
+    if (gum && (atari || mode.rounds)) { // leaves evaluated ahead of their simulations (sim_pre_kernel_mz): one entry per (game, slot)
         const size_t ne = size_t(pool.v_.games) * slots, A = size_t(desc_.action_size);
         if (pre_key_.n != ne * 4) {
             if (!pre_key_.alloc(ne * 4) || !pre_out_.alloc(ne * (3 * A + 2)) || !pre_stat_.alloc(512)) { setError("hipMalloc of the pre-evaluation entries failed"); return MZ_ERR_DEVICE; }
@@ -1460,18 +1475,20 @@ int Net::simRootNoiseMz(int games)
 int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* launched, bool want_alt, bool pairs)
 {
     *launched = false;
-    if (desc_.type != 2 || R < 1 || epoch == 0 || pre_key_.n == 0 || sim_args_host_.size() != sizeof(SimArgs)) { return MZ_OK; }
+    if ((desc_.type != 2 && desc_.type != 1) || R < 1 || epoch == 0 || pre_key_.n == 0 || sim_args_host_.size() != sizeof(SimArgs)) { return MZ_OK; }
     const SimArgs& a = *reinterpret_cast<const SimArgs*>(sim_args_host_.data());
     if (!a.pre_key || !a.use_gumbel) { return MZ_OK; }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
-    TowerArgs t2;
-    int cd = 0;
+    TowerArgs t1, t2;
+    int cd = 0, c0 = C; // (muzero_atari: the CIN0_PAD = C instances, its representation runs stand-alone)
+    if (desc_.type == 1 && !makeTowerArgs(repr_, true, true, &t1, &c0)) { return MZ_OK; }
     if (!makeTowerArgs(dyn_, false, true, &t2, &cd)) { return MZ_OK; }
-    const int c0 = C, cmax = std::max(cd, C);
+    const int cmax = std::max(cd, C);
     const size_t tile_bytes = size_t(cmax + C) * planeStride(H, W) * sizeof(float);
     if (gumbelSmemBytes(a.A) > tile_bytes) { return MZ_OK; }
     const size_t ctl_words = (4 + 4 + kGumbelMaxSample + 2 * size_t(max_depth) + 2 + 3) & ~size_t(3);
-    const size_t lds = tile_bytes + ctl_words * sizeof(int) + atariHeadsSmemFloats(a.ahp) * sizeof(float);
+    size_t lds = tile_bytes + ctl_words * sizeof(int) + (desc_.type == 2 ? atariHeadsSmemFloats(a.ahp) * sizeof(float) : 0);
+    if (desc_.type == 1) { lds = std::max(lds, size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float)); } // (the tower's zero fill covers two tiles of cmax channels; the board heads' scratch is tile 0)
     if (lds > 160 * 1024 || size_t(kTowerTiles) * cmax * planeStride(H, W) * sizeof(float) > lds) { return MZ_OK; }
     // the second expected leaf of every simulation rides along where the round leaves half of the CUs idle (the rounds of two on a pool of 64 games) and the
     // worker wants it (Worker::adaptRounds: while the round's simulations keep needing it); without it the idle half of the chip shortens the trunks instead
@@ -1511,6 +1528,10 @@ int Net::simPreEvalMz(int games, int max_depth, int s0, int R, int epoch, bool* 
     if (h * w <= 36 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimPreMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), games, s0, R, NH, epoch, lds, stream_, dense); }
     MZ_SIM_MZ_CLUSTER_CASES(MZ_SIM_PRE_LAUNCH)
 #undef MZ_SIM_PRE_LAUNCH
+#define MZ_SIM_PRE_LAUNCH_B(h, w, cin0, cdyn, cpad) \
+    if (desc_.type == 1 && H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { *launched = true; return launchSimPreMzT<h, w, cin0, cdyn, cpad>(reinterpret_cast<const SimArgs*>(sim_args_.p), games, s0, R, NH, epoch, lds, stream_, false); }
+    MZ_SIM_MZ_BOARD_PRE_CASES(MZ_SIM_PRE_LAUNCH_B)
+#undef MZ_SIM_PRE_LAUNCH_B
     return MZ_OK;
 }
 

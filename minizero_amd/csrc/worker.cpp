@@ -691,7 +691,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         defer_info_ = !cfg_.mz_manual_step;
         sim_root_host_ = desc.type == 2;
         { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
-        if (dev_gumbel_ && desc.type == 2 && cfg_.mz_sim_rounds && cfg_.mz_sim_split) {
+        if (dev_gumbel_ && (desc.type == 2 || (desc.type == 1 && cfg_.mz_sim_rounds_board)) && cfg_.mz_sim_rounds && cfg_.mz_sim_split) {
             planRounds();
             for (auto& L : lanes_) {
                 if (!L->h_prestat.alloc(512)) { setError("worker: allocation failed (round counters)"); return MZ_ERR_DEVICE; }
@@ -1796,7 +1796,9 @@ int Worker::runCyclesSim(int n)
         }
         // Gumbel rounds (mz_sim_rounds, muzero_atari): the launch is cut at the rounds whose leaves are evaluated ahead — [evaluation of the round's leaves]
         // [its simulations, which consume them in order] — with the stretches between them as ordinary parts; all queued back to back, no host step between
-        const bool use_rounds = root_on_device && !rounds_.empty() && sim0 == 1;
+        // (muzero_atari: the launch starts at simulation 1, behind the device-side root expansion; MuZero board games: at simulation 0, the root's initial inference,
+        // which goes out as a part of its own in front of the first round — a call that covers the whole move)
+        const bool use_rounds = !rounds_.empty() && ((root_on_device && sim0 == 1) || (!sim_root_host_ && sim_mz_ && sim0 == 0 && batch == n_ + 1 && cfg_.mz_sim_split));
         if (use_rounds) {
             parts = 0;
             int at = 0; // offset inside the batch
@@ -1835,7 +1837,7 @@ int Worker::runCyclesSim(int n)
                 const bool hg = host_gumbel && part == 0 && !root_on_device;
                 if (use_rounds) {
                     // the first round needs the noisy logits before simulation 1 runs: the noise goes out as a launch of its own
-                    if (part == 0 && noise_in_batch) { int rcn = L->net->simRootNoiseMz(L->n); if (rcn) { return rcn; } }
+                    if (sim0 + c0 == 1 && noise_in_batch) { int rcn = L->net->simRootNoiseMz(L->n); if (rcn) { return rcn; } }
                     if (pre_R[part] > 0) {
                         bool pre = false;
                         int rcp = MZ_OK;
@@ -2184,7 +2186,7 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         MZ_FIXED(actor_gumbel_sigma_visit_c) MZ_FIXED(actor_gumbel_sigma_scale_c) MZ_FIXED(zero_num_threads) MZ_FIXED(zero_num_parallel_games)
         MZ_FIXED(nn_type_name) MZ_FIXED(env_board_size) MZ_FIXED(env_go_komi) MZ_FIXED(env_go_ko_rule) MZ_FIXED(env_game) MZ_FIXED(atari_init_q)
         MZ_FIXED(env_atari_name) MZ_FIXED(env_atari_episode_length) MZ_FIXED(mz_pipeline_lanes) MZ_FIXED(mz_rng_streams) MZ_FIXED(mz_cpu_base) MZ_FIXED(mz_signal_wait)
-        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_sim_round_alt) MZ_FIXED(mz_sim_round_batch) MZ_FIXED(mz_sim_round_pairs) MZ_FIXED(mz_sim_round_leaves) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
+        MZ_FIXED(mz_sim_kernel) MZ_FIXED(mz_sim_cluster) MZ_FIXED(mz_sim_split) MZ_FIXED(mz_sim_rounds) MZ_FIXED(mz_sim_round_min) MZ_FIXED(mz_sim_round_alt) MZ_FIXED(mz_sim_round_batch) MZ_FIXED(mz_sim_rounds_board) MZ_FIXED(mz_sim_round_pairs) MZ_FIXED(mz_sim_round_leaves) MZ_FIXED(mz_manual_step) MZ_FIXED(mz_nn_precision) MZ_FIXED(mz_raw_observations) MZ_FIXED(mz_device_env) MZ_FIXED(mz_zero_copy)
         // the Atari-shaped environments keep a window of screens sized from these three at creation (ref atari.cpp:87); records of a larger window
         // would miss frames, so they are fixed where observations are kept (board games: free to change, like the reference)
         if (games_[0].env->hasObservations()) { MZ_FIXED(zero_actor_intermediate_sequence_length) MZ_FIXED(learner_n_step_return) MZ_FIXED(learner_muzero_unrolling_step) }

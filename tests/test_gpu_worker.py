@@ -438,6 +438,37 @@ def test_atari_gumbel_rounds_other_shapes_match_the_oracle(mz, oracle, m, n):
         assert st["pre_alt_hits"] > 0
 
 
+@pytest.mark.parametrize("games,n,m", [(5, 12, 8), (9, 16, 16), (3, 50, 16), (70, 9, 4)])
+def test_go_muzero_gumbel_rounds_are_equivalent(mz, oracle, games, n, m):
+    """Round 4: the Gumbel rounds of a MuZero BOARD game (mz_sim_rounds_board, default): the leaves of a round are evaluated ahead by sim_pre_kernel_mz with the board
+    heads (rescale + policy + tanh value, no reward), the root's initial inference is simulation 0 of the move's first launch and the noise goes out as its own
+    launch before the first round.  Records of whole-move calls must equal those without rounds and the oracle's; the counters must show leaves found."""
+    conf = (f"env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation={n}:zero_num_parallel_games={games}:actor_use_dirichlet_noise=false:"
+            f"actor_use_gumbel=true:actor_use_gumbel_noise=true:actor_gumbel_sample_size={m}")
+    args = ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "muzero")
+    kw = dict(vh=args[10], dv=args[11], type_name=args[12])
+    d, od = mz.make_desc(*args[:10], **kw), oracle.make_desc(*args[:10], **kw)
+    w = mz.generate_weights(d, 6)
+    moves = 40 if games < 20 else 12
+
+    def run(extra, chunks):
+        wk = mz.Worker(conf + extra + ":program_seed=19:nn_file_name=x.pt:zero_num_threads=2", d, w)
+        wk.command("start")
+        for c in chunks:
+            assert wk.run_cycles(c) == c
+        return wk.pop_lines(), wk.peek_records(games), wk.stats()
+
+    on, ron, son = run("", [n + 1] * moves)
+    off, roff, soff = run(":mz_sim_rounds_board=false", [n + 1] * moves)
+    assert soff["pre_evals"] == 0 and son["pre_evals"] > 0 and son["pre_hits"] >= games * min(m, n) * (moves - 1)  # at least the first round of every move
+    assert on == off and ron == roff
+    mixed, rmixed, _ = run("", [n + 1, 5, n - 4, 2 * (n + 1), (n + 1) * (moves - 4)])  # calls that end inside a move take the ordinary path for it
+    assert mixed == off and rmixed == roff
+    og = oracle.OracleGroup(conf + ":program_seed=19:nn_file_name=x.pt:zero_num_threads=1", od, w)
+    og.cycles((n + 1) * moves)
+    assert on == og.lines() and ron == og.peek_records(games)
+
+
 def test_go_muzero_gumbel_execution_modes_are_equivalent(mz, oracle):
     """MuZero board game with a Gumbel root: device Gumbel step + noise on the logits inside sim_kernel_mz vs lock-step vs oracle."""
     conf = ("env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=12:zero_num_parallel_games=5:actor_use_dirichlet_noise=false:"

@@ -40,6 +40,14 @@ def flops_per_leaf_eval(d):
     return conv, heads
 
 
+# beyond BASELINE.json: the shapes the reference's own worker script defaults to (scripts/zero-worker.sh:39: 64 games per GPU) with a Gumbel root — pools that leave most
+# CUs idle with one workgroup per game, where evaluating a Gumbel round's leaves side by side pays (round 4: MuZero board games too)
+EXTRA_CONFIGS = {
+    "c4g64": ("c4", "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=50:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+                    "actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:zero_num_parallel_games=64"),
+}
+
+
 def _by_kernel(s0, s1, launches):
     """Gumbel rounds (C5): how many launches of which kernel the `launches` rounds + simulation stretches were (worker stats)."""
     pre = s1.get("pre_launches", 0) - s0.get("pre_launches", 0)
@@ -60,15 +68,17 @@ def _by_kernel(s0, s1, launches):
 def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     """One config on device 0: a fresh worker, `warm` untimed moves, `moves` timed moves (one run_cycles call per move, like the `-mode sp`
     loop).  Returns the block bench.py (`other_configs`) and profiles/rNN_all_configs_n1.json both carry."""
-    d = mz.DESCS[key]()
+    dkey, base = EXTRA_CONFIGS.get(key, (key, None))
+    base = base or mz.CONFIGS[key]
+    d = mz.DESCS[dkey]()
     if threads is None:
         threads = max(1, mz.usable_cpus() - 1)
-    conf = f"{mz.CONFIGS[key]}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_rng_streams=0:mz_cpu_base=0{extra_conf}"
-    n = int(mz.CONFIGS[key].split("actor_num_simulation=")[1].split(":")[0])
-    games = int(mz.CONFIGS[key].split("zero_num_parallel_games=")[1].split(":")[0])
+    conf = f"{base}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_rng_streams=0:mz_cpu_base=0{extra_conf}"
+    n = int(base.split("actor_num_simulation=")[1].split(":")[0])
+    games = int(base.split("zero_num_parallel_games=")[1].split(":")[0])
     wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
     wk.command("start")
-    moves = moves or MOVES[key]
+    moves = moves or MOVES.get(key, 20)
     wk.run_cycles((WARM.get(key, 3) if warm is None else warm) * (n + 1))
     s0 = wk.stats()
     t0 = time.perf_counter()
@@ -87,8 +97,8 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     res = {"leaf_evals_per_sec": evals / dt, "ms_per_move": dt / moves * 1e3, "moves_per_sec": (s1["moves"] - s0["moves"]) / dt,
            "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "records_popped_between_moves": popped, "host_threads": threads if key != "c1" else 1,
            "leaves_evaluated_ahead": s1.get("pre_evals", 0) - s0.get("pre_evals", 0), "simulations_that_found_their_leaf": s1.get("pre_hits", 0) - s0.get("pre_hits", 0),
-           "config": mz.CONFIGS[key],
-           "roofline": {"kernel": KERNEL[key], "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "config": base,
+           "roofline": {"kernel": KERNEL.get(key, KERNEL.get(dkey)), "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": (ach / F32_MFMA_PEAK_TFLOPS) if ach else None, "launches": launches,
                         "launches_by_kernel": _by_kernel(s0, s1, launches),
                         "avg_launch_ms": gpu_ms / launches if launches else None, "flops_per_leaf_eval": conv + heads,
