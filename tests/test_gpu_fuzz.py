@@ -64,8 +64,16 @@ def test_random_configuration_matches_oracle(mz, oracle, seed):
     d, od = mz.make_desc(*dargs, **kw), oracle.make_desc(*dargs, **kw)
     w = mz.generate_weights(d, wseed)
     conf = f"{conf}:program_seed={pseed}:nn_file_name=/tmp/fuzz_{wseed}.pt"
-    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    # (round 4, from a generator of its own so that a seed's configuration stays what it was) the number of host RNG streams — the oracle then runs as many slave
+    # threads with the same static partition of the actors —, and for MuZero with a Gumbel root calls of whole moves: the Gumbel-round path of the board games
+    rng4 = np.random.default_rng(4000 + seed)
+    streams = int(rng4.choice([1, 1, 1, 2, 3, 4]))
+    if typ == "muzero" and "actor_use_gumbel=true" in conf and rng4.random() < 0.6:
+        n = int(conf.split("actor_num_simulation=")[1].split(":")[0])
+        chunks = [n + 1, n + 1, 2 * (n + 1), int(rng4.integers(1, n + 1)), 3 * (n + 1)]
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1" + (f":oracle_throughput_threads={streams}" if streams > 1 else ""), od, w)
     og.cycles(cycles)
+    wextra += f":mz_rng_streams={streams}"
     wk = mz.Worker(conf + ":zero_num_threads=2" + wextra, d, w)
     wk.command("start")
     done, k = 0, 0
@@ -129,8 +137,10 @@ def test_random_atari_configuration_matches_oracle(mz, oracle, seed):
     d, od = mz.make_desc(*dargs, **kw), oracle.make_desc(*dargs, **kw)
     w = mz.generate_weights(d, wseed)
     conf = f"{conf}:program_seed={pseed}:nn_file_name=/tmp/fuzz_atari_{wseed}.pt"
-    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    streams = int(np.random.default_rng(4000 + seed).choice([1, 1, 1, 2, 3, 4]))  # (round 4) host RNG streams = the oracle's slave threads, same static partition
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1" + (f":oracle_throughput_threads={streams}" if streams > 1 else ""), od, w)
     og.cycles(cycles)
+    wextra += f":mz_rng_streams={streams}"
     wk = mz.Worker(conf + ":zero_num_threads=2" + wextra, d, w)
     wk.command("start")
     done, k = 0, 0
