@@ -18,14 +18,32 @@
 
 namespace mz {
 
-// NL boards of H x W stacked in one padded plane: a zero row above the first board and below each board (shared by neighbours), a zero column left and right
+// NL boards of H x W stacked in one padded plane: a zero row above the first board and below each board (shared by neighbours) and ONE zero column per row, which is
+// the left border of its row and the right border of the row above (row stride W + 1).  With W + 2 columns the 16 pixels of an MFMA tile could only fall on 12 of
+// the 16 residues mod 16 (the B operand's ds_read_b32 then has two-way bank conflicts on a quarter of its lanes: 42 % conflict cycles with four leaves per
+// workgroup); an odd row stride spreads the positions over all residues, and tile t takes the t-th pixel of every residue class (net_body.h TileMap).
 template <int H, int W, int NL>
 struct StackGeo {
-    static constexpr int PW = W + 2, ROWS = 1 + NL * (H + 1), POS = ROWS * PW, DUMP = POS, P = H * W, PIX = NL * P;
+    static constexpr int PW = W + 1, ROWS = 1 + NL * (H + 1), POS = ROWS * PW + 1, DUMP = POS, P = H * W, PIX = NL * P;
     static constexpr int CS = POS + 1 + ((16 - (POS + 1) % 32) + 32) % 32; // > POS (the spare float), % 32 == 16 (net_dev.h planeStride)
     static constexpr int PT = (PIX + 15) / 16, PT0 = (PT + 1) / 2, PT1 = PT - PT0;
     __host__ __device__ static constexpr int pos(int j, int p) { return (1 + j * (H + 1) + p / W) * PW + p % W + 1; }
+    short q[PT * 16]; // pixel (leaf * P + point) of tile t, column n; -1: padding column
+    constexpr StackGeo() : q{}
+    {
+        for (int i = 0; i < PT * 16; ++i) { q[i] = -1; }
+        int cnt[16] = {};
+        short over[PIX + 1] = {};
+        int nover = 0;
+        for (int i = 0; i < PIX; ++i) {
+            const int r = pos(i / P, i % P) & 15;
+            if (cnt[r] < PT) { q[cnt[r]++ * 16 + r] = short(i); } else { over[nover++] = short(i); }
+        }
+        for (int sl = 0, k = 0; sl < PT * 16 && k < nover; ++sl) { if (q[sl] < 0) { q[sl] = over[k++]; } }
+    }
 };
+template <int H, int W, int NL>
+__device__ const StackGeo<H, W, NL> kStackGeo{};
 
 template <int H, int W, int NL, int NT>
 __device__ __forceinline__ PixSet<NT> makeStackPixSet(int lane, int tile0)
@@ -34,10 +52,10 @@ __device__ __forceinline__ PixSet<NT> makeStackPixSet(int lane, int tile0)
     PixSet<NT> px;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int q = (tile0 + j) * 16 + (lane & 15);
-        const bool real = q < G::PIX;
+        const int q = kStackGeo<H, W, NL>.q[(tile0 + j) * 16 + (lane & 15)];
+        const bool real = q >= 0;
         const int pp = real ? G::pos(q / G::P, q % G::P) : G::PW + 1;
-        px.q[j] = real ? q : -1;
+        px.q[j] = q;
         px.dst[j] = real ? pp : G::DUMP;
         px.off[j] = (lane >> 4) * G::CS + pp - G::PW - 1;
     }
@@ -162,52 +180,60 @@ __global__ __launch_bounds__(512) void pre_tower_kernel(const SimArgs* __restric
             towerIdle(ta);
         }
     }
-    // x = T1; T0 is free: per leaf the dense copies of the state and the heads' conv outputs
+    // x = T1; T0 is free: the leaves' dense copies of the state and the heads' conv outputs.  The NL leaves go through the steps TOGETHER, a group of 512 / NL
+    // threads per leaf (one leaf after the other on all 512 threads was 4 x 4 barriers of latency-bound work: 28 us of the 300 with four leaves)
     const int n1r = hp.reward.hc * P, n1v = hp.value.hc * P, n1 = n1r > n1v ? n1r : n1v;
-    float* xr = T0;                  // [C * P] the trunk's output (the reward head reads the UNscaled state)
-    float* xs = xr + C * P;          // [C * P] the rescaled state (value head, policy head, the slab)
-    float* redp = xs + C * P;        // [32]
-    float* fall = redp + 32;         // [NL][2][n1] conv1x1 + ReLU outputs of the two heads
-    const int half = tid >> 8, t = tid & 255;
-    for (int j = 0; j < NL; ++j) {
-        if (s_ctl[j].x == 0) { continue; } // (uniform)
-        for (int i = tid; i < C * P; i += 512) {
+    constexpr int TPL = 512 / NL, WPL = TPL / 64;      // threads / waves per leaf
+    float* xall = T0;                                  // [NL][C * P] the trunk's output, rescaled in place after the reward head's conv has read it
+    float* redp = xall + size_t(NL) * C * P;           // [2][8] per-wave minima / maxima
+    float* fall = redp + 32;                           // [NL][2][n1] conv1x1 + ReLU outputs of the two heads
+    const int j = tid / TPL, t = tid - j * TPL;        // this thread's leaf and its index in the leaf's group
+    const bool live = s_ctl[j].x != 0;
+    float* xr = xall + size_t(j) * C * P;
+    if (live) {
+        for (int i = t; i < C * P; i += TPL) {
             const int c = i / P, p = i - c * P;
             xr[i] = T1[c * CS + G::pos(j, p)];
         }
-        __syncthreads();
-        // scale_hidden_state (ref muzero_atari_network.py:189-198): exact min / max, one IEEE operation per element (net_atari_body.h atariHeadsBody)
+    }
+    __syncthreads();
+    // scale_hidden_state (ref muzero_atari_network.py:189-198): exact min / max (order-free), one IEEE operation per element (net_atari_body.h atariHeadsBody);
+    // the reward head's conv reads the UNscaled state: before the rescale
+    {
         float mn = 3.4e38f, mx = -3.4e38f;
-        for (int i = tid; i < C * P; i += 512) { const float v = xr[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        if (live) { for (int i = t; i < C * P; i += TPL) { const float v = xr[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; } }
         for (int o = 32; o > 0; o >>= 1) {
             const float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
             mn = m2 < mn ? m2 : mn;
             mx = x2 > mx ? x2 : mx;
         }
         if (lane == 0) { redp[wave] = mn; redp[16 + wave] = mx; }
-        __syncthreads();
-        mn = redp[0]; mx = redp[16];
-        for (int w = 1; w < 8; ++w) { mn = redp[w] < mn ? redp[w] : mn; mx = redp[16 + w] > mx ? redp[16 + w] : mx; }
+        if (live) { discreteConv<TPL>(hp.reward, xr, C, P, fall + (size_t(j) * 2 + 0) * n1, t); }
+    }
+    __syncthreads();
+    if (live) {
+        float mn = redp[j * WPL], mx = redp[16 + j * WPL];
+#pragma unroll
+        for (int w = 1; w < WPL; ++w) { mn = redp[j * WPL + w] < mn ? redp[j * WPL + w] : mn; mx = redp[16 + j * WPL + w] > mx ? redp[16 + j * WPL + w] : mx; }
         float scale = mx - mn;
         if (scale < 1e-5f) { scale += 1e-5f; }
         float* hd = a->hidden + size_t(s_ctl[j].w) * size_t(C) * P;
-        for (int i = tid; i < C * P; i += 512) {
+        for (int i = t; i < C * P; i += TPL) {
             const float v = (xr[i] - mn) / scale;
-            xs[i] = v;
+            xr[i] = v;
             hd[i] = v;
         }
-        __syncthreads();
-        // half 0: reward head's conv on the unscaled state, half 1: value head's conv on the rescaled state
-        discreteConv<256>(half == 0 ? hp.reward : hp.value, half == 0 ? xr : xs, C, P, fall + (size_t(j) * 2 + half) * n1, t);
-        __syncthreads();
     }
+    __syncthreads();
+    if (live) { discreteConv<TPL>(hp.value, xr, C, P, fall + (size_t(j) * 2 + 1) * n1, t); } // the value head's conv on the rescaled state
+    __syncthreads();
     // feature-major stores: NL adjacent samples per feature
     for (int i = tid; i < 2 * n1; i += 512) {
         const int h = i / n1, f = i - h * n1;
         if (f >= (h == 0 ? n1r : n1v)) { continue; }
         float* dst = fT + (size_t(h) * n1 + f) * NS + leaf0;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) { if (s_ctl[j].x != 0) { dst[j] = fall[(size_t(j) * 2 + h) * n1 + f]; } }
+        for (int jj = 0; jj < NL; ++jj) { if (s_ctl[jj].x != 0) { dst[jj] = fall[(size_t(jj) * 2 + h) * n1 + f]; } }
     }
 }
 
@@ -364,7 +390,7 @@ static int launchPreTower(const SimArgs* d_args, const int* ctl, int nleaves, fl
 {
     using G = StackGeo<6, 6, NL>;
     const size_t tile_bytes = size_t(CDYN_PAD + CPAD) * G::CS * sizeof(float);
-    const size_t epi = (size_t(2) * CPAD * G::P + 32 + size_t(NL) * 2 * n1) * sizeof(float); // lives in T0
+    const size_t epi = (size_t(NL) * CPAD * G::P + 32 + size_t(NL) * 2 * n1) * sizeof(float); // lives in T0
     if (epi > size_t(CDYN_PAD) * G::CS * sizeof(float) || tile_bytes > size_t(160) * 1024) { return MZ_ERR_ARG; }
     MZ_LDS_ATTR((pre_tower_kernel<6, 6, CDYN_PAD, CPAD, NL>), tile_bytes);
     hipLaunchKernelGGL((pre_tower_kernel<6, 6, CDYN_PAD, CPAD, NL>), dim3((nleaves + NL - 1) / NL), dim3(512), tile_bytes, s, d_args, ctl, nleaves, fT, NS);
