@@ -221,7 +221,7 @@ def main():
                                    "synthetic fixed-weight net (seed 0), Dirichlet noise + random rotation + softmax-count moves (reference defaults)",
                        "step": "one move of every game = 401 lock-step cycles = games x 401 leaf evaluations per GPU, per-move host work included",
                        "games_per_gpu": args.games, "actor_num_simulation": N_SIM, "leaf_evals_per_step": args.games * cpm * world,
-                       "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_cores": cores, "host_cpus_usable": usable,
+                       "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_rng_streams_per_gpu": threads, "host_cores": cores, "host_cpus_usable": usable,
                        "sharding": f"{world} x independent actor pools, no data-path collective", "backend": args.backend,
                        "ranks": [{"rank": r, "device": int(per_rank[5 * r]), "program_seed": int(per_rank[5 * r + 1]), "cpu_base": int(per_rank[5 * r + 2]),
                                   "host_threads": int(per_rank[5 * r + 3]), "first_record_crc32": int(per_rank[5 * r + 4])} for r in range(world)]},
@@ -260,7 +260,7 @@ def main():
                 r = run_configs.run_config(key, moves=args.other_moves)
                 out["other_configs"][key] = {"workload": r["config"], "leaf_evals_per_sec": r["leaf_evals_per_sec"], "ms_per_move": r["ms_per_move"],
                                              "games_in_pool": r["games_in_pool"], "moves_timed": r["moves_timed"], "host_threads": r["host_threads"],
-                                             "roofline": {k: r["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "flops_per_leaf_eval", "wall_frac")}}
+                                             "roofline": {k: r["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "launches_by_kernel", "flops_per_leaf_eval", "wall_frac")}}
         if world == 1 and not args.no_cpu_baseline:
             del worker
             out["cpu_baseline"] = cpu_baseline(base_conf + ":program_seed=1:nn_file_name=synthetic_go_6bx64_seed0.pt", args.cpu_seconds)
