@@ -176,6 +176,7 @@ private:
     std::vector<char> sim_args_host_;
     DevBuf<unsigned long long> sim_prof_; // MZ_SIM_PROF=1: per-phase tick counters of sim_kernel
     void dumpSimProf();
+    void dumpRoundsProf(); // sim_rounds.hip: MZ_SIM_PROF=1, the shader clock under the multi-leaf trunks
     DevBuf<unsigned> sim_sink_;
     DevBuf<char> sim_cluster_mem_; // cluster mode of the MuZero simulation kernel (sim_cluster.h): per-game exchange blocks
     DevBuf<int> pre_key_;          // leaves evaluated ahead: keys [games][slots][4], outputs [policy | logit | value | reward], counters

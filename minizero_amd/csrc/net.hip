@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ x,
 Net::~Net()
 {
     dumpSimProf();
+    dumpRoundsProf();
     if (own_stream_ && stream_) { (void)hipStreamDestroy(stream_); }
 }
 

@@ -119,6 +119,10 @@ __global__ __launch_bounds__(64) void pre_walk_kernel(const SimArgs* __restrict_
     }
 }
 
+// MZ_SIM_PROF=1: shader cycles (clock64) and 100-MHz wall ticks (wall_clock64) that workgroup 0 of the trunk kernels spent between its input staging and its epilogue,
+// per leaves-per-workgroup — their ratio is the shader clock under the trunks' MFMA load (printed by Net::dumpRoundsProf)
+__device__ unsigned long long g_trunk_clk[3][3];
+
 // ---- 2. the dynamics trunk of NL leaves + rescale + the heads' conv1x1 --------------------------------------------------------------------------------------
 // fT: [2 heads][n1 = hc * P features][NS samples] (sample = leaf index), the B operand of FC1
 template <int H, int W, int CDYN_PAD, int CPAD, int NL>
@@ -164,6 +168,9 @@ __global__ __launch_bounds__(512) void pre_tower_kernel(const SimArgs* __restric
         }
     }
     __syncthreads();
+    const bool tprof = a->prof != nullptr && blockIdx.x == 0 && tid == 0;
+    unsigned long long tc0 = 0, tw0 = 0;
+    if (tprof) { tc0 = clock64(); tw0 = wall_clock64(); }
     {
         const int ot = wave & 3, half = wave >> 2;
         if (ot < ta.OT && half == 0) {
@@ -179,6 +186,10 @@ __global__ __launch_bounds__(512) void pre_tower_kernel(const SimArgs* __restric
         } else {
             towerIdle(ta);
         }
+    }
+    if (tprof) {
+        constexpr int k = NL == 4 ? 2 : NL == 2 ? 1 : 0;
+        g_trunk_clk[k][0] += clock64() - tc0; g_trunk_clk[k][1] += wall_clock64() - tw0; g_trunk_clk[k][2] += 1;
     }
     // x = T1; T0 is free: the leaves' dense copies of the state and the heads' conv outputs.  The NL leaves go through the steps TOGETHER, a group of 512 / NL
     // threads per leaf (one leaf after the other on all 512 threads was 4 x 4 barriers of latency-bound work: 28 us of the 300 with four leaves)
@@ -412,6 +423,18 @@ static int launchPreFc(const FcHead& h0, const FcHead& h1, int NS, int ldo, hipS
     hipLaunchKernelGGL((pre_fc_kernel<NSB, CH, FEAT_OUT>), dim3(NS / (16 * NSB), ((nout + 15) / 16 + 3) / 4, 2), dim3(256), 0, s, h0, h1, NS, ldo);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
+}
+
+void Net::dumpRoundsProf()
+{
+    unsigned long long h[3][3];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trunk_clk), sizeof(h)) != hipSuccess) { return; }
+    for (int k = 0; k < 3; ++k) {
+        if (h[k][2] == 0) { continue; }
+        const double us = double(h[k][1]) / double(h[k][2]) * 0.01, cyc = double(h[k][0]) / double(h[k][2]);
+        fprintf(stderr, "[mz sim prof] trunks of %d leaves per workgroup: %.1f us and %.0f shader cycles from staging to epilogue (workgroup 0, %llu launches) -> shader clock %.2f GHz\n",
+                1 << k, us, cyc, h[k][2], cyc / us * 1e-3);
+    }
 }
 
 bool Net::hasPreBatch() const
