@@ -691,18 +691,18 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     double* rcp_w = reinterpret_cast<double*>(tiles + kTileFloats);
     const int rcp_n = a->rcp_n;
     for (int i = tid; i < rcp_n; i += 512) { rcp_w[i] = a->pv.rcp_tab[i]; }
-    __syncthreads();
-    LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w;
+    LdsCDouble* rcp_lds = (LdsCDouble*)rcp_w; // (one barrier for everything the launch keeps in LDS, below: three in a row cost every launch ~2 us, and a move of BASELINE configs[4] has thirteen)
     // path-speculation memory of the walk (pool_body.h): LDS copies of the sqrt / bias tables + the remembered paths
     const int tab_n = rcp_n - 2;
     double* sqrt_w = rcp_w + rcp_n;
     float* bias_w = reinterpret_cast<float*>(sqrt_w + tab_n);
     int* spec_w = reinterpret_cast<int*>(bias_w + tab_n + (tab_n & 1));
     for (int i = tid; i < tab_n; i += 512) { sqrt_w[i] = a->pv.sqrt_tab[i]; bias_w[i] = a->pv.bias_tab[i]; }
-    if (tid < kSpecWays) { spec_w[tid * kSpecWay] = 0; }
-    if (tid < 8) { spec_w[kSpecWays * kSpecWay + tid] = 0; }
-    if (tid < kHelpSegs) { spec_w[kSpecHelp + tid * kHelpSeg] = 0; }
-    __syncthreads();
+    if (!a->atari) { // (muzero_atari walks without path speculation: its memory holds the path block and the Gumbel state filled below, before the same barrier)
+        if (tid < kSpecWays) { spec_w[tid * kSpecWay] = 0; }
+        if (tid < 8) { spec_w[kSpecWays * kSpecWay + tid] = 0; }
+        if (tid < kHelpSegs) { spec_w[kSpecHelp + tid * kHelpSeg] = 0; }
+    }
     SpecMem spec{((a->no_spec & 1) || a->atari) ? nullptr : (LdsI32*)spec_w, (LdsCFloat*)bias_w, (LdsCDbl*)sqrt_w};
     float* head_scratch = reinterpret_cast<float*>(spec_w + kSpecWords);
     // muzero_atari (no path speculation: its memory is free): the simulation's path stays in LDS — the walk writes it, the probe, expand, backup and the
@@ -729,8 +729,8 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
                 kc[a->A + i] = a->pv.logit[size_t(g) * a->pv.cap + root.first_child + i];
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr; // MZ_SIM_PROF=1: [select, tower, heads, cand+expand] ticks + sims
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
