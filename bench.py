@@ -80,7 +80,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3, help="untimed warm-up moves")
     ap.add_argument("--games", type=int, default=256)
     ap.add_argument("--game-moves", type=int, default=164, help="moves of the games/s leg after the timed region (0 = skip)")
-    ap.add_argument("--threads", type=int, default=0, help="host threads for the per-move work (0 = cores / ranks)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for the per-move work (0 = cores / ranks); does NOT change the records (see --rng-streams)")
+    ap.add_argument("--rng-streams", type=int, default=16,
+                    help="host RNG generators per GPU (mz_rng_streams; ref actor_group.cpp:66-70: one per slave thread).  A FIXED number, so that the records behind `value` do not "
+                         "depend on the box's CPU quota: tests/test_gpu_baseline_nets.py::test_*_full_size_*_bench_streams compares exactly this mode with the oracle at full size")
+    ap.add_argument("--one-stream-moves", type=int, default=-1, help="timed moves of the extra leg with ONE RNG stream (the deterministic contract every parity test runs on; -1 = --steps, 0 = skip)")
     ap.add_argument("--lanes", type=int, default=1, help="software-pipelined lanes the games are split into")
     ap.add_argument("--zero-copy", type=int, default=3)
     ap.add_argument("--pin", type=int, default=1, help="pin the host threads of rank r to CPUs [r*threads, (r+1)*threads)")
@@ -126,11 +130,17 @@ def main():
     usable = mz.usable_cpus()  # affinity mask capped by the cgroup CPU quota: spinning past the quota gets the container throttled
     threads = args.threads or max(1, min(32, usable // max(1, world) - 1))  # spin-wait pool incl. the calling thread
     base_conf = mz.CONFIGS["c2"].replace("zero_num_parallel_games=256", f"zero_num_parallel_games={args.games}")
-    # mz_rng_streams=0: one generator per slave thread, as the reference has them with zero_num_threads = T (actor_group.cpp:66-70), so that the RNG-ordered host
-    # section of a move runs on the pool's threads; rank r's generators are program_seed + r * T + t: no two ranks share one
-    conf = (f"{base_conf}:zero_num_threads={threads}:mz_rng_streams=0:mz_pipeline_lanes={args.lanes}:mz_zero_copy={args.zero_copy}:mz_cpu_base={local_rank * threads if args.pin else -1}:program_seed={shard_seed(1, rank, threads)}:"
-            "nn_file_name=synthetic_go_6bx64_seed0.pt" + (":" + args.extra_conf if args.extra_conf else "") +
-            (":mz_nn_precision=bf16x3" if args.precision == "bf16x3" else ""))
+    # mz_rng_streams=S: S generators as the reference has them with zero_num_threads = S slave threads (actor_group.cpp:66-70), the games statically partitioned over them,
+    # so that the RNG-ordered host section of a move runs on the pool's threads whatever their number; rank r's generators are program_seed + r * S + t: no two ranks share one
+    streams = max(1, args.rng_streams)
+
+    def make_conf(nstreams):
+        return (f"{base_conf}:zero_num_threads={threads}:mz_rng_streams={nstreams}:mz_pipeline_lanes={args.lanes}:mz_zero_copy={args.zero_copy}:mz_cpu_base={local_rank * threads if args.pin else -1}:"
+                f"program_seed={shard_seed(1, rank, streams)}:nn_file_name=synthetic_go_6bx64_seed0.pt" + (":" + args.extra_conf if args.extra_conf else "") +
+                (":mz_nn_precision=bf16x3" if args.precision == "bf16x3" else "") +
+                # two RANKS on one device (test hook): kernels that assume an idle GPU to themselves stay off (another process cannot be seen from inside the worker)
+                (":mz_sim_round_pairs=false" if args.device_map and len(set(args.device_map.split(","))) < world else ""))
+    conf = make_conf(streams)
     desc = mz.DESCS["c2"]()
     # the optional synchronous weight broadcast (load_model fan-out): rank 0's blob is the one every rank loads
     weights = grp.broadcast_weights(mz.generate_weights(desc, 0))
@@ -173,9 +183,29 @@ def main():
     # what every rank ran with (device, seed, CPU range, first record): gathered as a sum of one-hot rows, printed by rank 0
     import zlib
     row = [0.0] * (5 * world)
-    row[5 * rank:5 * rank + 5] = [float(device), float(shard_seed(1, rank, threads)), float(local_rank * threads if args.pin else -1), float(threads),
+    row[5 * rank:5 * rank + 5] = [float(device), float(shard_seed(1, rank, streams)), float(local_rank * threads if args.pin else -1), float(threads),
                                   float(zlib.crc32(worker.peek_records(1)[0].encode()))]
     per_rank = grp.reduce(row, "sum")
+
+    # ---- one-stream leg (not `value`): the same workload with mz_rng_streams=1, the deterministic contract of the reference's zero_num_threads=1 that every
+    # parity test runs on — a round-to-round comparable number next to the S-stream headline.  A second worker on the same device; the first one idles (its pool sleeps)
+    one_stream = None
+    osm = args.steps if args.one_stream_moves < 0 else args.one_stream_moves
+    if osm > 0 and args.precision == "f32" and streams != 1:
+        w1 = mz.Worker(make_conf(1), desc, weights, device=device)
+        w1.command("start")
+        assert w1.run_cycles(max(1, args.warmup) * cpm) == max(1, args.warmup) * cpm
+        grp.barrier()
+        t1 = time.perf_counter()
+        for _ in range(osm):
+            assert w1.run_cycles(cpm) == cpm
+        grp.barrier()
+        dt1 = float(grp.reduce([time.perf_counter() - t1], "max")[0])
+        crc1 = zlib.crc32(w1.peek_records(1)[0].encode())
+        w1.close()
+        one_stream = {"value": args.games * cpm * osm * world / dt1, "unit": "leaf-evals/s", "ms_per_step": dt1 / osm * 1e3, "steps": osm, "warmup": max(1, args.warmup),
+                      "host_rng_streams_per_gpu": 1, "first_record_crc32_rank0": crc1,
+                      "note": "mz_rng_streams=1 (one generator, games in index order: the reference with zero_num_threads=1), same workload, timed after the headline on a fresh worker"}
     if rank == 0:
         evals = args.games * cpm * args.steps * world
         value = evals / dt
@@ -221,11 +251,12 @@ def main():
                                    "synthetic fixed-weight net (seed 0), Dirichlet noise + random rotation + softmax-count moves (reference defaults)",
                        "step": "one move of every game = 401 lock-step cycles = games x 401 leaf evaluations per GPU, per-move host work included",
                        "games_per_gpu": args.games, "actor_num_simulation": N_SIM, "leaf_evals_per_step": args.games * cpm * world,
-                       "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_rng_streams_per_gpu": threads, "host_cores": cores, "host_cpus_usable": usable,
+                       "pipeline_lanes": args.lanes, "host_threads_per_gpu": threads, "host_rng_streams_per_gpu": streams, "host_cores": cores, "host_cpus_usable": usable,
                        "sharding": f"{world} x independent actor pools, no data-path collective", "backend": args.backend,
                        "ranks": [{"rank": r, "device": int(per_rank[5 * r]), "program_seed": int(per_rank[5 * r + 1]), "cpu_base": int(per_rank[5 * r + 2]),
                                   "host_threads": int(per_rank[5 * r + 3]), "first_record_crc32": int(per_rank[5 * r + 4])} for r in range(world)]},
             "moves_per_sec": moves / dt, "games_finished_in_timed_region": games_done,
+            "one_rng_stream": one_stream,
             "games_per_sec": (g_games / g_dt) if g_dt > 0 else None,
             "games_leg": {"moves_per_game_slot": args.game_moves, "seconds": g_dt, "games_finished": g_games, "moves": g_moves,
                           "leaf_evals_per_sec": (g_evals / g_dt) if g_dt > 0 else None,

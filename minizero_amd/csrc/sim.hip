@@ -1323,6 +1323,7 @@ bool Net::hasSimKernelMz(int num_simulation) const
     {
         size_t head_floats = 0;
         if (desc_.type == 2) { AtariHeadParams hp; makeAtariHeadParams(&hp); head_floats = atariHeadsSmemFloats(hp); }
+        else { head_floats = (gumbelSmemBytes(desc_.action_size) + 3) / 4; } // the block simLaunchMz adds with Gumbel rounds (mode.rounds): a shape is only offered if it fits WITH it
         const size_t tile_bytes = size_t(kTowerTiles) * std::max(std::max(c0, cd), C) * planeStride(H, W) * sizeof(float);
         if (simLdsBound(tile_bytes, num_simulation, desc_.action_size, head_floats) > size_t(160) * 1024) { return false; }
     }

@@ -251,7 +251,8 @@ public:
             // back-pressure: a host that cannot compress as fast as the GPU plays (one helper thread against 64 sequences of 6 MB per 200 moves) must not
             // pile up raw observations without bound — the worker waits here, and is then exactly as fast as its compressor
             std::unique_lock<std::mutex> l(mu_);
-            done_cv_.wait(l, [&]() { return jobs_.size() < kMaxQueued; });
+            done_cv_.wait(l, [&]() { return jobs_.size() < kMaxQueued && (jobs_.empty() || queued_bytes_ + raw.size() <= kMaxQueuedBytes); });
+            queued_bytes_ += raw.size();
             jobs_.push_back(Job{line, std::move(raw), placeholder, placeholder_len});
         }
         cv_.notify_one();
@@ -264,7 +265,8 @@ public:
 
 private:
     struct Job { OutLine* line; std::string raw; const char* ph; size_t ph_len; };
-    static constexpr size_t kMaxQueued = 192;
+    static constexpr size_t kMaxQueued = 192, kMaxQueuedBytes = size_t(512) << 20; // raw observations waiting for a helper: by count and by bytes (a 200-move Atari sequence is 6 MB)
+    size_t queued_bytes_ = 0;
     void loop()
     {
         for (;;) {
@@ -275,7 +277,9 @@ private:
                 if (quit_) { return; }
                 j = std::move(jobs_.front());
                 jobs_.pop_front();
+                queued_bytes_ -= j.raw.size();
             }
+            done_cv_.notify_all(); // (a submit() may be waiting for room)
             std::string hex;
             const bool ok = compressToHex(reinterpret_cast<const uint8_t*>(j.raw.data()), j.raw.size(), &hex);
             const size_t at = ok ? j.line->text.find(j.ph) : std::string::npos;
@@ -346,9 +350,19 @@ std::string escapeSGF(const std::string& s) // ref base_env.h:303-313
 
 } // namespace
 
+// Workers of THIS process per physical device (one-process-for-all-GPUs with MZ_DEVICE_MAP=0,0, tools/multi_worker.py, a facade user with several actor groups): kernels
+// that assume a whole idle GPU — the pairs of workgroups per leaf of sim_pre_pair_kernel_mz, which spin on each other — are only used by a worker that is alone on
+// its device.  (Another PROCESS on the device cannot be seen from here: there the bounded wait + pairTrouble() of adaptRounds is the net, or mz_sim_round_pairs=false.)
+static std::atomic<int> g_workers_on_device[64];
+
 class Worker {
 public:
-    ~Worker() { obs_.reset(); } // the compressor's threads write into queued lines: they end before anything else goes
+    ~Worker()
+    {
+        obs_.reset(); // the compressor's threads write into queued lines: they end before anything else goes
+        if (counted_device_ >= 0) { g_workers_on_device[counted_device_].fetch_sub(1); }
+    }
+    int counted_device_ = -1;
     // shared != nullptr: the worker runs on the caller's network (BaseActor::setNetwork's shared_ptr, ref zero_actor.cpp:100-112) instead of its own copy
     int init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count, Net* shared = nullptr);
     int command(const std::string& line);
@@ -554,7 +568,7 @@ private:
     struct Round { int s0, R; float p_event = 0.0f; bool alt = false; }; // p_event: share of the recent moves in which a simulation of the round missed its leaf / took the second one
     std::vector<unsigned> prestat_prev_; // the counters as of the previous move (summed over the lanes)
     void adaptRounds();
-    bool pairsUsable() { return cfg_.mz_sim_round_pairs && lanes_.size() == 1 && net0().pairsAvailable(); } // two workgroups per leaf (sim.hip sim_pre_pair_kernel_mz)
+    bool pairsUsable() { return cfg_.mz_sim_round_pairs && lanes_.size() == 1 && net0().pairsAvailable() && (counted_device_ < 0 || g_workers_on_device[counted_device_].load() == 1); } // two workgroups per leaf (sim.hip sim_pre_pair_kernel_mz)
     int slab_slots_ = 0;        // hidden-state slots per game
     std::vector<Round> rounds_; // mz_sim_rounds: the rounds of a move whose leaves are evaluated ahead (first simulation, size), from the Gumbel schedule of (n, m)
     void planRounds();
@@ -569,6 +583,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     if (!conf || !cfg_.loadFromString(conf)) { return MZ_ERR_ARG; }
     desc_ = desc;
     device_ = device;
+    if (counted_device_ < 0 && device >= 0 && device < 64) { counted_device_ = device; g_workers_on_device[device].fetch_add(1); }
     if (cfg_.nn_type_name == "muzero" && desc.type == 0) { setError("nn_type_name=muzero but the network descriptor is alphazero"); return MZ_ERR_ARG; }
     if (cfg_.zero_num_parallel_games <= 0 || cfg_.actor_num_simulation <= 0) { setError("zero_num_parallel_games and actor_num_simulation must be > 0"); return MZ_ERR_ARG; }
     if (cfg_.zero_num_parallel_games > 4096) { setError("zero_num_parallel_games > 4096 (ref alphazero_network.h:120 kReserved_batch_size)"); return MZ_ERR_ARG; }
@@ -768,13 +783,15 @@ void Worker::planRounds()
 // evaluated ahead never changes a record (sim.hip simPreProbe); the batched pipeline (sim_rounds.hip) evaluates the doubled round with two leaves per workgroup.
 void Worker::adaptRounds()
 {
-    if (!cfg_.mz_sim_round_alt || sim_mode_.alt_base == 0) { return; }
     unsigned now[512] = {0};
     for (auto& L : lanes_) {
         if (!L->h_prestat.p) { return; }
         for (int i = 0; i < 512; ++i) { now[i] += L->h_prestat.p[i]; }
     }
-    if (now[129] != 0) { for (auto& L : lanes_) { L->net->pairTrouble(); } } // (sim_pre_pair_kernel_mz: a partner workgroup stayed out — the GPU is shared)
+    // (sim_pre_pair_kernel_mz: a partner workgroup stayed out — the GPU is shared.  Looked at whatever the second-leaf settings are: with mz_sim_round_alt=false every
+    // small round goes to the pairs, and a shared GPU would pay the partner's bounded wait in every round of every move)
+    if (now[129] != 0) { for (auto& L : lanes_) { L->net->pairTrouble(); } }
+    if (!cfg_.mz_sim_round_alt || sim_mode_.alt_base == 0) { return; }
     if (prestat_prev_.size() == 512) {
         const int cus = net0().cuCount();
         for (Round& rd : rounds_) {

@@ -65,6 +65,9 @@ def _by_kernel(s0, s1, launches):
     return out
 
 
+RNG_STREAMS = 16  # fixed (bench.py --rng-streams): the records do not depend on the box's CPU quota, and tests/test_gpu_baseline_nets.py checks this very mode at full size
+
+
 def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     """One config on device 0: a fresh worker, `warm` untimed moves, `moves` timed moves (one run_cycles call per move, like the `-mode sp`
     loop).  Returns the block bench.py (`other_configs`) and profiles/rNN_all_configs_n1.json both carry."""
@@ -73,7 +76,7 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     d = mz.DESCS[dkey]()
     if threads is None:
         threads = max(1, mz.usable_cpus() - 1)
-    conf = f"{base}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_rng_streams=0:mz_cpu_base=0{extra_conf}"
+    conf = f"{base}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_rng_streams={RNG_STREAMS if key != 'c1' else 1}:mz_cpu_base=0{extra_conf}"
     n = int(base.split("actor_num_simulation=")[1].split(":")[0])
     games = int(base.split("zero_num_parallel_games=")[1].split(":")[0])
     wk = mz.Worker(conf, d, mz.generate_weights(d, 0))
@@ -95,7 +98,7 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     sim_evals = (s1["sim_cycles"] - s0["sim_cycles"]) * games
     ach = (conv + heads) * sim_evals / (gpu_ms * 1e-3) / 1e12 if launches else None
     res = {"leaf_evals_per_sec": evals / dt, "ms_per_move": dt / moves * 1e3, "moves_per_sec": (s1["moves"] - s0["moves"]) / dt,
-           "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "records_popped_between_moves": popped, "host_threads": threads if key != "c1" else 1,
+           "games_per_sec": (s1["games"] - s0["games"]) / dt, "games_in_pool": games, "moves_timed": moves, "records_popped_between_moves": popped, "host_threads": threads if key != "c1" else 1, "host_rng_streams": RNG_STREAMS if key != "c1" else 1,
            "leaves_evaluated_ahead": s1.get("pre_evals", 0) - s0.get("pre_evals", 0), "simulations_that_found_their_leaf": s1.get("pre_hits", 0) - s0.get("pre_hits", 0),
            "config": base,
            "roofline": {"kernel": KERNEL.get(key, KERNEL.get(dkey)), "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
