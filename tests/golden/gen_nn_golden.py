@@ -7,7 +7,7 @@ outputs of the reference module (a few KB each, nn_<cfg>.npz).  Weights are NOT 
 regenerated from the repo's deterministic generator (same SplitMix64 stream in oracle/o_nn.cpp,
 minizero_amd/csrc/weights.cpp and below) and loaded into the reference module with load_state_dict.
 
-usage: python tests/golden/gen_nn_golden.py
+usage: python tests/golden/gen_nn_golden.py [name ...]
 """
 import os
 import sys
@@ -90,6 +90,16 @@ CONFIGS = {
     # BASELINE configs[4] network (the reference picks MuZeroAtariNetwork because "atari" is in the game name)
     "c5_atari_mz": ("atari_ms_pacman", 32, 96, 96, 64, 6, 6, 18, 6, 18, 256, 601, "muzero"),
     "small_atari_mz": ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero"),
+    # round 5: shapes beyond BASELINE.json — the reference's defaults (config/configuration.cpp:70-72: 1 block x 256 channels), wider / larger boards
+    # (go_unit.h:11: up to 19x19), channel counts that are no multiple of 16 (the run-time-shaped kernels)
+    "w_go9_1bx256_az": ("go_9x9", 18, 9, 9, 256, 9, 9, 1, 1, 82, 256, 1, "alphazero"),
+    "w_go9_6bx128_az": ("go_9x9", 18, 9, 9, 128, 9, 9, 1, 6, 82, 256, 1, "alphazero"),
+    "w_go19_6bx64_az": ("go_19x19", 18, 19, 19, 64, 19, 19, 1, 6, 362, 256, 1, "alphazero"),
+    "w_go7_2bx32_az": ("go_7x7", 18, 7, 7, 32, 7, 7, 1, 2, 50, 256, 1, "alphazero"),
+    "w_go13_2bx96_az": ("go_13x13", 18, 13, 13, 96, 13, 13, 1, 2, 170, 64, 1, "alphazero"),
+    "w_go5_3bx24_az": ("go_5x5", 18, 5, 5, 24, 5, 5, 1, 3, 26, 20, 1, "alphazero"),
+    "w_go9_2bx128_mz": ("go_9x9", 18, 9, 9, 128, 9, 9, 1, 2, 82, 256, 1, "muzero"),
+    "w_go7_1bx40_mz": ("go_7x7", 18, 7, 7, 40, 7, 7, 1, 1, 50, 32, 1, "muzero"),
 }
 
 
@@ -99,7 +109,10 @@ def float_planes(seed, shape):
 
 def main():
     torch.set_num_threads(1)
+    only = set(sys.argv[1:])  # optional: the names to (re)generate
     for name, args in CONFIGS.items():
+        if only and name not in only:
+            continue
         net = create_network(*args).eval()
         wseed = 0
         blob, specs = gen_weights_numpy(net, wseed)

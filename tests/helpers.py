@@ -34,3 +34,17 @@ def same_bits(a, b):
 
 def frac_bit_equal(a, b):
     return float(np.mean(bits(a) == bits(b)))
+
+
+# round 5: network shapes beyond BASELINE.json, goldens from the reference's Python (tests/golden/gen_nn_golden.py): the reference's default 1 block x 256 channels
+# (config/configuration.cpp:70-72), wider towers, 7x7 .. 19x19 Go (go_unit.h:11), channel counts that are no multiple of 16 (run-time-shaped kernels)
+WIDE_NN_CFG = {
+    "w_go9_1bx256_az": ("go_9x9", 18, 9, 9, 256, 9, 9, 1, 1, 82, 256, 1, "alphazero"),
+    "w_go9_6bx128_az": ("go_9x9", 18, 9, 9, 128, 9, 9, 1, 6, 82, 256, 1, "alphazero"),
+    "w_go19_6bx64_az": ("go_19x19", 18, 19, 19, 64, 19, 19, 1, 6, 362, 256, 1, "alphazero"),
+    "w_go7_2bx32_az": ("go_7x7", 18, 7, 7, 32, 7, 7, 1, 2, 50, 256, 1, "alphazero"),
+    "w_go13_2bx96_az": ("go_13x13", 18, 13, 13, 96, 13, 13, 1, 2, 170, 64, 1, "alphazero"),
+    "w_go5_3bx24_az": ("go_5x5", 18, 5, 5, 24, 5, 5, 1, 3, 26, 20, 1, "alphazero"),
+    "w_go9_2bx128_mz": ("go_9x9", 18, 9, 9, 128, 9, 9, 1, 2, 82, 256, 1, "muzero"),
+    "w_go7_1bx40_mz": ("go_7x7", 18, 7, 7, 40, 7, 7, 1, 1, 50, 32, 1, "muzero"),
+}

@@ -39,8 +39,11 @@ def test_bench_world_size_two_on_one_gpu(mz):
     assert abs(j["value"] - j["config"]["leaf_evals_per_step"] * steps / (j["ms_per_step"] * steps * 1e-3)) < 1e-6 * j["value"]
     r0, r1 = j["config"]["ranks"]
     assert (r0["rank"], r1["rank"]) == (0, 1) and r0["device"] == r1["device"] == 0
-    # ref actor_group.cpp:66-70: slave thread `id` seeds program_seed + id; a rank has host_threads generators (mz_rng_streams=0), rank r the ids r * T .. r * T + T - 1
-    assert r1["program_seed"] == r0["program_seed"] + r0["host_threads"] and r0["host_threads"] == r1["host_threads"] >= 1
+    # ref actor_group.cpp:66-70: slave thread `id` seeds program_seed + id; a rank has S = --rng-streams generators (mz_rng_streams=S, whatever its thread count),
+    # rank r the ids r * S .. r * S + S - 1
+    S = j["config"]["host_rng_streams_per_gpu"]
+    assert S == 16 and r1["program_seed"] == r0["program_seed"] + S and r0["host_threads"] == r1["host_threads"] == 2
+    assert j["one_rng_stream"]["value"] > 0 and j["one_rng_stream"]["host_rng_streams_per_gpu"] == 1
     assert r0["first_record_crc32"] != r1["first_record_crc32"]              # different seeds, different games
     a0, a1 = (range(r["cpu_base"], r["cpu_base"] + r["host_threads"]) for r in (r0, r1))
     assert not set(a0) & set(a1), "the ranks' CPU pinning ranges overlap"

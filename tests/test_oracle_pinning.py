@@ -23,6 +23,8 @@ NN_CFG = {
     "c4_go_mz": ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "muzero"),
     "small_go_az": ("go_9x9", 18, 9, 9, 8, 9, 9, 1, 1, 82, 16, 1, "alphazero"),
 }
+from helpers import WIDE_NN_CFG  # noqa: E402
+NN_CFG.update(WIDE_NN_CFG)
 ATARI_CFG = {
     "c5_atari_mz": ("atari_ms_pacman", 32, 96, 96, 64, 6, 6, 18, 6, 18, 256, 601, "muzero_atari"),
     "small_atari_mz": ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari"),
