@@ -12,6 +12,8 @@ struct ConvLayer {
     int cin, cin_pad, cout, cout_pad;
     size_t w_off, b_off; // offsets (floats) into Net::params_
     size_t w4_off;       // the same A-fragments, four channel groups interleaved per lane (one dwordx4 load = 4 k-steps): the fused tower's layout
+    size_t wq_off;       // ... with the input channels padded to a multiple of 16: [tap][oc-tile][cq chunks][lane][4] (net_wide_body.h); == w4_off when cin_pad % 16 == 0
+    int cq;              // dwordx4 chunks (16 input channels) per (tap, oc-tile) in the wq layout
 };
 
 struct HeadOffsets {
@@ -149,6 +151,13 @@ private:
     int launchTower(const std::vector<ConvLayer>& t, const float* in, float* out, int B, bool* launched, bool in_bits, bool has_stem = true);
     int launchHeads(const float* x, int B, float* policy, float* logit, float* value, float* hidden_dst, const int* dst_idx, bool scale_hidden);
     bool makeTowerArgs(const std::vector<ConvLayer>& t, bool in_bits, bool has_stem, TowerArgs* out, int* c0) const;
+    // shapes beyond the two-tile tower's (net_wide.hip): one-tile tower for 128 / 256 channels and 7x7 .. 19x19 boards; a run-time-shaped conv3x3 behind everything
+    bool makeWideArgs(const std::vector<ConvLayer>& t, bool in_bits, TowerArgs* out, int* c0q) const;
+    bool hasWideTower(const std::vector<ConvLayer>& t) const;
+    int launchTowerWide(const std::vector<ConvLayer>& t, const float* in, float* out, float* tmp, int B, bool* launched, bool in_bits);
+    int launchConvAny(const ConvLayer& L, const float* in, const float* skip, float* out, int B);
+    int unpackBits(const float* d_bits, int C, int B, float* d_feat);
+    DevBuf<float> unpacked_;    // f32 planes of a bit-packed batch (run-time-shaped kernels only)
     bool makeTowerArgsBf16(TowerArgsBf16* out) const;
     int packBf16(const std::vector<float>& packed);
     int launchTowerBf16(const float* d_feat, float* out, int B, bool in_bits);

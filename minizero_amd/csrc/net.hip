@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ x,
                                                     const int* __restrict__ dst_idx, int scale_hidden)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    headsBody(x, hp, policy, logit, value, hidden_dst, dst_idx, scale_hidden, blockIdx.x, threadIdx.x, 256, sm);
+    // (scale_hidden bit 1: the activations do not fit the LDS — headsBody reads (and rescales) them in global memory: dense planes, "row stride" 0)
+    if (scale_hidden & 2) { headsBody(x, hp, policy, logit, value, hidden_dst, dst_idx, scale_hidden & 1, blockIdx.x, threadIdx.x, 256, sm, x + size_t(blockIdx.x) * hp.C * hp.P, hp.P, 0); }
+    else { headsBody(x, hp, policy, logit, value, hidden_dst, dst_idx, scale_hidden, blockIdx.x, threadIdx.x, 256, sm); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,8 +357,7 @@ int Net::launchConv(const ConvLayer& L, const float* in, const float* skip, floa
     MZ_CONV_CASE(3, 3, 16)
     MZ_CONV_CASE(3, 3, 20)
 #undef MZ_CONV_CASE
-    setError("no conv3x3 kernel instance for %dx%d board with %d (padded) input channels", H, W, L.cin_pad);
-    return MZ_ERR_ARG;
+    return launchConvAny(L, in, skip, out, B); // any other shape: the run-time-shaped kernel (net_wide.hip)
 }
 
 template <int H, int W, int CIN0_PAD, int CPAD>
@@ -429,7 +430,13 @@ int Net::runTrunk(const std::vector<ConvLayer>& t, const float* d_in, int B, flo
     int frc = launchTower(t, d_in, act_[0].p, B, &launched, in_bits);
     if (frc) { return frc; }
     if (launched) { *d_out = act_[0].p; return MZ_OK; }
-    if (in_bits) { setError("bit-packed input needs the fused tower kernel (no instance for this network shape)"); return MZ_ERR_ARG; }
+    if ((frc = launchTowerWide(t, d_in, act_[0].p, act_[1].p, B, &launched, in_bits))) { return frc; } // one-tile tower: wide / large-board shapes
+    if (launched) { *d_out = act_[0].p; return MZ_OK; }
+    if (in_bits) { // the per-layer kernels read f32 planes
+        if (!unpacked_.ensure(size_t(B) * t[0].cin * P())) { setError("hipMalloc of the unpacked planes failed"); return MZ_ERR_DEVICE; }
+        if ((frc = unpackBits(d_in, t[0].cin, B, unpacked_.p))) { return frc; }
+        d_in = unpacked_.p;
+    }
     float *x = act_[0].p, *tmp = act_[1].p, *y = act_[2].p;
     int rc = launchConv(t[0], d_in, nullptr, x, B);
     if (rc) { return rc; }
@@ -457,8 +464,14 @@ int Net::launchHeads(const float* x, int B, float* policy, float* logit, float* 
     HeadParams hp;
     makeHeadParams(&hp);
     size_t lds = (size_t(hp.C) * hp.P + size_t(hp.PC) * hp.P + hp.P + hp.VH + hp.A + 16) * sizeof(float);
+    int x_global = 0;
+    if (lds > 160 * 1024) { // (e.g. 19x19 x 128 channels) the activations stay where they are: the chains read them from global memory
+        lds -= size_t(hp.C) * hp.P * sizeof(float);
+        x_global = 1;
+        if (lds > 160 * 1024) { setError("heads: %zu bytes of LDS needed for the policy / value planes", lds); return MZ_ERR_ARG; }
+    }
     if (lds > 48 * 1024) { MZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); }
-    hipLaunchKernelGGL(heads_kernel, dim3(B), dim3(256), lds, stream_, x, hp, policy, logit, value, hidden_dst, dst_idx, scale_hidden ? 1 : 0);
+    hipLaunchKernelGGL(heads_kernel, dim3(B), dim3(256), lds, stream_, x, hp, policy, logit, value, hidden_dst, dst_idx, (scale_hidden ? 1 : 0) | (x_global ? 2 : 0));
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }
@@ -480,7 +493,7 @@ bool Net::hasFusedTower()
                                   {3, 3, 4, 16}, {3, 3, 20, 16}};
     if (!use_fused_ || (repr_.size() % 2) == 0) { return false; }
     for (auto& i : inst) { if (i[0] == H && i[1] == W && i[2] == c0 && i[3] == C) { return true; } }
-    return false;
+    return hasWideTower(repr_);
 }
 
 int Net::forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, bool in_bits)

@@ -573,7 +573,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
     if (scale_hidden) { // min/max are order-free; (h - min) / scale is one IEEE op each
         float* xw = xlds ? const_cast<float*>(xlds) : xs;
         auto xidx = [&](int i) {
-            if (!xlds) { return i; }
+            if (!xlds || xpw == 0) { return i; } // (xpw == 0: dense planes — activations too large for the LDS, read where they lie in global memory)
             const int c = i / P, p = i - c * P;
             return c * xcs + (p / (xpw - 2) + 1) * xpw + p % (xpw - 2) + 1;
         };
@@ -605,7 +605,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
     for (int i = tid; i < (PC + 1) * P; i += NT) {
         const int j = i / P, p = i - j * P;
         const float* w = (j < PC) ? hp.pconv_w + j * C : hp.vconv_w;
-        const int xo = xlds ? (p / (xpw - 2) + 1) * xpw + p % (xpw - 2) + 1 : p;
+        const int xo = (xlds && xpw != 0) ? (p / (xpw - 2) + 1) * xpw + p % (xpw - 2) + 1 : p;
         const float acc = dotChain<16>(xrd + xo, xstride, w, 1, C);
         float v = acc + ((j < PC) ? hp.pconv_b[j] : hp.vconv_b[0]);
         v = v > 0.0f ? v : 0.0f;

@@ -196,6 +196,21 @@ ConvLayer packConv3(std::vector<float>& dst, const Folded& f)
                     }
         L.w4_off = append(dst, w4);
     }
+    // wide-tower layout (net_wide_body.h): whole dwordx4 chunks only — the input channels padded to a multiple of 16 (zero weights: an fma with a zero
+    // operand leaves the chain's value as it is); for layers whose channels are a multiple of 16 that is the w4 layout itself
+    L.cq = (f.cin + 15) / 16;
+    if (L.cin_pad % 16 == 0) {
+        L.wq_off = L.w4_off;
+    } else {
+        std::vector<float> wq(size_t(9) * OT * L.cq * 256, 0.0f);
+        for (int t = 0; t < 9; ++t)
+            for (int ot = 0; ot < OT; ++ot)
+                for (int cg = 0; cg < CG; ++cg)
+                    for (int l = 0; l < 64; ++l) {
+                        wq[((size_t(t) * OT + ot) * L.cq + (cg >> 2)) * 256 + size_t(l) * 4 + (cg & 3)] = wp[((size_t(t) * CG + cg) * OT + ot) * 64 + l];
+                    }
+        L.wq_off = append(dst, wq);
+    }
     std::vector<float> b(L.cout_pad, 0.0f);
     for (int oc = 0; oc < f.cout; ++oc) { b[oc] = f.b[oc]; }
     L.b_off = append(dst, b);
