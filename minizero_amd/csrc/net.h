@@ -95,6 +95,12 @@ public:
                   int* d_start = nullptr, bool host_start = false);
     // num_simulation: the kernels keep per-search tables / the path in LDS; searches too long for 160 KB use the lock-step kernels
     bool hasSimKernel(int board_n, int env_kind = 0, int num_simulation = 0) const; // env_kind: GoDevView::kind
+    // ... on the one-tile tower (sim_wide.inc, sim_wide_a.hip): Go with 128 / 256 hidden channels or on 7x7 / 13x13 / 19x19 boards
+    bool hasSimKernelWide(int board_n, int num_simulation) const;
+    bool simWidePlan(int board_n, int num_simulation, const HeadParams& hp, int channels, int W32, size_t leaf_bytes, size_t scratch_bytes, int* lf, size_t* lds,
+                     size_t* tile_bytes_out) const;
+    int simLaunchWide(const struct SimArgs& a, const GoDevView& gv, int max_depth, const uint8_t* d_rot, int sim0, int nsims, bool host_start, int lf, size_t lds, bool* launched);
+    int uploadSimArgs(const struct SimArgs& a);
     // MuZero (board games): the same for initial + recurrent inference; hidden states live in the caller's slab [games][slots][C * P]
     // nsims simulations (slots sim0 ..) of every game in one launch of sim_kernel_mz; muzero_atari: sim0 >= 1 (the root's 96x96 representation
     // runs as stand-alone kernels), value / reward come out of the kernel in game scale (d_reward: [games]).  root_given (sim0 == 0, nsims == 1): the

@@ -18,7 +18,8 @@ struct SimArgs {
     TowerArgs ta;
     HeadParams hp;
     const float* params;
-    float* act;                       // [games][C][P] tower output (input of the heads)
+    float* act;                       // [games][C][P] tower output (input of the heads); the one-tile tower's block x (net_wide_body.h)
+    float* act2;                      // [games][C][P] the one-tile tower's temporary
     float *policy, *logit, *value;    // heads outputs
     int *cand_count, *cand_action, *cand_player;
     float *cand_policy, *cand_logit, *value_io, *reward_io;
