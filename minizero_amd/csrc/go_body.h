@@ -757,6 +757,62 @@ __device__ __forceinline__ void candScatter(Cand* cs, Cand* out, int* stack, int
     }
 }
 
+// ... and for boards of more than 128 actions (13x13 / 19x19 Go: up to 362 candidates, whose rank sort on ONE wave is k^2 / 64 = 2 000 dependent LDS reads
+// per lane): the same three steps with up to six candidates per lane.  dense [384] floats, part [nw][2][384] counts.  k <= 384.
+constexpr int kCandCoopMaxW = 384;
+__device__ __forceinline__ void candDenseW(const Cand* cs, int k, int lane, float* dense)
+{
+#pragma unroll
+    for (int c = 0; c < kCandCoopMaxW / 64; ++c) { const int i = 64 * c + lane; dense[i] = i < k ? cs[i].policy : -3.402823466e+38f; }
+}
+__device__ __forceinline__ void candRankPartW(const float* dense, int k, int w, int nw, int lane, int* part /* [nw][2][384] */)
+{
+    constexpr int NC = kCandCoopMaxW / 64;
+    float p[NC];
+    int r[NC], eq[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { p[c] = dense[64 * c + lane]; r[c] = 0; eq[c] = 0; }
+    const int groups = (k + 3) >> 2, per = (groups + nw - 1) / nw;
+    for (int q = w * per; q < (w + 1) * per && q < groups; ++q) {
+        const float4 d = reinterpret_cast<const float4*>(dense)[q];
+        const float dj[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * q + e;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                r[c] += (dj[e] > p[c]) || (dj[e] == p[c] && j < 64 * c + lane);
+                eq[c] += (dj[e] == p[c]);
+            }
+        }
+    }
+    int* mine = part + w * 2 * kCandCoopMaxW;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { mine[64 * c + lane] = r[c]; mine[kCandCoopMaxW + 64 * c + lane] = eq[c]; }
+}
+__device__ __forceinline__ void candScatterW(Cand* cs, Cand* out, int* stack, int k, int nw, int lane, const int* part, int* err)
+{
+    constexpr int NC = kCandCoopMaxW / 64;
+    bool tie = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = 64 * c + lane;
+        int r = 0, e = 0;
+        for (int w = 0; w < nw; ++w) { const int* p = part + w * 2 * kCandCoopMaxW; r += p[i]; e += p[kCandCoopMaxW + i]; }
+        if (i < k) { out[r] = cs[i]; tie = tie || e > 1; } // every candidate equals itself once
+    }
+    waveSync();
+    if (k > 16 && __ballot(tie) != 0) { // ties among > 16 elements: only the exact introsort gives the reference's order
+        if (lane == 0) {
+            StdSortEmul<Cand, CandGreater> s{cs, CandGreater()};
+            if (!s.sort(k, stack) && err) { atomicExch(err, MZ_ERR_CAPACITY); }
+        }
+        waveSync();
+        for (int i = lane; i < k; i += 64) { out[i] = cs[i]; }
+        waveSync();
+    }
+}
+
 // AlphaZero candidates of a leaf (ref zero_actor.cpp:215-245): legal actions in action order, policy / logit looked up through
 // the rotation, sorted by policy; a terminal leaf has no children and its value is the game result (zero_actor.cpp:85)
 // step 1: the legal actions of the leaf, in action order, into cs[]; returns their number (0 at a terminal leaf)
@@ -819,5 +875,6 @@ __device__ __forceinline__ void azCandBody(const GoDevView& v, const float* __re
 // scratch of the cooperative variant behind the cs / out / stack block: dense[128] floats + nw x 256 partial counts
 inline size_t candCoopOffsetBytes(int A) { return (azCandSmemBytes(A) + 15) & ~size_t(15); }
 inline size_t candCoopSmemBytes(int A, int nw) { return candCoopOffsetBytes(A) + kCandCoopMax * sizeof(float) + size_t(nw) * 256 * sizeof(int); }
+inline size_t candCoopSmemBytesW(int A, int nw) { return candCoopOffsetBytes(A) + kCandCoopMaxW * sizeof(float) + size_t(nw) * 2 * kCandCoopMaxW * sizeof(int); }
 
 } // namespace mz

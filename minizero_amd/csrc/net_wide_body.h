@@ -34,6 +34,8 @@ struct WideGeo {
     static constexpr int passes(int wp) { return (groupTiles(wp) + NTMAX - 1) / NTMAX; }
     static constexpr int passTiles(int wp, int ps) { const int n = groupTiles(wp), k = passes(wp); return k == 0 ? 0 : n / k + (ps < n % k ? 1 : 0); }
     static constexpr int passStart(int wp, int ps) { int s = groupStart(wp); for (int i = 0; i < ps; ++i) { s += passTiles(wp, i); } return s; }
+    static constexpr bool singlePass() { for (int wp = 0; wp < WP; ++wp) { if (passes(wp) > 1) { return false; } } return true; }
+    static constexpr bool kSinglePass = singlePass(); // every wave holds all its accumulators at once: the layers' outputs go in place into the tile
 };
 template <int H, int W, int C>
 constexpr size_t wideTileFloats(int cin0q) { return size_t(cin0q > C ? cin0q : C) * WideGeo<H, W, C>::CS; }
@@ -51,9 +53,12 @@ __device__ __forceinline__ void wideStaticFor(F& f)
 }
 
 // One pass of one conv3x3 layer: NOT oc-tiles from `ot0` x the NT pixel tiles from `tile0`.  CQ = dwordx4 chunks (16 input channels) per (tap, oc-tile).
+// tout != nullptr (shapes whose waves run ONE pass): the outputs go IN PLACE into the tile the layer read — behind a workgroup barrier that every wave of the
+// workgroup passes once all MFMAs have been issued (waves without a pass: wideConv) — and to gout only where a later layer reads them as skip values (gout may
+// be nullptr); no trip through global memory between two layers.  tout == nullptr: the outputs go to gout, the caller stages them back (wideRestage).
 template <class G, int CQ, int NT, int NOT, bool CORNER>
 __device__ __forceinline__ void wideLayerPass(const float* __restrict__ tin, const float* gskip, float* gout, const float* __restrict__ wq,
-                                              const float* __restrict__ bias, int cout, int lane, int ot0, int tile0)
+                                              const float* __restrict__ bias, int cout, int lane, int ot0, int tile0, float* tout = nullptr)
 {
     constexpr int CS = G::CS, PW = G::PW, P = G::P, W = G::W, OT = G::OT;
     // A-fragments travel in units of UC dwordx4 chunks per oc-tile (4 chunks = 16 k-steps; 2 where a wave owns two oc-tiles: the two register sets of a
@@ -169,7 +174,7 @@ __device__ __forceinline__ void wideLayerPass(const float* __restrict__ tin, con
         }
         tapBody(std::integral_constant<int, 0>{}, 8, p0, p1);
     }
-    // epilogue: folded-BN bias (+ skip) + ReLU, NCHW to the workgroup's block in global memory.  D layout: column = lane & 15 (pixel), rows 4 * (lane >> 4) + r.
+    // epilogue: folded-BN bias (+ skip) + ReLU.  D layout: column = lane & 15 (pixel), rows 4 * (lane >> 4) + r.
     // gskip may BE gout (the second conv of a block writes the block's output over its input, lane by lane): every skip value is loaded before the first store,
     // so that the loads are one round trip and not one per store the compiler must keep them behind
     float sk[NOT][NT][4];
@@ -184,6 +189,7 @@ __device__ __forceinline__ void wideLayerPass(const float* __restrict__ tin, con
         }
     }
     asm volatile("" ::: "memory");
+    if (tout) { __syncthreads(); } // every wave has read its last B operand: the tile may be overwritten
 #pragma unroll
     for (int i = 0; i < NOT; ++i) {
         const int ocb = 16 * (ot0 + i) + 4 * (lane >> 4);
@@ -192,12 +198,16 @@ __device__ __forceinline__ void wideLayerPass(const float* __restrict__ tin, con
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int q = 16 * (tile0 + j) + (lane & 15);
+            const int pd = pixoff[j] - (lane >> 4) * CS + PW + 1; // the pixel's own position in a padded plane
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[i][j][r] + bv[r];
                 v = v + sk[i][j][r]; // without a skip: + 0 only turns -0 into +0, which the ReLU does anyway
                 v = v > 0.0f ? v : 0.0f;
-                if (q < P && ocb + r < cout) { gout[(ocb + r) * P + q] = v; }
+                if (q < P && ocb + r < cout) {
+                    if (tout) { tout[(ocb + r) * CS + pd] = v; }
+                    if (gout) { gout[(ocb + r) * P + q] = v; }
+                }
             }
         }
     }
@@ -216,28 +226,30 @@ constexpr bool wideUsesNT(int n, bool corner)
 }
 template <class G, int CQ, int N = 1>
 __device__ __forceinline__ void wideDispatchNT(int nt, bool corner, const float* __restrict__ tin, const float* gskip, float* gout, const float* __restrict__ wq,
-                                               const float* __restrict__ bias, int cout, int lane, int ot0, int tile0)
+                                               const float* __restrict__ bias, int cout, int lane, int ot0, int tile0, float* tout)
 {
     if constexpr (N <= 12) {
-        if constexpr (wideUsesNT<G>(N, false)) { if (nt == N && !corner) { wideLayerPass<G, CQ, N, G::NOT, false>(tin, gskip, gout, wq, bias, cout, lane, ot0, tile0); return; } }
-        if constexpr (wideUsesNT<G>(N, true)) { if (nt == N && corner) { wideLayerPass<G, CQ, N, G::NOT, true>(tin, gskip, gout, wq, bias, cout, lane, ot0, tile0); return; } }
-        wideDispatchNT<G, CQ, N + 1>(nt, corner, tin, gskip, gout, wq, bias, cout, lane, ot0, tile0);
+        if constexpr (wideUsesNT<G>(N, false)) { if (nt == N && !corner) { wideLayerPass<G, CQ, N, G::NOT, false>(tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout); return; } }
+        if constexpr (wideUsesNT<G>(N, true)) { if (nt == N && corner) { wideLayerPass<G, CQ, N, G::NOT, true>(tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout); return; } }
+        wideDispatchNT<G, CQ, N + 1>(nt, corner, tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout);
     }
 }
 
-// one conv3x3 layer by the 8 waves of the workgroup (no barrier inside): wave -> (oc-tiles, pixel group), the group's passes one after the other; one code copy
-// per distinct pass size
+// one conv3x3 layer by the 8 waves of the workgroup: wave -> (oc-tiles, pixel group), the group's passes one after the other; one code copy per distinct pass size.
+// tout == nullptr: outputs to gout, no barrier inside.  tout != nullptr (G::kSinglePass shapes): outputs in place into the tile (+ gout where given), ONE workgroup
+// barrier inside (between the last MFMA and the first write); the caller passes the barrier behind the layer.
 template <class G, int CQ>
 __device__ __forceinline__ void wideConv(const float* __restrict__ tin, const float* gskip, float* gout, const float* __restrict__ wq,
-                                         const float* __restrict__ bias, int cout, int wave, int lane)
+                                         const float* __restrict__ bias, int cout, int wave, int lane, float* tout = nullptr)
 {
     wave = __builtin_amdgcn_readfirstlane(wave);
     const int wo = wave % G::WO, wp = wave / G::WO, ot0 = wo * G::NOT;
     const int np = G::passes(wp);
+    if (tout && np == 0) { __syncthreads(); return; } // a wave without tiles keeps the barrier count
 #pragma unroll 1
     for (int ps = 0; ps < np; ++ps) {
         const int nt = G::passTiles(wp, ps), t0 = G::passStart(wp, ps);
-        wideDispatchNT<G, CQ>(nt, G::kCorner && t0 + nt == G::PT, tin, gskip, gout, wq, bias, cout, lane, ot0, t0);
+        wideDispatchNT<G, CQ>(nt, G::kCorner && t0 + nt == G::PT, tin, gskip, gout, wq, bias, cout, lane, ot0, t0, tout);
     }
 }
 
@@ -297,12 +309,25 @@ __device__ __forceinline__ float* wideTowerBody(const float* __restrict__ in, co
         }
     }
     __syncthreads();
+    if constexpr (G::kSinglePass) {
+        // in place: a layer's outputs overwrite the tile it read (behind the barrier inside wideConv); x also goes to global memory, where the second conv of
+        // the block finds its skip values.  The temporary never leaves the LDS; gt is not used.
+        wideConv<G, CIN0Q / 16>(tile, nullptr, gx, params + ta.w_off[0], params + ta.b_off[0], ta.C, wave, lane, tile);
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < ta.nlayers; l += 2) { // residual blocks (ref network_unit.py:14-23): t = relu(conv1(x)); x = relu(conv2(t) + x)
+            wideConv<G, C / 16>(tile, nullptr, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, wave, lane, tile);
+            __syncthreads();
+            wideConv<G, C / 16>(tile, gx, gx, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, wave, lane, tile);
+            __syncthreads();
+        }
+        (void)to_lds; (void)gt;
+        return tile;
+    }
     // stem: tile -> x
     wideConv<G, CIN0Q / 16>(tile, nullptr, gx, params + ta.w_off[0], params + ta.b_off[0], ta.C, wave, lane);
     __syncthreads();
     if (ta.nlayers > 1 || to_lds) {
-        if constexpr (CIN0Q > C) { // the stem's input planes beyond C would stay behind as stale channels: no layer reads them (CQ = C / 16), nothing to do
-        }
         wideRestage<G>(gx, tile, tid);
         __syncthreads();
     }

@@ -237,7 +237,9 @@ __device__ __forceinline__ void selectBody(const PoolView& v, const int* __restr
         const int N = static_cast<int>(cur.count - 1);
         const float bias = bias_tab[N];
         const double sqrtN = sqrt_tab[N];
-        if (nc <= 128) { // (with value rescaling the normalised means come from normalizedMean() itself: the reciprocal trick covers the plain case)
+        // (a node of more than 128 children — 13x13 / 19x19 Go — takes the same path below the root whenever the children that need a look are at most 128:
+        //  the visited-prefix argument does not depend on the node's width)
+        if (nc <= 128 || (node != 0 && min(nc, static_cast<int>(static_cast<unsigned>(cur.players) >> 16) + 1) <= 128)) { // (with value rescaling the normalised means come from normalizedMean() itself: the reciprocal trick covers the plain case)
             // Children are stored in descending prior order and an unvisited child can only be chosen while every child before it has
             // been visited (equal init-Q, u monotone in the prior, ties go to the higher prior / lower index), so the visited children
             // of a node are a PREFIX of its children and the arg-max is among that prefix plus the first unvisited child.  The prefix

@@ -835,7 +835,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
         int lf = 0;
         size_t lds = 0, tile_bytes = 0;
         if (!simWidePlan(gv.n, pool.v_.max_depth - 3, a.hp, gv.channels, gv.W32, goLeafSmemBytes(gv, pool.v_.max_depth), scratch, &lf, &lds, &tile_bytes)) { return MZ_OK; }
-        a.cand_coop = candCoopSmemBytes(gv.A, 8) <= tile_bytes ? 1 : 0;
+        a.cand_coop = (gv.A > kCandCoopMax && gv.A <= kCandCoopMaxW && candCoopSmemBytesW(gv.A, 8) <= tile_bytes) ? 2 : candCoopSmemBytes(gv.A, 8) <= tile_bytes ? 1 : 0;
         return simLaunchWide(a, gv, pool.v_.max_depth, d_rot, sim0, nsims, host_start, lf, lds, launched);
     }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;

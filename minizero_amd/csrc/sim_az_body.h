@@ -199,14 +199,20 @@ __device__ __noinline__ void simCandGather(CSimArgs* __restrict__ a, int rot, in
     Cand* cs = reinterpret_cast<Cand*>(tiles);
     const int k = azCandGather(gv, xchg + x.policy() - ga, xchg + x.logit() - ga, rot, g, lane, cs);
     waveSync();
-    if (k > kCandCoopMax || !a->cand_coop) { if (k > 0) { orderCandidates(cs, cs + gv.A, reinterpret_cast<int*>(cs + 2 * gv.A), k, lane, a->err); } }
+    // (cand_coop 2: boards of more than 128 actions — up to six candidates per lane, candRankPartW)
+    if (a->cand_coop == 2 && k > 0 && k <= kCandCoopMaxW) { candDenseW(cs, k, lane, simCandDense(tiles, gv.A)); }
+    else if (k > kCandCoopMax || !a->cand_coop) { if (k > 0) { orderCandidates(cs, cs + gv.A, reinterpret_cast<int*>(cs + 2 * gv.A), k, lane, a->err); } }
     else { candDense(cs, k, lane, simCandDense(tiles, gv.A)); }
     if (lane == 0) { reinterpret_cast<int*>(sc)[1] = k; } // cand_count: read by every wave after the barrier
     MZ_LPROF(7);
 }
 
-__device__ __forceinline__ void simCandRank(int A, int k, int wave, int lane, float* tiles)
+__device__ __forceinline__ void simCandRank(int A, int k, int wave, int lane, float* tiles, int coop = 1)
 {
+    if (coop == 2) {
+        if (k > 0 && k <= kCandCoopMaxW) { float* dense = simCandDense(tiles, A); candRankPartW(dense, k, wave, 8, lane, reinterpret_cast<int*>(dense + kCandCoopMaxW)); }
+        return;
+    }
     if (k <= 0 || k > kCandCoopMax) { return; }
     float* dense = simCandDense(tiles, A);
     candRankPart(dense, k, wave, 8, lane, reinterpret_cast<int*>(dense + kCandCoopMax));
@@ -249,7 +255,12 @@ __device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, in
     Cand* cs = reinterpret_cast<Cand*>(tiles);
     Cand* out = cs + gv.A;
     const int k = reinterpret_cast<const int*>(sc)[1];
-    if (k > 0 && k <= kCandCoopMax && a->cand_coop) {
+    if (a->cand_coop == 2) {
+        if (k > 0 && k <= kCandCoopMaxW) {
+            float* dense = simCandDense(tiles, gv.A);
+            candScatterW(cs, out, reinterpret_cast<int*>(out + gv.A), k, 8, lane, reinterpret_cast<const int*>(dense + kCandCoopMaxW), a->err);
+        }
+    } else if (k > 0 && k <= kCandCoopMax && a->cand_coop) {
         float* dense = simCandDense(tiles, gv.A);
         candScatter(cs, out, reinterpret_cast<int*>(out + gv.A), k, 8, lane, reinterpret_cast<const int*>(dense + kCandCoopMax), a->err);
     }

@@ -45,7 +45,19 @@ def flops_per_leaf_eval(d):
 EXTRA_CONFIGS = {
     "c4g64": ("c4", "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=50:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
                     "actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:zero_num_parallel_games=64"),
+    # round 5: shapes beyond BASELINE.json on the one-tile tower (sim_wide.inc sim_kernel_wide), BASELINE configs[1]'s search (n = 400, 256 games, one game per CU)
+    "w9x128": ("w9x128", "env_game=go:env_board_size=9:actor_num_simulation=400:zero_num_parallel_games=256"),    # 9x9 Go, 6 blocks x 128 channels
+    "w9x256": ("w9x256", "env_game=go:env_board_size=9:actor_num_simulation=400:zero_num_parallel_games=256"),    # 9x9 Go, the reference's default network: 1 block x 256 channels
+    "w19x64": ("w19x64", "env_game=go:env_board_size=19:actor_num_simulation=400:zero_num_parallel_games=256"),   # 19x19 Go, 6 blocks x 64 channels
 }
+EXTRA_DESCS = {
+    "w9x128": lambda: mz.make_desc("go_9x9", 18, 9, 9, 128, 9, 9, 1, 6, 82),
+    "w9x256": lambda: mz.make_desc("go_9x9", 18, 9, 9, 256, 9, 9, 1, 1, 82),
+    "w19x64": lambda: mz.make_desc("go_19x19", 18, 19, 19, 64, 19, 19, 1, 6, 362),
+}
+MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2})
+WARM.update({"w9x128": 1, "w9x256": 1, "w19x64": 1})
+KERNEL.update({"w9x128": "sim_kernel_wide<9,9,32,128,2>", "w9x256": "sim_kernel_wide<9,9,32,256,2>", "w19x64": "sim_kernel_wide<19,19,32,64,6>"})
 
 
 def _by_kernel(s0, s1, launches):
@@ -73,7 +85,7 @@ def run_config(key, moves=None, threads=None, extra_conf="", warm=None):
     loop).  Returns the block bench.py (`other_configs`) and profiles/rNN_all_configs_n1.json both carry."""
     dkey, base = EXTRA_CONFIGS.get(key, (key, None))
     base = base or mz.CONFIGS[key]
-    d = mz.DESCS[dkey]()
+    d = (EXTRA_DESCS.get(dkey) or mz.DESCS[dkey])()
     if threads is None:
         threads = max(1, mz.usable_cpus() - 1)
     conf = f"{base}:program_seed=1:nn_file_name=synthetic.pt:zero_num_threads={threads if key != 'c1' else 1}:mz_rng_streams={RNG_STREAMS if key != 'c1' else 1}:mz_cpu_base=0{extra_conf}"
