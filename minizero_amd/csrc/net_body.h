@@ -547,6 +547,9 @@ __device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
 // the body of heads_kernel for sample `b`, run by NT threads (a multiple of 64, >= 128); `sm` = (C*P + PC*P + P + VH + A + 16) floats of LDS
 // With xlds and without scale_hidden it passes exactly TWO workgroup barriers (after the conv1x1, after the FCs): the simulation kernel runs the second half
 // of the Go leaf beside it on waves that have no share of the heads (sim.hip simLeafRest / go_body.h goLeafBody PART 2), and those waves pass the same two.
+// BIGA (boards of more than 128 actions, 13x13 / 19x19 Go: the policy FC is a 722-step chain per logit at 19x19): the weights of the long chains 64 steps ahead, and the
+// value FC1 on the threads the policy FC leaves free (two hidden units per thread, interleaved) instead of behind it on the same threads.  Same chains, same bits.
+template <bool BIGA = false>
 __device__ __forceinline__ void headsBody(const float* __restrict__ x, const HeadParams& hp, float* __restrict__ policy, float* __restrict__ logit,
                                           float* __restrict__ value, float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int scale_hidden,
                                           int b, int tid, int NT, float* __restrict__ sm, const float* __restrict__ xlds = nullptr, int xcs = 0,
@@ -616,11 +619,24 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
 
     // policy FC (one logit per thread, waves 0..) and value FC1 (one hidden unit per thread, on other waves when there are enough)
     for (int a = tid; a < A; a += NT) {
-        const float v = dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P) + hp.pfc_b[a];
+        const float v = (BIGA ? dotChain<64>(pf, 1, hp.pfc_wT + a, A, PC * P) : dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P)) + hp.pfc_b[a];
         lg[a] = v;
         logit[size_t(b) * A + a] = v;
     }
-    {
+    if (BIGA && NT == 512 && A <= 384) {
+        if (tid >= 384) {
+            for (int o = tid - 384; o < VH; o += 256) { // hidden units o and o + 128: two independent chains of P steps, interleaved
+                const int o2 = o + 128 < VH ? o + 128 : o;
+                const float* const xs2[2] = {vf, vf};
+                const float* const ws2[2] = {hp.vfc1_wT + o, hp.vfc1_wT + o2};
+                float acc2[2];
+                dotChainK<32, 2>(xs2, 1, ws2, VH, P, acc2);
+                const float v0 = acc2[0] + hp.vfc1_b[o], v1 = acc2[1] + hp.vfc1_b[o2];
+                h1[o] = v0 > 0.0f ? v0 : 0.0f;
+                if (o + 128 < VH) { h1[o2] = v1 > 0.0f ? v1 : 0.0f; }
+            }
+        }
+    } else {
         const int vo = (NT >= 256 && A <= 128) ? 128 : 0; // first thread of the value FC1 group
         for (int o = (tid - vo + NT) % NT; o < VH; o += NT) {
             const float v = dotChain<16>(vf, 1, hp.vfc1_wT + o, VH, P) + hp.vfc1_b[o];

@@ -148,7 +148,11 @@ typedef __attribute__((address_space(3))) const double LdsCDbl;
 constexpr int kSpecCap = 128;                                   // levels remembered per path
 constexpr int kSpecWay = 4 + 3 * kSpecCap;                      // words of one remembered path: [0] length, then node / first_child / num_children per level
 constexpr int kGw = 4, kLv = 64 / kGw;                          // lanes per predicted level (its first children) and levels per pass
-constexpr int kSpecWays = 16;                                   // remembered paths (one per recently walked root child)
+#ifndef MZ_SPEC_WAYS
+#define MZ_SPEC_WAYS 16 // (a translation unit whose kernels have little LDS to spare defines fewer — a power of two: sim_wide_c.hip, 19x19 Go)
+#endif
+constexpr int kSpecWays = MZ_SPEC_WAYS;                         // remembered paths (one per recently walked root child)
+static_assert((kSpecWays & (kSpecWays - 1)) == 0 && kSpecWays >= 2 && kSpecWays <= 64, "a power of two of at most one wave's lanes");
 // Helper segments (selectSpecHelper): while wave 0 walks levels 1 .. 16 of a remembered path, waves 1 .. 3 evaluate levels 17 .. 32, 33 .. 48 and 49 .. 64 of the path the
 // PREVIOUS walk took, each into its own result block; wave 0 takes a block over when it arrives at the block's entry node with all 16 levels before it accepted.
 constexpr int kHelpSegs = 3;                                    // helper waves / segments of kLv levels behind the first

@@ -316,7 +316,7 @@ __device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, 
 }
 
 // the heads read the tower's last activations where they are (an LDS tile); tile 0 (the blocks' temporary) is free for their scratch
-template <int WPE>
+template <int WPE, bool BIGA = false>
 __device__ __forceinline__ void simHeadsImpl(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw, float* xchg)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
@@ -327,15 +327,15 @@ __device__ __forceinline__ void simHeadsImpl(CSimArgs* __restrict__ a, int g, in
     const HeadParams hp = ldc(&a->hp);
     const SimXchg x{hp.A + (hp.A & 1)};
     const size_t ga = size_t(g) * hp.A;
-    headsBody(nullptr, hp, xchg + x.policy() - ga, xchg + x.logit() - ga, xchg + x.scalars() - g, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
+    headsBody<BIGA>(nullptr, hp, xchg + x.policy() - ga, xchg + x.logit() - ga, xchg + x.scalars() - g, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
     MZ_HPROF(1);
 }
 // a non-inlined device function saves the callee-saved VGPRs it uses on entry (scratch stores + loads by all 8 waves): worth it for the
 // 9x9 kernels (the heads keep their own register budget, and their version needs none saved), not for the 128-VGPR 8x8 / 3x3 kernels
-template <int WPE>
+template <int WPE, bool BIGA = false>
 __device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw, float* xchg)
 {
-    simHeadsImpl<WPE>(a, g, tid, tiles, xtile, xcs, xpw, xchg);
+    simHeadsImpl<WPE, BIGA>(a, g, tid, tiles, xtile, xcs, xpw, xchg);
 }
 
 // 8x8 boards: three tower tiles are 80 KB of LDS, so TWO games share a CU (16 waves) if the kernel stays within 128 VGPRs: one game's

@@ -5,16 +5,16 @@
 namespace mz {
 
 bool simWideLaunchPart1(int H, int W, int c0q, int C, int cpl, const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, int lf, size_t lds,
-                        hipStream_t s, size_t* tile_bytes, int* rc);
+                        hipStream_t s, size_t* tile_bytes, int* rc, int* spec_words);
 bool simWideLaunchPart2(int H, int W, int c0q, int C, int cpl, const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, int lf, size_t lds,
-                        hipStream_t s, size_t* tile_bytes, int* rc);
+                        hipStream_t s, size_t* tile_bytes, int* rc, int* spec_words);
 
 static bool simWideAny(int H, int W, int c0q, int C, int cpl, const SimArgs* d_args, int games, const uint8_t* d_rot, int sim0, int nsims, int host_start, int lf, size_t lds,
-                       hipStream_t s, size_t* tile_bytes, int* rc)
+                       hipStream_t s, size_t* tile_bytes, int* rc, int* spec_words = nullptr)
 {
-    return simWideLaunchPart0(H, W, c0q, C, cpl, d_args, games, d_rot, sim0, nsims, host_start, lf, lds, s, tile_bytes, rc) ||
-           simWideLaunchPart1(H, W, c0q, C, cpl, d_args, games, d_rot, sim0, nsims, host_start, lf, lds, s, tile_bytes, rc) ||
-           simWideLaunchPart2(H, W, c0q, C, cpl, d_args, games, d_rot, sim0, nsims, host_start, lf, lds, s, tile_bytes, rc);
+    return simWideLaunchPart0(H, W, c0q, C, cpl, d_args, games, d_rot, sim0, nsims, host_start, lf, lds, s, tile_bytes, rc, spec_words) ||
+           simWideLaunchPart1(H, W, c0q, C, cpl, d_args, games, d_rot, sim0, nsims, host_start, lf, lds, s, tile_bytes, rc, spec_words) ||
+           simWideLaunchPart2(H, W, c0q, C, cpl, d_args, games, d_rot, sim0, nsims, host_start, lf, lds, s, tile_bytes, rc, spec_words);
 }
 
 // The LDS plan of sim_kernel_wide for a search of n simulations on a board of board_n x board_n points: false = no instance, or the mandatory blocks do not fit.
@@ -29,8 +29,8 @@ bool Net::simWidePlan(int board_n, int num_simulation, const HeadParams& hp, int
     if (H != board_n || W != board_n) { return false; }
     const int cpl = (board_n * board_n + 63) / 64;
     size_t tile_bytes = 0;
-    int rc = MZ_OK;
-    if (!simWideAny(H, W, c0q, C, cpl, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, &tile_bytes, &rc)) { return false; }
+    int rc = MZ_OK, spec_words = kSpecWords;
+    if (!simWideAny(H, W, c0q, C, cpl, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, &tile_bytes, &rc, &spec_words)) { return false; }
     const size_t rcp_n = size_t(num_simulation) + 5, max_depth = size_t(num_simulation) + 3, A = desc_.action_size;
     const size_t heads = (size_t(hp.PC) * hp.P + hp.P + hp.VH + hp.A + 16) * sizeof(float);
     size_t need = tile_bytes + rcp_n * sizeof(double) + (2 * max_depth + 2 + ((simXchgWords(int(A), channels, W32) + 1) & ~size_t(1))) * sizeof(float) + heads + 16;
@@ -42,7 +42,7 @@ bool Net::simWidePlan(int board_n, int num_simulation, const HeadParams& hp, int
     const bool beside = hp.VH <= 256 && (hp.PC + 1) * hp.P <= 384 && hp.A <= 384; // waves 6 and 7 have no share of the heads (sim_az_body.h)
     const size_t leaf = (leaf_bytes + 7) & ~size_t(7);
     if (beside && (f & 2) && need + leaf <= cap) { f |= 4; need += leaf; }
-    const size_t spec = rcp_n * (sizeof(double) + sizeof(float)) + kSpecWords * sizeof(int) + 8;
+    const size_t spec = rcp_n * (sizeof(double) + sizeof(float)) + size_t(spec_words) * sizeof(int) + 8;
     if (need + spec <= cap) { f |= 1; need += spec; }
     if (lf) { *lf = f; }
     if (lds) { *lds = need; }
