@@ -22,7 +22,7 @@ cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/d
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc1a -- python bench.py $SHORT > $O/bench_pmc1a.json 2> $O/pmc1a.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc1b -- python bench.py $SHORT > $O/bench_pmc1b.json 2> $O/pmc1b.err
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc2 -- python bench.py $SHORT > $O/bench_pmc2.json 2> $O/pmc2.err
-for k in c3 c4 c5; do
+for k in c3 c4 c5 w9x128 w19x64; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$k -- python tools/run_configs.py $k --out $O/configs_prof_$k.json > $O/stats_$k.log 2>&1
   cp $(find $O/stats_$k -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$k.csv 2>/dev/null
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcA_$k -- python tools/run_configs.py $k --out $O/tmp.json > $O/pmcA_$k.log 2>&1
@@ -58,11 +58,15 @@ def summarize(tag, a_dir, b_dir, c_dir, cycles, note):
                     "lds_conflict_frac": s["SQ_LDS_BANK_CONFLICT"] / max(1.0, s["SQ_LDS_IDX_ACTIVE"])})
     json.dump(out, open(f"{O}/{tag}.json", "w"), indent=1)
 summarize("pmc_sim", "pmc1a", "pmc1b", "pmc2", 5 * 401, "over all launches of `python bench.py --steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline` (5 moves x 401 cycles x 256 games)")
-MOVES = {"c3": (40 + 3) * 17, "c4": (20 + 3) * 51, "c5": (40 + 14) * 51}
+MOVES = {"c3": (40 + 3) * 17, "c4": (20 + 3) * 51, "c5": (40 + 14) * 51, "w9x128": (3 + 1) * 401, "w19x64": (2 + 1) * 401}
 for k, cyc in MOVES.items():
     summarize(f"pmc_{k}", f"pmcA_{k}", f"pmcB_{k}", f"pmcC_{k}", cyc, f"over all simulation-kernel launches of `python tools/run_configs.py {k}` ({cyc} lock-step cycles incl. warm-up)")
 PY
 timeout 900 python tools/run_configs.py --out $O/configs.json > $O/configs.log 2>&1
+# round 5: shapes beyond BASELINE.json on the one-tile tower (sim_kernel_wide): a roofline block each, the stand-alone towers, the in-kernel phase profile
+timeout 600 python tools/run_configs.py w9x128 w9x256 w19x64 --out $O/wide_configs.json > $O/wide_configs.log 2>&1
+timeout 300 python tools/time_wide.py 256 > $O/time_wide.log 2>&1; cp gpurun_out/time_wide.json $O/time_wide_towers.json
+for k in w9x128 w19x64; do MZ_SIM_PROF=1 timeout 200 python tools/run_configs.py $k --moves 1 --out $O/tmp.json 2>&1 | grep "sim prof" > $O/sim_prof_$k.txt; done
 MZ_SIM_PROF=1 timeout 200 python bench.py $SHORT 2>&1 | grep "sim prof" > $O/sim_prof.txt
 MZ_SIM_PROF=1 timeout 200 python tools/run_configs.py c5 --out $O/tmp.json 2>&1 | grep "sim prof" > $O/sim_prof_c5_rounds.txt
 MZ_SIM_PROF=1 timeout 200 python tools/run_configs.py c5 --conf mz_sim_rounds=false --out $O/tmp.json 2>&1 | grep "sim prof" > $O/sim_prof_c5_no_rounds.txt
@@ -80,7 +84,7 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_c5 -- pytho
 python tools/c5_move_timeline.py $(find $O/trace_c5 -name "*kernel_trace.csv" | head -1) > $O/c5_move_timeline.txt 2>&1
 rm -rf $O/trace_c5
 rm -rf $O/stats $O/stats_c* $O/pmc1a $O/pmc1b $O/pmc2 $O/pmcA_* $O/pmcB_* $O/pmcC_* $O/tmp.json
-ls -la $O | head -40; cat $O/pmc_sim.json; for k in c3 c4 c5; do cat $O/pmc_$k.json; done; python tools/kstats.py $O/kernel_stats.csv | head -6
+ls -la $O | head -40; cat $O/pmc_sim.json; for k in c3 c4 c5 w9x128 w19x64; do cat $O/pmc_$k.json; done; python tools/kstats.py $O/kernel_stats.csv | head -6
 python - <<'PY'
 import json
 j = json.load(open("gpurun_out/refresh/bench.json")); print("f32", round(j["value"]), j["ms_per_step"], j["games_per_sec"], j["roofline"]["frac"], j["cpu_baseline"]["value"])
