@@ -131,6 +131,10 @@ public:
     // network that both counted from 1 would take each other's stale entries for their own (same parent slot, same action, same number)
     int nextPreEpoch() { pre_epoch_counter_ = pre_epoch_counter_ == 0x7fffffff ? 1 : pre_epoch_counter_ + 1; return pre_epoch_counter_; }
     bool hasSimKernelMz(int num_simulation = 0) const;
+    bool hasPreBoard() const; // MuZero board games: is there a kernel that evaluates a Gumbel round's leaves ahead for this shape?
+    // MuZero board games on the one-tile tower (sim_wide_mz.hip sim_kernel_mz_wide)
+    bool simMzWidePlan(int num_simulation, int* lf, size_t* lds, size_t* tile_bytes_out, int* c0q_out, int* cdq_out) const;
+    int simLaunchMzWide(const struct SimArgs& a, int games, int sim0, int nsims, int host_start, int lf, size_t lds, int c0q, int cdq, bool* launched);
     int expandAtariFeatures(const uint8_t* d_raw, int raw_bytes, int B, float* d_feat);
     int shiftExpandAtariFeatures(const uint8_t* d_prev, const uint8_t* d_newest, const uint8_t* d_meta, uint8_t* d_cur, int raw_bytes, int B, float* d_feat); // raw observations -> float planes (net_atari.hip)
     void makeAtariHeadParams(AtariHeadParams* out) const; // net_atari.hip

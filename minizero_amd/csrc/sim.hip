@@ -1,215 +1,7 @@
 #include "sim_az_body.h"
+#include "sim_mz_body.h"
 
 namespace mz {
-
-// ---- MuZero (board games; ref muzero_network.h:97-178, zero_actor.cpp:215-245): no leaf environment.  The leaf is evaluated from
-// its parent's hidden state (slab slot `hslot[parent]`) and the move; its children are ALL actions (the root: the legal ones) in
-// the reference's sort order; the new hidden state is rescaled to [0, 1] per sample and written to the slab slot of this simulation.
-__device__ __noinline__ void simMzCandGather(CSimArgs* __restrict__ a, int g, int lane, float* tiles, int* kshare, int* lds_path = nullptr)
-{
-    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
-    g = __builtin_amdgcn_readfirstlane(g);
-    const PoolView v = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
-    const int A = a->A, len = v.path_len[g], depth = len - 1;
-    Cand* cs = reinterpret_cast<Cand*>(tiles);
-    int k = 0;
-    for (int base = 0; base < A; base += 64) {
-        const int ac = base + lane;
-        const bool leg = ac < A && (depth > 0 || ((a->root_legal[size_t(g) * a->LW + (ac >> 6)] >> (ac & 63)) & 1)); // legality is only known at the root (zero_actor.cpp:238)
-        const unsigned long long m = __ballot(leg);
-        if (leg) { cs[k + __popcll(m & ((1ull << lane) - 1))] = Cand{ac, a->policy[size_t(g) * A + ac], a->logit[size_t(g) * A + ac]}; }
-        k += __popcll(m);
-    }
-    waveSync();
-    if (k > kCandCoopMax || !a->cand_coop) { orderCandidates(cs, cs + A, reinterpret_cast<int*>(cs + 2 * A), k, lane, a->err); }
-    else { candDense(cs, k, lane, simCandDense(tiles, A)); }
-    if (lane == 0) { *kshare = k; }
-}
-
-// given: the network outputs of this leaf come from the stand-alone kernels (the muzero_atari root: value / reward still in the transformed scale)
-// part 0: everything; part 1: the candidate list and the new children (needs the policy only); part 2: value / reward + backup (the cluster kernel runs
-// part 1 while the value and reward heads of the game's other workgroups are still busy)
-// presorted: a leaf that was evaluated ahead (simPreProbe) — `slot` is its entry, which holds the sorted candidate list
-// lds_path: the simulation's path lives in LDS (simPathView) instead of the pool's arrays
-__device__ __noinline__ void simMzCandExpand(CSimArgs* __restrict__ a, int slot, int g, int lane, float* tiles, int k, bool given = false, int part = 0, bool presorted = false,
-                                             int* lds_path = nullptr)
-{
-    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
-    g = __builtin_amdgcn_readfirstlane(g);
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    k = __builtin_amdgcn_readfirstlane(k);
-    part = __builtin_amdgcn_readfirstlane(part);
-    const PoolView v = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
-    const int A = a->A, len = v.path_len[g], depth = len - 1;
-    if (part != 2 && !presorted) {
-        Cand* cs = reinterpret_cast<Cand*>(tiles);
-        Cand* out = cs + A;
-        if (k > 0 && k <= kCandCoopMax && a->cand_coop) {
-            float* dense = simCandDense(tiles, A);
-            candScatter(cs, out, reinterpret_cast<int*>(out + A), k, 8, lane, reinterpret_cast<const int*>(dense + kCandCoopMax), a->err);
-        }
-        for (int i = lane; i < k; i += 64) {
-            a->cand_action[size_t(g) * A + i] = out[i].action;
-            a->cand_policy[size_t(g) * A + i] = out[i].policy;
-            a->cand_logit[size_t(g) * A + i] = out[i].logit;
-        }
-    }
-    if (presorted && part == 0) {
-        // A leaf evaluated ahead: its sorted candidate list lies in its entry (= its slab slot) — all A actions (legality is only known at the root,
-        // zero_actor.cpp:238) — and its value and reward too; everything expand + backup need is loaded side by side, nothing goes through the game's arrays
-        const size_t e = size_t(g) * a->slots + slot, off = (e - g) * A;
-        const int rt = a->root_turn[g];
-        const ExpandGiven eg{k, (a->num_players == 2 && (depth & 1)) ? 3 - rt : rt, a->pre_value[e], a->atari ? a->pre_reward[e] : 0.0f};
-        MZ_LPROF(23);
-        expandBackupBody(v, a->cand_count, a->pre_action + off, a->pre_policy + off, a->pre_logit + off, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, 0, &eg);
-        MZ_LPROF(24);
-        return;
-    }
-    if (lane == 0) {
-        if (part != 2) {
-            const int rt = a->root_turn[g];
-            a->cand_count[g] = k;
-            a->cand_player[g] = (a->num_players == 2 && (depth & 1)) ? 3 - rt : rt; // the children are moved by the player to move at the leaf
-        }
-        if (part != 1) {
-            const bool inv = given && a->atari; // the host path's invertValueHost() of both (worker.cpp buildCandidates)
-            a->value_io[g] = inv ? invertValueDev(a->value[g]) : a->value[g];
-            a->reward_io[g] = a->atari ? (inv ? invertValueDev(a->reward[g]) : a->reward[g]) : 0.0f; // board games have no reward head (ref muzero_network.h:129)
-        }
-    }
-    waveSync();
-    MZ_LPROF(23);
-    if (presorted) { // (cluster kernel, part 1: the children of a leaf evaluated ahead; part 2 takes value and reward from the game's arrays, simPreProbe put them there)
-        const size_t off = (size_t(g) * a->slots + slot - g) * A;
-        expandBackupBody(v, a->cand_count, a->pre_action + off, a->pre_policy + off, a->pre_logit + off, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, part);
-    } else {
-        expandBackupBody(v, a->cand_count, a->cand_action, a->cand_policy, a->cand_logit, a->cand_player, a->value_io, a->reward_io, slot, a->err, g, lane, tiles, part);
-    }
-    MZ_LPROF(24);
-}
-
-// The Gumbel step of simulation `next_slot`, ahead of the backup of the simulation in flight (gumbel_body.h `bump`): true if a->start[g] and the state are
-// those the step after the backup would write.  The cluster kernel runs it on its owner while the other workgroups' value / reward heads are still busy.
-__device__ __noinline__ bool simGumbelAhead(CSimArgs* __restrict__ a, int next_slot, int g, int lane, float* tiles, float bump_cnt = -1.0f, int* lds_path = nullptr,
-                                            int* state_lds = nullptr, const int* kids = nullptr)
-{
-    g = __builtin_amdgcn_readfirstlane(g);
-    next_slot = __builtin_amdgcn_readfirstlane(next_slot);
-    const PoolView pv = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
-    GumbelView gum = ldc(&a->gum);
-    if (state_lds) { gum.state = state_lds - size_t(g) * (3 + kGumbelMaxSample); }
-    const int len = pv.path_len[g];
-    if (len < 2) { return false; }
-    const int child = pv.path[size_t(g) * pv.max_depth + 1] - (kids ? kids[0] : pv.rec[size_t(g) * pv.cap].first_child);
-    const int st = gumbelStepBody(pv, gum, next_slot, g, lane, tiles, child, bump_cnt, kids);
-    if (st >= 0 && lane == 0) { a->start[g] = st; }
-    waveSync();
-    return st >= 0;
-}
-
-__device__ __noinline__ void simMzSelect(CSimArgs* __restrict__ a, int slot, bool host_start, int g, int lane, float* tiles, LdsCDouble* rcp, SpecMem spec,
-                                         bool gumbel_done = false, bool noise_done = false, int serial = 0, int* lds_path = nullptr, int* state_lds = nullptr)
-{
-    serial = __builtin_amdgcn_readfirstlane(serial);
-    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    g = __builtin_amdgcn_readfirstlane(g);
-    MZ_LPROF(0);
-    if (slot == 1 && a->root_noise && !noise_done) { simApplyRootNoise<2>(a, g, lane); }
-    if (a->use_gumbel && !gumbel_done) { simGumbelStart<2>(a, slot, host_start, g, lane, tiles, state_lds); }
-    MZ_LPROF(20);
-    const PoolView pv = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
-    selectBody<true>(pv, a->use_gumbel ? a->start : nullptr, g, lane, rcp, spec, serial);
-    MZ_LPROF(21);
-}
-
-// Leaves evaluated ahead (sim_pre_kernel_mz): does the entry of simulation `slot` hold THIS leaf — the same parent hidden state (slab slot `src`) and the
-// same action, written in this move (`epoch`)?  Then its value and reward are copied to the game's arrays and the slab slot
-// that holds its hidden state is returned (`slot`, or alt_base + slot for the second expected leaf); -1: not evaluated ahead.  The simulation then runs
-// exactly as if the kernel had evaluated the leaf itself: candidates, expand (the node remembers the returned slot), backup.
-__device__ __forceinline__ int simPreProbe(CSimArgs* __restrict__ a, int epoch, int g, int slot, int src, int action, int lane)
-{
-    if (epoch == 0 || !a->pre_key) { return -1; }
-    size_t e = size_t(g) * a->slots + slot;
-    const int* key = a->pre_key + e * 4;
-    bool hit = __builtin_amdgcn_readfirstlane((key[2] == epoch && key[0] == src && key[1] == action) ? 1 : 0) != 0;
-    int eslot = slot;
-    if (!hit && a->alt_base) { // the second expected leaf of this simulation (entry and slab slot alt_base + slot)
-        const int* key2 = key + size_t(a->alt_base) * 4;
-        hit = __builtin_amdgcn_readfirstlane((key2[2] == epoch && key2[0] == src && key2[1] == action) ? 1 : 0) != 0;
-        if (hit) { e += a->alt_base; eslot += a->alt_base; if (a->pre_stat && lane == 0) { atomicAdd(a->pre_stat + 128, 1u); if (slot < 126) { atomicAdd(a->pre_stat + 256 + slot, 1u); } } } // ([256 + s]: by simulation, Worker::adaptRounds)
-    }
-    if (!hit) {
-        if (a->pre_stat && key[2] == epoch && lane == 0 && slot < 126) { atomicAdd(a->pre_stat + 2 + slot, 1u); } // (monitoring: which simulations of a move miss, MZ_SIM_PROF)
-        return -1;
-    }
-    if (lane == 0) { // (the entry's sorted candidate list is read where it lies: simMzCandExpand)
-        a->value[g] = a->pre_value[e];
-        a->reward[g] = a->pre_reward[e];
-        if (a->pre_stat) { atomicAdd(a->pre_stat, 1u); }
-    }
-    waveSync();
-    return eslot;
-}
-
-// scale_hidden_state (ref muzero_network.py:81-88) of the tower's output where it lies (padded planes in LDS), in place, and the rescaled state
-// to the slab slot `hd`: min / max are order-free, (h - min) / scale is one IEEE operation per element.  H, W compile-time: with run-time
-// geometry the three integer divisions per element and pass cost more than the arithmetic (heads 21.5 -> 13 us on BASELINE configs[3])
-template <int H, int W>
-__device__ __forceinline__ void rescaleTile(float* __restrict__ xt, int C, float* __restrict__ hd, int tid, float* __restrict__ red)
-{
-    constexpr int P = H * W, PW = W + 2, CS = planeStride(H, W);
-    const int lane = tid & 63, wave = tid >> 6;
-    MZ_HPROF(0);
-    float mn = 3.4e38f, mx = -3.4e38f;
-    for (int i = tid; i < C * P; i += 512) {
-        const int c = i / P, p = i - c * P;
-        const float v = xt[c * CS + (p / W + 1) * PW + p % W + 1];
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const float m2 = __shfl_xor(mn, o), x2 = __shfl_xor(mx, o);
-        mn = m2 < mn ? m2 : mn;
-        mx = x2 > mx ? x2 : mx;
-    }
-    if (lane == 0) { red[wave] = mn; red[8 + wave] = mx; }
-    __syncthreads();
-    MZ_HPROF(1);
-    mn = red[0]; mx = red[8];
-    for (int w = 1; w < 8; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[8 + w] > mx ? red[8 + w] : mx; }
-    float scale = mx - mn;
-    if (scale < 1e-5f) { scale += 1e-5f; }
-    for (int i = tid; i < C * P; i += 512) {
-        const int c = i / P, p = i - c * P, k = c * CS + (p / W + 1) * PW + p % W + 1;
-        const float v = (xt[k] - mn) / scale;
-        xt[k] = v;
-        hd[i] = v;
-    }
-    MZ_HPROF(2);
-    __syncthreads();
-    MZ_HPROF(3);
-}
-
-template <int H, int W>
-__device__ __forceinline__ void simMzHeads(CSimArgs* __restrict__ a, int slot, int g, int tid, float* tiles, float* scratch, float* xtile)
-{
-    // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    g = __builtin_amdgcn_readfirstlane(g);
-    constexpr int xcs = planeStride(H, W), xpw = W + 2;
-    if (a->atari) { // 601-bin value / reward heads, rescaled hidden state to the slab slot of this simulation, value and reward in game scale
-        const AtariHeadParams hp = ldc(&a->ahp);
-        float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
-        atariHeadsBody<256>(nullptr, xtile, xcs, xpw, hp, a->policy, a->logit, a->value, a->reward, hd, 1, 1, g, tid, scratch);
-        return;
-    }
-    const HeadParams hp = ldc(&a->hp);
-    float* hd = a->hidden + (size_t(g) * a->slots + slot) * size_t(hp.C) * hp.P;
-    rescaleTile<H, W>(xtile, hp.C, hd, tid, tiles); // tile 0 (the blocks' temporary) is free: its first words hold the reduction scratch
-    headsBody(nullptr, hp, a->policy, a->logit, a->value, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
-    MZ_HPROF(4);
-}
 
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
 __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start, int pre_epoch)
@@ -882,9 +674,25 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     return MZ_OK;
 }
 
+// MuZero board games whose Gumbel rounds can be evaluated ahead (sim_pre_kernel_mz instances; the one-tile kernels of sim_wide_mz.hip have none)
+bool Net::hasPreBoard() const
+{
+    if (desc_.type != 1 || !use_fused_) { return false; }
+    TowerArgs t1, t2;
+    int c0 = 0, cd = 0;
+    if (!makeTowerArgs(repr_, true, true, &t1, &c0) || !makeTowerArgs(dyn_, false, true, &t2, &cd)) { return false; }
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+#define MZ_SIM_PRE_HAS_B(h, w, cin0, cdyn, cpad) \
+    if (H == h && W == w && c0 == cin0 && cd == cdyn && C == cpad) { return true; }
+    MZ_SIM_MZ_BOARD_PRE_CASES(MZ_SIM_PRE_HAS_B)
+#undef MZ_SIM_PRE_HAS_B
+    return false;
+}
+
 bool Net::hasSimKernelMz(int num_simulation) const
 {
     if ((desc_.type != 1 && desc_.type != 2) || !use_fused_) { return false; }
+    if (simMzWidePlan(num_simulation, nullptr, nullptr, nullptr, nullptr, nullptr)) { return true; } // board games on the one-tile tower (sim_wide_mz.hip)
     TowerArgs t1, t2;
     int c0 = 0, cd = 0;
     if (desc_.type == 2) { c0 = desc_.num_hidden_channels; } // the root's representation never runs in the kernel: the CIN0_PAD = C instance
@@ -918,9 +726,16 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     SimArgs a;
     memset(&a, 0, sizeof(a));
     int c0 = 0, cd = 0;
-    if (atari) { c0 = desc_.num_hidden_channels; }
-    else if (!makeTowerArgs(repr_, true, true, &a.ta, &c0)) { return MZ_OK; }
-    if (!makeTowerArgs(dyn_, false, true, &a.ta_dyn, &cd)) { return MZ_OK; }
+    int wide_lf = 0;
+    size_t wide_lds = 0, wide_tile = 0;
+    const bool wide = !atari && precision_ == 0 && simMzWidePlan(pool.v_.max_depth - 3, &wide_lf, &wide_lds, &wide_tile, &c0, &cd);
+    if (wide) {
+        if (!makeWideArgs(repr_, true, &a.ta, &c0) || !makeWideArgs(dyn_, false, &a.ta_dyn, &cd)) { return MZ_OK; }
+    } else {
+        if (atari) { c0 = desc_.num_hidden_channels; }
+        else if (!makeTowerArgs(repr_, true, true, &a.ta, &c0)) { return MZ_OK; }
+        if (!makeTowerArgs(dyn_, false, true, &a.ta_dyn, &cd)) { return MZ_OK; }
+    }
     int rc = ensureBatch(pool.v_.games);
     if (rc) { return rc; }
     size_t head_floats = 0;
@@ -943,6 +758,7 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
     a.cand_policy = pool.d_cand_policy_.p; a.cand_logit = pool.d_cand_logit_.p; a.value_io = pool.d_value_.p; a.reward_io = pool.d_reward_.p;
     a.err = pool.errFlag();
     a.rcp_n = pool.rcpEntries();
+    a.act = act_[0].p; a.act2 = act_[1].p;
     a.hidden = d_hidden; a.slots = slots;
     a.alt_base = (atari && gum && mode.alt_base > 0 && 2 * mode.alt_base <= slots) ? mode.alt_base : 0; a.root_feat = d_root_feat; a.root_legal = d_root_legal; a.root_turn = d_root_turn;
     a.A = desc_.action_size; a.LW = (desc_.action_size + 63) / 64; a.num_players = num_players;
@@ -972,6 +788,10 @@ int Net::simLaunchMz(Pool& pool, float* d_hidden, int slots, const unsigned* d_r
             MZ_HIP(hipMemset(sim_prof_.p, 0, sim_prof_.n * sizeof(unsigned long long)));
         }
         a.prof = sim_prof_.p;
+    }
+    if (wide) { // sim_kernel_mz_wide (sim_wide_mz.hip): no leaves evaluated ahead (pre_epoch is ignored: every simulation evaluates its own leaf)
+        a.cand_coop = candCoopSmemBytes(a.A, 8) <= wide_tile ? 1 : 0;
+        return simLaunchMzWide(a, pool.v_.games, sim0, nsims, (host_start ? 1 : 0) | (noise_applied ? 4 : 0), wide_lf, wide_lds, c0, cd, launched);
     }
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width, C = desc_.num_hidden_channels;
     const int cmax = std::max(std::max(c0, cd), C);

@@ -706,7 +706,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
         defer_info_ = !cfg_.mz_manual_step;
         sim_root_host_ = desc.type == 2;
         { int rcg = setupDeviceGumbel(); if (rcg) { return rcg; } }
-        if (dev_gumbel_ && (desc.type == 2 || (desc.type == 1 && cfg_.mz_sim_rounds_board)) && cfg_.mz_sim_rounds && cfg_.mz_sim_split) {
+        if (dev_gumbel_ && (desc.type == 2 || (desc.type == 1 && cfg_.mz_sim_rounds_board && net0().hasPreBoard())) && cfg_.mz_sim_rounds && cfg_.mz_sim_split) {
             planRounds();
             for (auto& L : lanes_) {
                 if (!L->h_prestat.alloc(512)) { setError("worker: allocation failed (round counters)"); return MZ_ERR_DEVICE; }

@@ -112,3 +112,27 @@ def test_shape_without_any_instance_runs_lock_step(mz, oracle):
     conv3x3_any — no error, same records as the oracle."""
     args = ("go_13x13", 18, 13, 13, 96, 13, 13, 1, 1, 170, 32, 1, "alphazero")
     _run(mz, oracle, GO.format(n=13, sims=6, games=3), args, [7 * 4 + 2], expect_sim=False)
+
+
+# ---- MuZero board games on the one-tile tower (sim_wide_mz.hip sim_kernel_mz_wide) ----
+MZGO = "env_game=go:env_board_size={n}:nn_type_name=muzero:actor_num_simulation={sims}:zero_num_parallel_games={games}"
+
+
+@pytest.mark.parametrize("n,c,blocks,sims,games,moves", [(9, 128, 2, 16, 5, 4), (9, 256, 1, 10, 3, 3), (7, 64, 2, 12, 6, 5), (13, 64, 1, 10, 3, 3), (19, 64, 1, 8, 2, 2)])
+def test_wide_muzero_instances(mz, oracle, n, c, blocks, sims, games, moves):
+    """Representation trunk at the root, dynamics trunk (hidden state of the parent's slab slot + the move's plane) at every other leaf, rescaled hidden states
+    into the slab: records against the oracle, the simulation kernel is what ran."""
+    args = (f"go_{n}x{n}", 18, n, n, c, n, n, 1, blocks, n * n + 1, 64, 1, "muzero")
+    lines, recs, st = _run(mz, oracle, MZGO.format(n=n, sims=sims, games=games), args, [(sims + 1) * moves - 4, 4 + 2], wseed=2)
+    assert st["moves"] == games * moves
+
+
+def test_wide_muzero_gumbel_and_modes(mz, oracle):
+    """A Gumbel root on the wide MuZero kernel (device-side sequential halving; the rounds' leaves are NOT evaluated ahead for these shapes), and the same games on
+    the lock-step kernels."""
+    args = ("go_9x9", 18, 9, 9, 128, 9, 9, 1, 1, 82, 32, 1, "muzero")
+    gum = ":actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:actor_gumbel_sample_size=8"
+    a = _run(mz, oracle, MZGO.format(n=9, sims=24, games=5) + gum, args, [25 * 3 + 3], seed=9)
+    assert a[2]["pre_evals"] == 0
+    b = _run(mz, oracle, MZGO.format(n=9, sims=24, games=5) + gum, args, [25 * 3 + 3], seed=9, wextra=":mz_sim_kernel=false", expect_sim=False)
+    assert a[1] == b[1]
