@@ -168,6 +168,8 @@ static int launchTiledT(const ConvLayer& L, const float* params, const float* in
     return MZ_OK;
 }
 
+int launchConvAnyStrided(const ConvLayer& L, int stride, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s); // net_wide.hip
+
 static int launchTiled(const ConvLayer& L, int stride, const float* params, const float* in, const float* skip, float* out, int B, int H, int W,
                        hipStream_t s, int cus)
 {
@@ -182,8 +184,7 @@ static int launchTiled(const ConvLayer& L, int stride, const float* params, cons
     MZ_TILED_CASE(1, 16, 1)
     MZ_TILED_CASE(2, 16, 2) // conv2 16 -> 32
 #undef MZ_TILED_CASE
-    setError("no tiled conv3x3 instance for stride %d, %d (padded) input channels, %d output-channel tiles", stride, L.cin_pad, ot);
-    return MZ_ERR_ARG;
+    return launchConvAnyStrided(L, stride, params, in, skip, out, B, H, W, s); // any other width: the run-time-shaped kernel (net_wide.hip)
 }
 
 static DiscreteParams discreteParams(const float* p, const DiscreteHeadOffsets& o)
@@ -253,8 +254,18 @@ int Net::initialAtari(const float* d_feat, int B, float* d_policy, float* d_logi
     if (!at_.tail.empty()) {
         bool launched = false;
         if ((rc = launchTower(at_.tail, b0, act_[0].p, B, &launched, false, false))) { return rc; }
-        if (!launched) { setError("no fused tower instance for the %dx%d x %d-channel representation tail", H, W, C); return MZ_ERR_ARG; }
-        x = act_[0].p;
+        if (launched) { x = act_[0].p; }
+        else { // any other width: residual blocks layer by layer (launchConv ends in the run-time-shaped kernel)
+            const float* xin = b0;
+            float *tmp = act_[1].p, *y = act_[0].p, *y2 = act_[2].p;
+            for (size_t i = 0; i + 1 < at_.tail.size(); i += 2) { // ref network_unit.py:14-23
+                if ((rc = launchConv(at_.tail[i], xin, nullptr, tmp, B))) { return rc; }
+                if ((rc = launchConv(at_.tail[i + 1], tmp, xin, y, B))) { return rc; }
+                xin = y;
+                float* s = y; y = y2; y2 = s;
+            }
+            x = xin;
+        }
     }
     return launchAtariHeads(*this, P, heads_, at_, x, B, d_policy, d_logit, d_value, nullptr, d_hidden, d_dst_idx, false, stream_);
 }
@@ -284,9 +295,10 @@ int Net::recurrentAtari(const float* d_hidden_src, const int* d_src_idx, const f
     MZ_HIP(hipGetLastError());
     bool launched = false;
     if ((rc = launchTower(dyn_, rec_in_.p, act_[0].p, B, &launched, false, true))) { return rc; }
-    if (!launched) { setError("no fused tower instance for the muzero_atari dynamics network"); return MZ_ERR_ARG; }
+    float* xo = act_[0].p;
+    if (!launched && (rc = runTrunk(dyn_, rec_in_.p, B, &xo))) { return rc; } // any other width: layer by layer
     if (conv_only_) { return MZ_OK; }
-    return launchAtariHeads(*this, params_.p, heads_, at_, act_[0].p, B, d_policy, d_logit, d_value, d_reward, d_hidden_dst, d_dst_idx, true, stream_);
+    return launchAtariHeads(*this, params_.p, heads_, at_, xo, B, d_policy, d_logit, d_value, d_reward, d_hidden_dst, d_dst_idx, true, stream_);
 }
 
 __global__ void invert_value_kernel(const float* __restrict__ in, int n, float* __restrict__ out)

@@ -75,6 +75,63 @@ __global__ __launch_bounds__(256) void conv3x3_any(const float* __restrict__ in,
     }
 }
 
+// ... and with a stride and rectangular planes (the stride-2 stem convs and the 48x48 .. 12x12 residual blocks of a muzero_atari representation whose width has
+// no conv3x3_tiled instance, ref muzero_atari_network.py:21-70): output (oy, ox) reads input (oy * stride + dy, ox * stride + dx), pad 1
+__global__ __launch_bounds__(256) void conv3x3_any_strided(const float* __restrict__ in, int cin, int CG, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                           const float* __restrict__ skip, float* __restrict__ out, int cout, int OT, int H, int W, int stride)
+{
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1, Po = Ho * Wo, Pi = H * W;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kc = lane >> 4;
+    const float* src = in + size_t(b) * cin * Pi;
+    int q[4], pos[4];
+    unsigned mask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        q[j] = 64 * blockIdx.y + 16 * j + (lane & 15);
+        const bool ok = q[j] < Po;
+        const int y = ok ? (q[j] / Wo) * stride : 0, x = ok ? (q[j] % Wo) * stride : 0;
+        pos[j] = y * W + x;
+        unsigned m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (ok && yy >= 0 && yy < H && xx >= 0 && xx < W) { m |= 1u << t; }
+        }
+        mask[j] = m;
+    }
+    for (int ot = wave; ot < OT; ot += 4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+        for (int t = 0; t < 9; ++t) {
+            const int d = (t / 3 - 1) * W + (t % 3 - 1);
+            for (int cg = 0; cg < CG; ++cg) {
+                const float a = wp[((size_t(t) * CG + cg) * OT + ot) * 64 + lane];
+                const int c = 4 * cg + kc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float bv = 0.0f;
+                    if (c < cin && ((mask[j] >> t) & 1u)) { bv = src[size_t(c) * Pi + pos[j] + d]; }
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        float* dst = out + size_t(b) * cout * Po;
+        const float* sk = skip ? skip + size_t(b) * cout * Po : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oc = 16 * ot + 4 * kc + r;
+                if (q[j] < Po && oc < cout) {
+                    float v = acc[j][r] + bias[oc];
+                    if (sk) { v = v + sk[size_t(oc) * Po + q[j]]; }
+                    dst[size_t(oc) * Po + q[j]] = v > 0.0f ? v : 0.0f;
+                }
+            }
+        }
+    }
+}
+
 // one bit per point -> f32 0 / 1 planes (the lock-step worker stages bit-packed planes; the run-time-shaped kernels read floats)
 __global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned* __restrict__ bits, int C, int P, float* __restrict__ feat)
 {
@@ -167,6 +224,15 @@ int Net::launchConvAny(const ConvLayer& L, const float* in, const float* skip, f
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width;
     hipLaunchKernelGGL(conv3x3_any, dim3(B, (H * W + 63) / 64), dim3(256), 0, stream_, in, L.cin, L.cin_pad / 4, params_.p + L.w_off, params_.p + L.b_off, skip, out, L.cout,
                        L.cout_pad / 16, H, W);
+    MZ_HIP(hipGetLastError());
+    return MZ_OK;
+}
+
+int launchConvAnyStrided(const ConvLayer& L, int stride, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s)
+{
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    hipLaunchKernelGGL(conv3x3_any_strided, dim3(B, (Ho * Wo + 63) / 64), dim3(256), 0, s, in, L.cin, L.cin_pad / 4, params + L.w_off, params + L.b_off, skip, out, L.cout,
+                       L.cout_pad / 16, H, W, stride);
     MZ_HIP(hipGetLastError());
     return MZ_OK;
 }

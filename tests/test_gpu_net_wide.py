@@ -105,3 +105,23 @@ def test_any_shape_is_served(mz, oracle, args):
         act[0, 3] = 1.0  # the second sample passes (all-zero plane, ref go.cpp:310-315)
         a, b = net.recurrent_inference(h, act), onet.recurrent(h, act)
         assert same_bits(a[4], b[4]) and same_bits(a[1], b[1]) and same_bits(a[2], b[2])
+
+
+def test_muzero_atari_network_of_another_width(mz, oracle):
+    """muzero_atari with 96 hidden channels (no conv3x3_tiled / fused-tower instance: ref muzero_atari_network.py:21-70 builds any width): the strided
+    run-time-shaped convolutions for the 96x96 representation, residual blocks layer by layer, the 601-bin heads — bit-exact against the oracle."""
+    args = ("atari_ms_pacman", 32, 96, 96, 96, 6, 6, 18, 1, 18, 48, 601, "muzero_atari")
+    d, od = _descs(mz, oracle, args)
+    w = mz.generate_weights(d, 3)
+    net, onet = mz.Net(d, w), oracle.OracleNet(od, w)
+    x = counter_u01(21, 2 * 32 * 96 * 96).reshape(2, -1).astype(np.float32)
+    p, l, v, h = net.initial_inference(x)
+    op, ol, ov, oh = onet.initial(x)
+    assert same_bits(h, oh), f"hidden not bit-exact: {frac_bit_equal(h, oh):.4f}"
+    assert same_bits(l, ol) and same_bits(p, op) and same_bits(v, ov)
+    act = np.zeros((2, 18, 36), np.float32)
+    act[0, 5] = 1.0
+    act[1, 11] = 1.0
+    a, b = net.recurrent_inference(h, act.reshape(2, -1)), onet.recurrent(h, act.reshape(2, -1))
+    for u, t in zip(a, b):
+        assert same_bits(u, t)
