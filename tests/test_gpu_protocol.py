@@ -100,3 +100,66 @@ def test_one_process_drives_every_visible_gpu(mz, oracle, tmp_path, name, game, 
         raise
     assert f"{games} games on {G} GPU(s)" in err, err[-2000:]
     assert min(cursor.values()) >= lines_per_dev, f"per-device records seen: {cursor}"
+
+
+EIGHT = [
+    # BASELINE configs[0] on eight logical devices
+    ("tictactoe", "tictactoe", ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9, 256, 1, "alphazero"), "actor_num_simulation=16", 8 * 5 + 3, 17, 12, 200, 1),
+    # BASELINE configs[4]'s node: 512 games = 64 per device (the Gumbel rounds' batched pipeline, pairs refused: eight workers share the GPU), on the small
+    # muzero_atari test network so that eight CPU oracles finish in a minute; short episodes / sequences so that records leave early
+    ("atari", "atari", ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari"),
+     "nn_type_name=muzero:actor_num_simulation=50:actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:"
+     "actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:actor_mcts_reward_discount=0.997:atari_init_q=true:zero_actor_intermediate_sequence_length=3:"
+     "learner_n_step_return=1:learner_muzero_unrolling_step=1:env_atari_episode_length=5", 512, 51, 8, 24, 1),  # (the devices start one after the other: ample expected lines)
+    # ... and with two RNG streams per worker: device g's generators are program_seed + 2 g, + 2 g + 1 (actor_group.cpp:66-70 across a node)
+    ("tictactoe_two_streams", "tictactoe", ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9, 256, 1, "alphazero"), "actor_num_simulation=16:mz_rng_streams=2", 8 * 6, 17, 10, 200, 2),
+]
+
+
+@pytest.mark.parametrize("name,game,args,extra,games,cpm,lines_per_dev,moves,S", EIGHT, ids=[e[0] for e in EIGHT])
+def test_one_process_eight_logical_devices(mz, oracle, tmp_path, name, game, args, extra, games, cpm, lines_per_dev, moves, S):
+    """The G = 8 rehearsal (ref actor_group.cpp:24-50,168-187; scripts/zero-worker.sh:159-162: ONE `-mode sp` process for the node's eight GPUs): eight logical
+    devices on GPU 0 (MZ_DEVICE_MAP=0,0,0,0,0,0,0,0), eight host threads driving eight workers, one stdout.  Every printed line must be the next record of exactly
+    one device's stream, device g = games {i % 8 == g} seeded program_seed + g * S (S RNG streams per worker) — eight OracleGroups say what those are."""
+    from minizero_amd.export_weights import write_mzw
+    env = dict(os.environ)
+    G = 8
+    env["MZ_DEVICE_MAP"] = ",".join(["0"] * G)
+    exe = os.path.join(ROOT, "apps", "mzgpu_sp")
+    kw = dict(vh=args[10], dv=args[11], type_name=args[12])
+    d, od = mz.make_desc(*args[:10], **kw), oracle.make_desc(*args[:10], **kw)
+    w = mz.generate_weights(d, 0)
+    pt = str(tmp_path / "weight_iter_0.pt")
+    write_mzw(pt[:-3] + ".mzw", d, w)
+    conf_str = f"nn_file_name={pt}:program_seed=5:{extra}:zero_num_parallel_games={games}:zero_num_threads={G}"
+    p = subprocess.Popen([exe, "-conf_str", conf_str, "-mode", "sp", "-game", game], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    p.stdin.write("start\n")
+    p.stdin.flush()
+    oextra = extra.replace(":mz_rng_streams=2", "")
+    expected = {}
+    for g in range(G):
+        n_g = len(range(g, games, G))
+        og = oracle.OracleGroup(f"env_game={game}:{oextra}:zero_num_parallel_games={n_g}:program_seed={5 + g * S}:nn_file_name={pt}:zero_num_threads=1" +
+                                (f":oracle_throughput_threads={S}" if S > 1 else ""), od, w)
+        og.cycles(cpm * moves)
+        expected[g] = og.lines()
+        assert len(expected[g]) >= lines_per_dev, f"device {g}: the oracle finished {len(expected[g])} records"
+    cursor = {g: 0 for g in range(G)}
+    seen = 0
+    while min(cursor.values()) < lines_per_dev and all(cursor[g] < len(expected[g]) for g in range(G)):
+        l = p.stdout.readline().rstrip("\n")
+        assert l, "the worker stopped printing: " + p.stderr.read()[-2000:]
+        assert l.startswith("SelfPlay ") and l.endswith(" #") and l.count("SelfPlay ") == 1, "a torn line under eight writer threads: " + l[:200]
+        owners = [g for g in range(G) if cursor[g] < len(expected[g]) and expected[g][cursor[g]] == l]
+        assert owners, "a line that is not the next record of any device: " + l[:160]
+        cursor[owners[0]] += 1
+        seen += 1
+    p.stdin.write("quit\n")
+    p.stdin.flush()
+    try:
+        _, err = p.communicate(timeout=180)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    assert f"{games} games on {G} GPU(s)" in err, err[-2000:]
+    assert min(cursor.values()) >= lines_per_dev, f"per-device records seen: {cursor}"
