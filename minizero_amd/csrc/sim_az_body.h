@@ -450,6 +450,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (prof) { t1 = wall_clock64(); }
         const float* xt;
         if constexpr (BF) { xt = simTowerBf16<H, W>(a, g, tid, tiles, xchg); }
+        else if constexpr (WPE == 4) {
+            // The 128-VGPR build (two games per CU): as a function of its own the tower saved and restored 20 callee-saved VGPRs per call — 8 waves x 5 KB each way
+            // per simulation, most of the 118 KB of HBM traffic per leaf evaluation that rocprofv3 showed for BASELINE configs[2] (profiles/r04_pmc_c3.json).  Its
+            // 2 pixel tiles per wave fit the kernel's own budget.
+            const GoDevView gvt = simLeafView(ldc(&a->gv), xchg, g);
+            xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(gvt.feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
+        }
         else { xt = simTower<H, W, CIN0_PAD, CPAD>(a, g, tid, tiles, xchg); } // its own function: its own register budget
         __syncthreads();
         if (prof) { t2 = wall_clock64(); }
