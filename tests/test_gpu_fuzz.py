@@ -71,6 +71,23 @@ def test_random_configuration_matches_oracle(mz, oracle, seed):
     if typ == "muzero" and "actor_use_gumbel=true" in conf and rng4.random() < 0.6:
         n = int(conf.split("actor_num_simulation=")[1].split(":")[0])
         chunks = [n + 1, n + 1, 2 * (n + 1), int(rng4.integers(1, n + 1)), 3 * (n + 1)]
+    # (round 5, again from a generator of its own) network shapes beyond the 8-channel test nets — Go on the one-tile tower's simulation kernel (32 channels on 7x7 / 9x9:
+    # sim_kernel_wide, sim_kernel_mz_wide has no 32-channel instance: lock-step there) or on a shape with no instance at all (5x5 x 24 channels: conv3x3_any, lock-step) —,
+    # up to 16 RNG streams (what bench.py times), and now and then a BASELINE-size pool of the short games
+    rng5 = np.random.default_rng(5000 + seed)
+    if dargs[0] == "go_9x9" and rng5.random() < 0.3:
+        bn, ch = ((7, 32), (9, 32), (5, 24))[int(rng5.integers(0, 3))]
+        dargs = (f"go_{bn}x{bn}", 18, bn, bn, ch, bn, bn, 1, 1, bn * bn + 1)
+        conf = conf.replace("env_board_size=9", f"env_board_size={bn}")
+        d, od = mz.make_desc(*dargs, **kw), oracle.make_desc(*dargs, **kw)
+        w = mz.generate_weights(d, wseed)
+    if rng5.random() < 0.25:
+        streams = int(rng5.choice([6, 8, 16]))
+    if dargs[0] != "go_9x9" and not dargs[0].startswith("go_") and rng5.random() < 0.04:
+        big = int(rng5.choice([256, 1024]))
+        gcur = int(conf.split("zero_num_parallel_games=")[1].split(":")[0])
+        conf = conf.replace(f"zero_num_parallel_games={gcur}:", f"zero_num_parallel_games={big}:")
+        cycles = min(cycles, 6 * (int(conf.split("actor_num_simulation=")[1].split(":")[0]) + 1))  # a few moves of the big pool
     og = oracle.OracleGroup(conf + ":zero_num_threads=1" + (f":oracle_throughput_threads={streams}" if streams > 1 else ""), od, w)
     og.cycles(cycles)
     wextra += f":mz_rng_streams={streams}"
@@ -138,6 +155,9 @@ def test_random_atari_configuration_matches_oracle(mz, oracle, seed):
     w = mz.generate_weights(d, wseed)
     conf = f"{conf}:program_seed={pseed}:nn_file_name=/tmp/fuzz_atari_{wseed}.pt"
     streams = int(np.random.default_rng(4000 + seed).choice([1, 1, 1, 2, 3, 4]))  # (round 4) host RNG streams = the oracle's slave threads, same static partition
+    rng5 = np.random.default_rng(5000 + seed)  # (round 5, from a generator of its own) up to 16 RNG streams: what bench.py / run_configs.py time
+    if rng5.random() < 0.25:
+        streams = int(rng5.choice([6, 8, 16]))
     og = oracle.OracleGroup(conf + ":zero_num_threads=1" + (f":oracle_throughput_threads={streams}" if streams > 1 else ""), od, w)
     og.cycles(cycles)
     wextra += f":mz_rng_streams={streams}"
