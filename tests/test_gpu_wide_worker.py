@@ -136,3 +136,27 @@ def test_wide_muzero_gumbel_and_modes(mz, oracle):
     assert a[2]["pre_evals"] == 0
     b = _run(mz, oracle, MZGO.format(n=9, sims=24, games=5) + gum, args, [25 * 3 + 3], seed=9, wextra=":mz_sim_kernel=false", expect_sim=False)
     assert a[1] == b[1]
+
+
+# ---- the shapes run_configs.py times (w9x128, w9x256, w19x64), at its pool size: 256 games = one game per CU on the whole chip, 16 RNG streams; the search is cut to ~100
+# simulations per move so that the CPU oracle finishes in tens of seconds (the kernels, the LDS plans and the launch split are those of n = 400 only in their table sizes) ----
+@pytest.mark.slow
+@pytest.mark.parametrize("n,c,blocks,sims", [(9, 128, 6, 100), (9, 256, 1, 140), (19, 64, 6, 80)])
+def test_wide_full_pool_256_games_one_move(mz, oracle, n, c, blocks, sims):
+    args = (f"go_{n}x{n}", 18, n, n, c, n, n, 1, blocks, n * n + 1, 256, 1, "alphazero")
+    kw = dict(vh=args[10], dv=args[11], type_name=args[12])
+    d, od = mz.make_desc(*args[:10], **kw), oracle.make_desc(*args[:10], **kw)
+    w = mz.generate_weights(d, 0)
+    conf = GO.format(n=n, sims=sims, games=256) + ":program_seed=1:nn_file_name=/tmp/w/wide_full.pt"
+    total = sims + 1 + 5
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1:oracle_throughput_threads=16", od, w)
+    og.cycles(total)
+    wk = mz.Worker(conf + f":mz_rng_streams=16:zero_num_threads={max(2, mz.usable_cpus() - 1)}", d, w)
+    wk.command("start")
+    assert wk.run_cycles(sims + 1) == sims + 1 and wk.run_cycles(5) == 5
+    st = wk.stats()
+    assert st["sim_launches"] >= 3 and st["moves"] == 256 and st["leaf_evals"] == og.leaf_evals() == total * 256
+    assert wk.pop_lines() == og.lines()
+    recs, orecs = wk.peek_records(256), og.peek_records(256)
+    for g, (a, b) in enumerate(zip(recs, orecs)):
+        assert a == b, f"game {g}: records as they stand differ:\n  hip   : {a[:600]}\n  oracle: {b[:600]}"
