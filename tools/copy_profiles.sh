@@ -21,6 +21,7 @@ cp $S/c5_no_rounds.json $D/${R}_c5_without_rounds.json
 cp $S/c5_round3_path.json $D/${R}_c5_round3_path_one_workgroup_per_leaf.json
 cp $S/c5_no_pairs.json $D/${R}_c5_without_pairs.json
 cp $S/wide_configs.json $D/${R}_wide_configs_n1.json
+cp $S/c5_512_games_one_gpu.json $D/${R}_c5_512_games_one_gpu_not_the_baseline_shard.json
 cp $S/time_wide_towers.json $D/${R}_time_wide_towers.json
 for k in w9x128 w19x64; do cp $S/sim_prof_$k.txt $D/${R}_sim_prof_$k.txt; done
 ls $D/${R}_* | wc -l

@@ -50,13 +50,15 @@ EXTRA_CONFIGS = {
     "w9x256": ("w9x256", "env_game=go:env_board_size=9:actor_num_simulation=400:zero_num_parallel_games=256"),    # 9x9 Go, the reference's default network: 1 block x 256 channels
     "w19x64": ("w19x64", "env_game=go:env_board_size=19:actor_num_simulation=400:zero_num_parallel_games=256"),   # 19x19 Go, 6 blocks x 64 channels
 }
+# ... and BASELINE configs[4]'s whole node (512 games) on ONE GPU — NOT the BASELINE shard (64 games per GPU): what the same kernels reach when the pool fills the chip
+EXTRA_CONFIGS["c5x512"] = ("c5", mz.CONFIGS["c5"].replace("zero_num_parallel_games=64", "zero_num_parallel_games=512"))
 EXTRA_DESCS = {
     "w9x128": lambda: mz.make_desc("go_9x9", 18, 9, 9, 128, 9, 9, 1, 6, 82),
     "w9x256": lambda: mz.make_desc("go_9x9", 18, 9, 9, 256, 9, 9, 1, 1, 82),
     "w19x64": lambda: mz.make_desc("go_19x19", 18, 19, 19, 64, 19, 19, 1, 6, 362),
 }
-MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2})
-WARM.update({"w9x128": 1, "w9x256": 1, "w19x64": 1})
+MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2, "c5x512": 30})
+WARM.update({"w9x128": 1, "w9x256": 1, "w19x64": 1, "c5x512": 14})
 KERNEL.update({"w9x128": "sim_kernel_wide<9,9,32,128,2>", "w9x256": "sim_kernel_wide<9,9,32,256,2>", "w19x64": "sim_kernel_wide<19,19,32,64,6>"})
 
 
