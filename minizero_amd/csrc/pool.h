@@ -45,7 +45,8 @@ public:
                      const float* value, const float* reward);
     int rootSetNoise(const uint8_t* mask, const float* policy, const float* logit, const float* noise);
     int rootRead(int* num_children, int* action, float* count, float* mean, float* policy, float* logit, float* noise, float* value, float* reward,
-                 float* root_count, float* root_mean, float* root_value, float* bound_lo, float* bound_hi, int* bound_size);
+                 float* root_count, float* root_mean, float* root_value, float* bound_lo, float* bound_hi, int* bound_size, bool launched_ahead = false);
+    int rootReadLaunch(); // rootRead's kernel (+ copies) queued without waiting; the next rootRead(..., launched_ahead = true) only waits and unpacks
     int readNodes(int game, int n, int* action, int* player, int* num_children, int* first_child, float* mean, float* count, float* policy,
                   float* logit, float* noise, float* value, float* reward);
     int numNodes(int game);

@@ -341,8 +341,9 @@ int Pool::rootSetNoise(const uint8_t* mask, const float* policy, const float* lo
     return MZ_OK;
 }
 
-int Pool::rootRead(int* num_children, int* action, float* count, float* mean, float* policy, float* logit, float* noise, float* value, float* reward,
-                   float* root_count, float* root_mean, float* root_value, float* bound_lo, float* bound_hi, int* bound_size)
+// the kernel (+ copies) of rootRead, queued on the stream without waiting: the worker puts it right behind the launch that completes a move's search, so that the
+// statistics are on their way while the host still waits for that launch (a launch + a wake-up less on the critical path between two moves)
+int Pool::rootReadLaunch()
 {
     MZ_HIP(hipSetDevice(device_));
     const size_t G = v_.games, GA = G * v_.A;
@@ -357,6 +358,15 @@ int Pool::rootRead(int* num_children, int* action, float* count, float* mean, fl
         MZ_HIP(hipMemcpyAsync(h_rr_f_.p, d_rr_f_.p, (7 * GA + 5 * G) * sizeof(float), hipMemcpyDeviceToHost, stream_));
         MZ_HIP(hipMemcpyAsync(h_rr_i_.p, d_rr_i_.p, (G + GA + G) * sizeof(int), hipMemcpyDeviceToHost, stream_));
     }
+    return MZ_OK;
+}
+
+int Pool::rootRead(int* num_children, int* action, float* count, float* mean, float* policy, float* logit, float* noise, float* value, float* reward,
+                   float* root_count, float* root_mean, float* root_value, float* bound_lo, float* bound_hi, int* bound_size, bool launched_ahead)
+{
+    MZ_HIP(hipSetDevice(device_));
+    const size_t G = v_.games, GA = G * v_.A;
+    if (!launched_ahead) { int rc = rootReadLaunch(); if (rc) { return rc; } }
     MZ_HIP(hipStreamSynchronize(stream_));
     const float* f = h_rr_f_.p;
     const int* iv = h_rr_i_.p;

@@ -186,7 +186,7 @@ __device__ __forceinline__ void simLeafPlanes(CSimArgs* __restrict__ a, int rot,
 __device__ __forceinline__ float* simCandDense(float* tiles, int A) { return reinterpret_cast<float*>(reinterpret_cast<char*>(tiles) + ((2 * size_t(A) * sizeof(Cand) + kSortStackBytes + 16 + 15) & ~size_t(15))); }
 
 template <int WPE>
-__device__ __noinline__ void simCandGather(CSimArgs* __restrict__ a, int rot, int g, int lane, float* tiles, float* xchg)
+__device__ __forceinline__ void simCandGatherImpl(CSimArgs* __restrict__ a, int rot, int g, int lane, float* tiles, float* xchg)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -205,6 +205,15 @@ __device__ __noinline__ void simCandGather(CSimArgs* __restrict__ a, int rot, in
     else { candDense(cs, k, lane, simCandDense(tiles, gv.A)); }
     if (lane == 0) { reinterpret_cast<int*>(sc)[1] = k; } // cand_count: read by every wave after the barrier
     MZ_LPROF(7);
+}
+
+// (a function of its own with its own register budget.  It saves and restores the callee-saved VGPRs it uses — 25 here, 78 in simCandExpand, 256 bytes each per call, one
+// wave — which is what is left of BASELINE configs[2]'s HBM traffic; calling the bodies inline in the 128-VGPR kernels was measured and lost: the kernel then spills 47
+// VGPRs whose reloads sit in these single-wave phases — 32.5 -> 47.8 MB per cycle, 2.03 -> 2.02 M leaf-evals/s)
+template <int WPE>
+__device__ __noinline__ void simCandGather(CSimArgs* __restrict__ a, int rot, int g, int lane, float* tiles, float* xchg)
+{
+    simCandGatherImpl<WPE>(a, rot, g, lane, tiles, xchg);
 }
 
 __device__ __forceinline__ void simCandRank(int A, int k, int wave, int lane, float* tiles, int coop = 1)
@@ -238,7 +247,7 @@ __device__ __noinline__ void simBackupOnly(CSimArgs* __restrict__ a, int slot, i
 }
 
 template <int WPE>
-__device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, float* xchg, int part)
+__device__ __forceinline__ void simCandExpandImpl(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, float* xchg, int part)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
     g = __builtin_amdgcn_readfirstlane(g);
@@ -271,6 +280,12 @@ __device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, in
     expandBackupBody(pv, cand_count, cand_action, xchg + x.cpolicy() - ga, xchg + x.clogit() - ga, cand_player, sc + 3 - g, sc + 4 - g, slot, a->err, g,
                      lane, tiles, part);
     MZ_LPROF(12);
+}
+
+template <int WPE>
+__device__ __noinline__ void simCandExpand(CSimArgs* __restrict__ a, int rot, int slot, int g, int lane, float* tiles, float* xchg, int part)
+{
+    simCandExpandImpl<WPE>(a, rot, slot, g, lane, tiles, xchg, part);
 }
 
 // Root exploration noise (ref zero_actor.cpp:194-213): policy = (1 - eps) * policy + eps * noise for the root's children, in storage

@@ -443,6 +443,7 @@ private:
         PinBuf<uint32_t> h_rootfeat; DevBuf<uint32_t> d_rootfeat;
         PinBuf<unsigned long long> h_rootlegal; DevBuf<unsigned long long> d_rootlegal;
         PinBuf<int> h_rootturn; DevBuf<int> d_rootturn;
+        bool rr_ahead = false;                // the root statistics of the finished search are already on their way (Pool::rootReadLaunch behind the move's last launch)
         PinBuf<unsigned> h_prestat;           // Gumbel rounds: the network's counters of leaves evaluated ahead, copied behind every move's launches (adaptRounds)
         PinBuf<int> h_gum; DevBuf<int> d_gum; // Gumbel state of every game (gumbel.h): the device runs the halving between simulations
         PinBuf<float> h_noise;   // Dirichlet noise of the root children drawn ahead of the launch [game][A]
@@ -1444,7 +1445,8 @@ int Worker::phase1(Lane& L, bool root_expansion, bool done, bool launch_select)
             const size_t o = size_t(g0) * A_;
             rc = L.pool.rootRead(rr_nc_.data() + g0, rr_action_.data() + o, rr_count_.data() + o, rr_mean_.data() + o, rr_policy_.data() + o,
                                  rr_logit_.data() + o, rr_noise_.data() + o, rr_value_.data() + o, rr_reward_.data() + o, rr_root_count_.data() + g0,
-                                 rr_root_mean_.data() + g0, rr_root_value_.data() + g0, rr_lo_.data() + g0, rr_hi_.data() + g0, rr_bsize_.data() + g0);
+                                 rr_root_mean_.data() + g0, rr_root_value_.data() + g0, rr_lo_.data() + g0, rr_hi_.data() + g0, rr_bsize_.data() + g0, L.rr_ahead);
+            L.rr_ahead = false;
             if (rc) { return rc; }
             if ((rc = L.pool.checkError())) { return rc; }
         }
@@ -1879,6 +1881,14 @@ int Worker::runCyclesSim(int n)
                 if (!use_rounds || part == parts - 1) { MZ_HIP(hipEventRecord(L->ev1[use_rounds ? 0 : part], L->stream)); }
                 if (use_rounds && part == parts - 1 && L->h_prestat.p) { int rcc = L->net->simPreCountersAsync(L->h_prestat.p); if (rcc) { return rcc; } }
                 ++stats_.sim_launches;
+                // the launch that completes the move's search: the root statistics the per-move host logic reads next are queued right behind it
+                L->rr_ahead = false;
+                static const bool rr_ahead_on = !getenv("MZ_NO_RR_AHEAD"); // (A/B switch)
+                if (rr_ahead_on && part == parts - 1 && sim0 + batch == n_ + 1 && !cfg_.mz_manual_step && L->pool.stream_ == L->stream) {
+                    int rcr = L->pool.rootReadLaunch();
+                    if (rcr) { return rcr; }
+                    L->rr_ahead = true;
+                }
             }
         }
         stats_.sim_cycles += batch;
