@@ -423,10 +423,18 @@ template <bool GW, class T>
 struct WPtr { typedef const T* type; };
 template <class T>
 struct WPtr<true, T> { typedef __attribute__((address_space(1))) const T* type; };
-template <int CH, bool GW = false>
-__device__ __forceinline__ void dotChainPart(float& acc, int& i0, const float* __restrict__ x, int xs, const float* __restrict__ w_, size_t ws, int n)
+// XL: the x operand is known to lie in LDS — read with ds_read instead of through the generic pointer.  A FLAT load counts on vmcnt AND lgkmcnt and completes out
+// of order with respect to global loads, so the wait for an x value loaded that way is a wait for every weight load in flight: the prefetch is void (the 722-step
+// policy chains of a 19x19 board: 47 us of heads).
+template <bool XL, class T>
+struct XPtr { typedef const T* type; };
+template <class T>
+struct XPtr<true, T> { typedef __attribute__((address_space(3))) const T* type; };
+template <int CH, bool GW = false, bool XL = false>
+__device__ __forceinline__ void dotChainPart(float& acc, int& i0, const float* __restrict__ x_, int xs, const float* __restrict__ w_, size_t ws, int n)
 {
     typename WPtr<GW, float>::type w = (typename WPtr<GW, float>::type)w_;
+    typename XPtr<XL, float>::type x = (typename XPtr<XL, float>::type)x_;
     for (; i0 + CH <= n; i0 += CH) {
         float wv[CH];
 #pragma unroll
@@ -435,26 +443,27 @@ __device__ __forceinline__ void dotChainPart(float& acc, int& i0, const float* _
         for (int k = 0; k < CH; ++k) { acc = __builtin_fmaf(x[(i0 + k) * xs], wv[k], acc); }
     }
 }
-template <int CH, bool GW = false>
+template <int CH, bool GW = false, bool XL = false>
 __device__ __forceinline__ float dotChain(const float* __restrict__ x, int xs, const float* __restrict__ w, size_t ws, int n)
 {
     float acc = 0.0f;
     int i0 = 0;
-    dotChainPart<CH, GW>(acc, i0, x, xs, w, ws, n);
-    if (CH > 16) { dotChainPart<16, GW>(acc, i0, x, xs, w, ws, n); } // the tail of a deep prefetch in shallower groups, not one load at a time
-    if (CH > 4) { dotChainPart<4, GW>(acc, i0, x, xs, w, ws, n); }
-    for (; i0 < n; ++i0) { acc = __builtin_fmaf(x[i0 * xs], ((typename WPtr<GW, float>::type)w)[size_t(i0) * ws], acc); }
+    dotChainPart<CH, GW, XL>(acc, i0, x, xs, w, ws, n);
+    if (CH > 16) { dotChainPart<16, GW, XL>(acc, i0, x, xs, w, ws, n); } // the tail of a deep prefetch in shallower groups, not one load at a time
+    if (CH > 4) { dotChainPart<4, GW, XL>(acc, i0, x, xs, w, ws, n); }
+    for (; i0 < n; ++i0) { acc = __builtin_fmaf(((typename XPtr<XL, float>::type)x)[i0 * xs], ((typename WPtr<GW, float>::type)w)[size_t(i0) * ws], acc); }
     return acc;
 }
 
 // K independent chains per thread (each one the same ordered f32 chain as dotChain): the weights of CH steps of all K chains are in flight
 // together and the K dependent fma sequences interleave, so a latency-bound thread with several outputs finishes them in the time of one
-template <int CH, int K, bool GW = false>
-__device__ __forceinline__ void dotChainK(const float* const (&x)[K], int xs, const float* const (&w_)[K], size_t ws, int n, float (&acc)[K])
+template <int CH, int K, bool GW = false, bool XL = false>
+__device__ __forceinline__ void dotChainK(const float* const (&x_)[K], int xs, const float* const (&w_)[K], size_t ws, int n, float (&acc)[K])
 {
     typename WPtr<GW, float>::type w[K];
+    typename XPtr<XL, float>::type x[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { acc[k] = 0.0f; w[k] = (typename WPtr<GW, float>::type)w_[k]; }
+    for (int k = 0; k < K; ++k) { acc[k] = 0.0f; w[k] = (typename WPtr<GW, float>::type)w_[k]; x[k] = (typename XPtr<XL, float>::type)x_[k]; }
     int i0 = 0;
     for (; i0 + CH <= n; i0 += CH) {
         float wv[K][CH];
@@ -609,7 +618,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
         const int j = i / P, p = i - j * P;
         const float* w = (j < PC) ? hp.pconv_w + j * C : hp.vconv_w;
         const int xo = (xlds && xpw != 0) ? (p / (xpw - 2) + 1) * xpw + p % (xpw - 2) + 1 : p;
-        const float acc = dotChain<16>(xrd + xo, xstride, w, 1, C);
+        const float acc = (BIGA && xlds && xpw != 0) ? dotChain<16, true, true>(xrd + xo, xstride, w, 1, C) : dotChain<16>(xrd + xo, xstride, w, 1, C);
         float v = acc + ((j < PC) ? hp.pconv_b[j] : hp.vconv_b[0]);
         v = v > 0.0f ? v : 0.0f;
         if (j < PC) { pf[i] = v; } else { vf[p] = v; }
@@ -619,7 +628,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
 
     // policy FC (one logit per thread, waves 0..) and value FC1 (one hidden unit per thread, on other waves when there are enough)
     for (int a = tid; a < A; a += NT) {
-        const float v = (BIGA ? dotChain<64>(pf, 1, hp.pfc_wT + a, A, PC * P) : dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P)) + hp.pfc_b[a];
+        const float v = (BIGA ? dotChain<64, true, true>(pf, 1, hp.pfc_wT + a, A, PC * P) : dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P)) + hp.pfc_b[a];
         lg[a] = v;
         logit[size_t(b) * A + a] = v;
     }
@@ -630,7 +639,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
                 const float* const xs2[2] = {vf, vf};
                 const float* const ws2[2] = {hp.vfc1_wT + o, hp.vfc1_wT + o2};
                 float acc2[2];
-                dotChainK<32, 2>(xs2, 1, ws2, VH, P, acc2);
+                dotChainK<32, 2, true, true>(xs2, 1, ws2, VH, P, acc2);
                 const float v0 = acc2[0] + hp.vfc1_b[o], v1 = acc2[1] + hp.vfc1_b[o2];
                 h1[o] = v0 > 0.0f ? v0 : 0.0f;
                 if (o + 128 < VH) { h1[o2] = v1 > 0.0f ? v1 : 0.0f; }
@@ -648,7 +657,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
 
     // value FC2 + tanh: one sequential chain (wave 1, lane 0) while wave 0 does the softmax
     if (tid == 64) {
-        const float acc = dotChain<16>(h1, 1, hp.vfc2_w, 1, VH);
+        const float acc = BIGA ? dotChain<32, true, true>(h1, 1, hp.vfc2_w, 1, VH) : dotChain<16>(h1, 1, hp.vfc2_w, 1, VH);
         value[b] = mz_tanhf(acc + hp.vfc2_b[0]);
     }
     if (wave == 0) {

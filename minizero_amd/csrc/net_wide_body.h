@@ -36,6 +36,10 @@ struct WideGeo {
     static constexpr int passStart(int wp, int ps) { int s = groupStart(wp); for (int i = 0; i < ps; ++i) { s += passTiles(wp, i); } return s; }
     static constexpr bool singlePass() { for (int wp = 0; wp < WP; ++wp) { if (passes(wp) > 1) { return false; } } return true; }
     static constexpr bool kSinglePass = singlePass(); // every wave holds all its accumulators at once: the layers' outputs go in place into the tile
+    static constexpr int maxPassTiles() { int m = 0; for (int wp = 0; wp < WP; ++wp) { for (int ps = 0; ps < passes(wp); ++ps) { m = passTiles(wp, ps) > m ? passTiles(wp, ps) : m; } } return m; }
+    // the next layer's first A unit is fetched ahead only where its 16 registers do not push the kernel into spills (measured: 19x19 x 64 with 12 tiles per wave and
+    // the two-oc-tile waves of 256 channels are at the 256-VGPR limit without it)
+    static constexpr bool kPrefetchNext = NOT == 1 && maxPassTiles() <= 8;
 };
 template <int H, int W, int C>
 constexpr size_t wideTileFloats(int cin0q) { return size_t(cin0q > C ? cin0q : C) * WideGeo<H, W, C>::CS; }
@@ -56,9 +60,12 @@ __device__ __forceinline__ void wideStaticFor(F& f)
 // tout != nullptr (shapes whose waves run ONE pass): the outputs go IN PLACE into the tile the layer read — behind a workgroup barrier that every wave of the
 // workgroup passes once all MFMAs have been issued (waves without a pass: wideConv) — and to gout only where a later layer reads them as skip values (gout may
 // be nullptr); no trip through global memory between two layers.  tout == nullptr: the outputs go to gout, the caller stages them back (wideRestage).
-template <class G, int CQ, int NT, int NOT, bool CORNER>
+// wq_next / apre (in-place shapes): the NEXT layer's first unit of A-fragments (CQN chunks per tap there) is fetched into `apre` before this layer's barrier, and this
+// layer takes its own first unit from `apre` when the previous one left it there (have_pre): a layer then does not start with an exposed trip to the L2.
+template <class G, int CQ, int NT, int NOT, bool CORNER, int CQN = CQ>
 __device__ __forceinline__ void wideLayerPass(const float* __restrict__ tin, const float* gskip, float* gout, const float* __restrict__ wq,
-                                              const float* __restrict__ bias, int cout, int lane, int ot0, int tile0, float* tout = nullptr)
+                                              const float* __restrict__ bias, int cout, int lane, int ot0, int tile0, float* tout, const float* __restrict__ wq_next,
+                                              float (&apre)[NOT][NOT >= 2 ? 8 : 16], bool have_pre)
 {
     constexpr int CS = G::CS, PW = G::PW, P = G::P, W = G::W, OT = G::OT;
     // A-fragments travel in units of UC dwordx4 chunks per oc-tile (4 chunks = 16 k-steps; 2 where a wave owns two oc-tiles: the two register sets of a
@@ -151,14 +158,50 @@ __device__ __forceinline__ void wideLayerPass(const float* __restrict__ tin, con
         };
         wideStaticFor<0, UPT>(oneUnit);
     };
-    loadUnit(a[0], 0, 0);
+    if (have_pre) {
+#pragma unroll
+        for (int i = 0; i < NOT; ++i) {
+#pragma unroll
+            for (int c = 0; c < 4 * UC; ++c) { a[0][i][c] = apre[i][c]; }
+        }
+    } else {
+        loadUnit(a[0], 0, 0);
+    }
+    // the folded-BN bias of this wave's output channels: fetched here, used in the epilogue (there it was an exposed trip to the L2 per layer)
+    // (where a wave owns two oc-tiles — 256 channels, at the register limit — it is fetched after the k-loop as before)
+    float bv[NOT][4];
+    auto loadBias = [&]() {
+#pragma unroll
+        for (int i = 0; i < NOT; ++i) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + 16 * (ot0 + i) + 4 * (lane >> 4));
+            bv[i][0] = b4.x; bv[i][1] = b4.y; bv[i][2] = b4.z; bv[i][3] = b4.w;
+        }
+    };
+    if constexpr (NOT == 1) { loadBias(); }
     int p0[NT], p1[NT];
     setTap(p0, 0);
 #pragma unroll
     for (int j = 0; j < NT; ++j) { bc[j] = tin[p0[j]]; }
+    // the skip values (the block's input x, in global memory): every one is loaded before the first store — gskip may BE gout, the second conv of a block writes the
+    // block's output over its input lane by lane — and, where they are few (<= 24 registers), before the last tap, so that they arrive under its MFMAs
+    float sk[NOT][NT][4];
+    auto loadSkips = [&]() {
+#pragma unroll
+        for (int i = 0; i < NOT; ++i) {
+            const int ocb = 16 * (ot0 + i) + 4 * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int q = 16 * (tile0 + j) + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sk[i][j][r] = (gskip && q < P && ocb + r < cout) ? gskip[(ocb + r) * P + q] : 0.0f; }
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    constexpr bool kEarlySkips = NT * NOT <= 6;
     if constexpr (UPT % 2 == 0) { // the buffer parity returns to a[0] after every tap
 #pragma unroll 1
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < 8; ++t) {
             setTap(p1, t + 1);
             tapBody(std::integral_constant<int, 0>{}, t, p0, p1);
 #pragma unroll
@@ -172,36 +215,36 @@ __device__ __forceinline__ void wideLayerPass(const float* __restrict__ tin, con
             setTap(p0, t + 2);
             tapBody(std::integral_constant<int, 1>{}, t + 1, p1, p0);
         }
-        tapBody(std::integral_constant<int, 0>{}, 8, p0, p1);
+    }
+    if constexpr (kEarlySkips) { loadSkips(); }
+    tapBody(std::integral_constant<int, 0>{}, 8, p0, p1);
+    if constexpr (!kEarlySkips) { loadSkips(); }
+    if constexpr (NOT != 1) { loadBias(); }
+    if (wq_next) { // the next layer's first unit: in flight during the barrier and the epilogue
+        constexpr int nchn = UC < CQN ? UC : CQN;
+#pragma unroll
+        for (int i = 0; i < NOT; ++i) {
+            const float* base = wq_next + size_t(ot0 + i) * CQN * 256 + lane * 4;
+#pragma unroll
+            for (int c = 0; c < nchn; ++c) {
+                const float4 w = *reinterpret_cast<const float4*>(base + c * 256);
+                apre[i][4 * c] = w.x; apre[i][4 * c + 1] = w.y; apre[i][4 * c + 2] = w.z; apre[i][4 * c + 3] = w.w;
+            }
+        }
+        asm volatile("" ::: "memory");
     }
     // epilogue: folded-BN bias (+ skip) + ReLU.  D layout: column = lane & 15 (pixel), rows 4 * (lane >> 4) + r.
-    // gskip may BE gout (the second conv of a block writes the block's output over its input, lane by lane): every skip value is loaded before the first store,
-    // so that the loads are one round trip and not one per store the compiler must keep them behind
-    float sk[NOT][NT][4];
-#pragma unroll
-    for (int i = 0; i < NOT; ++i) {
-        const int ocb = 16 * (ot0 + i) + 4 * (lane >> 4);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int q = 16 * (tile0 + j) + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { sk[i][j][r] = (gskip && q < P && ocb + r < cout) ? gskip[(ocb + r) * P + q] : 0.0f; }
-        }
-    }
-    asm volatile("" ::: "memory");
     if (tout) { __syncthreads(); } // every wave has read its last B operand: the tile may be overwritten
 #pragma unroll
     for (int i = 0; i < NOT; ++i) {
         const int ocb = 16 * (ot0 + i) + 4 * (lane >> 4);
-        const float4 b4 = *reinterpret_cast<const float4*>(bias + ocb);
-        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int q = 16 * (tile0 + j) + (lane & 15);
             const int pd = pixoff[j] - (lane >> 4) * CS + PW + 1; // the pixel's own position in a padded plane
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] + bv[r];
+                float v = acc[i][j][r] + bv[i][r];
                 v = v + sk[i][j][r]; // without a skip: + 0 only turns -0 into +0, which the ReLU does anyway
                 v = v > 0.0f ? v : 0.0f;
                 if (q < P && ocb + r < cout) {
@@ -224,23 +267,27 @@ constexpr bool wideUsesNT(int n, bool corner)
     }
     return false;
 }
-template <class G, int CQ, int N = 1>
+template <class G>
+struct WidePre { float a[G::NOT][G::NOT >= 2 ? 8 : 16]; bool have; }; // the next layer's first unit of A-fragments, fetched ahead (wideLayerPass)
+
+template <class G, int CQ, int CQN, int N = 1>
 __device__ __forceinline__ void wideDispatchNT(int nt, bool corner, const float* __restrict__ tin, const float* gskip, float* gout, const float* __restrict__ wq,
-                                               const float* __restrict__ bias, int cout, int lane, int ot0, int tile0, float* tout)
+                                               const float* __restrict__ bias, int cout, int lane, int ot0, int tile0, float* tout, const float* __restrict__ wq_next, WidePre<G>& pre)
 {
     if constexpr (N <= 12) {
-        if constexpr (wideUsesNT<G>(N, false)) { if (nt == N && !corner) { wideLayerPass<G, CQ, N, G::NOT, false>(tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout); return; } }
-        if constexpr (wideUsesNT<G>(N, true)) { if (nt == N && corner) { wideLayerPass<G, CQ, N, G::NOT, true>(tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout); return; } }
-        wideDispatchNT<G, CQ, N + 1>(nt, corner, tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout);
+        if constexpr (wideUsesNT<G>(N, false)) { if (nt == N && !corner) { wideLayerPass<G, CQ, N, G::NOT, false, CQN>(tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout, wq_next, pre.a, pre.have); return; } }
+        if constexpr (wideUsesNT<G>(N, true)) { if (nt == N && corner) { wideLayerPass<G, CQ, N, G::NOT, true, CQN>(tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout, wq_next, pre.a, pre.have); return; } }
+        wideDispatchNT<G, CQ, CQN, N + 1>(nt, corner, tin, gskip, gout, wq, bias, cout, lane, ot0, tile0, tout, wq_next, pre);
     }
 }
 
 // one conv3x3 layer by the 8 waves of the workgroup: wave -> (oc-tiles, pixel group), the group's passes one after the other; one code copy per distinct pass size.
 // tout == nullptr: outputs to gout, no barrier inside.  tout != nullptr (G::kSinglePass shapes): outputs in place into the tile (+ gout where given), ONE workgroup
 // barrier inside (between the last MFMA and the first write); the caller passes the barrier behind the layer.
-template <class G, int CQ>
+// wq_next (in-place shapes only): the weights of the layer that follows, CQN chunks per tap — its first unit is fetched ahead into `pre`
+template <class G, int CQ, int CQN = CQ>
 __device__ __forceinline__ void wideConv(const float* __restrict__ tin, const float* gskip, float* gout, const float* __restrict__ wq,
-                                         const float* __restrict__ bias, int cout, int wave, int lane, float* tout = nullptr)
+                                         const float* __restrict__ bias, int cout, int wave, int lane, float* tout, const float* __restrict__ wq_next, WidePre<G>& pre)
 {
     wave = __builtin_amdgcn_readfirstlane(wave);
     const int wo = wave % G::WO, wp = wave / G::WO, ot0 = wo * G::NOT;
@@ -249,8 +296,9 @@ __device__ __forceinline__ void wideConv(const float* __restrict__ tin, const fl
 #pragma unroll 1
     for (int ps = 0; ps < np; ++ps) {
         const int nt = G::passTiles(wp, ps), t0 = G::passStart(wp, ps);
-        wideDispatchNT<G, CQ>(nt, G::kCorner && t0 + nt == G::PT, tin, gskip, gout, wq, bias, cout, lane, ot0, t0, tout);
+        wideDispatchNT<G, CQ, CQN>(nt, G::kCorner && t0 + nt == G::PT, tin, gskip, gout, wq, bias, cout, lane, ot0, t0, tout, G::kPrefetchNext ? wq_next : nullptr, pre);
     }
+    pre.have = G::kPrefetchNext && wq_next != nullptr;
 }
 
 // a layer's outputs [C][P] (global, written by this workgroup before the barrier the caller has passed) into the interior of the tile's padded planes
@@ -312,20 +360,24 @@ __device__ __forceinline__ float* wideTowerBody(const float* __restrict__ in, co
     if constexpr (G::kSinglePass) {
         // in place: a layer's outputs overwrite the tile it read (behind the barrier inside wideConv); x also goes to global memory, where the second conv of
         // the block finds its skip values.  The temporary never leaves the LDS; gt is not used.
-        wideConv<G, CIN0Q / 16>(tile, nullptr, gx, params + ta.w_off[0], params + ta.b_off[0], ta.C, wave, lane, tile);
+        WidePre<G> pre;
+        pre.have = false;
+        wideConv<G, CIN0Q / 16, C / 16>(tile, nullptr, gx, params + ta.w_off[0], params + ta.b_off[0], ta.C, wave, lane, tile, ta.nlayers > 1 ? params + ta.w_off[1] : nullptr, pre);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < ta.nlayers; l += 2) { // residual blocks (ref network_unit.py:14-23): t = relu(conv1(x)); x = relu(conv2(t) + x)
-            wideConv<G, C / 16>(tile, nullptr, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, wave, lane, tile);
+            wideConv<G, C / 16>(tile, nullptr, nullptr, params + ta.w_off[l], params + ta.b_off[l], ta.C, wave, lane, tile, params + ta.w_off[l + 1], pre);
             __syncthreads();
-            wideConv<G, C / 16>(tile, gx, gx, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, wave, lane, tile);
+            wideConv<G, C / 16>(tile, gx, gx, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, wave, lane, tile, l + 2 < ta.nlayers ? params + ta.w_off[l + 2] : nullptr, pre);
             __syncthreads();
         }
         (void)to_lds; (void)gt;
         return tile;
     }
     // stem: tile -> x
-    wideConv<G, CIN0Q / 16>(tile, nullptr, gx, params + ta.w_off[0], params + ta.b_off[0], ta.C, wave, lane);
+    WidePre<G> nopre;
+    nopre.have = false;
+    wideConv<G, CIN0Q / 16>(tile, nullptr, gx, params + ta.w_off[0], params + ta.b_off[0], ta.C, wave, lane, nullptr, nullptr, nopre);
     __syncthreads();
     if (ta.nlayers > 1 || to_lds) {
         wideRestage<G>(gx, tile, tid);
@@ -333,11 +385,11 @@ __device__ __forceinline__ float* wideTowerBody(const float* __restrict__ in, co
     }
 #pragma unroll 1
     for (int l = 1; l < ta.nlayers; l += 2) { // residual blocks (ref network_unit.py:14-23): t = relu(conv1(x)); x = relu(conv2(t) + x)
-        wideConv<G, C / 16>(tile, nullptr, gt, params + ta.w_off[l], params + ta.b_off[l], ta.C, wave, lane);
+        wideConv<G, C / 16>(tile, nullptr, gt, params + ta.w_off[l], params + ta.b_off[l], ta.C, wave, lane, nullptr, nullptr, nopre);
         __syncthreads();
         wideRestage<G>(gt, tile, tid);
         __syncthreads();
-        wideConv<G, C / 16>(tile, gx, gx, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, wave, lane);
+        wideConv<G, C / 16>(tile, gx, gx, params + ta.w_off[l + 1], params + ta.b_off[l + 1], ta.C, wave, lane, nullptr, nullptr, nopre);
         __syncthreads();
         if (l + 2 < ta.nlayers || to_lds) {
             wideRestage<G>(gx, tile, tid);

@@ -64,7 +64,7 @@ for k, cyc in MOVES.items():
 PY
 timeout 900 python tools/run_configs.py --out $O/configs.json > $O/configs.log 2>&1
 # round 5: shapes beyond BASELINE.json on the one-tile tower (sim_kernel_wide): a roofline block each, the stand-alone towers, the in-kernel phase profile
-timeout 600 python tools/run_configs.py w9x128 w9x256 w19x64 --out $O/wide_configs.json > $O/wide_configs.log 2>&1
+timeout 600 python tools/run_configs.py w9x128 w9x256 w19x64 w9x128mz --out $O/wide_configs.json > $O/wide_configs.log 2>&1
 timeout 300 python tools/run_configs.py c5x512 --out $O/c5_512_games_one_gpu.json > /dev/null 2>&1
 timeout 300 python tools/time_wide.py 256 > $O/time_wide.log 2>&1; cp gpurun_out/time_wide.json $O/time_wide_towers.json
 for k in w9x128 w19x64; do MZ_SIM_PROF=1 timeout 200 python tools/run_configs.py $k --moves 1 --out $O/tmp.json 2>&1 | grep "sim prof" > $O/sim_prof_$k.txt; done

@@ -52,14 +52,16 @@ EXTRA_CONFIGS = {
 }
 # ... and BASELINE configs[4]'s whole node (512 games) on ONE GPU — NOT the BASELINE shard (64 games per GPU): what the same kernels reach when the pool fills the chip
 EXTRA_CONFIGS["c5x512"] = ("c5", mz.CONFIGS["c5"].replace("zero_num_parallel_games=64", "zero_num_parallel_games=512"))
+EXTRA_CONFIGS["w9x128mz"] = ("w9x128mz", "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=50:zero_num_parallel_games=256")  # BASELINE configs[3]'s search, 6 blocks x 128 channels
 EXTRA_DESCS = {
+    "w9x128mz": lambda: mz.make_desc("go_9x9", 18, 9, 9, 128, 9, 9, 1, 6, 82, type_name="muzero"),
     "w9x128": lambda: mz.make_desc("go_9x9", 18, 9, 9, 128, 9, 9, 1, 6, 82),
     "w9x256": lambda: mz.make_desc("go_9x9", 18, 9, 9, 256, 9, 9, 1, 1, 82),
     "w19x64": lambda: mz.make_desc("go_19x19", 18, 19, 19, 64, 19, 19, 1, 6, 362),
 }
-MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2, "c5x512": 30})
+MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2, "c5x512": 30, "w9x128mz": 10})
 WARM.update({"w9x128": 1, "w9x256": 1, "w19x64": 1, "c5x512": 14})
-KERNEL.update({"w9x128": "sim_kernel_wide<9,9,32,128,2>", "w9x256": "sim_kernel_wide<9,9,32,256,2>", "w19x64": "sim_kernel_wide<19,19,32,64,6>"})
+KERNEL.update({"w9x128mz": "sim_kernel_mz_wide<9,9,32,144,128>", "w9x128": "sim_kernel_wide<9,9,32,128,2>", "w9x256": "sim_kernel_wide<9,9,32,256,2>", "w19x64": "sim_kernel_wide<19,19,32,64,6>"})
 
 
 def _by_kernel(s0, s1, launches):
