@@ -160,6 +160,11 @@ public:
     void parallelFor(int count, const std::function<void(int)>& fn)
     {
         if (n_ == 1 || count < 2) { for (int i = 0; i < count; ++i) { fn(i); } return; }
+        // Close the finished epoch BEFORE fn_ / count_ / chunk_ change.  A worker that the OS descheduled inside work() between its load of state_ = (E, count_old)
+        // and its `b >= count_` test would otherwise test against the NEXT call's (larger) count, win the compare-exchange on the still unchanged state and run
+        // items of an epoch that does not exist yet — through a function object that may be gone (found by round 5's fuzz sweep under eight-fold CPU
+        // oversubscription: a segmentation fault in about one of 3 000 cases).  With the state moved first, that compare-exchange fails and the worker leaves.
+        state_.store((state_.load(std::memory_order_relaxed) & 0xffffffff00000000ull) | 0x7fffffffull, std::memory_order_release);
         fn_ = &fn;
         count_ = count;
         chunk_ = std::max(1, count / (n_ * 4));
