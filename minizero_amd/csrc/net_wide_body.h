@@ -2,9 +2,11 @@
 // wide towers (128 / 256 hidden channels: the reference's default network is 1 block x 256 channels, config/configuration.cpp:70-72) and large
 // boards (13x13, 19x19 Go: go_unit.h:11).  Same arithmetic as net_body.h (per output one k-ordered fmaf chain, tap-major, channel
 // ascending = the chain of v_mfma_f32_16x16x4_f32 steps), another data flow:
-//   * ONE LDS tile [C][CS] holds the current layer's input (zero-padded planes); a layer's outputs go to a per-workgroup block in global memory
-//     (two blocks of C x P floats: x and the temporary, L2-resident) and are staged back into the tile for the next layer — the second conv of a
-//     block reads its skip values from x and writes the block's output over them, lane by lane (the same in-place rule as the two-tile tower).
+//   * ONE LDS tile [C][CS] holds the current layer's input (zero-padded planes).  Shapes whose waves hold all their accumulators at once (WideGeo::kSinglePass:
+//     every instance so far) run a layer as MFMAs -> workgroup barrier -> epilogue, and the epilogue writes the outputs IN PLACE over the tile the layer has
+//     just read; the block input x also goes to a per-workgroup block in global memory (L2-resident), where the second conv of the block finds its skip
+//     values — read back by the very lane that wrote them.  (Shapes with several passes per wave stage every layer through global memory: wideRestage.)
+//     The bias, the skip values (where they are few) and the next layer's first A unit (where the registers allow) are fetched ahead of the barrier.
 //   * wave w of the 8 owns NOT = OT / WO adjacent output-channel tiles (WO = min(OT, 8) wave columns) x the pixel tiles of its pixel group
 //     (8 / WO groups), in passes of at most 12 accumulator tiles; pixel tiles are 16 CONSECUTIVE pixels (coalesced 64-byte runs to global memory;
 //     the B operand's bank conflicts were measured not to matter).
