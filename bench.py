@@ -233,7 +233,7 @@ def main():
         # HBM traffic from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; the x2 on
         # gfx950 per MI355X_MICROARCH.md, re-calibrated on a known-size copy kernel with the same 4-B/lane access, see profiles/README.md)
         traffic, traffic_src = None, None
-        for name in ("r04_pmc_sim.json", "r03_pmc_sim.json", "r02_pmc_sim.json", "r01_pmc_sim.json"):
+        for name in ("r05_pmc_sim.json", "r04_pmc_sim.json", "r03_pmc_sim.json", "r02_pmc_sim.json", "r01_pmc_sim.json"):
             try:
                 j = json.load(open(os.path.join(ROOT, "profiles", name)))
                 per_cycle = j.get("bytes_per_cycle", j.get("bytes_per_step"))

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
     // muzero_atari (no path speculation: its memory is free): the simulation's path stays in LDS — the walk writes it, the probe, expand, backup and the
     // next Gumbel step read it — instead of going through the pool's arrays in global memory (a round trip each)
     int* lds_path = (a->atari && 2 * a->pv.max_depth + 2 <= kSpecWords) ? spec_w : nullptr;
-    const PoolView v = lds_path ? simPathView(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
+    const PoolView v = lds_path ? simPathViewSafe(ldc(&a->pv), lds_path, g) : ldc(&a->pv);
     // ... and behind them the Gumbel root's state and what its step reads of the root's children (first_child, num_children, visit counts, logits): the step
     // that runs beside a simulation's expand + backup (below) then makes no trip to global memory (6.5 -> ~2 us: it had become the longer of the two)
     int* gum_state = nullptr;
@@ -55,6 +55,13 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         }
     }
     __syncthreads();
+    // THIS game's path arrays as the kernel body reads them.  The PoolView of simPathView points `g * max_depth` elements in FRONT of the LDS block (the bodies add
+    // them back); inside the non-inlined phase functions those are generic pointers and 64-bit arithmetic, but here the compiler sees that the pointer is LDS and may
+    // fold the bias into a DS instruction's 16-bit offset — as soon as g * max_depth * 4 exceeds the block's own LDS offset (260 Atari-shaped games at n = 50) the
+    // address leaves the LDS, the read returns nothing and the slab index built from it faults (found with 512 games on one GPU, round 5).  No bias here.
+    const int* const my_path = lds_path ? lds_path : v.path + size_t(g) * v.max_depth;
+    const int* const my_pact = lds_path ? lds_path + a->pv.max_depth : v.path_action + size_t(g) * v.max_depth;
+    const int* const my_len = lds_path ? lds_path + 2 * a->pv.max_depth : v.path_len + g;
     unsigned long long* prof = a->prof ? a->prof + size_t(g) * 8 : nullptr; // MZ_SIM_PROF=1: [select, tower, heads, cand+expand] ticks + sims
     for (int s = 0; s < nsims; ++s) {
         const int slot = sim0 + s; // simulation index within the move = hidden-state slot of its leaf
@@ -75,9 +82,9 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         bool hit = false;
         if (pre_epoch != 0 && slot >= 1 && !given) {
             if (wave == 0) {
-                const int len = v.path_len[g];
-                const int* path = v.path + size_t(g) * v.max_depth;
-                const int h = simPreProbe(a, pre_epoch, g, slot, v.hslot[size_t(g) * v.cap + path[len - 2]], v.path_action[size_t(g) * v.max_depth + len - 1], lane);
+                const int len = *my_len;
+                const int* path = my_path;
+                const int h = simPreProbe(a, pre_epoch, g, slot, v.hslot[size_t(g) * v.cap + path[len - 2]], my_pact[len - 1], lane);
                 if (lane == 0) {
                     s_pre_hit = h;
                     s_bump_cnt = v.rec[size_t(g) * v.cap + path[1]].count; // the root child on this path, before this simulation's backup
@@ -94,10 +101,10 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
         } else if (slot == 0) { // initial inference: representation trunk on the root planes (board games; muzero_atari roots never come here)
             xt = towerBody<H, W, CIN0_PAD, CPAD>(reinterpret_cast<const float*>(a->root_feat), a->params, *(const TowerArgs*)&a->ta, nullptr, g, tid, tiles);
         } else { // recurrent inference: dynamics trunk on (parent hidden state, move)
-            const int len = v.path_len[g];
-            const int* path = v.path + size_t(g) * v.max_depth;
+            const int len = *my_len;
+            const int* path = my_path;
             const int src = v.hslot[size_t(g) * v.cap + path[len - 2]];
-            const int action = v.path_action[size_t(g) * v.max_depth + len - 1];
+            const int action = my_pact[len - 1];
             const float* hsrc = a->hidden + (size_t(g) * a->slots + src) * size_t(a->hp.C) * a->hp.P;
             xt = towerBody<H, W, CDYN_PAD, CPAD, (H * W <= 36)>(nullptr, a->params, *(const TowerArgs*)&a->ta_dyn, nullptr, g, tid, tiles, hsrc, action,
                                                                a->action_planes); // 6x6 = muzero_atari: stream the tower's weights (net_body.h loadW4)
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__
             if (lane == 0) { s_gum_ahead = done ? 1 : 0; }
         }
         if (gum_kids && tid == 64 && slot >= 1 && !given) { // this simulation's visit to the root child on its path, in the launch's copy of the counts (after the step ahead read them)
-            const int child = v.path[size_t(g) * v.max_depth + 1] - gum_kids[0];
+            const int child = my_path[1] - gum_kids[0];
             if (child >= 0 && child < a->A) { reinterpret_cast<float*>(gum_kids + 2)[child] += 1.0f; }
         }
         __syncthreads();
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, 4))) v
         if (ok) {
             if (lane == 0) { ctl[3] = fc + st_l[3 + r]; }
             waveSync();
-            const PoolView pl = simPathView(v, path_l, g);
+            const PoolView pl = simPathViewSafe(v, path_l, g);
             selectBody<false>(pl, ctl + 3 - g, g, lane, v.rcp_tab);
             waveSync();
             const int len = path_l[2 * v.max_depth];
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(512) void sim_pre_pair_kernel_mz(const SimArgs* __r
         if (ok) {
             if (lane == 0) { s_ctl[3] = fc + st_l[3 + r]; }
             waveSync();
-            const PoolView pl = simPathView(v, path_l, g);
+            const PoolView pl = simPathViewSafe(v, path_l, g);
             selectBody<false>(pl, s_ctl + 3 - g, g, lane, v.rcp_tab);
             waveSync();
             const int len = path_l[2 * v.max_depth];

@@ -93,4 +93,20 @@ __device__ __forceinline__ PoolView simPathView(PoolView pv, int* lds_path, int 
     return pv;
 }
 
+// The same view for use INSIDE a kernel body (or a function inlined into one), where the compiler can see that `lds_path` is LDS: the biased pointers above lie
+// in front of the block (undefined behaviour by the letter), and with the provenance in sight the compiler may fold the bias into a DS instruction's offset — the
+// address then leaves the LDS as soon as g * max_depth * 4 exceeds the block's LDS offset (260 Atari-shaped games at n = 50; never with BASELINE's 64): reads return
+// nothing, the slab index built from them faults.  Laundering the pointers makes them opaque generic pointers: 64-bit arithmetic, flat accesses, always in the aperture.
+template <class T>
+__device__ __forceinline__ T* opaquePtr(T* p)
+{
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ PoolView simPathViewSafe(PoolView pv, int* lds_path, int g)
+{
+    pv = simPathView(pv, opaquePtr(lds_path), g);
+    return pv;
+}
+
 } // namespace mz

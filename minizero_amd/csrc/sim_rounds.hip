@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void pre_walk_kernel(const SimArgs* __restrict_
     if (ok) {
         if (lane == 0) { ctl[3] = fc + st_l[3 + r]; }
         waveSync();
-        const PoolView pl = simPathView(v, path_l, g);
+        const PoolView pl = simPathViewSafe(v, path_l, g);
         selectBody<false>(pl, ctl + 3 - g, g, lane, v.rcp_tab);
         waveSync();
         const int len = path_l[2 * v.max_depth];

@@ -613,3 +613,26 @@ def test_atari_cluster_other_search_settings(mz, variant):
     assert lockstep == cluster
     assert lockstep == single
     assert lockstep == default
+
+
+@pytest.mark.parametrize("games,n,extra", [(300, 50, ""), (300, 50, ":mz_sim_rounds=false"), (170, 100, ":mz_sim_round_batch=false"), (540, 24, "")])
+def test_atari_pools_larger_than_the_chip(mz, oracle, games, n, extra):
+    """More Atari-shaped games on ONE GPU than BASELINE's shard of 64 (a one-GPU deployment of the reference's 512-game configuration): pools beyond 256 workgroups,
+    and — the regression this test pins — beyond the pool size at which a game's index times max_depth exceeds the LDS offset of the simulation's path block
+    (260 games at n = 50, 137 at n = 100): the MuZero simulation kernels read that block through pointers biased by the game's offset, and where the compiler could
+    see that they were LDS pointers the biased address left the LDS — a GPU memory fault from `run_configs.py c5x512` in round 5.  Records against the oracle, two moves."""
+    conf = (ATARI_SMALL.replace("actor_num_simulation=8", f"actor_num_simulation={n}").replace("actor_gumbel_sample_size=4", "actor_gumbel_sample_size=8")
+            .replace("zero_num_parallel_games=5", f"zero_num_parallel_games={games}") + ":program_seed=3:nn_file_name=x.pt")
+    kw = dict(vh=ATARI_ARGS[10], dv=ATARI_ARGS[11], type_name=ATARI_ARGS[12])
+    d, od = mz.make_desc(*ATARI_ARGS[:10], **kw), oracle.make_desc(*ATARI_ARGS[:10], **kw)
+    w = mz.generate_weights(d, 5)
+    cycles = 2 * (n + 1) + 3
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1:oracle_throughput_threads=8", od, w)
+    og.cycles(cycles)
+    wk = mz.Worker(conf + extra + ":zero_num_threads=4:mz_rng_streams=8", d, w)
+    wk.command("start")
+    assert wk.run_cycles(n + 1) == n + 1 and wk.run_cycles(n + 1) == n + 1 and wk.run_cycles(3) == 3
+    st = wk.stats()
+    assert st["sim_launches"] > 0 and st["moves"] == 2 * games
+    assert wk.pop_lines() == og.lines()
+    assert wk.peek_records(games) == og.peek_records(games)
