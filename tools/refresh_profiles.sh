@@ -13,7 +13,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 O=gpurun_out/refresh
 rm -rf $O; mkdir -p $O
-SHORT="--steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline --other-moves 0"
+SHORT="--steps 4 --warmup 1 --game-moves 0 --no-cpu-baseline --other-moves 0 --one-stream-moves 0"
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --steps 20 --warmup 5 --precision bf16x3 --no-cpu-baseline --other-moves 0 > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py $SHORT > $O/bench_profiled.json 2> $O/stats.err
