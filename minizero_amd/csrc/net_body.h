@@ -558,7 +558,10 @@ __device__ __forceinline__ float orderedSumWave(const float* x, int n, int lane)
 // of the Go leaf beside it on waves that have no share of the heads (sim.hip simLeafRest / go_body.h goLeafBody PART 2), and those waves pass the same two.
 // BIGA (boards of more than 128 actions, 13x13 / 19x19 Go: the policy FC is a 722-step chain per logit at 19x19): the weights of the long chains 64 steps ahead, and the
 // value FC1 on the threads the policy FC leaves free (two hidden units per thread, interleaved) instead of behind it on the same threads.  Same chains, same bits.
-template <bool BIGA = false>
+// FP ("fast pointers", simulation kernels only: activations and scratch are LDS, weights global memory): every chain reads its weights with GLOBAL loads and its x
+// operand with DS reads instead of through the generic pointers (flat loads: their completion is counted on both counters, so that the wait for an LDS operand waits
+// for every weight in flight).  BIGA implies it.
+template <bool BIGA = false, bool FP = BIGA>
 __device__ __forceinline__ void headsBody(const float* __restrict__ x, const HeadParams& hp, float* __restrict__ policy, float* __restrict__ logit,
                                           float* __restrict__ value, float* __restrict__ hidden_dst, const int* __restrict__ dst_idx, int scale_hidden,
                                           int b, int tid, int NT, float* __restrict__ sm, const float* __restrict__ xlds = nullptr, int xcs = 0,
@@ -618,7 +621,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
         const int j = i / P, p = i - j * P;
         const float* w = (j < PC) ? hp.pconv_w + j * C : hp.vconv_w;
         const int xo = (xlds && xpw != 0) ? (p / (xpw - 2) + 1) * xpw + p % (xpw - 2) + 1 : p;
-        const float acc = (BIGA && xlds && xpw != 0) ? dotChain<16, true, true>(xrd + xo, xstride, w, 1, C) : dotChain<16>(xrd + xo, xstride, w, 1, C);
+        const float acc = (FP && xlds && xpw != 0) ? dotChain<16, true, true>(xrd + xo, xstride, w, 1, C) : dotChain<16>(xrd + xo, xstride, w, 1, C);
         float v = acc + ((j < PC) ? hp.pconv_b[j] : hp.vconv_b[0]);
         v = v > 0.0f ? v : 0.0f;
         if (j < PC) { pf[i] = v; } else { vf[p] = v; }
@@ -628,7 +631,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
 
     // policy FC (one logit per thread, waves 0..) and value FC1 (one hidden unit per thread, on other waves when there are enough)
     for (int a = tid; a < A; a += NT) {
-        const float v = (BIGA ? dotChain<64, true, true>(pf, 1, hp.pfc_wT + a, A, PC * P) : dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P)) + hp.pfc_b[a];
+        const float v = (BIGA ? dotChain<64, true, true>(pf, 1, hp.pfc_wT + a, A, PC * P) : FP ? dotChain<16, true, true>(pf, 1, hp.pfc_wT + a, A, PC * P) : dotChain<16>(pf, 1, hp.pfc_wT + a, A, PC * P)) + hp.pfc_b[a];
         lg[a] = v;
         logit[size_t(b) * A + a] = v;
     }
@@ -648,7 +651,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
     } else {
         const int vo = (NT >= 256 && A <= 128) ? 128 : 0; // first thread of the value FC1 group
         for (int o = (tid - vo + NT) % NT; o < VH; o += NT) {
-            const float v = dotChain<16>(vf, 1, hp.vfc1_wT + o, VH, P) + hp.vfc1_b[o];
+            const float v = (FP ? dotChain<16, true, true>(vf, 1, hp.vfc1_wT + o, VH, P) : dotChain<16>(vf, 1, hp.vfc1_wT + o, VH, P)) + hp.vfc1_b[o];
             h1[o] = v > 0.0f ? v : 0.0f;
         }
     }
@@ -657,7 +660,7 @@ __device__ __forceinline__ void headsBody(const float* __restrict__ x, const Hea
 
     // value FC2 + tanh: one sequential chain (wave 1, lane 0) while wave 0 does the softmax
     if (tid == 64) {
-        const float acc = BIGA ? dotChain<32, true, true>(h1, 1, hp.vfc2_w, 1, VH) : dotChain<16>(h1, 1, hp.vfc2_w, 1, VH);
+        const float acc = BIGA ? dotChain<32, true, true>(h1, 1, hp.vfc2_w, 1, VH) : FP ? dotChain<16, true, true>(h1, 1, hp.vfc2_w, 1, VH) : dotChain<16>(h1, 1, hp.vfc2_w, 1, VH);
         value[b] = mz_tanhf(acc + hp.vfc2_b[0]);
     }
     if (wave == 0) {

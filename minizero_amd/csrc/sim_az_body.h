@@ -73,6 +73,10 @@ __device__ unsigned long long g_bp[20];
 #include <cstdlib>
 #include <vector>
 
+#ifndef MZ_HEADS_FP
+#define MZ_HEADS_FP 0 // (experiment switch: the two-tile 9x9 kernels' heads with global / DS loads instead of flat loads)
+#endif
+
 namespace mz {
 
 
@@ -331,7 +335,7 @@ __device__ __noinline__ void simGumbelStart(CSimArgs* __restrict__ a, int slot, 
 }
 
 // the heads read the tower's last activations where they are (an LDS tile); tile 0 (the blocks' temporary) is free for their scratch
-template <int WPE, bool BIGA = false>
+template <int WPE, bool BIGA = false, bool FP = BIGA>
 __device__ __forceinline__ void simHeadsImpl(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw, float* xchg)
 {
     // arguments of a device function arrive in VGPRs: tell the compiler which ones are wave-uniform
@@ -342,15 +346,15 @@ __device__ __forceinline__ void simHeadsImpl(CSimArgs* __restrict__ a, int g, in
     const HeadParams hp = ldc(&a->hp);
     const SimXchg x{hp.A + (hp.A & 1)};
     const size_t ga = size_t(g) * hp.A;
-    headsBody<BIGA>(nullptr, hp, xchg + x.policy() - ga, xchg + x.logit() - ga, xchg + x.scalars() - g, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
+    headsBody<BIGA, FP>(nullptr, hp, xchg + x.policy() - ga, xchg + x.logit() - ga, xchg + x.scalars() - g, nullptr, nullptr, 0, g, tid, 512, tiles, xtile, xcs, xpw);
     MZ_HPROF(1);
 }
 // a non-inlined device function saves the callee-saved VGPRs it uses on entry (scratch stores + loads by all 8 waves): worth it for the
 // 9x9 kernels (the heads keep their own register budget, and their version needs none saved), not for the 128-VGPR 8x8 / 3x3 kernels
-template <int WPE, bool BIGA = false>
+template <int WPE, bool BIGA = false, bool FP = BIGA>
 __device__ __noinline__ void simHeads(CSimArgs* __restrict__ a, int g, int tid, float* tiles, const float* xtile, int xcs, int xpw, float* xchg)
 {
-    simHeadsImpl<WPE, BIGA>(a, g, tid, tiles, xtile, xcs, xpw, xchg);
+    simHeadsImpl<WPE, BIGA, FP>(a, g, tid, tiles, xtile, xcs, xpw, xchg);
 }
 
 // 8x8 boards: three tower tiles are 80 KB of LDS, so TWO games share a CU (16 waves) if the kernel stays within 128 VGPRs: one game's
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(simWavesPer
         if (prof) { t2 = wall_clock64(); }
         if constexpr (WPE == 4) { simHeadsImpl<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
         else if (leaf_smem && wave >= 6) { simLeafRest<CPL>(a, rot, slot, g, lane, xchg, seen_lds, leaf_smem, 7 - wave); }
-        else { simHeads<WPE>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
+        else { simHeads<WPE, false, (MZ_HEADS_FP != 0)>(a, g, tid, tiles, xt, planeStride(H, W), W + 2, xchg); }
         __syncthreads();
         if (prof) { t3 = wall_clock64(); }
         if (wave == 0) { simCandGather<WPE>(a, rot, g, lane, tiles, xchg); }
