@@ -6,6 +6,9 @@
 #include <vector>
 __shared__ unsigned long long s_tprof[8][64];
 __shared__ int s_tprof_n[8];
+#ifdef NO_TPROF // timing only (-DNO_TPROF): the stamps themselves cost ~3.5 k cycles per layer
+#define MZ_TPROF(slot) do { } while (0)
+#else
 #define MZ_TPROF(slot)                                                                                   \
     do {                                                                                                 \
         if ((threadIdx.x & 63) == 0) {                                                                   \
@@ -14,6 +17,7 @@ __shared__ int s_tprof_n[8];
             s_tprof_n[w_] = i_ + 1;                                                                      \
         }                                                                                                \
     } while (0)
+#endif
 #include "net_dev.h"
 #include "net_body.h"
 using namespace mz;
@@ -23,9 +27,11 @@ __global__ __launch_bounds__(512) void tower_prof(const float* in, const float* 
 {
     extern __shared__ __attribute__((aligned(16))) float tiles[];
     if ((threadIdx.x & 63) == 0) { s_tprof_n[threadIdx.x >> 6] = 0; }
+    const unsigned long long c0 = clock64(), w0 = wall_clock64(); // shader-clock cycles against the constant 100 MHz counter: the clock the kernel really ran at
     __syncthreads();
     towerBody<H, W, CIN0_PAD, CPAD>(in, params, ta, out, blockIdx.x, threadIdx.x, tiles);
     __syncthreads();
+    if (blockIdx.x == 1 && threadIdx.x == 0) { prof[8 * 64] = clock64() - c0; prof[8 * 64 + 1] = wall_clock64() - w0; }
     if (blockIdx.x == 0 && threadIdx.x < 8) { for (int i = 0; i < 64; ++i) { prof[threadIdx.x * 64 + i] = i < s_tprof_n[threadIdx.x] ? s_tprof[threadIdx.x][i] : 0; } }
 }
 
@@ -46,19 +52,20 @@ int main()
     hipMalloc(&params, off * 4); hipMemcpy(params, hp.data(), off * 4, hipMemcpyHostToDevice);
     hipMalloc(&in, size_t(B) * 18 * 3 * 4); hipMemset(in, 0x5a, size_t(B) * 18 * 3 * 4);
     hipMalloc(&out, size_t(B) * C * 81 * 4);
-    hipMalloc(&prof, 8 * 64 * 8);
+    hipMalloc(&prof, (8 * 64 + 2) * 8);
     const size_t lds = size_t(kTowerTiles) * 64 * planeStride(H, W) * 4;
     hipFuncSetAttribute(reinterpret_cast<const void*>(tower_prof<H, W, C0, C>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < 5; ++it) {
         hipEventRecord(e0);
-        for (int k = 0; k < 20; ++k) { hipLaunchKernelGGL((tower_prof<H, W, C0, C>), dim3(B), dim3(512), lds, 0, reinterpret_cast<const float*>(in), params, ta, out, prof); }
+        for (int k = 0; k < 200; ++k) { hipLaunchKernelGGL((tower_prof<H, W, C0, C>), dim3(B), dim3(512), lds, 0, reinterpret_cast<const float*>(in), params, ta, out, prof); }
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("launch: %.1f us\n", ms * 1000 / 20);
+        printf("launch: %.1f us\n", ms * 1000 / 200);
     }
-    std::vector<unsigned long long> h(8 * 64);
+    std::vector<unsigned long long> h(8 * 64 + 2);
     hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
+    printf("workgroup 1: %llu shader cycles in %llu ticks of the 100 MHz counter = %.0f MHz\n", h[512], h[513], double(h[512]) / double(h[513]) * 100.0);
     // per wave: sequence of (slot, clock): 0 start, 1 issued, 2 epilogue, 3 barrier
     for (int w = 0; w < 8; ++w) {
         printf("wave %d:", w);
