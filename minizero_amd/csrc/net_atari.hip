@@ -78,6 +78,25 @@ __global__ __launch_bounds__(256) void conv3x3_tiled(const float* __restrict__ i
         for (int j = 0; j < ROWS; ++j) { bv[j] = xs[lane_off + cg * 4 * PLANE + (row0 + j) * STRIDE * PC + tapoff]; }
     };
     bload(bc, 0, 0);
+    // the epilogue's operands (bias, residual input) are fetched now: asked for behind the MFMA loop, every workgroup of a CU — they run in step — sat through
+    // the round trip with nothing else to issue (tools/ab_atari_root.sh with the phases switched off one by one: staging 10, MFMAs 28, epilogue 11 of 48 us)
+    float* dst = out + size_t(b) * cout * Ho * Wo;
+    const float* sk = skip ? skip + size_t(b) * cout * Ho * Wo : nullptr;
+    const int ox = ox0 + (lane & 15);
+    float ebias[4], eskip[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oc = 16 * ot + 4 * (lane >> 4) + r;
+        ebias[r] = bias[oc < cout ? oc : 0];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int oy = oy0 + row0 + j;
+            const bool ok = sk && oy < Ho && ox < Wo && oc < cout;
+            const float x = (sk ? sk : bias)[ok ? (size_t(oc) * Ho + oy) * Wo + ox : 0];
+            eskip[j][r] = ok ? x : 0.0f;
+        }
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {
         const int tn = t < 8 ? t + 1 : 8;
@@ -98,9 +117,6 @@ __global__ __launch_bounds__(256) void conv3x3_tiled(const float* __restrict__ i
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) { a_cur[cg] = a_nxt[cg]; }
     }
-    float* dst = out + size_t(b) * cout * Ho * Wo;
-    const float* sk = skip ? skip + size_t(b) * cout * Ho * Wo : nullptr;
-    const int ox = ox0 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const int oy = oy0 + row0 + j;
@@ -108,10 +124,9 @@ __global__ __launch_bounds__(256) void conv3x3_tiled(const float* __restrict__ i
         for (int r = 0; r < 4; ++r) {
             const int oc = 16 * ot + 4 * (lane >> 4) + r;
             if (oy < Ho && ox < Wo && oc < cout) {
-                const size_t o = (size_t(oc) * Ho + oy) * Wo + ox;
-                float v = acc[j][r] + bias[oc];
-                if (sk) { v = v + sk[o]; }
-                dst[o] = v > 0.0f ? v : 0.0f;
+                float v = acc[j][r] + ebias[r];
+                if (sk) { v = v + eskip[j][r]; }
+                dst[(size_t(oc) * Ho + oy) * Wo + ox] = v > 0.0f ? v : 0.0f;
             }
         }
     }
