@@ -183,6 +183,10 @@ private:
     AtariLayers at_;
     DevBuf<float> at_buf_[3];   // muzero_atari representation activations (largest stage: [B][C/2][H/2][W/2])
     int at_batch_ = 0;
+    DevBuf<float> at_out_;      // the representation's 6x6 output of the whole batch (the two halves of initialAtari write their parts)
+    static constexpr int kReprParts = 4;
+    hipStream_t at_streams_[kReprParts - 1] = {}; // the other parts of the batch: their layers run beside the first part's, a phase apart (initialAtari)
+    hipEvent_t at_fork_ = nullptr, at_join_[kReprParts - 1] = {};
     int initialAtari(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, float* d_hidden, const int* d_dst_idx);
     int recurrentAtari(const float* d_hidden_src, const int* d_src_idx, const float* d_action_planes, const int* d_action_ids, int B, float* d_policy,
                        float* d_logit, float* d_value, float* d_reward, float* d_hidden_dst, const int* d_dst_idx);

@@ -164,6 +164,9 @@ Net::~Net()
 {
     dumpSimProf();
     dumpRoundsProf();
+    for (hipStream_t s : at_streams_) { if (s) { (void)hipStreamDestroy(s); } }
+    if (at_fork_) { (void)hipEventDestroy(at_fork_); }
+    for (hipEvent_t e : at_join_) { if (e) { (void)hipEventDestroy(e); } }
     if (own_stream_ && stream_) { (void)hipStreamDestroy(stream_); }
 }
 

@@ -236,35 +236,69 @@ int Net::initialAtari(const float* d_feat, int B, float* d_policy, float* d_logi
     if (rc) { return rc; }
     int H = desc_.input_channel_height, W = desc_.input_channel_width;
     const int C = desc_.num_hidden_channels;
+    const size_t stage = size_t(C / 2) * (H / 2) * (W / 2); // floats per sample of the largest stage
     if (B > at_batch_) {
         MZ_HIP(hipStreamSynchronize(stream_));
-        const size_t n = size_t(B) * (C / 2) * (H / 2) * (W / 2);
-        for (auto& b : at_buf_) { if (!b.alloc(n)) { setError("hipMalloc of the representation buffers failed"); return MZ_ERR_DEVICE; } }
+        for (auto& b : at_buf_) { if (!b.alloc(size_t(B) * stage)) { setError("hipMalloc of the representation buffers failed"); return MZ_ERR_DEVICE; } }
+        if (!at_out_.alloc(size_t(B) * hiddenSize())) { setError("hipMalloc of the representation buffers failed"); return MZ_ERR_DEVICE; }
         at_batch_ = B;
     }
-    float *b0 = at_buf_[0].p, *b1 = at_buf_[1].p, *b2 = at_buf_[2].p;
     const float* P = params_.p;
-    // ref muzero_atari_network.py:21-39
-    if ((rc = launchTiled(at_.conv1, 2, P, d_feat, nullptr, b0, B, H, W, stream_, cu_count_))) { return rc; }
-    H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
-    if ((rc = launchTiled(at_.rb1[0], 1, P, b0, nullptr, b1, B, H, W, stream_, cu_count_))) { return rc; }
-    if ((rc = launchTiled(at_.rb1[1], 1, P, b1, b0, b2, B, H, W, stream_, cu_count_))) { return rc; }
-    if ((rc = launchTiled(at_.conv2, 2, P, b2, nullptr, b0, B, H, W, stream_, cu_count_))) { return rc; }
-    H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1;
-    if ((rc = launchTiled(at_.rb2[0], 1, P, b0, nullptr, b1, B, H, W, stream_, cu_count_))) { return rc; }
-    if ((rc = launchTiled(at_.rb2[1], 1, P, b1, b0, b2, B, H, W, stream_, cu_count_))) { return rc; }
-    auto pool = [&](const float* in, float* out) -> int {
-        const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, total = B * C * Ho * Wo;
-        hipLaunchKernelGGL(avgpool3s2_kernel, dim3((total + 255) / 256), dim3(256), 0, stream_, in, C, H, W, out, total);
-        MZ_HIP(hipGetLastError());
-        H = Ho; W = Wo;
+    const int H0 = H, W0 = W;
+    int Hout = 0, Wout = 0;
+    // the layers of `n` samples from sample `first` on, on stream `s` (ref muzero_atari_network.py:21-39).  Every stage of these samples lives in
+    // [first * stage, (first + n) * stage) of the three buffers, whatever the stage's size: two parts of the batch never touch each other's floats
+    auto chain = [&](int first, int n, hipStream_t s) -> int {
+        float *b0 = at_buf_[0].p + size_t(first) * stage, *b1 = at_buf_[1].p + size_t(first) * stage, *b2 = at_buf_[2].p + size_t(first) * stage;
+        int h = H0, w = W0, rcc;
+        auto pool = [&](const float* in, float* out) -> int {
+            const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1, total = n * C * Ho * Wo;
+            hipLaunchKernelGGL(avgpool3s2_kernel, dim3((total + 255) / 256), dim3(256), 0, s, in, C, h, w, out, total);
+            MZ_HIP(hipGetLastError());
+            h = Ho; w = Wo;
+            return MZ_OK;
+        };
+        if ((rcc = launchTiled(at_.conv1, 2, P, d_feat + size_t(first) * featSize(), nullptr, b0, n, h, w, s, cu_count_))) { return rcc; }
+        h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
+        if ((rcc = launchTiled(at_.rb1[0], 1, P, b0, nullptr, b1, n, h, w, s, cu_count_))) { return rcc; }
+        if ((rcc = launchTiled(at_.rb1[1], 1, P, b1, b0, b2, n, h, w, s, cu_count_))) { return rcc; }
+        if ((rcc = launchTiled(at_.conv2, 2, P, b2, nullptr, b0, n, h, w, s, cu_count_))) { return rcc; }
+        h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
+        if ((rcc = launchTiled(at_.rb2[0], 1, P, b0, nullptr, b1, n, h, w, s, cu_count_))) { return rcc; }
+        if ((rcc = launchTiled(at_.rb2[1], 1, P, b1, b0, b2, n, h, w, s, cu_count_))) { return rcc; }
+        if ((rcc = pool(b2, b0))) { return rcc; }
+        if ((rcc = launchTiled(at_.rb3[0], 1, P, b0, nullptr, b1, n, h, w, s, cu_count_))) { return rcc; }
+        if ((rcc = launchTiled(at_.rb3[1], 1, P, b1, b0, b2, n, h, w, s, cu_count_))) { return rcc; }
+        if ((rcc = pool(b2, at_out_.p + size_t(first) * hiddenSize()))) { return rcc; }
+        Hout = h; Wout = w;
         return MZ_OK;
     };
-    if ((rc = pool(b2, b0))) { return rc; }
-    if ((rc = launchTiled(at_.rb3[0], 1, P, b0, nullptr, b1, B, H, W, stream_, cu_count_))) { return rc; }
-    if ((rc = launchTiled(at_.rb3[1], 1, P, b1, b0, b2, B, H, W, stream_, cu_count_))) { return rc; }
-    if ((rc = pool(b2, b0))) { return rc; }
+    // A batch that fills the chip several times over runs as two halves on two streams.  The 4-5 workgroups a CU holds of one of these layers start together and
+    // stay in step — all of them stage their patch, then all of them issue MFMAs, then all of them store (tools/ab_atari_root.sh: staging 10, MFMAs 28, epilogue
+    // 11 of 48 us, nothing overlapping); the second half's launches arrive a phase later and fill what the first leaves idle.  Samples are independent: same outputs.
+    static const int parts_env = getenv("MZ_REPR_PARTS") ? atoi(getenv("MZ_REPR_PARTS")) : 2; // (A/B switch; 1 = the whole batch on the network's stream)
+    const int parts = std::max(1, std::min({parts_env, kReprParts, B / 16}));
+    if (parts > 1) {
+        if (!at_fork_) {
+            for (hipStream_t& s : at_streams_) { MZ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+            for (hipEvent_t& e : at_join_) { MZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+            MZ_HIP(hipEventCreateWithFlags(&at_fork_, hipEventDisableTiming));
+        }
+        MZ_HIP(hipEventRecord(at_fork_, stream_)); // the features, and every earlier reader of the buffers
+        for (int k = parts - 1; k >= 0; --k) {
+            const int first = int(size_t(B) * k / parts), end = int(size_t(B) * (k + 1) / parts);
+            hipStream_t s = k == 0 ? stream_ : at_streams_[k - 1];
+            if (k > 0) { MZ_HIP(hipStreamWaitEvent(s, at_fork_, 0)); }
+            if ((rc = chain(first, end - first, s))) { return rc; }
+            if (k > 0) { MZ_HIP(hipEventRecord(at_join_[k - 1], s)); }
+        }
+        for (int k = 1; k < parts; ++k) { MZ_HIP(hipStreamWaitEvent(stream_, at_join_[k - 1], 0)); }
+    } else if ((rc = chain(0, B, stream_))) {
+        return rc;
+    }
+    H = Hout; W = Wout;
     if (H != desc_.hidden_channel_height || W != desc_.hidden_channel_width) { setError("internal: representation output %dx%d", H, W); return MZ_ERR_ARG; }
+    float* b0 = at_out_.p;
     const float* x = b0;
     if (!at_.tail.empty()) {
         bool launched = false;
