@@ -22,6 +22,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <immintrin.h>
 #include <thread>
 
 namespace mzo {
@@ -210,9 +211,15 @@ void Net::generateRaw(const NetDesc& d, uint64_t seed, float* out)
 }
 
 // ---- folded layers ----
-struct Conv { int cin, cout, k; std::vector<float> w, b; }; // w[oc][c][ky][kx] folded, b folded
+struct Conv {
+    int cin, cout, k;
+    std::vector<float> w, b;  // w[oc][c][ky][kx] folded, b folded
+    std::vector<float> wk;    // 3x3 only: the same weights as wk[t][c][oc] (oc padded with zeros to a multiple of 16) for convChains(), built once (finishConv)
+    int cout_pad = 0;
+};
 struct Linear { int in, out; std::vector<float> w, b; };
 
+static void finishConv(Conv& c);
 static Conv takeConvBN(const float*& p, int cin, int cout, int k)
 {
     Conv c{cin, cout, k, {}, {}};
@@ -227,6 +234,7 @@ static Conv takeConvBN(const float*& p, int cin, int cout, int k)
         float t = (b[oc] - mu[oc]) * s;
         c.b[oc] = t + be[oc];
     }
+    finishConv(c);
     return c;
 }
 static Linear takeLinear(const float*& p, int in, int out)
@@ -239,38 +247,79 @@ static Linear takeLinear(const float*& p, int in, int out)
     return l;
 }
 
-// conv3x3 pad1, optional skip, relu.  in[cin][H][W] -> out[cout][H][W]
-static void conv3x3(const Conv& cv, int H, int Wd, const float* in, const float* skip, float* out)
+// The (tap, channel)-ordered fmaf chain of every (pixel, output channel) of a 3x3 convolution, pad 1, stride S — the arithmetic of the header, one IEEE fma per
+// step, nothing reassociated: the chains of 4 pixels x 16 output channels advance side by side in registers (8 lanes of a ymm = 8 output channels; vfmadd is
+// the same correctly rounded fma as fmaf), which only changes how many chains are in flight, not one bit of any of them.  A tap outside the plane multiplies
+// by 0.0f like the scalar loop did.  (The scalar loop kept its accumulators in memory: 4 GFLOP/s per thread; this one runs at the FMA ports' rate.)
+static void finishConv(Conv& c)
 {
-    const int P = H * Wd, cin = cv.cin, cout = cv.cout;
-    // weights re-laid as wk[t][c][oc] so the oc loop vectorises; per (pixel, oc) the chain order is (t, c).
-    thread_local std::vector<float> wk, acc;
-    wk.resize(size_t(9) * cin * cout);
-    for (int oc = 0; oc < cout; ++oc)
-        for (int c = 0; c < cin; ++c)
-            for (int t = 0; t < 9; ++t) { wk[(size_t(t) * cin + c) * cout + oc] = cv.w[(size_t(oc) * cin + c) * 9 + t]; }
-    acc.resize(cout);
-    for (int y = 0; y < H; ++y) {
-        for (int x = 0; x < Wd; ++x) {
-            std::fill(acc.begin(), acc.end(), 0.0f);
-            for (int t = 0; t < 9; ++t) {
-                int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                bool inside = (yy >= 0 && yy < H && xx >= 0 && xx < Wd);
-                for (int c = 0; c < cin; ++c) {
-                    float xv = inside ? in[c * P + yy * Wd + xx] : 0.0f;
-                    const float* wr = &wk[(size_t(t) * cin + c) * cout];
-                    for (int oc = 0; oc < cout; ++oc) { acc[oc] = __builtin_fmaf(xv, wr[oc], acc[oc]); }
+    if (c.k != 3) { return; }
+    c.cout_pad = (c.cout + 15) / 16 * 16;
+    c.wk.assign(size_t(9) * c.cin * c.cout_pad, 0.0f);
+    for (int oc = 0; oc < c.cout; ++oc)
+        for (int ch = 0; ch < c.cin; ++ch)
+            for (int t = 0; t < 9; ++t) { c.wk[(size_t(t) * c.cin + ch) * c.cout_pad + oc] = c.w[(size_t(oc) * c.cin + ch) * 9 + t]; }
+}
+
+template <int NP>
+static inline void convChains(const Conv& cv, int H, int Wd, int stride, int Wo, const float* in, const float* skip, float* out, int p0, int Po)
+{
+    static const float kZero = 0.0f;
+    const int cin = cv.cin, cout = cv.cout, cp = cv.cout_pad, Pi = H * Wd;
+    const float* base[9][NP];
+    size_t step[9][NP];
+    for (int j = 0; j < NP; ++j) {
+        const int p = p0 + j, y = p / Wo, x = p - y * Wo;
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y * stride + t / 3 - 1, xx = x * stride + t % 3 - 1;
+            const bool inside = (yy >= 0 && yy < H && xx >= 0 && xx < Wd);
+            base[t][j] = inside ? in + yy * Wd + xx : &kZero;
+            step[t][j] = inside ? size_t(Pi) : 0;
+        }
+    }
+    for (int o0 = 0; o0 < cp; o0 += 16) {
+        __m256 acc[NP][2];
+        for (int j = 0; j < NP; ++j) { acc[j][0] = _mm256_setzero_ps(); acc[j][1] = _mm256_setzero_ps(); }
+        for (int t = 0; t < 9; ++t) {
+            const float* wr = &cv.wk[size_t(t) * cin * cp + o0];
+            const float* bp[NP];
+            size_t st[NP];
+            for (int j = 0; j < NP; ++j) { bp[j] = base[t][j]; st[j] = step[t][j]; }
+            for (int c = 0; c < cin; ++c, wr += cp) {
+                const __m256 w0 = _mm256_loadu_ps(wr), w1 = _mm256_loadu_ps(wr + 8);
+                for (int j = 0; j < NP; ++j) {
+                    const __m256 xv = _mm256_broadcast_ss(bp[j]);
+                    bp[j] += st[j];
+                    acc[j][0] = _mm256_fmadd_ps(xv, w0, acc[j][0]);
+                    acc[j][1] = _mm256_fmadd_ps(xv, w1, acc[j][1]);
                 }
             }
-            int p = y * Wd + x;
-            for (int oc = 0; oc < cout; ++oc) {
-                float v = acc[oc] + cv.b[oc];
-                if (skip) { v = v + skip[oc * P + p]; }
-                out[oc * P + p] = v > 0.0f ? v : 0.0f;
+        }
+        for (int j = 0; j < NP; ++j) {
+            alignas(32) float a[16];
+            _mm256_store_ps(a, acc[j][0]);
+            _mm256_store_ps(a + 8, acc[j][1]);
+            const int p = p0 + j;
+            for (int i = 0; i < 16 && o0 + i < cout; ++i) {
+                const int oc = o0 + i;
+                float v = a[i] + cv.b[oc];
+                if (skip) { v = v + skip[size_t(oc) * Po + p]; }
+                out[size_t(oc) * Po + p] = v > 0.0f ? v : 0.0f;
             }
         }
     }
 }
+
+// conv3x3 pad 1 with stride, optional skip, relu.  in[cin][H][W] -> out[cout][Ho][Wo]
+static void conv3x3s(const Conv& cv, int H, int Wd, int stride, const float* in, const float* skip, float* out)
+{
+    assert(cv.k == 3 && !cv.wk.empty());
+    const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1, Po = Ho * Wo;
+    int p = 0;
+    for (; p + 4 <= Po; p += 4) { convChains<4>(cv, H, Wd, stride, Wo, in, skip, out, p, Po); }
+    for (; p < Po; ++p) { convChains<1>(cv, H, Wd, stride, Wo, in, skip, out, p, Po); }
+}
+static void conv3x3(const Conv& cv, int H, int Wd, const float* in, const float* skip, float* out) { conv3x3s(cv, H, Wd, 1, in, skip, out); }
 static void conv1x1relu(const Conv& cv, int P, const float* in, float* out)
 {
     for (int oc = 0; oc < cv.cout; ++oc)
@@ -396,35 +445,6 @@ public:
 // muzero_atari — ref network/py/muzero_atari_network.py:7-198, network_unit.py:67-87,
 // muzero_network.h:157-174 (601-bin decode), utils/utils.h:102-108 (invertValue)
 // =====================================================================================
-// conv3x3 pad 1 with stride; same (tap, channel) fmaf chain as conv3x3()
-static void conv3x3s(const Conv& cv, int H, int Wd, int stride, const float* in, const float* skip, float* out)
-{
-    const int cin = cv.cin, cout = cv.cout, Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1, Pi = H * Wd, Po = Ho * Wo;
-    std::vector<float> wk(size_t(9) * cin * cout), acc(cout);
-    for (int oc = 0; oc < cout; ++oc)
-        for (int c = 0; c < cin; ++c)
-            for (int t = 0; t < 9; ++t) { wk[(size_t(t) * cin + c) * cout + oc] = cv.w[(size_t(oc) * cin + c) * 9 + t]; }
-    for (int y = 0; y < Ho; ++y) {
-        for (int x = 0; x < Wo; ++x) {
-            std::fill(acc.begin(), acc.end(), 0.0f);
-            for (int t = 0; t < 9; ++t) {
-                int yy = y * stride + t / 3 - 1, xx = x * stride + t % 3 - 1;
-                bool inside = (yy >= 0 && yy < H && xx >= 0 && xx < Wd);
-                for (int c = 0; c < cin; ++c) {
-                    float xv = inside ? in[c * Pi + yy * Wd + xx] : 0.0f;
-                    const float* wr = &wk[(size_t(t) * cin + c) * cout];
-                    for (int oc = 0; oc < cout; ++oc) { acc[oc] = __builtin_fmaf(xv, wr[oc], acc[oc]); }
-                }
-            }
-            int p = y * Wo + x;
-            for (int oc = 0; oc < cout; ++oc) {
-                float v = acc[oc] + cv.b[oc];
-                if (skip) { v = v + skip[oc * Po + p]; }
-                out[oc * Po + p] = v > 0.0f ? v : 0.0f;
-            }
-        }
-    }
-}
 // AvgPool2d(kernel 3, stride 2, padding 1), count_include_pad: sum in (ky, kx) order, / 9
 static void avgpool3s2(int C, int H, int Wd, const float* in, float* out)
 {
