@@ -7,6 +7,8 @@
 //                 channel ascending), an MFMA step with a zero operand leaving the chain's value as it is.
 #include "net.h"
 #include "net_wide_body.h"
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace mz {
@@ -69,6 +71,144 @@ __global__ __launch_bounds__(256) void conv3x3_any(const float* __restrict__ in,
                     float v = acc[j][r] + bias[oc];
                     if (sk) { v = v + sk[size_t(oc) * P + q[j]]; }
                     dst[size_t(oc) * P + q[j]] = v > 0.0f ? v : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+// conv3x3_band — the run-time-shaped convolution with its B operand in LDS (round 5, behind every shape without a fused instance: 19x19 x 128 / 256, 13x13 x 96,
+// 11x11 x 48, ...).  conv3x3_any reads every B value from global memory, five loads per MFMA: 17-35 TFLOP/s.  Here a workgroup takes a BAND of TH output rows of one sample
+// (grid = samples x bands; TH is chosen on the host so that the band's padded patch of ALL input channels fits the LDS — the contract's chain is tap-major, so a
+// channel-chunked patch would have to be staged nine times), stages the (TH + 2) x (W + 2) patch once and runs the layer out of it like the towers do: pixel tiles are 16
+// consecutive pixels of the band, a JOB is one oc-tile x up to 6 pixel tiles (accumulators that share the A fragment), the 8 waves take the jobs round-robin.  A fragments
+// (weights.cpp `wp` layout: [tap][channel group][oc-tile][64], i.e. linear in the flattened step) travel in chunks of 8 k-steps, double-buffered; the B values of step
+// s + 1 are read before the MFMAs of step s are issued.  Same chain per output as everywhere: tap-major, channels ascending, zero operands for the border and the padding.
+template <int NT>
+__device__ __forceinline__ void bandJob(const float* __restrict__ xs, const float* __restrict__ wl, int CG, int OT, int CS, int PW, const int (&lb)[6], f32x4 (&acc)[6])
+{
+    const int CG8 = (CG + 7) >> 3, nchunks = 9 * CG8;
+    const size_t astep = size_t(OT) * 64; // floats between the A fragments of two consecutive steps
+    float a_cur[8], a_nxt[8], bc[NT];
+    auto loadA = [&](float (&a)[8], int t, int cg0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cg = cg0 + u < CG ? cg0 + u : CG - 1; // (no branch around a load: steps beyond the tap fetch its last fragment again)
+            a[u] = wl[size_t(t * CG + cg) * astep];
+        }
+    };
+    auto bload = [&](float (&b)[NT], int t, int cg) {
+        const int o = (t / 3) * PW + (t % 3) + 4 * cg * CS;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { b[j] = xs[lb[j] + o]; }
+    };
+    int t = 0, cg0 = 0;
+    loadA(a_cur, 0, 0);
+    bload(bc, 0, 0);
+#pragma unroll 1
+    for (int i = 0; i < nchunks; ++i) {
+        int tn = t, cgn = cg0 + 8;
+        if (cgn >= CG) { cgn = 0; tn = t + 1; }
+        const bool last = i + 1 == nchunks;
+        if (!last) { loadA(a_nxt, tn, cgn); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cg = cg0 + u;
+            if (cg < CG) { // wave-uniform
+                float bn[NT];
+                const bool in_tap = cg + 1 < CG;
+                if (in_tap) { bload(bn, t, cg + 1); } else if (!last) { bload(bn, tn, cgn); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u], bc[j], acc[j], 0, 0, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (in_tap || !last) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) { bc[j] = bn[j]; }
+                }
+            }
+        }
+        if (!last) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a_cur[u] = a_nxt[u]; }
+        }
+        t = tn; cg0 = cgn;
+    }
+}
+
+__global__ __launch_bounds__(512) void conv3x3_band(const float* __restrict__ in, int cin, int CG, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                    const float* __restrict__ skip, float* __restrict__ out, int cout, int OT, int H, int W, int TH, int CS)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[]; // [4 * CG][CS]: the band's padded patch, channel-major
+    const int b = blockIdx.x, r0 = blockIdx.y * TH, th = H - r0 < TH ? H - r0 : TH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kc = lane >> 4;
+    const int P = H * W, PW = W + 2, PP = (th + 2) * PW, cin_pad = 4 * CG;
+    const float* src = in + size_t(b) * cin * P;
+    // the patch: a thread keeps ONE position of the padded plane (bounds test and source offset once) and walks a slice of the channels, eight loads in flight; a band has
+    // few positions (19x19, TH = 4: 126) and many channels, so the 512 threads are G = 512 / PP groups of PP threads and group k takes the channel batches k, k + G, ...
+    // (one group walking all 128 channels was 16 dependent trips to the L2 per layer: 16 of a layer's 125 us)
+    {
+        const int G = PP < 512 ? 512 / PP : 1, grp = tid / PP;
+        for (int pos = G > 1 ? tid - grp * PP : tid; pos < PP && grp < G; pos += 512) {
+            const int r = pos / PW, q = pos - r * PW;
+            const int iy = r0 + r - 1, ix = q - 1;
+            const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float* p = src + (inside ? iy * W + ix : 0);
+            for (int c0 = 8 * grp; c0 < cin_pad; c0 += 8 * G) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = inside && c0 + u < cin;
+                    const float x = p[ok ? size_t(c0 + u) * P : 0];
+                    v[u] = ok ? x : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { if (c0 + u < cin_pad) { xs[(c0 + u) * CS + pos] = v[u]; } }
+            }
+        }
+    }
+    __syncthreads();
+    const int npix = th * W, ntiles = (npix + 15) >> 4, npg = (ntiles + 5) / 6, njobs = OT * npg;
+    float* dst = out + size_t(b) * cout * P + r0 * W;
+    const float* sk = skip ? skip + size_t(b) * cout * P + r0 * W : nullptr;
+    for (int job = wave; job < njobs; job += 8) {
+        const int ot = job / npg, pg = job - ot * npg;
+        const int nt = ntiles - 6 * pg < 6 ? ntiles - 6 * pg : 6; // pixel tiles of this job (wave-uniform)
+        int lb[6], pq[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int q = (6 * pg + j) * 16 + (lane & 15);
+            const bool ok = j < nt && q < npix;
+            const int y = ok ? q / W : 0, x = ok ? q - y * W : 0;
+            lb[j] = kc * CS + y * PW + x; // top-left tap of the pixel's window in the padded patch, channel kc of a group
+            pq[j] = ok ? q : -1;
+        }
+        f32x4 acc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+        const float* wl = wp + size_t(ot) * 64 + lane;
+        switch (nt) {
+            case 6: bandJob<6>(xs, wl, CG, OT, CS, PW, lb, acc); break;
+            case 5: bandJob<5>(xs, wl, CG, OT, CS, PW, lb, acc); break;
+            case 4: bandJob<4>(xs, wl, CG, OT, CS, PW, lb, acc); break;
+            case 3: bandJob<3>(xs, wl, CG, OT, CS, PW, lb, acc); break;
+            case 2: bandJob<2>(xs, wl, CG, OT, CS, PW, lb, acc); break;
+            default: bandJob<1>(xs, wl, CG, OT, CS, PW, lb, acc); break;
+        }
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int oc = 16 * ot + 4 * kc + r; bv[r] = bias[oc < cout ? oc : 0]; }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (pq[j] < 0) { continue; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oc = 16 * ot + 4 * kc + r;
+                if (oc < cout) {
+                    float v = acc[j][r] + bv[r];
+                    if (sk) { v = v + sk[size_t(oc) * P + pq[j]]; }
+                    dst[size_t(oc) * P + pq[j]] = v > 0.0f ? v : 0.0f;
                 }
             }
         }
@@ -219,9 +359,44 @@ int Net::launchTowerWide(const std::vector<ConvLayer>& t, const float* in, float
     return MZ_OK;
 }
 
+// The band height of conv3x3_band for a layer shape: the TH whose bands cost the fewest MFMA-issue cycles (the slowest SIMD's share of a band's jobs, in pixel
+// tiles, x the layer's steps) plus staging cycles, among those whose patch fits the LDS.  TH = 0: no band fits (more than ~2000 input channels).
+struct BandPlan { int TH = 0, CS = 0; size_t lds = 0; };
+static BandPlan planBand(int H, int W, int cin_pad, int OT)
+{
+    BandPlan best;
+    double best_cost = 0.0;
+    for (int TH = 1; TH <= H; ++TH) {
+        const int PP = (TH + 2) * (W + 2);
+        const int CS = PP + ((16 - PP % 32) + 32) % 32; // >= PP, % 32 == 16 (net_dev.h planeStride: the four channels of a k-group on different banks)
+        const size_t lds = size_t(cin_pad) * CS * sizeof(float);
+        if (lds > size_t(156) * 1024) { break; }
+        const int nb = (H + TH - 1) / TH;
+        double cost = 0.0;
+        for (int k = 0; k < nb; ++k) {
+            const int th = std::min(TH, H - k * TH), ntiles = (th * W + 15) / 16, npg = (ntiles + 5) / 6;
+            int load[4] = {0, 0, 0, 0}; // pixel tiles per SIMD (waves w and w + 4 share one)
+            for (int job = 0; job < OT * npg; ++job) { load[(job % 8) % 4] += std::min(6, ntiles - 6 * (job % npg)); }
+            const int mx = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
+            cost += double(mx) * 9.0 * (cin_pad / 4) * 32.0 + double(cin_pad) * (th + 2) * (W + 2) / 8.0 + 4000.0; // MFMA issue + staging (~32 B per cycle and CU) + launch / barrier / epilogue
+        }
+        if (best.TH == 0 || cost < best_cost) { best.TH = TH; best.CS = CS; best.lds = lds; best_cost = cost; }
+    }
+    return best;
+}
+
 int Net::launchConvAny(const ConvLayer& L, const float* in, const float* skip, float* out, int B)
 {
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width;
+    static const bool no_band = getenv("MZ_NO_CONV_BAND") != nullptr; // (A/B: the round-5 kernel that reads its B operand from global memory)
+    const BandPlan bp = no_band ? BandPlan() : planBand(H, W, L.cin_pad, L.cout_pad / 16);
+    if (bp.TH > 0) {
+        MZ_LDS_ATTR(conv3x3_band, size_t(160) * 1024);
+        hipLaunchKernelGGL(conv3x3_band, dim3(B, (H + bp.TH - 1) / bp.TH), dim3(512), bp.lds, stream_, in, L.cin, L.cin_pad / 4, params_.p + L.w_off, params_.p + L.b_off, skip, out,
+                           L.cout, L.cout_pad / 16, H, W, bp.TH, bp.CS);
+        MZ_HIP(hipGetLastError());
+        return MZ_OK;
+    }
     hipLaunchKernelGGL(conv3x3_any, dim3(B, (H * W + 63) / 64), dim3(256), 0, stream_, in, L.cin, L.cin_pad / 4, params_.p + L.w_off, params_.p + L.b_off, skip, out, L.cout,
                        L.cout_pad / 16, H, W);
     MZ_HIP(hipGetLastError());

@@ -15,7 +15,12 @@ PEAK = 157.3
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 names = sys.argv[2:] or sorted(WIDE_NN_CFG)
 extra = {"c2_go_az": ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "alphazero"),
-         "x_go19_2bx128_az": ("go_19x19", 18, 19, 19, 128, 19, 19, 1, 2, 362, 256, 1, "alphazero")}
+         "x_go19_2bx128_az": ("go_19x19", 18, 19, 19, 128, 19, 19, 1, 2, 362, 256, 1, "alphazero"),
+         # shapes without a fused instance: per-layer run-time-shaped kernels (net_wide.hip conv3x3_band; MZ_NO_CONV_BAND=1: conv3x3_any)
+         "x_go19_2bx256_az": ("go_19x19", 18, 19, 19, 256, 19, 19, 1, 2, 362, 256, 1, "alphazero"),
+         "x_go13_2bx96_az": ("go_13x13", 18, 13, 13, 96, 13, 13, 1, 2, 170, 256, 1, "alphazero"),
+         "x_go11_2bx48_az": ("go_11x11", 18, 11, 11, 48, 11, 11, 1, 2, 122, 64, 1, "alphazero"),
+         "x_go9_2bx192_az": ("go_9x9", 18, 9, 9, 192, 9, 9, 1, 2, 82, 256, 1, "alphazero")}
 out = {}
 for name in names:
     args = WIDE_NN_CFG.get(name) or extra[name]
