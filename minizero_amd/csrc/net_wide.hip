@@ -87,62 +87,74 @@ __global__ __launch_bounds__(256) void conv3x3_any(const float* __restrict__ in,
 template <int NT>
 __device__ __forceinline__ void bandJob(const float* __restrict__ xs, const float* __restrict__ wl, int CG, int OT, int CS, int PW, const int (&lb)[6], f32x4 (&acc)[6])
 {
-    const int CG8 = (CG + 7) >> 3, nchunks = 9 * CG8;
-    const size_t astep = size_t(OT) * 64; // floats between the A fragments of two consecutive steps
+    // The layer's k-steps flattened: s = tap * CG + channel group, S = 9 * CG of them; the A fragment of step s lies at wl[s * OT * 64] (weights.cpp `wp`), so chunks of
+    // 8 steps need no tap boundaries.  The main loop's body is straight-line code — 8 steps, no branch (the first version guarded every step with `cg < CG` and the
+    // compiler's conservative waits at the joins made every MFMA wait for the LDS read issued just before it: 0.43 of peak at 19x19 x 256) —, the S % 8 last steps run one by one.
+    const int S = 9 * CG, nfull = S >> 3;
+    const size_t astep = size_t(OT) * 64;
     float a_cur[8], a_nxt[8], bc[NT];
-    auto loadA = [&](float (&a)[8], int t, int cg0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int cg = cg0 + u < CG ? cg0 + u : CG - 1; // (no branch around a load: steps beyond the tap fetch its last fragment again)
-            a[u] = wl[size_t(t * CG + cg) * astep];
+    // (t, cg) of the step whose B values are being FETCHED, as the LDS offset o = tap offset + 4 * cg * CS, advanced with scalar selects
+    int cg = 0, tcol = 0, rowoff = 0, o = 0;
+    auto advance = [&]() {
+        ++cg;
+        o += 4 * CS;
+        if (cg == CG) {
+            cg = 0;
+            ++tcol;
+            if (tcol == 3) { tcol = 0; rowoff += PW; }
+            o = rowoff + tcol;
         }
     };
-    auto bload = [&](float (&b)[NT], int t, int cg) {
-        const int o = (t / 3) * PW + (t % 3) + 4 * cg * CS;
+    auto bload = [&](float (&b)[NT]) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) { b[j] = xs[lb[j] + o]; }
     };
-    int t = 0, cg0 = 0;
-    loadA(a_cur, 0, 0);
-    bload(bc, 0, 0);
+    {
+        float b0[NT];
+        bload(b0);
+        // (through a VALU move: a bc that is the direct target of an LDS read at the loop's entry keeps the compiler's wait-count analysis pessimistic inside the loop)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { asm volatile("v_mov_b32 %0, %1" : "=v"(bc[j]) : "v"(b0[j])); }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a_cur[u] = wl[size_t(u < S ? u : S - 1) * astep]; }
 #pragma unroll 1
-    for (int i = 0; i < nchunks; ++i) {
-        int tn = t, cgn = cg0 + 8;
-        if (cgn >= CG) { cgn = 0; tn = t + 1; }
-        const bool last = i + 1 == nchunks;
-        if (!last) { loadA(a_nxt, tn, cgn); }
+    for (int i = 0; i < nfull; ++i) {
+        const int s1 = 8 * (i + 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a_nxt[u] = wl[size_t(s1 + u < S ? s1 + u : S - 1) * astep]; } // (no branch around a load: beyond the layer, its last fragment again)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int cg = cg0 + u;
-            if (cg < CG) { // wave-uniform
-                float bn[NT];
-                const bool in_tap = cg + 1 < CG;
-                if (in_tap) { bload(bn, t, cg + 1); } else if (!last) { bload(bn, tn, cgn); }
-                __builtin_amdgcn_sched_barrier(0);
+            float bn[NT];
+            if (8 * i + u + 1 < S) { advance(); } // (the layer's very last step fetches its own operands again)
+            bload(bn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) { acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u], bc[j], acc[j], 0, 0, 0); }
-                __builtin_amdgcn_sched_barrier(0);
-                if (in_tap || !last) {
+            for (int j = 0; j < NT; ++j) { acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u], bc[j], acc[j], 0, 0, 0); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) { bc[j] = bn[j]; }
-                }
-            }
+            for (int j = 0; j < NT; ++j) { bc[j] = bn[j]; }
         }
-        if (!last) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a_cur[u] = a_nxt[u]; }
-        }
-        t = tn; cg0 = cgn;
+        for (int u = 0; u < 8; ++u) { a_cur[u] = a_nxt[u]; }
+    }
+#pragma unroll 1
+    for (int s = 8 * nfull; s < S; ++s) { // bc = the operands of step s (fetched by the step before)
+        const float a = wl[size_t(s) * astep];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[j], acc[j], 0, 0, 0); }
+        if (s + 1 < S) { advance(); bload(bc); }
     }
 }
 
 __global__ __launch_bounds__(512) void conv3x3_band(const float* __restrict__ in, int cin, int CG, const float* __restrict__ wp, const float* __restrict__ bias,
-                                                    const float* __restrict__ skip, float* __restrict__ out, int cout, int OT, int H, int W, int TH, int CS)
+                                                    const float* __restrict__ skip, float* __restrict__ out, int cout, int OT, int H, int W, int TH, int CS, int GM)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[]; // [4 * CG][CS]: the band's padded patch, channel-major
     const int b = blockIdx.x, r0 = blockIdx.y * TH, th = H - r0 < TH ? H - r0 : TH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kc = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, kc = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave-uniform for the compiler too: the job, its oc-tile and its tile count are scalars)
     const int P = H * W, PW = W + 2, PP = (th + 2) * PW, cin_pad = 4 * CG;
     const float* src = in + size_t(b) * cin * P;
     // the patch: a thread keeps ONE position of the padded plane (bounds test and source offset once) and walks a slice of the channels, eight loads in flight; a band has
@@ -169,16 +181,16 @@ __global__ __launch_bounds__(512) void conv3x3_band(const float* __restrict__ in
         }
     }
     __syncthreads();
-    const int npix = th * W, ntiles = (npix + 15) >> 4, npg = (ntiles + 5) / 6, njobs = OT * npg;
+    const int npix = th * W, ntiles = (npix + 15) >> 4, npg = (ntiles + GM - 1) / GM, njobs = OT * npg; // GM <= 6: pixel tiles per job (host: planBand)
     float* dst = out + size_t(b) * cout * P + r0 * W;
     const float* sk = skip ? skip + size_t(b) * cout * P + r0 * W : nullptr;
     for (int job = wave; job < njobs; job += 8) {
         const int ot = job / npg, pg = job - ot * npg;
-        const int nt = ntiles - 6 * pg < 6 ? ntiles - 6 * pg : 6; // pixel tiles of this job (wave-uniform)
+        const int nt = ntiles - GM * pg < GM ? ntiles - GM * pg : GM; // pixel tiles of this job (wave-uniform)
         int lb[6], pq[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int q = (6 * pg + j) * 16 + (lane & 15);
+            const int q = (GM * pg + j) * 16 + (lane & 15);
             const bool ok = j < nt && q < npix;
             const int y = ok ? q / W : 0, x = ok ? q - y * W : 0;
             lb[j] = kc * CS + y * PW + x; // top-left tap of the pixel's window in the padded patch, channel kc of a group
@@ -359,9 +371,9 @@ int Net::launchTowerWide(const std::vector<ConvLayer>& t, const float* in, float
     return MZ_OK;
 }
 
-// The band height of conv3x3_band for a layer shape: the TH whose bands cost the fewest MFMA-issue cycles (the slowest SIMD's share of a band's jobs, in pixel
+// The band height (and the pixel tiles per job) of conv3x3_band for a layer shape: the TH whose bands cost the fewest MFMA-issue cycles (the slowest SIMD's share of a band's jobs, in pixel
 // tiles, x the layer's steps) plus staging cycles, among those whose patch fits the LDS.  TH = 0: no band fits (more than ~2000 input channels).
-struct BandPlan { int TH = 0, CS = 0; size_t lds = 0; };
+struct BandPlan { int TH = 0, CS = 0, GM = 6; size_t lds = 0; };
 static BandPlan planBand(int H, int W, int cin_pad, int OT)
 {
     BandPlan best;
@@ -372,15 +384,18 @@ static BandPlan planBand(int H, int W, int cin_pad, int OT)
         const size_t lds = size_t(cin_pad) * CS * sizeof(float);
         if (lds > size_t(156) * 1024) { break; }
         const int nb = (H + TH - 1) / TH;
-        double cost = 0.0;
-        for (int k = 0; k < nb; ++k) {
-            const int th = std::min(TH, H - k * TH), ntiles = (th * W + 15) / 16, npg = (ntiles + 5) / 6;
-            int load[4] = {0, 0, 0, 0}; // pixel tiles per SIMD (waves w and w + 4 share one)
-            for (int job = 0; job < OT * npg; ++job) { load[(job % 8) % 4] += std::min(6, ntiles - 6 * (job % npg)); }
-            const int mx = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
-            cost += double(mx) * 9.0 * (cin_pad / 4) * 32.0 + double(cin_pad) * (th + 2) * (W + 2) / 8.0 + 4000.0; // MFMA issue + staging (~32 B per cycle and CU) + launch / barrier / epilogue
+        for (int GM = 6; GM >= 2; --GM) { // pixel tiles per job: fewer = more jobs for the 8 waves (narrow layers), more = fewer A fragments fetched
+            double cost = 0.0;
+            for (int k = 0; k < nb; ++k) {
+                const int th = std::min(TH, H - k * TH), ntiles = (th * W + 15) / 16, npg = (ntiles + GM - 1) / GM;
+                int load[4] = {0, 0, 0, 0}; // pixel tiles per SIMD (waves w and w + 4 share one)
+                for (int job = 0; job < OT * npg; ++job) { load[(job % 8) % 4] += std::min(GM, ntiles - GM * (job % npg)); }
+                const int mx = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
+                // MFMA issue of the slowest SIMD + staging (~32 B per cycle and CU) + launch / barrier / prologue and epilogue of the jobs
+                cost += double(mx) * 9.0 * (cin_pad / 4) * 32.0 + double(cin_pad) * (th + 2) * (W + 2) / 8.0 + 4000.0 + 1500.0 * ((OT * npg + 7) / 8);
+            }
+            if (best.TH == 0 || cost < best_cost) { best.TH = TH; best.CS = CS; best.GM = GM; best.lds = lds; best_cost = cost; }
         }
-        if (best.TH == 0 || cost < best_cost) { best.TH = TH; best.CS = CS; best.lds = lds; best_cost = cost; }
     }
     return best;
 }
@@ -393,7 +408,7 @@ int Net::launchConvAny(const ConvLayer& L, const float* in, const float* skip, f
     if (bp.TH > 0) {
         MZ_LDS_ATTR(conv3x3_band, size_t(160) * 1024);
         hipLaunchKernelGGL(conv3x3_band, dim3(B, (H + bp.TH - 1) / bp.TH), dim3(512), bp.lds, stream_, in, L.cin, L.cin_pad / 4, params_.p + L.w_off, params_.p + L.b_off, skip, out,
-                           L.cout, L.cout_pad / 16, H, W, bp.TH, bp.CS);
+                           L.cout, L.cout_pad / 16, H, W, bp.TH, bp.CS, bp.GM);
         MZ_HIP(hipGetLastError());
         return MZ_OK;
     }

@@ -86,6 +86,12 @@ def test_wide_muzero_initial_and_recurrent(mz, oracle, name):
     ("othello_10x10", 4, 10, 10, 20, 10, 10, 1, 2, 101, 24, 1, "alphazero"),
     ("go_6x6", 18, 6, 6, 72, 6, 6, 1, 1, 37, 16, 1, "muzero"),
     ("go_2x2", 18, 2, 2, 4, 2, 2, 1, 1, 5, 3, 1, "alphazero"),
+    # conv3x3_band's shapes: five bands of 4 / 3 rows with the 147-KB patch (19x19 x 256), bands of 12 + 1 rows (13x13 x 96), a layer whose k-steps are no multiple of the
+    # chunk of 8 with three jobs on eight waves (7x7 x 36: 9 channel groups), a board wider than a workgroup has threads for one patch row pass (25x25: 27 x 27 positions)
+    ("go_19x19", 18, 19, 19, 256, 19, 19, 1, 1, 362, 64, 1, "alphazero"),
+    ("go_13x13", 18, 13, 13, 96, 13, 13, 1, 1, 170, 32, 1, "alphazero"),
+    ("go_7x7", 18, 7, 7, 36, 7, 7, 1, 1, 50, 16, 1, "muzero"),
+    ("go_25x25", 18, 25, 25, 40, 25, 25, 1, 1, 626, 16, 1, "alphazero"),
 ], ids=lambda a: f"{a[0]}_{a[8]}bx{a[4]}_{a[12]}")
 def test_any_shape_is_served(mz, oracle, args):
     """No network create_network.py can build for a board game ends in "no kernel instance": shapes with neither a fused nor a one-tile tower instance run on
