@@ -116,13 +116,15 @@ __device__ __forceinline__ void bandJob(const float* __restrict__ xs, const floa
 #pragma unroll
         for (int j = 0; j < NT; ++j) { asm volatile("v_mov_b32 %0, %1" : "=v"(bc[j]) : "v"(b0[j])); }
     }
+    // A fragments travel TWO chunks ahead of their MFMAs (one chunk = 8 x NT x 32 cycles of the wave's own issue: not always an L2 round trip under load) in three
+    // register sets whose roles rotate — the loop body is three chunks, no set is ever copied (a copy waits for the loads it copies)
+    float a_nn[8];
+    auto loadA = [&](float (&a)[8], int s0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { a_cur[u] = wl[size_t(u < S ? u : S - 1) * astep]; }
-#pragma unroll 1
-    for (int i = 0; i < nfull; ++i) {
-        const int s1 = 8 * (i + 1);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { a_nxt[u] = wl[size_t(s1 + u < S ? s1 + u : S - 1) * astep]; } // (no branch around a load: beyond the layer, its last fragment again)
+        for (int u = 0; u < 8; ++u) { a[u] = wl[size_t(s0 + u < S ? s0 + u : S - 1) * astep]; } // (no branch around a load: beyond the layer, its last fragment again)
+    };
+    auto chunk = [&](const float (&a_use)[8], float (&a_load)[8], int i) {
+        loadA(a_load, 8 * (i + 2));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -131,13 +133,24 @@ __device__ __forceinline__ void bandJob(const float* __restrict__ xs, const floa
             bload(bn);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u], bc[j], acc[j], 0, 0, 0); }
+            for (int j = 0; j < NT; ++j) { acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_use[u], bc[j], acc[j], 0, 0, 0); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NT; ++j) { bc[j] = bn[j]; }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { a_cur[u] = a_nxt[u]; }
+    };
+    loadA(a_cur, 0);
+    loadA(a_nxt, 8);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 3 <= nfull; i += 3) {
+        chunk(a_cur, a_nn, i);
+        chunk(a_nxt, a_cur, i + 1);
+        chunk(a_nn, a_nxt, i + 2);
+    }
+    if (i < nfull) { // one or two chunks are left (roles as at the top of the loop body)
+        chunk(a_cur, a_nn, i);
+        if (i + 1 < nfull) { chunk(a_nxt, a_cur, i + 1); }
     }
 #pragma unroll 1
     for (int s = 8 * nfull; s < S; ++s) { // bc = the operands of step s (fetched by the step before)
@@ -148,7 +161,7 @@ __device__ __forceinline__ void bandJob(const float* __restrict__ xs, const floa
     }
 }
 
-__global__ __launch_bounds__(512) void conv3x3_band(const float* __restrict__ in, int cin, int CG, const float* __restrict__ wp, const float* __restrict__ bias,
+__global__ __launch_bounds__(1024) void conv3x3_band(const float* __restrict__ in, int cin, int CG, const float* __restrict__ wp, const float* __restrict__ bias,
                                                     const float* __restrict__ skip, float* __restrict__ out, int cout, int OT, int H, int W, int TH, int CS, int GM)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[]; // [4 * CG][CS]: the band's padded patch, channel-major
@@ -158,11 +171,11 @@ __global__ __launch_bounds__(512) void conv3x3_band(const float* __restrict__ in
     const int P = H * W, PW = W + 2, PP = (th + 2) * PW, cin_pad = 4 * CG;
     const float* src = in + size_t(b) * cin * P;
     // the patch: a thread keeps ONE position of the padded plane (bounds test and source offset once) and walks a slice of the channels, eight loads in flight; a band has
-    // few positions (19x19, TH = 4: 126) and many channels, so the 512 threads are G = 512 / PP groups of PP threads and group k takes the channel batches k, k + G, ...
+    // few positions (19x19, TH = 4: 126) and many channels, so the workgroup's threads are G = threads / PP groups of PP threads and group k takes the channel batches k, k + G, ...
     // (one group walking all 128 channels was 16 dependent trips to the L2 per layer: 16 of a layer's 125 us)
     {
-        const int G = PP < 512 ? 512 / PP : 1, grp = tid / PP;
-        for (int pos = G > 1 ? tid - grp * PP : tid; pos < PP && grp < G; pos += 512) {
+        const int NTH = blockDim.x, G = PP < NTH ? NTH / PP : 1, grp = tid / PP;
+        for (int pos = G > 1 ? tid - grp * PP : tid; pos < PP && grp < G; pos += NTH) {
             const int r = pos / PW, q = pos - r * PW;
             const int iy = r0 + r - 1, ix = q - 1;
             const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
@@ -184,7 +197,8 @@ __global__ __launch_bounds__(512) void conv3x3_band(const float* __restrict__ in
     const int npix = th * W, ntiles = (npix + 15) >> 4, npg = (ntiles + GM - 1) / GM, njobs = OT * npg; // GM <= 6: pixel tiles per job (host: planBand)
     float* dst = out + size_t(b) * cout * P + r0 * W;
     const float* sk = skip ? skip + size_t(b) * cout * P + r0 * W : nullptr;
-    for (int job = wave; job < njobs; job += 8) {
+    const int nwaves = blockDim.x >> 6; // 8, or 16 where the patch leaves room for one workgroup per CU only (host: planBand)
+    for (int job = wave; job < njobs; job += nwaves) {
         const int ot = job / npg, pg = job - ot * npg;
         const int nt = ntiles - GM * pg < GM ? ntiles - GM * pg : GM; // pixel tiles of this job (wave-uniform)
         int lb[6], pq[6];
@@ -373,7 +387,7 @@ int Net::launchTowerWide(const std::vector<ConvLayer>& t, const float* in, float
 
 // The band height (and the pixel tiles per job) of conv3x3_band for a layer shape: the TH whose bands cost the fewest MFMA-issue cycles (the slowest SIMD's share of a band's jobs, in pixel
 // tiles, x the layer's steps) plus staging cycles, among those whose patch fits the LDS.  TH = 0: no band fits (more than ~2000 input channels).
-struct BandPlan { int TH = 0, CS = 0, GM = 6; size_t lds = 0; };
+struct BandPlan { int TH = 0, CS = 0, GM = 6, NW = 8; size_t lds = 0; };
 static BandPlan planBand(int H, int W, int cin_pad, int OT)
 {
     BandPlan best;
@@ -384,17 +398,20 @@ static BandPlan planBand(int H, int W, int cin_pad, int OT)
         const size_t lds = size_t(cin_pad) * CS * sizeof(float);
         if (lds > size_t(156) * 1024) { break; }
         const int nb = (H + TH - 1) / TH;
-        for (int GM = 6; GM >= 2; --GM) { // pixel tiles per job: fewer = more jobs for the 8 waves (narrow layers), more = fewer A fragments fetched
+        // 16 waves per CU hide what 8 do not (19x19 x 128: two workgroups of 8 waves with bands of 4 rows 0.59 of peak, one with bands of 10 rows 0.50): a patch that
+        // leaves room for one workgroup per CU gets 16 waves in it
+        const int NW = lds > size_t(78) * 1024 ? 16 : 8;
+        for (int GM = 6; GM >= 2; --GM) { // pixel tiles per job: fewer = more jobs for the waves (narrow layers), more = fewer A fragments fetched
             double cost = 0.0;
             for (int k = 0; k < nb; ++k) {
                 const int th = std::min(TH, H - k * TH), ntiles = (th * W + 15) / 16, npg = (ntiles + GM - 1) / GM;
-                int load[4] = {0, 0, 0, 0}; // pixel tiles per SIMD (waves w and w + 4 share one)
-                for (int job = 0; job < OT * npg; ++job) { load[(job % 8) % 4] += std::min(GM, ntiles - GM * (job % npg)); }
+                int load[4] = {0, 0, 0, 0}; // pixel tiles per SIMD (waves w, w + 4, ... share one)
+                for (int job = 0; job < OT * npg; ++job) { load[(job % NW) % 4] += std::min(GM, ntiles - GM * (job % npg)); }
                 const int mx = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
                 // MFMA issue of the slowest SIMD + staging (~32 B per cycle and CU) + launch / barrier / prologue and epilogue of the jobs
-                cost += double(mx) * 9.0 * (cin_pad / 4) * 32.0 + double(cin_pad) * (th + 2) * (W + 2) / 8.0 + 4000.0 + 1500.0 * ((OT * npg + 7) / 8);
+                cost += double(mx) * 9.0 * (cin_pad / 4) * 32.0 + double(cin_pad) * (th + 2) * (W + 2) / 8.0 + 12000.0 + 5000.0 * ((OT * npg + NW - 1) / NW);
             }
-            if (best.TH == 0 || cost < best_cost) { best.TH = TH; best.CS = CS; best.GM = GM; best.lds = lds; best_cost = cost; }
+            if (best.TH == 0 || cost < best_cost) { best.TH = TH; best.CS = CS; best.GM = GM; best.NW = NW; best.lds = lds; best_cost = cost; }
         }
     }
     return best;
@@ -404,10 +421,16 @@ int Net::launchConvAny(const ConvLayer& L, const float* in, const float* skip, f
 {
     const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width;
     static const bool no_band = getenv("MZ_NO_CONV_BAND") != nullptr; // (A/B: the round-5 kernel that reads its B operand from global memory)
-    const BandPlan bp = no_band ? BandPlan() : planBand(H, W, L.cin_pad, L.cout_pad / 16);
+    BandPlan bp = no_band ? BandPlan() : planBand(H, W, L.cin_pad, L.cout_pad / 16);
+    if (const char* e = getenv("MZ_BAND_TH")) { // (experiments: a forced band height / tiles per job, where the patch fits)
+        const int TH = std::max(1, std::min(H, atoi(e))), PP = (TH + 2) * (W + 2), CS = PP + ((16 - PP % 32) + 32) % 32;
+        if (bp.TH > 0 && size_t(L.cin_pad) * CS * sizeof(float) <= size_t(156) * 1024) { bp.TH = TH; bp.CS = CS; bp.lds = size_t(L.cin_pad) * CS * sizeof(float); }
+        if (const char* g = getenv("MZ_BAND_GM")) { bp.GM = std::max(1, std::min(6, atoi(g))); }
+        if (const char* w = getenv("MZ_BAND_NW")) { bp.NW = atoi(w) == 16 ? 16 : 8; }
+    }
     if (bp.TH > 0) {
         MZ_LDS_ATTR(conv3x3_band, size_t(160) * 1024);
-        hipLaunchKernelGGL(conv3x3_band, dim3(B, (H + bp.TH - 1) / bp.TH), dim3(512), bp.lds, stream_, in, L.cin, L.cin_pad / 4, params_.p + L.w_off, params_.p + L.b_off, skip, out,
+        hipLaunchKernelGGL(conv3x3_band, dim3(B, (H + bp.TH - 1) / bp.TH), dim3(64 * bp.NW), bp.lds, stream_, in, L.cin, L.cin_pad / 4, params_.p + L.w_off, params_.p + L.b_off, skip, out,
                            L.cout, L.cout_pad / 16, H, W, bp.TH, bp.CS, bp.GM);
         MZ_HIP(hipGetLastError());
         return MZ_OK;

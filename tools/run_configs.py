@@ -49,6 +49,10 @@ EXTRA_CONFIGS = {
     "w9x128": ("w9x128", "env_game=go:env_board_size=9:actor_num_simulation=400:zero_num_parallel_games=256"),    # 9x9 Go, 6 blocks x 128 channels
     "w9x256": ("w9x256", "env_game=go:env_board_size=9:actor_num_simulation=400:zero_num_parallel_games=256"),    # 9x9 Go, the reference's default network: 1 block x 256 channels
     "w19x64": ("w19x64", "env_game=go:env_board_size=19:actor_num_simulation=400:zero_num_parallel_games=256"),   # 19x19 Go, 6 blocks x 64 channels
+    # shapes WITHOUT a simulation-kernel instance: the lock-step worker on the per-layer kernels (net_wide.hip conv3x3_band; MZ_NO_CONV_BAND=1 in the environment: conv3x3_any);
+    # no simulation-kernel launches to time, the block's roofline.wall_frac is the figure
+    "l19x128": ("l19x128", "env_game=go:env_board_size=19:actor_num_simulation=400:zero_num_parallel_games=256"),  # 19x19 Go, 6 blocks x 128 channels (one tile = 237 KB)
+    "l13x96": ("l13x96", "env_game=go:env_board_size=13:actor_num_simulation=400:zero_num_parallel_games=256"),    # 13x13 Go, 6 blocks x 96 channels (no 16 * 2^k)
 }
 # ... and BASELINE configs[4]'s whole node (512 games) on ONE GPU — NOT the BASELINE shard (64 games per GPU): what the same kernels reach when the pool fills the chip
 EXTRA_CONFIGS["c5x512"] = ("c5", mz.CONFIGS["c5"].replace("zero_num_parallel_games=64", "zero_num_parallel_games=512"))
@@ -58,10 +62,13 @@ EXTRA_DESCS = {
     "w9x128": lambda: mz.make_desc("go_9x9", 18, 9, 9, 128, 9, 9, 1, 6, 82),
     "w9x256": lambda: mz.make_desc("go_9x9", 18, 9, 9, 256, 9, 9, 1, 1, 82),
     "w19x64": lambda: mz.make_desc("go_19x19", 18, 19, 19, 64, 19, 19, 1, 6, 362),
+    "l19x128": lambda: mz.make_desc("go_19x19", 18, 19, 19, 128, 19, 19, 1, 6, 362),
+    "l13x96": lambda: mz.make_desc("go_13x13", 18, 13, 13, 96, 13, 13, 1, 6, 170),
 }
-MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2, "c5x512": 30, "w9x128mz": 10})
-WARM.update({"w9x128": 1, "w9x256": 1, "w19x64": 1, "c5x512": 14})
-KERNEL.update({"w9x128mz": "sim_kernel_mz_wide<9,9,32,144,128>", "w9x128": "sim_kernel_wide<9,9,32,128,2>", "w9x256": "sim_kernel_wide<9,9,32,256,2>", "w19x64": "sim_kernel_wide<19,19,32,64,6>"})
+MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2, "c5x512": 30, "w9x128mz": 10, "l19x128": 1, "l13x96": 2})
+WARM.update({"w9x128": 1, "w9x256": 1, "w19x64": 1, "c5x512": 14, "l19x128": 1, "l13x96": 1})
+KERNEL.update({"w9x128mz": "sim_kernel_mz_wide<9,9,32,144,128>", "w9x128": "sim_kernel_wide<9,9,32,128,2>", "w9x256": "sim_kernel_wide<9,9,32,256,2>", "w19x64": "sim_kernel_wide<19,19,32,64,6>",
+               "l19x128": "conv3x3_band (lock-step worker: per-layer kernels)", "l13x96": "conv3x3_band (lock-step worker: per-layer kernels)"})
 
 
 def _by_kernel(s0, s1, launches):
