@@ -10,6 +10,7 @@
 // heads_atari     — reward head (on the UN-scaled hidden state), min/max rescale + slab scatter, policy head, value head;
 //                   the 601-way softmax expectation is computed in index order; invertValue stays on the host (double libm).
 #include "net.h"
+#include <cstdlib>
 #include "net_dev.h"
 #include "net_body.h"
 #include "net_atari_body.h"
@@ -184,11 +185,18 @@ static int launchTiledT(const ConvLayer& L, const float* params, const float* in
 }
 
 int launchConvAnyStrided(const ConvLayer& L, int stride, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s); // net_wide.hip
+int launchConvBand(const ConvLayer& L, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s, int cus, bool* launched); // net_wide.hip
 
 static int launchTiled(const ConvLayer& L, int stride, const float* params, const float* in, const float* skip, float* out, int B, int H, int W,
                        hipStream_t s, int cus)
 {
     const int ot = L.cout_pad / 16;
+    static const bool band = getenv("MZ_ATARI_BAND") != nullptr; // (experiment: the stride-1 layers of the representation on net_wide.hip conv3x3_band)
+    if (band && stride == 1) {
+        bool launched = false;
+        const int rc = launchConvBand(L, params, in, skip, out, B, H, W, s, cus, &launched);
+        if (rc != MZ_OK || launched) { return rc; }
+    }
 #define MZ_TILED_CASE(st, c, o) \
     if (stride == st && L.cin_pad == c && ot == o) { return launchTiledT<st, c, o>(L, params, in, skip, out, B, H, W, s, cus); }
     MZ_TILED_CASE(2, 32, 2) // conv1 32 -> 32 (C = 64)

@@ -8,6 +8,7 @@
 #include "net.h"
 #include "net_wide_body.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -385,10 +386,11 @@ int Net::launchTowerWide(const std::vector<ConvLayer>& t, const float* in, float
     return MZ_OK;
 }
 
-// The band height (and the pixel tiles per job) of conv3x3_band for a layer shape: the TH whose bands cost the fewest MFMA-issue cycles (the slowest SIMD's share of a band's jobs, in pixel
-// tiles, x the layer's steps) plus staging cycles, among those whose patch fits the LDS.  TH = 0: no band fits (more than ~2000 input channels).
+// The band height, the pixel tiles per job and the waves per workgroup of conv3x3_band for a layer shape and a batch: the (TH, GM) with the shortest estimated launch —
+// rounds of workgroups over the CUs x (MFMA issue of a band's slowest SIMD, in pixel tiles x the layer's steps, + staging + fixed costs) — among the bands whose patch
+// fits the LDS.  TH = 0: no band fits (more than ~2000 input channels).
 struct BandPlan { int TH = 0, CS = 0, GM = 6, NW = 8; size_t lds = 0; };
-static BandPlan planBand(int H, int W, int cin_pad, int OT)
+static BandPlan planBand(int H, int W, int cin_pad, int OT, int B, int cus)
 {
     BandPlan best;
     double best_cost = 0.0;
@@ -401,39 +403,54 @@ static BandPlan planBand(int H, int W, int cin_pad, int OT)
         // 16 waves per CU hide what 8 do not (19x19 x 128: two workgroups of 8 waves with bands of 4 rows 0.59 of peak, one with bands of 10 rows 0.50): a patch that
         // leaves room for one workgroup per CU gets 16 waves in it
         const int NW = lds > size_t(78) * 1024 ? 16 : 8;
+        const int slots = NW == 16 ? 1 : 2; // workgroups per CU (16 waves)
+        const double rounds = std::ceil(double(B) * nb / (double(std::max(1, cus)) * slots));
         for (int GM = 6; GM >= 2; --GM) { // pixel tiles per job: fewer = more jobs for the waves (narrow layers), more = fewer A fragments fetched
-            double cost = 0.0;
+            double mfma = 0.0, fixed = 0.0;
             for (int k = 0; k < nb; ++k) {
                 const int th = std::min(TH, H - k * TH), ntiles = (th * W + 15) / 16, npg = (ntiles + GM - 1) / GM;
                 int load[4] = {0, 0, 0, 0}; // pixel tiles per SIMD (waves w, w + 4, ... share one)
                 for (int job = 0; job < OT * npg; ++job) { load[(job % NW) % 4] += std::min(GM, ntiles - GM * (job % npg)); }
                 const int mx = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
-                // MFMA issue of the slowest SIMD + staging (~32 B per cycle and CU) + launch / barrier / prologue and epilogue of the jobs
-                cost += double(mx) * 9.0 * (cin_pad / 4) * 32.0 + double(cin_pad) * (th + 2) * (W + 2) / 8.0 + 12000.0 + 5000.0 * ((OT * npg + NW - 1) / NW);
+                mfma += double(mx) * 9.0 * (cin_pad / 4) * 32.0;                                                              // MFMA issue of the slowest SIMD
+                fixed += double(cin_pad) * (th + 2) * (W + 2) / 8.0 + 12000.0 + 5000.0 * ((OT * npg + NW - 1) / NW);           // staging (~32 B per cycle and CU), barrier, the jobs' prologues and epilogues
             }
+            // workgroups that share a CU share its MFMA pipes; their fixed parts overlap
+            const double cost = rounds * (slots * mfma + fixed) / nb;
             if (best.TH == 0 || cost < best_cost) { best.TH = TH; best.CS = CS; best.GM = GM; best.NW = NW; best.lds = lds; best_cost = cost; }
         }
     }
     return best;
 }
 
-int Net::launchConvAny(const ConvLayer& L, const float* in, const float* skip, float* out, int B)
+// conv3x3_band for a stride-1 layer (weights.cpp `wp` layout at L.w_off); *launched = false: no band fits, nothing was launched
+int launchConvBand(const ConvLayer& L, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s, int cus, bool* launched)
 {
-    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width;
-    static const bool no_band = getenv("MZ_NO_CONV_BAND") != nullptr; // (A/B: the round-5 kernel that reads its B operand from global memory)
-    BandPlan bp = no_band ? BandPlan() : planBand(H, W, L.cin_pad, L.cout_pad / 16);
-    if (const char* e = getenv("MZ_BAND_TH")) { // (experiments: a forced band height / tiles per job, where the patch fits)
+    *launched = false;
+    BandPlan bp = planBand(H, W, L.cin_pad, L.cout_pad / 16, B, cus);
+    if (const char* e = getenv("MZ_BAND_TH")) { // (experiments: a forced band height / tiles per job / waves, where the patch fits)
         const int TH = std::max(1, std::min(H, atoi(e))), PP = (TH + 2) * (W + 2), CS = PP + ((16 - PP % 32) + 32) % 32;
         if (bp.TH > 0 && size_t(L.cin_pad) * CS * sizeof(float) <= size_t(156) * 1024) { bp.TH = TH; bp.CS = CS; bp.lds = size_t(L.cin_pad) * CS * sizeof(float); }
         if (const char* g = getenv("MZ_BAND_GM")) { bp.GM = std::max(1, std::min(6, atoi(g))); }
         if (const char* w = getenv("MZ_BAND_NW")) { bp.NW = atoi(w) == 16 ? 16 : 8; }
     }
-    if (bp.TH > 0) {
-        MZ_LDS_ATTR(conv3x3_band, size_t(160) * 1024);
-        hipLaunchKernelGGL(conv3x3_band, dim3(B, (H + bp.TH - 1) / bp.TH), dim3(64 * bp.NW), bp.lds, stream_, in, L.cin, L.cin_pad / 4, params_.p + L.w_off, params_.p + L.b_off, skip, out,
-                           L.cout, L.cout_pad / 16, H, W, bp.TH, bp.CS, bp.GM);
-        MZ_HIP(hipGetLastError());
-        return MZ_OK;
+    if (bp.TH <= 0) { return MZ_OK; }
+    MZ_LDS_ATTR(conv3x3_band, size_t(160) * 1024);
+    hipLaunchKernelGGL(conv3x3_band, dim3(B, (H + bp.TH - 1) / bp.TH), dim3(64 * bp.NW), bp.lds, s, in, L.cin, L.cin_pad / 4, params + L.w_off, params + L.b_off, skip, out,
+                       L.cout, L.cout_pad / 16, H, W, bp.TH, bp.CS, bp.GM);
+    MZ_HIP(hipGetLastError());
+    *launched = true;
+    return MZ_OK;
+}
+
+int Net::launchConvAny(const ConvLayer& L, const float* in, const float* skip, float* out, int B)
+{
+    const int H = desc_.hidden_channel_height, W = desc_.hidden_channel_width;
+    static const bool no_band = getenv("MZ_NO_CONV_BAND") != nullptr; // (A/B: the round-5 kernel that reads its B operand from global memory)
+    if (!no_band) {
+        bool launched = false;
+        const int rc = launchConvBand(L, params_.p, in, skip, out, B, H, W, stream_, cu_count_, &launched);
+        if (rc != MZ_OK || launched) { return rc; }
     }
     hipLaunchKernelGGL(conv3x3_any, dim3(B, (H * W + 63) / 64), dim3(256), 0, stream_, in, L.cin, L.cin_pad / 4, params_.p + L.w_off, params_.p + L.b_off, skip, out, L.cout,
                        L.cout_pad / 16, H, W);
