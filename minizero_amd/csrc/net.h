@@ -96,8 +96,8 @@ public:
     // num_simulation: the kernels keep per-search tables / the path in LDS; searches too long for 160 KB use the lock-step kernels
     bool hasSimKernel(int board_n, int env_kind = 0, int num_simulation = 0) const; // env_kind: GoDevView::kind
     // ... on the one-tile tower (sim_wide.inc, sim_wide_a.hip): Go with 128 / 256 hidden channels or on 7x7 / 13x13 / 19x19 boards
-    bool hasSimKernelWide(int board_n, int num_simulation) const;
-    bool simWidePlan(int board_n, int num_simulation, const HeadParams& hp, int channels, int W32, size_t leaf_bytes, size_t scratch_bytes, int* lf, size_t* lds,
+    bool hasSimKernelWide(int board_n, int env_kind, int num_simulation) const;
+    bool simWidePlan(int board_n, int env_kind, int num_simulation, const HeadParams& hp, int channels, int W32, size_t leaf_bytes, size_t scratch_bytes, int* lf, size_t* lds,
                      size_t* tile_bytes_out) const;
     int simLaunchWide(const struct SimArgs& a, const GoDevView& gv, int max_depth, const uint8_t* d_rot, int sim0, int nsims, bool host_start, int lf, size_t lds, bool* launched);
     int uploadSimArgs(const struct SimArgs& a);

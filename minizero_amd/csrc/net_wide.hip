@@ -322,6 +322,10 @@ __global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned* __rest
     X(13, 13, 32, 128) \
     X(19, 19, 32, 32)  /* 19x19 Go */ \
     X(19, 19, 32, 64)  \
+    X(8, 8, 16, 128)   /* Othello (4 input planes) at the reference's default width and half of it */ \
+    X(8, 8, 16, 256)   \
+    X(3, 3, 16, 128)   /* TicTacToe: docs/Training.md's first example trains it with the default 1 block x 256 channels */ \
+    X(3, 3, 16, 256)   \
     X(9, 9, 144, 128)  /* MuZero dynamics: hidden + one action plane */ \
     X(9, 9, 272, 256)  \
     X(7, 7, 80, 64)    \

@@ -556,7 +556,7 @@ int Net::uploadSimArgs(const SimArgs& a)
     return MZ_OK;
 }
 
-bool Net::hasSimKernelWide(int board_n, int num_simulation) const
+bool Net::hasSimKernelWide(int board_n, int env_kind, int num_simulation) const
 {
     if (desc_.type != 0 || !use_fused_ || repr_.empty()) { return false; }
     HeadParams hp;
@@ -566,13 +566,13 @@ bool Net::hasSimKernelWide(int board_n, int num_simulation) const
     const int max_depth = num_simulation + 3;
     size_t scratch = std::max(std::max(goLeafSmemBytes(gv, max_depth), azCandSmemBytes(gv.A)), gumbelSmemBytes(gv.A));
     scratch = std::max(scratch, size_t(2) * (size_t(num_simulation) + 8) * sizeof(float));
-    return simWidePlan(board_n, num_simulation, hp, desc_.num_input_channels, (gv.P + 31) / 32, goLeafSmemBytes(gv, max_depth), scratch, nullptr, nullptr, nullptr);
+    return simWidePlan(board_n, env_kind, num_simulation, hp, desc_.num_input_channels, (gv.P + 31) / 32, goLeafSmemBytes(gv, max_depth), scratch, nullptr, nullptr, nullptr);
 }
 
 bool Net::hasSimKernel(int board_n, int env_kind, int num_simulation) const
 {
     if (desc_.type != 0 || !use_fused_) { return false; }
-    if (env_kind == 0 && hasSimKernelWide(board_n, num_simulation)) { return true; } // Go on the one-tile tower (sim_wide.inc): wide / large-board shapes
+    if (hasSimKernelWide(board_n, env_kind, num_simulation)) { return true; } // the one-tile tower (sim_wide.inc): wide / large-board shapes
     TowerArgs ta;
     int c0 = 0;
     if (!makeTowerArgs(repr_, true, true, &ta, &c0)) { return false; }
@@ -598,7 +598,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     SimArgs a;
     memset(&a, 0, sizeof(a)); // compared bytewise below: no indeterminate padding
     int c0 = 0;
-    const bool wide = gv.kind == 0 && precision_ == 0 && hasSimKernelWide(gv.n, pool.v_.max_depth - 3);
+    const bool wide = precision_ == 0 && hasSimKernelWide(gv.n, gv.kind, pool.v_.max_depth - 3);
     if (wide) { if (!makeWideArgs(repr_, true, &a.ta, &c0)) { return MZ_OK; } }
     else if (!makeTowerArgs(repr_, true, true, &a.ta, &c0)) { return MZ_OK; }
     int rc = ensureBatch(gv.games);
@@ -633,7 +633,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
         scratch = std::max(scratch, size_t(2) * pool.v_.bound_cap * sizeof(float));
         int lf = 0;
         size_t lds = 0, tile_bytes = 0;
-        if (!simWidePlan(gv.n, pool.v_.max_depth - 3, a.hp, gv.channels, gv.W32, goLeafSmemBytes(gv, pool.v_.max_depth), scratch, &lf, &lds, &tile_bytes)) { return MZ_OK; }
+        if (!simWidePlan(gv.n, gv.kind, pool.v_.max_depth - 3, a.hp, gv.channels, gv.W32, goLeafSmemBytes(gv, pool.v_.max_depth), scratch, &lf, &lds, &tile_bytes)) { return MZ_OK; }
         a.cand_coop = (gv.A > kCandCoopMax && gv.A <= kCandCoopMaxW && candCoopSmemBytesW(gv.A, 8) <= tile_bytes) ? 2 : candCoopSmemBytes(gv.A, 8) <= tile_bytes ? 1 : 0;
         return simLaunchWide(a, gv, pool.v_.max_depth, d_rot, sim0, nsims, host_start, lf, lds, launched);
     }

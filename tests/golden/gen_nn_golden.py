@@ -100,6 +100,8 @@ CONFIGS = {
     "w_go5_3bx24_az": ("go_5x5", 18, 5, 5, 24, 5, 5, 1, 3, 26, 20, 1, "alphazero"),
     "w_go9_2bx128_mz": ("go_9x9", 18, 9, 9, 128, 9, 9, 1, 2, 82, 256, 1, "muzero"),
     "w_go7_1bx40_mz": ("go_7x7", 18, 7, 7, 40, 7, 7, 1, 1, 50, 32, 1, "muzero"),
+    "w_oth8_1bx256_az": ("othello_8x8", 4, 8, 8, 256, 8, 8, 1, 1, 65, 256, 1, "alphazero"),
+    "w_ttt_1bx256_az": ("tictactoe", 4, 3, 3, 256, 3, 3, 1, 1, 9, 256, 1, "alphazero"),
 }
 
 

@@ -88,6 +88,24 @@ def test_other_wide_instances(mz, oracle, n, c, blocks, sims, games, moves):
     assert st["moves"] == games * moves
 
 
+@pytest.mark.parametrize("game,n,planes,c,blocks,sims,games,cycles,extra", [
+    ("othello", 8, 4, 256, 1, 12, 5, 13 * 8 + 5, ""),      # the reference's default network (1 block x 256 channels, configuration.cpp:70-72) on Othello: sim_kernel_wide<8,8,16,256,0>
+    ("othello", 8, 4, 128, 2, 10, 6, 11 * 70, ""),         # whole games (forced passes, two-pass ends) on <8,8,16,128,0>
+    ("othello", 8, 4, 256, 1, 16, 4, 17 * 6 + 2, ":actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:actor_gumbel_sample_size=8"),  # BASELINE configs[2]'s root
+    ("tictactoe", 3, 4, 256, 1, 16, 8, 17 * 24, ""),       # docs/Training.md's first example: `train tictactoe az` = TicTacToe with the default 1 block x 256: <3,3,16,256,-1>, whole games
+    ("tictactoe", 3, 4, 128, 2, 8, 5, 9 * 20 + 4, ""),
+])
+def test_othello_and_tictactoe_on_the_one_tile_tower(mz, oracle, game, n, planes, c, blocks, sims, games, cycles, extra):
+    """The wide simulation kernel is not Go's alone: Othello (two bitboards per node) and TicTacToe leaves on the one-tile tower at 128 / 256 channels — the shapes the
+    reference's default configuration gives these games.  Records against OracleGroup; the counters say that the simulation kernel ran."""
+    name = {"othello": "othello_8x8", "tictactoe": "tictactoe"}[game]
+    args = (name, planes, n, n, c, n, n, 1, blocks, n * n + (1 if game == "othello" else 0), 64, 1, "alphazero")
+    conf = f"env_game={game}:" + (f"env_board_size={n}:" if game == "othello" else "") + f"actor_num_simulation={sims}:zero_num_parallel_games={games}" + extra
+    lines, recs, st = _run(mz, oracle, conf, args, [cycles], wseed=5)
+    if cycles >= 9 * 20:
+        assert len(lines) >= 1
+
+
 def test_go9_1bx256_gumbel_and_count_selection(mz, oracle):
     """The wide kernel with a Gumbel root (device-side sequential halving) and, separately, without noise and with count selection."""
     args = ("go_9x9", 18, 9, 9, 256, 9, 9, 1, 1, 82, 32, 1, "alphazero")
@@ -109,7 +127,7 @@ def test_wide_modes_are_equivalent(mz, oracle):
 
 def test_shape_without_any_instance_runs_lock_step(mz, oracle):
     """13x13 Go with 96 channels: neither a fused nor a one-tile tower (96 is no power-of-two multiple of 16): the worker falls back to the lock-step kernels on
-    conv3x3_any — no error, same records as the oracle."""
+    conv3x3_band — no error, same records as the oracle."""
     args = ("go_13x13", 18, 13, 13, 96, 13, 13, 1, 1, 170, 32, 1, "alphazero")
     _run(mz, oracle, GO.format(n=13, sims=6, games=3), args, [7 * 4 + 2], expect_sim=False)
 
