@@ -49,6 +49,9 @@ EXTRA_CONFIGS = {
     "w9x128": ("w9x128", "env_game=go:env_board_size=9:actor_num_simulation=400:zero_num_parallel_games=256"),    # 9x9 Go, 6 blocks x 128 channels
     "w9x256": ("w9x256", "env_game=go:env_board_size=9:actor_num_simulation=400:zero_num_parallel_games=256"),    # 9x9 Go, the reference's default network: 1 block x 256 channels
     "w19x64": ("w19x64", "env_game=go:env_board_size=19:actor_num_simulation=400:zero_num_parallel_games=256"),   # 19x19 Go, 6 blocks x 64 channels
+    # the reference's default network (1 block x 256 channels) on the other two games with a device leaf: BASELINE configs[2]'s search on Othello, configs[0]'s on TicTacToe with 256 games
+    "w8x256oth": ("w8x256oth", mz.CONFIGS["c3"]),
+    "w3x256ttt": ("w3x256ttt", "env_game=tictactoe:actor_num_simulation=16:zero_num_parallel_games=256"),
     # shapes WITHOUT a simulation-kernel instance: the lock-step worker on the per-layer kernels (net_wide.hip conv3x3_band; MZ_NO_CONV_BAND=1 in the environment: conv3x3_any);
     # no simulation-kernel launches to time, the block's roofline.wall_frac is the figure
     "l19x128": ("l19x128", "env_game=go:env_board_size=19:actor_num_simulation=400:zero_num_parallel_games=256"),  # 19x19 Go, 6 blocks x 128 channels (one tile = 237 KB)
@@ -62,12 +65,15 @@ EXTRA_DESCS = {
     "w9x128": lambda: mz.make_desc("go_9x9", 18, 9, 9, 128, 9, 9, 1, 6, 82),
     "w9x256": lambda: mz.make_desc("go_9x9", 18, 9, 9, 256, 9, 9, 1, 1, 82),
     "w19x64": lambda: mz.make_desc("go_19x19", 18, 19, 19, 64, 19, 19, 1, 6, 362),
+    "w8x256oth": lambda: mz.make_desc("othello_8x8", 4, 8, 8, 256, 8, 8, 1, 1, 65),
+    "w3x256ttt": lambda: mz.make_desc("tictactoe", 4, 3, 3, 256, 3, 3, 1, 1, 9),
     "l19x128": lambda: mz.make_desc("go_19x19", 18, 19, 19, 128, 19, 19, 1, 6, 362),
     "l13x96": lambda: mz.make_desc("go_13x13", 18, 13, 13, 96, 13, 13, 1, 6, 170),
 }
-MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2, "c5x512": 30, "w9x128mz": 10, "l19x128": 1, "l13x96": 2})
-WARM.update({"w9x128": 1, "w9x256": 1, "w19x64": 1, "c5x512": 14, "l19x128": 1, "l13x96": 1})
+MOVES.update({"w9x128": 3, "w9x256": 3, "w19x64": 2, "c5x512": 30, "w9x128mz": 10, "l19x128": 1, "l13x96": 2, "w8x256oth": 30, "w3x256ttt": 100})
+WARM.update({"w9x128": 1, "w9x256": 1, "w19x64": 1, "c5x512": 14, "l19x128": 1, "l13x96": 1, "w8x256oth": 3, "w3x256ttt": 20})
 KERNEL.update({"w9x128mz": "sim_kernel_mz_wide<9,9,32,144,128>", "w9x128": "sim_kernel_wide<9,9,32,128,2>", "w9x256": "sim_kernel_wide<9,9,32,256,2>", "w19x64": "sim_kernel_wide<19,19,32,64,6>",
+               "w8x256oth": "sim_kernel_wide<8,8,16,256,0>", "w3x256ttt": "sim_kernel_wide<3,3,16,256,-1>",
                "l19x128": "conv3x3_band (lock-step worker: per-layer kernels)", "l13x96": "conv3x3_band (lock-step worker: per-layer kernels)"})
 
 
