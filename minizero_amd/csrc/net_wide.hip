@@ -330,7 +330,10 @@ __global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned* __rest
     X(9, 9, 272, 256)  \
     X(7, 7, 80, 64)    \
     X(13, 13, 80, 64)  \
-    X(19, 19, 80, 64)
+    X(19, 19, 80, 64)  \
+    X(8, 8, 272, 256)  /* MuZero dynamics on the Othello / TicTacToe boards */ \
+    X(8, 8, 144, 128)  \
+    X(3, 3, 272, 256)
 
 template <int H, int W, int CIN0Q, int C>
 static int launchTowerWideT(const TowerArgs& ta, const float* params, const float* in, float* out, float* tmp, int B, hipStream_t s)

@@ -101,7 +101,10 @@ static int launchSimMzWideT(const SimArgs* d_args, int games, int sim0, int nsim
     X(9, 9, 32, 272, 256)  /* the reference's default width (configuration.cpp:71) */ \
     X(7, 7, 32, 80, 64)    \
     X(13, 13, 32, 80, 64)  \
-    X(19, 19, 32, 80, 64)
+    X(19, 19, 32, 80, 64)  \
+    X(8, 8, 16, 272, 256)  /* Othello and TicTacToe (MuZero has no leaf environment: only the board differs) with the default network */ \
+    X(8, 8, 16, 144, 128)  \
+    X(3, 3, 16, 272, 256)
 
 // the LDS plan: false = no instance, or the mandatory blocks do not fit.  *lf bit 0: path speculation
 bool Net::simMzWidePlan(int num_simulation, int* lf, size_t* lds, size_t* tile_bytes_out, int* c0q_out, int* cdq_out) const

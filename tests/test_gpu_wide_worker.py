@@ -145,6 +145,20 @@ def test_wide_muzero_instances(mz, oracle, n, c, blocks, sims, games, moves):
     assert st["moves"] == games * moves
 
 
+@pytest.mark.parametrize("game,n,c,blocks,sims,games,cycles", [
+    ("othello", 8, 256, 1, 12, 5, 13 * 6 + 4),   # MuZero has no leaf environment: only the board differs — sim_kernel_mz_wide<8,8,16,272,256>, the default network
+    ("othello", 8, 128, 2, 10, 4, 11 * 66),      # whole games on <8,8,16,144,128>
+    ("tictactoe", 3, 256, 1, 12, 6, 13 * 22),    # <3,3,16,272,256>, whole games
+])
+def test_wide_muzero_on_othello_and_tictactoe(mz, oracle, game, n, c, blocks, sims, games, cycles):
+    name = {"othello": "othello_8x8", "tictactoe": "tictactoe"}[game]
+    args = (name, 4, n, n, c, n, n, 1, blocks, n * n + (1 if game == "othello" else 0), 64, 1, "muzero")
+    conf = f"env_game={game}:" + (f"env_board_size={n}:" if game == "othello" else "") + f"nn_type_name=muzero:actor_num_simulation={sims}:zero_num_parallel_games={games}"
+    lines, recs, st = _run(mz, oracle, conf, args, [cycles], wseed=6)
+    if cycles > 13 * 20:
+        assert len(lines) >= 1
+
+
 def test_wide_muzero_gumbel_and_modes(mz, oracle):
     """A Gumbel root on the wide MuZero kernel (device-side sequential halving; the rounds' leaves are NOT evaluated ahead for these shapes), and the same games on
     the lock-step kernels."""
