@@ -288,7 +288,8 @@ def main():
             import run_configs
             out["other_configs"] = {}
             for key in ("c3", "c4", "c5"):
-                r = run_configs.run_config(key, moves=args.other_moves)
+                # (C5's moves are 3.5 ms each: 30 of them are 0.1 s, and one host hiccup on a loaded box showed as 0.64 M instead of 0.92 M in a round-5 line — its leg is four times as many moves)
+                r = run_configs.run_config(key, moves=args.other_moves * (4 if key == "c5" else 1))
                 out["other_configs"][key] = {"workload": r["config"], "leaf_evals_per_sec": r["leaf_evals_per_sec"], "ms_per_move": r["ms_per_move"],
                                              "games_in_pool": r["games_in_pool"], "moves_timed": r["moves_timed"], "host_threads": r["host_threads"],
                                              "roofline": {k: r["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "launches_by_kernel", "flops_per_leaf_eval", "wall_frac")}}
