@@ -1,10 +1,12 @@
 // Network kernels for the shapes beyond BASELINE.json (gfx950, -ffp-contract=off; arithmetic order: DESIGN.md §4):
 //  tower_wide   — the whole trunk of one sample per workgroup with ONE activation tile in LDS (net_wide_body.h): 128 / 256 hidden channels (the
 //                 reference's default network is 1 block x 256 channels, config/configuration.cpp:70-72), 7x7 / 13x13 / 19x19 Go (go_unit.h:11)
-//  conv3x3_any  — a 3x3 convolution of ANY shape (run-time H, W, channels): the instance behind everything else, so that no network the reference's
-//                 create_network.py can build (network/py/create_network.py, network_unit.py:6-87) ends in "no kernel instance".  The B operand is read
-//                 straight from global memory (L1 / L2) with the window's border test per lane; the chain per output is the contract's (tap-major,
-//                 channel ascending), an MFMA step with a zero operand leaving the chain's value as it is.
+//  conv3x3_band — a 3x3 convolution of ANY shape (run-time H, W, channels) with its B operand in LDS: a workgroup stages a band of output rows of one sample and runs
+//                 the layer out of it like the towers do.  The instance behind everything else, so that no network the reference's create_network.py can build
+//                 (network/py/create_network.py, network_unit.py:6-87) ends in "no kernel instance" — and does not crawl either (0.5-0.6 of the f32-MFMA peak).
+//  conv3x3_any  — its predecessor and fallback (layers of more than ~2000 input channels; MZ_NO_CONV_BAND=1): the B operand read straight from global memory
+//                 (L1 / L2) with the window's border test per lane.  Both: the chain per output is the contract's (tap-major, channel ascending), an MFMA step
+//                 with a zero operand leaving the chain's value as it is.
 #include "net.h"
 #include "net_wide_body.h"
 #include <algorithm>
