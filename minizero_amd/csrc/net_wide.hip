@@ -436,6 +436,7 @@ static BandPlan planBand(int H, int W, int cin_pad, int OT, int B, int cus)
 int launchConvBand(const ConvLayer& L, const float* params, const float* in, const float* skip, float* out, int B, int H, int W, hipStream_t s, int cus, bool* launched)
 {
     *launched = false;
+    if (B <= 0) { *launched = true; return MZ_OK; } // (an empty batch: nothing to launch, and nothing for the caller to fall back to)
     BandPlan bp = planBand(H, W, L.cin_pad, L.cout_pad / 16, B, cus);
     if (const char* e = getenv("MZ_BAND_TH")) { // (experiments: a forced band height / tiles per job / waves, where the patch fits)
         const int TH = std::max(1, std::min(H, atoi(e))), PP = (TH + 2) * (W + 2), CS = PP + ((16 - PP % 32) + 32) % 32;

@@ -115,6 +115,7 @@ int mzo_env_num_input_channels(void* e) { return static_cast<Env*>(e)->getNumInp
 int mzo_env_board_size(void* e) { return static_cast<Env*>(e)->getBoardSize(); }
 float mzo_env_reward(void* e) { return static_cast<Env*>(e)->getReward(); }
 float mzo_invert_value(float v) { return invertValue(v); }
+int mzo_conv_selftest(int cin, int cout, int H, int W, int stride, int with_skip, uint64_t seed) { return convSelfTest(cin, cout, H, W, stride, with_skip, seed); }
 float mzo_transform_value(float v) { return transformValue(v); }
 int mzo_env_seed(void* e)
 {

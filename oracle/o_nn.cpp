@@ -320,6 +320,54 @@ static void conv3x3s(const Conv& cv, int H, int Wd, int stride, const float* in,
     for (; p < Po; ++p) { convChains<1>(cv, H, Wd, stride, Wo, in, skip, out, p, Po); }
 }
 static void conv3x3(const Conv& cv, int H, int Wd, const float* in, const float* skip, float* out) { conv3x3s(cv, H, Wd, 1, in, skip, out); }
+// The scalar statement of the same convolution — one fmaf per step, the accumulators in memory: what conv3x3s() was before its chains were register-blocked.  Kept as the
+// definition convChains() is checked against on the CPU (tests/test_oracle_pinning.py::test_register_blocked_convolution_is_the_scalar_chain), not used by any forward.
+static void conv3x3sScalar(const Conv& cv, int H, int Wd, int stride, const float* in, const float* skip, float* out)
+{
+    const int cin = cv.cin, cout = cv.cout, Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1, Pi = H * Wd, Po = Ho * Wo;
+    for (int y = 0; y < Ho; ++y)
+        for (int x = 0; x < Wo; ++x)
+            for (int oc = 0; oc < cout; ++oc) {
+                float acc = 0.0f;
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y * stride + t / 3 - 1, xx = x * stride + t % 3 - 1;
+                    const bool inside = (yy >= 0 && yy < H && xx >= 0 && xx < Wd);
+                    for (int c = 0; c < cin; ++c) {
+                        const float xv = inside ? in[c * Pi + yy * Wd + xx] : 0.0f;
+                        acc = __builtin_fmaf(xv, cv.w[(size_t(oc) * cin + c) * 9 + t], acc);
+                    }
+                }
+                float v = acc + cv.b[oc];
+                if (skip) { v = v + skip[oc * Po + y * Wo + x]; }
+                out[oc * Po + y * Wo + x] = v > 0.0f ? v : 0.0f;
+            }
+}
+// 0: every output bit of conv3x3s() equals the scalar chain's on a seeded random layer (weights and inputs in [-1, 1), a few exact zeros and denormal-sized values among them)
+int convSelfTest(int cin, int cout, int H, int Wd, int stride, int with_skip, uint64_t seed)
+{
+    Conv c{cin, cout, 3, {}, {}};
+    c.w.resize(size_t(cout) * cin * 9);
+    c.b.resize(cout);
+    uint64_t st = seed * 0x9E3779B97F4A7C15ULL + 12345;
+    auto rnd = [&]() {
+        st = mix64(st + 0x9E3779B97F4A7C15ULL);
+        const unsigned r = unsigned(st >> 40);
+        if ((r & 63) == 0) { return 0.0f; }
+        const float u = float(r) * 5.9604644775390625e-08f * 2.0f - 1.0f;
+        return (r & 63) == 1 ? u * 1e-38f : u;
+    };
+    for (auto& v : c.w) { v = rnd(); }
+    for (auto& v : c.b) { v = rnd(); }
+    finishConv(c);
+    const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1;
+    std::vector<float> in(size_t(cin) * H * Wd), sk(size_t(cout) * Ho * Wo), a(sk.size()), b(sk.size());
+    for (auto& v : in) { v = rnd(); }
+    for (auto& v : sk) { v = rnd(); }
+    conv3x3s(c, H, Wd, stride, in.data(), with_skip ? sk.data() : nullptr, a.data());
+    conv3x3sScalar(c, H, Wd, stride, in.data(), with_skip ? sk.data() : nullptr, b.data());
+    return memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0 ? 0 : 1;
+}
+
 static void conv1x1relu(const Conv& cv, int P, const float* in, float* out)
 {
     for (int oc = 0; oc < cv.cout; ++oc)

@@ -282,6 +282,7 @@ public:
 float mz_expf(float x);  // deterministic expf shared (by specification) with the HIP kernels
 float mz_tanhf(float x);
 float invertValue(float value); // ref utils/utils.h:102-108
+int convSelfTest(int cin, int cout, int H, int Wd, int stride, int with_skip, uint64_t seed); // o_nn.cpp: the register-blocked convolution against the scalar chain (0 = every bit equal)
 float transformValue(float value); // ref utils/utils.h:93-100
 
 // ----------------------------------------------------------------------------

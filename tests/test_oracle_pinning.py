@@ -202,3 +202,16 @@ def test_tag_map_matches_reference_vector_map(oracle):
         L.mzo_tagmap_apply(e["ops"].encode(), buf, len(buf))
         assert buf.value.decode() == e["out"], e["ops"]
     assert fx["go_unit"] == {"kMaxGoBoardSize": 19, "kGoNumPlayer": 2, "sizeof_GoHashKey": 8, "GoBitboard_bits": 361, "kGoName_len": 2}
+
+
+def test_register_blocked_convolution_is_the_scalar_chain(oracle):
+    """oracle/o_nn.cpp convChains keeps the (tap, channel)-ordered fmaf chains of 4 pixels x 16 output channels in AVX2 registers; every output bit must equal the scalar
+    loop that defines the contract (conv3x3sScalar) — channel counts off the blocks of 16, pixel counts off the blocks of 4, strides, with and without the skip input,
+    zeros and denormal-sized values in the data."""
+    L = oracle.lib()
+    L.mzo_conv_selftest.restype = C.c_int
+    L.mzo_conv_selftest.argtypes = [C.c_int] * 6 + [C.c_uint64]
+    cases = [(1, 1, 1, 1, 1), (3, 5, 2, 3, 1), (18, 64, 9, 9, 1), (20, 33, 7, 5, 1), (64, 64, 8, 8, 1), (32, 32, 11, 13, 2), (17, 48, 6, 6, 2), (96, 96, 13, 13, 1), (4, 256, 3, 3, 1), (40, 17, 25, 4, 1)]
+    for seed, (cin, cout, H, W, stride) in enumerate(cases):
+        for skip in (0, 1):
+            assert L.mzo_conv_selftest(cin, cout, H, W, stride, skip, seed + 1) == 0, (cin, cout, H, W, stride, skip)
