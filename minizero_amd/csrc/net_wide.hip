@@ -10,6 +10,9 @@
 #include "net.h"
 #include "net_wide_body.h"
 #include <algorithm>
+#include <array>
+#include <map>
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -437,7 +440,17 @@ int launchConvBand(const ConvLayer& L, const float* params, const float* in, con
 {
     *launched = false;
     if (B <= 0) { *launched = true; return MZ_OK; } // (an empty batch: nothing to launch, and nothing for the caller to fall back to)
-    BandPlan bp = planBand(H, W, L.cin_pad, L.cout_pad / 16, B, cus);
+    // (the plan of a layer shape and batch is remembered: the search over band heights is tens of microseconds of host time, a lock-step cycle asks for 13 of them)
+    BandPlan bp;
+    {
+        static std::mutex mu;
+        static std::map<std::array<int, 6>, BandPlan> plans;
+        const std::array<int, 6> key{H, W, L.cin_pad, L.cout_pad / 16, B, cus};
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = plans.find(key);
+        if (it == plans.end()) { it = plans.emplace(key, planBand(H, W, L.cin_pad, L.cout_pad / 16, B, cus)).first; }
+        bp = it->second;
+    }
     if (const char* e = getenv("MZ_BAND_TH")) { // (experiments: a forced band height / tiles per job / waves, where the patch fits)
         const int TH = std::max(1, std::min(H, atoi(e))), PP = (TH + 2) * (W + 2), CS = PP + ((16 - PP % 32) + 32) % 32;
         if (bp.TH > 0 && size_t(L.cin_pad) * CS * sizeof(float) <= size_t(156) * 1024) { bp.TH = TH; bp.CS = CS; bp.lds = size_t(L.cin_pad) * CS * sizeof(float); }
