@@ -214,7 +214,7 @@ void Net::generateRaw(const NetDesc& d, uint64_t seed, float* out)
 struct Conv {
     int cin, cout, k;
     std::vector<float> w, b;  // w[oc][c][ky][kx] folded, b folded
-    std::vector<float> wk;    // 3x3 only: the same weights as wk[t][c][oc] (oc padded with zeros to a multiple of 16) for convChains(), built once (finishConv)
+    std::vector<float> wk;    // 3x3 only: the same weights as wk[t][c][oc] (oc padded with zeros to a multiple of 32) for convChains(), built once (finishConv)
     int cout_pad = 0;
 };
 struct Linear { int in, out; std::vector<float> w, b; };
@@ -254,7 +254,7 @@ static Linear takeLinear(const float*& p, int in, int out)
 static void finishConv(Conv& c)
 {
     if (c.k != 3) { return; }
-    c.cout_pad = (c.cout + 15) / 16 * 16;
+    c.cout_pad = (c.cout + 31) / 32 * 32; // (blocks of 16 output channels on AVX2, of 32 on AVX-512)
     c.wk.assign(size_t(9) * c.cin * c.cout_pad, 0.0f);
     for (int oc = 0; oc < c.cout; ++oc)
         for (int ch = 0; ch < c.cin; ++ch)
@@ -310,14 +310,82 @@ static inline void convChains(const Conv& cv, int H, int Wd, int stride, int Wo,
     }
 }
 
-// conv3x3 pad 1 with stride, optional skip, relu.  in[cin][H][W] -> out[cout][Ho][Wo]
-static void conv3x3s(const Conv& cv, int H, int Wd, int stride, const float* in, const float* skip, float* out)
+// The same chains on AVX-512 where the CPU has it (run-time dispatch; MZO_NO_AVX512=1 keeps the AVX2 path): 8 pixels x 32 output channels = 16 accumulators of 16
+// lanes.  vfmadd231ps on a zmm lane is the same correctly rounded fma: the outputs are the same bits on either path (convSelfTest runs both against the scalar chain).
+template <int NP>
+__attribute__((target("avx512f"))) static inline void convChains512(const Conv& cv, int H, int Wd, int stride, int Wo, const float* in, const float* skip, float* out, int p0, int Po)
 {
-    assert(cv.k == 3 && !cv.wk.empty());
+    static const float kZero = 0.0f;
+    const int cin = cv.cin, cout = cv.cout, cp = cv.cout_pad, Pi = H * Wd;
+    const float* base[9][NP];
+    size_t step[9][NP];
+    for (int j = 0; j < NP; ++j) {
+        const int p = p0 + j, y = p / Wo, x = p - y * Wo;
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y * stride + t / 3 - 1, xx = x * stride + t % 3 - 1;
+            const bool inside = (yy >= 0 && yy < H && xx >= 0 && xx < Wd);
+            base[t][j] = inside ? in + yy * Wd + xx : &kZero;
+            step[t][j] = inside ? size_t(Pi) : 0;
+        }
+    }
+    for (int o0 = 0; o0 < cp; o0 += 32) {
+        __m512 acc[NP][2];
+        for (int j = 0; j < NP; ++j) { acc[j][0] = _mm512_setzero_ps(); acc[j][1] = _mm512_setzero_ps(); }
+        for (int t = 0; t < 9; ++t) {
+            const float* wr = &cv.wk[size_t(t) * cin * cp + o0];
+            const float* bp[NP];
+            size_t st[NP];
+            for (int j = 0; j < NP; ++j) { bp[j] = base[t][j]; st[j] = step[t][j]; }
+            for (int c = 0; c < cin; ++c, wr += cp) {
+                const __m512 w0 = _mm512_loadu_ps(wr), w1 = _mm512_loadu_ps(wr + 16);
+                for (int j = 0; j < NP; ++j) {
+                    const __m512 xv = _mm512_set1_ps(*bp[j]);
+                    bp[j] += st[j];
+                    acc[j][0] = _mm512_fmadd_ps(xv, w0, acc[j][0]);
+                    acc[j][1] = _mm512_fmadd_ps(xv, w1, acc[j][1]);
+                }
+            }
+        }
+        for (int j = 0; j < NP; ++j) {
+            alignas(64) float a[32];
+            _mm512_store_ps(a, acc[j][0]);
+            _mm512_store_ps(a + 16, acc[j][1]);
+            const int p = p0 + j;
+            for (int i = 0; i < 32 && o0 + i < cout; ++i) {
+                const int oc = o0 + i;
+                float v = a[i] + cv.b[oc];
+                if (skip) { v = v + skip[size_t(oc) * Po + p]; }
+                out[size_t(oc) * Po + p] = v > 0.0f ? v : 0.0f;
+            }
+        }
+    }
+}
+__attribute__((target("avx512f"))) static void conv3x3s512(const Conv& cv, int H, int Wd, int stride, const float* in, const float* skip, float* out)
+{
+    const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1, Po = Ho * Wo;
+    int p = 0;
+    for (; p + 8 <= Po; p += 8) { convChains512<8>(cv, H, Wd, stride, Wo, in, skip, out, p, Po); }
+    for (; p + 2 <= Po; p += 2) { convChains512<2>(cv, H, Wd, stride, Wo, in, skip, out, p, Po); }
+    for (; p < Po; ++p) { convChains512<1>(cv, H, Wd, stride, Wo, in, skip, out, p, Po); }
+}
+static bool useAvx512()
+{
+    static const bool yes = __builtin_cpu_supports("avx512f") && getenv("MZO_NO_AVX512") == nullptr;
+    return yes;
+}
+
+// conv3x3 pad 1 with stride, optional skip, relu.  in[cin][H][W] -> out[cout][Ho][Wo]
+static void conv3x3sAvx2(const Conv& cv, int H, int Wd, int stride, const float* in, const float* skip, float* out)
+{
     const int Ho = (H - 1) / stride + 1, Wo = (Wd - 1) / stride + 1, Po = Ho * Wo;
     int p = 0;
     for (; p + 4 <= Po; p += 4) { convChains<4>(cv, H, Wd, stride, Wo, in, skip, out, p, Po); }
     for (; p < Po; ++p) { convChains<1>(cv, H, Wd, stride, Wo, in, skip, out, p, Po); }
+}
+static void conv3x3s(const Conv& cv, int H, int Wd, int stride, const float* in, const float* skip, float* out)
+{
+    assert(cv.k == 3 && !cv.wk.empty());
+    if (useAvx512()) { conv3x3s512(cv, H, Wd, stride, in, skip, out); } else { conv3x3sAvx2(cv, H, Wd, stride, in, skip, out); }
 }
 static void conv3x3(const Conv& cv, int H, int Wd, const float* in, const float* skip, float* out) { conv3x3s(cv, H, Wd, 1, in, skip, out); }
 // The scalar statement of the same convolution — one fmaf per step, the accumulators in memory: what conv3x3s() was before its chains were register-blocked.  Kept as the
@@ -363,9 +431,15 @@ int convSelfTest(int cin, int cout, int H, int Wd, int stride, int with_skip, ui
     std::vector<float> in(size_t(cin) * H * Wd), sk(size_t(cout) * Ho * Wo), a(sk.size()), b(sk.size());
     for (auto& v : in) { v = rnd(); }
     for (auto& v : sk) { v = rnd(); }
-    conv3x3s(c, H, Wd, stride, in.data(), with_skip ? sk.data() : nullptr, a.data());
     conv3x3sScalar(c, H, Wd, stride, in.data(), with_skip ? sk.data() : nullptr, b.data());
-    return memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0 ? 0 : 1;
+    conv3x3sAvx2(c, H, Wd, stride, in.data(), with_skip ? sk.data() : nullptr, a.data());
+    int bad = memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0 ? 0 : 1;
+    if (__builtin_cpu_supports("avx512f")) { // (both vector paths, whatever the dispatch would pick)
+        std::fill(a.begin(), a.end(), -1.0f);
+        conv3x3s512(c, H, Wd, stride, in.data(), with_skip ? sk.data() : nullptr, a.data());
+        bad |= memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0 ? 0 : 2;
+    }
+    return bad;
 }
 
 static void conv1x1relu(const Conv& cv, int P, const float* in, float* out)
