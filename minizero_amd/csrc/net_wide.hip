@@ -451,11 +451,14 @@ int launchConvBand(const ConvLayer& L, const float* params, const float* in, con
         if (it == plans.end()) { it = plans.emplace(key, planBand(H, W, L.cin_pad, L.cout_pad / 16, B, cus)).first; }
         bp = it->second;
     }
-    if (const char* e = getenv("MZ_BAND_TH")) { // (experiments: a forced band height / tiles per job / waves, where the patch fits)
-        const int TH = std::max(1, std::min(H, atoi(e))), PP = (TH + 2) * (W + 2), CS = PP + ((16 - PP % 32) + 32) % 32;
+    static const char* const force_th = getenv("MZ_BAND_TH"); // (experiments: a forced band height / tiles per job / waves, where the patch fits; read once)
+    static const char* const force_gm = getenv("MZ_BAND_GM");
+    static const char* const force_nw = getenv("MZ_BAND_NW");
+    if (force_th) {
+        const int TH = std::max(1, std::min(H, atoi(force_th))), PP = (TH + 2) * (W + 2), CS = PP + ((16 - PP % 32) + 32) % 32;
         if (bp.TH > 0 && size_t(L.cin_pad) * CS * sizeof(float) <= size_t(156) * 1024) { bp.TH = TH; bp.CS = CS; bp.lds = size_t(L.cin_pad) * CS * sizeof(float); }
-        if (const char* g = getenv("MZ_BAND_GM")) { bp.GM = std::max(1, std::min(6, atoi(g))); }
-        if (const char* w = getenv("MZ_BAND_NW")) { bp.NW = atoi(w) == 16 ? 16 : 8; }
+        if (force_gm) { bp.GM = std::max(1, std::min(6, atoi(force_gm))); }
+        if (force_nw) { bp.NW = atoi(force_nw) == 16 ? 16 : 8; }
     }
     if (bp.TH <= 0) { return MZ_OK; }
     MZ_LDS_ATTR(conv3x3_band, size_t(160) * 1024);
