@@ -72,7 +72,7 @@ def test_random_configuration_matches_oracle(mz, oracle, seed):
         n = int(conf.split("actor_num_simulation=")[1].split(":")[0])
         chunks = [n + 1, n + 1, 2 * (n + 1), int(rng4.integers(1, n + 1)), 3 * (n + 1)]
     # (round 5, again from a generator of its own) network shapes beyond the 8-channel test nets — Go on the one-tile tower's simulation kernel (32 channels on 7x7 / 9x9:
-    # sim_kernel_wide, sim_kernel_mz_wide has no 32-channel instance: lock-step there) or on a shape with no instance at all (5x5 x 24 channels: conv3x3_any, lock-step) —,
+    # sim_kernel_wide, sim_kernel_mz_wide has no 32-channel instance: lock-step there) or on a shape with no instance at all (5x5 x 24 channels: conv3x3_band, lock-step) —,
     # up to 16 RNG streams (what bench.py times), and now and then a BASELINE-size pool of the short games
     rng5 = np.random.default_rng(5000 + seed)
     if dargs[0] == "go_9x9" and rng5.random() < 0.3:

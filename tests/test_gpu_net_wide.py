@@ -1,6 +1,6 @@
 """GPU parity of the inference path on shapes beyond BASELINE.json (round 5): the reference's default 1 block x 256 channels (config/configuration.cpp:70-72),
 128-channel towers, 7x7 / 13x13 / 19x19 Go (go_unit.h:11) on the one-tile tower (net_wide.hip tower_wide), channel counts that are no multiple of 16 and boards
-without an instance on the run-time-shaped conv3x3_any — against the CPU oracle (bit-exact: same k-ordered chains) and against goldens generated from the
+without an instance on the run-time-shaped conv3x3_band — against the CPU oracle (bit-exact: same k-ordered chains) and against goldens generated from the
 reference's own Python modules (tests/golden/gen_nn_golden.py; <= 1e-4, north star 1e-3).  Math: network/py/network_unit.py:6-87, alphazero_network.py:90-113,
 muzero_network.py:137-164; loadModel accepts any of these shapes (network/network.cpp:14-42)."""
 import os
@@ -95,7 +95,7 @@ def test_wide_muzero_initial_and_recurrent(mz, oracle, name):
 ], ids=lambda a: f"{a[0]}_{a[8]}bx{a[4]}_{a[12]}")
 def test_any_shape_is_served(mz, oracle, args):
     """No network create_network.py can build for a board game ends in "no kernel instance": shapes with neither a fused nor a one-tile tower instance run on
-    conv3x3_any, bit-exact against the oracle."""
+    conv3x3_band (net_wide.hip: a band of output rows staged in LDS), bit-exact against the oracle."""
     d, od = _descs(mz, oracle, args)
     w = mz.generate_weights(d, 7)
     net, onet = mz.Net(d, w), oracle.OracleNet(od, w)
