@@ -8,7 +8,14 @@
 // G = min(mz_device_count(), zero_num_parallel_games) workers, worker g owns the games {i : i % G == g} on device g, is driven by its own
 // host thread and seeds program_seed + g (the reference's slave thread g seeds program_seed + g, actor_group.cpp:66-70); stdout is written
 // under one mutex (actor_group.cpp:42-49).  The main thread reads stdin; every command is applied by each device thread between two moves
-// of its games (the reference applies commands between two cycles of the CPU phase, actor_group.cpp:200-219).
+// of its games (the reference applies commands between two cycles of the CPU phase, actor_group.cpp:200-219: a move boundary is one of the
+// cycle boundaries it could have picked — any schedule of commands against cycles is a schedule the reference can produce — and the latency
+// is at most one move of the device's games).  Each device says on stderr AFTER HOW MANY CYCLES it applied a command
+// ("[mzgpu] device 1: load_model ... after 357 cycles"), so a run can be replayed exactly (tests/test_gpu_iteration.py does, against the oracle).
+//
+// Weight files are read ONCE per process: nn_file_name at start-up and every `load_model <path>` are opened and parsed by
+// the thread that reads stdin (mz_weights_read) and the parsed blob is handed to every device's worker (mz_worker_load_model) — the reference
+// lets every network re-read the file (actor_group.cpp:227-232), G reads and G TorchScript parses per iteration on a G-GPU node.
 #pragma once
 #include "mzgpu_config.h"
 #include "network.h"
@@ -16,6 +23,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -42,6 +50,7 @@ public:
         for (size_t g = 0; g < devices_.size(); ++g) { threads.emplace_back([this, g]() { deviceLoop(static_cast<int>(g)); }); }
         handleIO(); // returns on quit / end of stdin
         for (auto& t : threads) { t.join(); }
+        std::cerr << "[mzgpu] weight files read: " << mz_weight_file_reads() << std::endl; // one per file, whatever the number of devices
     }
 
     inline int getNumDevices() const { return static_cast<int>(devices_.size()); }
@@ -88,9 +97,15 @@ protected:
             const int per_worker = std::max(1, threads / G), streams_key = number("mz_rng_streams", 1), S = std::max(1, streams_key == 0 ? per_worker : streams_key);
             const std::string conf = conf_ + ":zero_num_parallel_games=" + std::to_string(d.games) + ":program_seed=" + std::to_string(seed + g * S) +
                                      ":zero_num_threads=" + std::to_string(per_worker);
-            d.worker = mz_worker_create(d.gpu, conf.c_str(), nullptr, nullptr, 0); // reads nn_file_name itself
+            if (g == 0) { // one read for all devices
+                const std::string file = config::mzgpuConfValue(conf_, "nn_file_name");
+                if (file.empty()) { std::cerr << "ActorGroup: nn_file_name is empty" << std::endl; exit(0); }
+                first_weights_ = readWeights(file);
+            }
+            d.worker = mz_worker_create(d.gpu, conf.c_str(), mz_weights_desc(first_weights_.get()), mz_weights_data(first_weights_.get()), mz_weights_count(first_weights_.get()));
             if (!d.worker) { std::cerr << mz_last_error() << std::endl; exit(0); }
         }
+        first_weights_.reset();
         std::cerr << "[mzgpu] " << total_games << " games on " << G << " GPU(s)" << std::endl;
     }
 
@@ -100,14 +115,24 @@ protected:
         while (!quit_.load() && getline(std::cin, command)) {
             const std::string prefix = command.substr(0, command.find(' '));
             if (!isIgnored(prefix)) { std::cerr << "[command] " << command << std::endl; }
+            Command c{command, nullptr};
+            if (prefix == "load_model" && !isIgnored(prefix) && command.find(' ') != std::string::npos) { c.weights = readWeights(command.substr(command.find(' ') + 1)); }
             {
                 std::lock_guard<std::mutex> lock(mutex_);
-                commands_.push_back(command);
+                commands_.push_back(std::move(c));
             }
             if (prefix == "quit" && !isIgnored(prefix)) { return; }
         }
         std::lock_guard<std::mutex> lock(mutex_);
-        commands_.push_back("quit"); // stdin closed == the server went away
+        commands_.push_back(Command{"quit", nullptr}); // stdin closed == the server went away
+    }
+
+    // Network::loadModel's read (ref network/network.h:18-37), once per file and process; a file that does not load ends the worker like the reference's assert
+    static std::shared_ptr<mz_weights> readWeights(const std::string& path)
+    {
+        mz_weights* w = mz_weights_read(path.c_str());
+        if (!w) { std::cerr << mz_last_error() << std::endl; exit(0); }
+        return std::shared_ptr<mz_weights>(w, mz_weights_free);
     }
 
     bool isIgnored(const std::string& prefix) const // zero_actor_ignored_command (ref actor_group.cpp:204-212)
@@ -135,17 +160,28 @@ protected:
 
     virtual bool handleCommand(Device& d) // ref actor_group.cpp:200-252
     {
-        std::deque<std::string> cmds;
+        std::deque<Command> cmds;
         {
             std::lock_guard<std::mutex> lock(mutex_);
             for (; d.next_command < commands_.size(); ++d.next_command) { cmds.push_back(commands_[d.next_command]); }
         }
-        for (const std::string& command : cmds) {
+        for (const Command& c : cmds) {
+            const std::string& command = c.line;
             const std::string prefix = command.substr(0, command.find(' '));
-            const int rc = mz_worker_command(d.worker, command.c_str()); // the worker applies zero_actor_ignored_command itself
+            const int rc = c.weights ? mz_worker_load_model(d.worker, command.substr(command.find(' ') + 1).c_str(), mz_weights_desc(c.weights.get()),
+                                                            mz_weights_data(c.weights.get()), mz_weights_count(c.weights.get()))
+                                     : mz_worker_command(d.worker, command.c_str()); // the worker applies zero_actor_ignored_command itself
             if (rc < 0) { std::cerr << mz_last_error() << std::endl; exit(0); }
             if (rc == 1) { drainGames(d); return false; } // quit
             if (isIgnored(prefix)) { continue; }
+            if (prefix == "load_model" || prefix == "reset_actors" || prefix == "update_config" || prefix == "start" || prefix == "stop") {
+                mz_worker_stats st;
+                if (mz_worker_get_stats(d.worker, &st) == MZ_OK) {
+                    std::ostringstream oss; // one write: device threads share stderr
+                    oss << "[mzgpu] device " << (&d - devices_.data()) << ": " << command << " after " << st.cycles << " cycles\n";
+                    std::cerr << oss.str() << std::flush;
+                }
+            }
             if (prefix == "start") { d.running = true; }
             if (prefix == "stop") { d.running = false; drainGames(d); }
         }
@@ -180,7 +216,9 @@ protected:
     int gpu_id_;
     std::vector<Device> devices_;
     std::mutex mutex_, out_mutex_;
-    std::deque<std::string> commands_;
+    struct Command { std::string line; std::shared_ptr<mz_weights> weights; }; // weights: the parsed file of a load_model line
+    std::deque<Command> commands_;
+    std::shared_ptr<mz_weights> first_weights_;
     std::atomic<bool> quit_{false};
 };
 

@@ -68,6 +68,17 @@ int mz_net_read_pt(const char* path, mz_net_desc* desc_out, float* weights_out, 
  * "x.pt" — the sibling flat blob "x.mzw" (magic "MZW1", mz_net_desc, uint64 count, f32 data: minizero_amd/export_weights.py). */
 int mz_net_read_weight_file(const char* path, mz_net_desc* desc_out, float* weights_out, size_t capacity, size_t* count_out);
 
+/* The same, read ONCE and kept: what a process that drives several devices hands to each of them instead of letting every network
+ * re-read the file (the reference does the latter, actor/actor_group.cpp:227-232; SURVEY.md 8(e) asks for one read).  NULL + mz_last_error()
+ * on failure.  mz_weight_file_reads(): how many weight files this process has opened and parsed so far (any entry point). */
+typedef struct mz_weights mz_weights;
+mz_weights* mz_weights_read(const char* path);
+const mz_net_desc* mz_weights_desc(const mz_weights* w);
+const float* mz_weights_data(const mz_weights* w);
+size_t mz_weights_count(const mz_weights* w);
+void mz_weights_free(mz_weights* w);
+uint64_t mz_weight_file_reads(void);
+
 /* createNetwork(file, gpu_id) (ref network/create_network.h:11-30): here the caller hands the parsed
  * blob; device must be a valid GPU ordinal (gpu_id == -1 / CPU is NOT supported: MZ_ERR_DEVICE). */
 mz_net* mz_net_create(int device, const mz_net_desc* desc, const float* weights, size_t count);
@@ -180,6 +191,9 @@ void mz_worker_destroy(mz_worker* w);
  * Returns 1 for quit, 0, or a negative error. */
 int mz_worker_command(mz_worker* w, const char* line);
 int mz_worker_set_weights(mz_worker* w, const float* weights, size_t count);
+/* `load_model <path>` for a caller that has already read the file (mz_weights_read — one read for all the devices of a process): the same
+ * hyper-parameter check, reload and rename as the command, without opening anything.  With a shared network: rename only. */
+int mz_worker_load_model(mz_worker* w, const char* path, const mz_net_desc* desc, const float* weights, size_t count);
 /* run n lock-step cycles (one simulation of every game per cycle, ref actor_group.cpp:139-147);
  * returns the number of cycles actually run (0 while stopped) or a negative error.  Cycles of one call that need nothing from the host
  * run as ONE kernel launch: call with mz_worker_cycles_per_move() (= actor_num_simulation + 1) and poll commands between calls. */

@@ -5,4 +5,4 @@ This package only binds include/mzgpu.h with ctypes; there is no Python or CPU f
 point raises MzError when the HIP library is missing or no GPU is visible.
 """
 from .lib import (MzError, NetDesc, SearchCfg, WorkerStats, Net, Pool, Worker, Env, DataLoader, load, lib_path, make_desc,  # noqa: F401
-                  param_count, generate_weights, device_count, usable_cpus, godev_playout, envdev_playout, sort_candidates, invert_values_device, read_pt, read_weight_file, DESCS, CONFIGS)
+                  param_count, generate_weights, device_count, usable_cpus, godev_playout, envdev_playout, sort_candidates, invert_values_device, read_pt, read_weight_file, read_weights_once, weight_file_reads, DESCS, CONFIGS)

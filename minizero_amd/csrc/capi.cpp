@@ -2,6 +2,7 @@
 // The worker and environment entry points live in worker.cpp / env.cpp.
 #include "net.h"
 #include "pool.h"
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -18,8 +19,12 @@ void setError(const char* fmt, ...)
 }
 const char* lastError() { return g_err; }
 
+static std::atomic<uint64_t> g_weight_file_reads{0};
+uint64_t weightFileReads() { return g_weight_file_reads.load(); }
+
 bool readWeightFile(const std::string& path_in, mz_net_desc* desc, std::vector<float>* weights)
 {
+    g_weight_file_reads.fetch_add(1);
     std::string path = path_in;
     mz_net_desc d;
     std::vector<float> w;
@@ -119,6 +124,21 @@ int mz_net_read_weight_file(const char* path, mz_net_desc* desc_out, float* weig
     }
     return MZ_OK;
 }
+
+// one open + one parse, kept: what a driver of several devices hands to each of them (include/minizero/actor_group.h)
+struct mz_weights { mz_net_desc desc; std::vector<float> data; };
+mz_weights* mz_weights_read(const char* path)
+{
+    if (!path) { mz::setError("mz_weights_read: NULL path"); return nullptr; }
+    std::unique_ptr<mz_weights> w(new mz_weights());
+    if (!mz::readWeightFile(path, &w->desc, &w->data)) { return nullptr; }
+    return w.release();
+}
+const mz_net_desc* mz_weights_desc(const mz_weights* w) { return w ? &w->desc : nullptr; }
+const float* mz_weights_data(const mz_weights* w) { return w ? w->data.data() : nullptr; }
+size_t mz_weights_count(const mz_weights* w) { return w ? w->data.size() : 0; }
+void mz_weights_free(mz_weights* w) { delete w; }
+uint64_t mz_weight_file_reads(void) { return mz::weightFileReads(); }
 
 mz_net* mz_net_create(int device, const mz_net_desc* desc, const float* weights, size_t count)
 {

@@ -371,6 +371,7 @@ public:
     // shared != nullptr: the worker runs on the caller's network (BaseActor::setNetwork's shared_ptr, ref zero_actor.cpp:100-112) instead of its own copy
     int init(int device, const char* conf, const mz_net_desc& desc, const float* weights, size_t count, Net* shared = nullptr);
     int command(const std::string& line);
+    int loadModel(const std::string& path, const mz_net_desc& file_desc, const float* weights, size_t count);
     int setWeights(const float* w, size_t n)
     {
         pending_weights_.assign(w, w + n);
@@ -2161,6 +2162,30 @@ int Worker::peekRecord(int game, char* buf, int cap, const char* const* keys, co
     return len;
 }
 
+// load_model with the file's content in hand (Network::loadModel of every network of this worker, ref actor_group.cpp:227-232, network.h:18-37)
+int Worker::loadModel(const std::string& path, const mz_net_desc& file_desc, const float* weights, size_t count)
+{
+    MZ_HIP(hipSetDevice(device_));
+    mz_net_desc a = file_desc, b = desc_;
+    a.game_name[sizeof(a.game_name) - 1] = 0;
+    memset(a.game_name, 0, sizeof(a.game_name)); // (the game's name is the trainer's label, not a shape)
+    memset(b.game_name, 0, sizeof(b.game_name));
+    if (memcmp(&a, &b, sizeof(a)) != 0) {
+        setError("load_model %s: the file's hyper-parameters are not those of the running network (%s, %d blocks x %d channels)", path.c_str(),
+                 desc_.game_name, desc_.num_blocks, desc_.num_hidden_channels);
+        return MZ_ERR_ARG;
+    }
+    if (!shared_net_) {
+        for (auto& L : lanes_) {
+            MZ_HIP(hipStreamSynchronize(L->stream));
+            int rc = L->net->reload(weights, count);
+            if (rc) { return rc; }
+        }
+    }
+    cfg_.nn_file_name = path;
+    return MZ_OK;
+}
+
 int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
 {
     const std::string prefix = line.substr(0, line.find(' '));
@@ -2186,25 +2211,13 @@ int Worker::command(const std::string& line) // ref actor_group.cpp:200-252
         }
         if (pending_weights_.empty()) { // the reference's path: every network re-reads the file (actor_group.cpp:227-232)
             mz_net_desc nd;
-            if (!readWeightFile(path, &nd, &pending_weights_)) { pending_weights_.clear(); return MZ_ERR_ARG; }
-            nd.game_name[sizeof(nd.game_name) - 1] = 0;
-            mz_net_desc a = nd, b = desc_;
-            memset(a.game_name, 0, sizeof(a.game_name));
-            memset(b.game_name, 0, sizeof(b.game_name));
-            if (memcmp(&a, &b, sizeof(a)) != 0) {
-                pending_weights_.clear();
-                setError("load_model %s: the file's hyper-parameters are not those of the running network (%s, %d blocks x %d channels)", path.c_str(),
-                         desc_.game_name, desc_.num_blocks, desc_.num_hidden_channels);
-                return MZ_ERR_ARG;
-            }
+            std::vector<float> file;
+            if (!readWeightFile(path, &nd, &file)) { return MZ_ERR_ARG; }
+            return loadModel(path, nd, file.data(), file.size());
         }
-        for (auto& L : lanes_) {
-            MZ_HIP(hipStreamSynchronize(L->stream));
-            int rc = L->net->reload(pending_weights_.data(), pending_weights_.size());
-            if (rc) { pending_weights_.clear(); return rc; }
-        }
-        pending_weights_.clear();
-        cfg_.nn_file_name = path;
+        std::vector<float> staged;
+        staged.swap(pending_weights_);
+        return loadModel(path, desc_, staged.data(), staged.size());
     } else if (prefix == "update_config") {
         if (line.find(' ') == std::string::npos) { setError("update_config needs a configuration string"); return MZ_ERR_ARG; }
         WorkerConfig nc = cfg_;
@@ -2274,6 +2287,11 @@ int mz_worker_command(mz_worker* w, const char* line)
 {
     if (!w || !line) { mz::setError("mz_worker_command: NULL argument"); return MZ_ERR_ARG; }
     return w->w.command(line);
+}
+int mz_worker_load_model(mz_worker* w, const char* path, const mz_net_desc* desc, const float* weights, size_t count)
+{
+    if (!w || !path || !desc || !weights) { mz::setError("mz_worker_load_model: NULL argument"); return MZ_ERR_ARG; }
+    return w->w.loadModel(path, *desc, weights, count);
 }
 int mz_worker_set_weights(mz_worker* w, const float* weights, size_t count)
 {

@@ -120,6 +120,17 @@ def load():
         L.mz_worker_destroy.argtypes = [vp]
         L.mz_worker_command.argtypes = [vp, C.c_char_p]
         L.mz_worker_set_weights.argtypes = [vp, fp, C.c_size_t]
+        L.mz_worker_load_model.argtypes = [vp, C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t]
+        L.mz_weights_read.restype = vp
+        L.mz_weights_read.argtypes = [C.c_char_p]
+        L.mz_weights_desc.restype = C.POINTER(NetDesc)
+        L.mz_weights_desc.argtypes = [vp]
+        L.mz_weights_data.restype = fp
+        L.mz_weights_data.argtypes = [vp]
+        L.mz_weights_count.restype = C.c_size_t
+        L.mz_weights_count.argtypes = [vp]
+        L.mz_weights_free.argtypes = [vp]
+        L.mz_weight_file_reads.restype = C.c_uint64
         L.mz_worker_run_cycles.argtypes = [vp, C.c_int]
         L.mz_worker_cycles_per_move.argtypes = [vp]
         L.mz_net_read_weight_file.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -213,6 +224,26 @@ def read_weight_file(path):
     _check(L, L.mz_net_read_weight_file(path.encode(), C.byref(d), None, 0, C.byref(n)))
     w = np.empty(n.value, np.float32)
     _check(L, L.mz_net_read_weight_file(path.encode(), C.byref(d), _f(w), n.value, C.byref(n)))
+    return d, w
+
+
+def weight_file_reads():
+    """weight files this process has opened and parsed through libmzgpu so far"""
+    return int(load().mz_weight_file_reads())
+
+
+def read_weights_once(path):
+    """mz_weights_read: (desc, blob) from ONE open + parse of `path` (.pt, or its .mzw sibling)"""
+    L = load()
+    h = L.mz_weights_read(path.encode())
+    if not h:
+        raise MzError("mz_weights_read failed: " + _err(L))
+    try:
+        d = NetDesc.from_buffer_copy(L.mz_weights_desc(h).contents)
+        n = L.mz_weights_count(h)
+        w = np.ctypeslib.as_array(L.mz_weights_data(h), shape=(n,)).copy()
+    finally:
+        L.mz_weights_free(h)
     return d, w
 
 
@@ -375,10 +406,15 @@ class Pool:
 class Worker:
     """Mirror of minizero::actor::ActorGroup (`-mode sp`, ref actor/actor_group.cpp:136-252)."""
 
-    def __init__(self, conf, desc=None, weights=None, device=0):
-        """desc / weights None: the network is read from the configuration's nn_file_name (.pt, or its .mzw sibling)"""
+    def __init__(self, conf, desc=None, weights=None, device=0, shared=None):
+        """desc / weights None: the network is read from the configuration's nn_file_name (.pt, or its .mzw sibling);
+        shared: a Net the worker runs ON instead of loading its own copy (BaseActor::setNetwork, mz_worker_create_shared)"""
         self.L = load()
-        if desc is None:
+        self.shared = shared  # keeps the caller's network alive
+        if shared is not None:
+            self.h = self.L.mz_worker_create_shared(device, conf.encode(), shared.h)
+            desc = shared.desc
+        elif desc is None:
             self.h = self.L.mz_worker_create(device, conf.encode(), None, None, 0)
         else:
             w = np.ascontiguousarray(weights, np.float32)
@@ -403,6 +439,11 @@ class Worker:
     def set_weights(self, weights):
         w = np.ascontiguousarray(weights, np.float32)
         _check(self.L, self.L.mz_worker_set_weights(self.h, _f(w), w.size))
+
+    def load_model(self, path, desc, weights):
+        """`load_model <path>` for a caller that has read the file already (one read for all devices: mz_weights_read)"""
+        w = np.ascontiguousarray(weights, np.float32)
+        return _check(self.L, self.L.mz_worker_load_model(self.h, path.encode(), C.byref(desc), _f(w), w.size))
 
     def run_cycles(self, n):
         return _check(self.L, self.L.mz_worker_run_cycles(self.h, n))

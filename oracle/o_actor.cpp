@@ -415,6 +415,37 @@ void Group::cycle() // ref actor_group.cpp:81-114 (one CPU phase + one GPU phase
     ++cycles_;
 }
 
+int Group::command(const std::string& line, const float* raw, size_t nraw) // ref actor_group.cpp:200-252
+{
+    const std::string prefix = line.substr(0, line.find(' '));
+    { // zero_actor_ignored_command (:204-212; default "reset_actors", configuration.cpp:47)
+        std::istringstream ign(cfg_.zero_actor_ignored_command);
+        std::string tok;
+        while (ign >> tok) { if (tok == prefix) { return 0; } }
+    }
+    if (prefix == "reset_actors") { // :222-225 — every actor's reset() on the MAIN thread, i.e. with the main thread's generator (utils/random.h:38 thread_local)
+        for (auto& a : actors_) {
+            Random* own = a->rng_;
+            a->rng_ = &main_rng_; a->mcts_.rng_ = &main_rng_; a->env_->rng_ = &main_rng_;
+            a->reset();
+            a->rng_ = own; a->mcts_.rng_ = own; a->env_->rng_ = own;
+        }
+        // do_cpu_job_ = true: the next cycle starts with a CPU phase — every cycle() does; nothing of the last GPU phase is consumed (batch ids are -1)
+    } else if (prefix == "load_model") { // :226-232 — config::nn_file_name = args[1]; every network re-reads the file
+        if (line.find(' ') == std::string::npos || !raw) { return -1; }
+        std::unique_ptr<Net> nn = Net::create(nd_, raw, nraw);
+        if (!nn) { return -1; }
+        cfg_.nn_file_name = line.substr(line.find(' ') + 1);
+        net_ = std::move(nn);
+        q_.net = net_.get();
+    } else if (prefix == "update_config") { // :233-241
+        if (line.find(' ') == std::string::npos || !cfg_.loadFromString(line.substr(line.find(' ') + 1))) { return -1; }
+    } else if (prefix == "start") { running_ = true; }
+    else if (prefix == "stop") { running_ = false; }
+    else if (prefix == "quit") { return 1; }
+    return 0; // anything else (keep_alive, ...) falls through handleCommand's chain
+}
+
 void Group::traceBefore(int i)
 {
     ZeroActor& a = *actors_[i];

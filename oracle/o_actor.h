@@ -45,6 +45,11 @@ class Group {
 public:
     Group(const Config& cfg, const NetDesc& nd, const float* raw, size_t nraw);
     void cycle();
+    // one line of the stdin protocol, applied between two cycles (ref actor_group.cpp:200-252: handleCommand runs on the main thread while
+    // do_cpu_job_ is true, i.e. after a GPU phase and before the next CPU phase); `raw` = the parameters of the file load_model names
+    // (the oracle reads no files).  1: quit, 0: done / ignored, -1: malformed
+    int command(const std::string& line, const float* raw, size_t nraw);
+    bool running_ = true; // the tests drive cycle() directly; `stop` / `start` gate mzo_group_cycles like running_ gates ActorGroup::run (:140)
     Config cfg_;
     NetDesc nd_;
     std::unique_ptr<Net> net_;

@@ -295,7 +295,17 @@ void* mzo_group_create(const char* conf, const NetDesc* d, const float* raw, lon
 }
 void mzo_group_destroy(void* g) { delete static_cast<Group*>(g); }
 void mzo_group_set_trace(void* g, int on) { static_cast<Group*>(g)->trace_ = on != 0; }
-void mzo_group_cycles(void* g, int n) { for (int i = 0; i < n; ++i) { static_cast<Group*>(g)->cycle(); } }
+// runs n cycles while the group is started (a `stop` command makes this a no-op like ActorGroup::run's `if (!running_) continue`, actor_group.cpp:140); cycles run
+int mzo_group_cycles(void* g, int n)
+{
+    Group* grp = static_cast<Group*>(g);
+    if (!grp->running_) { return 0; }
+    for (int i = 0; i < n; ++i) { grp->cycle(); }
+    return n;
+}
+// one protocol line between two cycles; raw/n: the parameters of the file a load_model line names
+int mzo_group_command(void* g, const char* line, const float* raw, long n) { return static_cast<Group*>(g)->command(line, raw, static_cast<size_t>(n)); }
+unsigned long long mzo_group_num_cycles(void* g) { return static_cast<Group*>(g)->cycles_; }
 unsigned long long mzo_group_leaf_evals(void* g) { return static_cast<Group*>(g)->q_.leaf_evals; }
 unsigned long long mzo_group_games(void* g) { return static_cast<Group*>(g)->games_; }
 int mzo_group_num_lines(void* g) { return static_cast<int>(static_cast<Group*>(g)->lines_.size()); }

@@ -122,6 +122,9 @@ def lib():
     L.mzo_group_destroy.argtypes = [C.c_void_p]
     L.mzo_group_set_trace.argtypes = [C.c_void_p, C.c_int]
     L.mzo_group_cycles.argtypes = [C.c_void_p, C.c_int]
+    L.mzo_group_command.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_long]
+    L.mzo_group_num_cycles.restype = C.c_ulonglong
+    L.mzo_group_num_cycles.argtypes = [C.c_void_p]
     L.mzo_group_leaf_evals.restype = C.c_ulonglong
     L.mzo_group_leaf_evals.argtypes = [C.c_void_p]
     L.mzo_group_games.restype = C.c_ulonglong
@@ -249,7 +252,17 @@ class OracleGroup:
         self.L.mzo_group_set_trace(self.h, int(on))
 
     def cycles(self, n):
-        self.L.mzo_group_cycles(self.h, n)
+        return self.L.mzo_group_cycles(self.h, n)
+
+    def command(self, line, weights=None):
+        """One stdin-protocol line between two cycles (ref actor_group.cpp:200-252); `weights` = the parameters of the file a load_model line names."""
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        rc = self.L.mzo_group_command(self.h, line.encode(), None if w is None else fptr(w), 0 if w is None else w.size)
+        assert rc >= 0, "oracle refused: " + line
+        return rc
+
+    def num_cycles(self):
+        return self.L.mzo_group_num_cycles(self.h)
 
     def leaf_evals(self):
         return self.L.mzo_group_leaf_evals(self.h)

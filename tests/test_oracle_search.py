@@ -99,3 +99,32 @@ def test_go_game_reaches_move_cap_and_scores(oracle):
     for l in lines:
         assert LINE.match(l), l
         assert "KM[7.500000]" in l and "GM[go_9x9]" in l and "SZ[9]" in l
+
+
+def test_group_commands_between_cycles(oracle):
+    """Group::command (ref actor_group.cpp:200-252) on the CPU: `stop` gates the cycles, an ignored reset_actors and a load_model of the SAME weights
+    change nothing, a load_model of other weights changes the records from that cycle on (and the EV tag), reset_actors outside the ignore list drops
+    the games in flight, update_config is seen by the next decision."""
+    conf = "env_game=tictactoe:actor_num_simulation=16:zero_num_parallel_games=4:program_seed=3:nn_file_name=/m/weight_iter_0.pt:zero_num_threads=1"
+    od = oracle.desc_c1()
+    w0, w1 = oracle.gen_weights(od, 0), oracle.gen_weights(od, 1)
+
+    def play(schedule, extra=""):
+        og = oracle.OracleGroup(conf + extra, od, w0)
+        for step in schedule:
+            if isinstance(step, int):
+                og.cycles(step)
+            else:
+                og.command(*step)
+        return og.lines(), og.peek_records(4), og.num_cycles()
+
+    base = play([17 * 30])
+    assert play([17 * 10 + 5, ("stop",), 50, ("start",), 17 * 20 - 5]) == base
+    assert play([17 * 10 + 5, ("reset_actors",), ("load_model /m/weight_iter_0.pt", w0), ("keep_alive",), 17 * 20 - 5]) == base
+    swapped = play([17 * 10 + 5, ("load_model /m/weight_iter_1.pt", w1), 17 * 20 - 5])
+    k = next(i for i, (a, b) in enumerate(zip(base[0], swapped[0])) if a != b)
+    assert k > 0 and all("EV[weight_iter_0.pt]" in l for l in swapped[0][:k]) and "EV[weight_iter_1.pt]" in swapped[0][-1]
+    reset = play([17 * 10 + 5, ("reset_actors",), 17 * 20 - 5], ":zero_actor_ignored_command=keep_alive")
+    assert reset[0][:len(base[0]) // 4] == base[0][:len(base[0]) // 4] and reset[0] != base[0] and reset[2] == base[2]
+    hot = play([17 * 10, ("update_config actor_select_action_softmax_temperature=0.05",), 17 * 20])
+    assert hot[0] != base[0] and hot[0][:3] == base[0][:3]
