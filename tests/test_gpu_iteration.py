@@ -30,6 +30,7 @@ GO_MZ_C4 = ("go_9x9", 18, 9, 9, 64, 9, 9, 1, 6, 82, 256, 1, "muzero")         # 
 OTH_AZ = ("othello_8x8", 4, 8, 8, 8, 8, 8, 1, 1, 65, 16, 1, "alphazero")
 OTH_AZ_C3 = ("othello_8x8", 4, 8, 8, 64, 8, 8, 1, 6, 65, 256, 1, "alphazero")  # configs[2]'s network: sim_kernel<8,8,4,64,0>
 ATARI = ("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari")
+ATARI_C5 = ("atari_ms_pacman", 32, 96, 96, 64, 6, 6, 18, 6, 18, 256, 601, "muzero_atari")  # configs[4]'s network: the Gumbel rounds' kernels
 TTT = ("tictactoe", 4, 3, 3, 16, 3, 3, 1, 2, 9, 256, 1, "alphazero")
 
 GUMBEL = ("actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:"
@@ -38,6 +39,10 @@ ATARI_CONF = ("env_game=atari:nn_type_name=muzero:actor_num_simulation=8:actor_u
               "actor_use_gumbel_noise=true:actor_gumbel_sample_size=4:actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:"
               "actor_mcts_reward_discount=0.997:atari_init_q=true:zero_actor_intermediate_sequence_length=6:learner_n_step_return=2:"
               "learner_muzero_unrolling_step=1:env_atari_episode_length=20:zero_num_parallel_games=4")
+ATARI_C5_CONF = ("env_game=atari:nn_type_name=muzero:actor_num_simulation=50:actor_use_dirichlet_noise=false:actor_use_gumbel=true:"
+                 "actor_use_gumbel_noise=true:actor_gumbel_sample_size=16:actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:"
+                 "actor_mcts_reward_discount=0.997:atari_init_q=true:zero_actor_intermediate_sequence_length=4:learner_n_step_return=1:"
+                 "learner_muzero_unrolling_step=1:env_atari_episode_length=12:zero_num_parallel_games=6")
 APPLY_RESET = "zero_actor_ignored_command=keep_alive"  # reset_actors out of the ignore list: the games in flight are dropped
 
 
@@ -140,9 +145,11 @@ CASES = {
     "go_az_c2_net": (GO_AZ_C2, "env_game=go:env_board_size=9:actor_num_simulation=24:zero_num_parallel_games=5", 25, 11, 13, 9, 12, 0),
     "go_mz_small": (GO_MZ, "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=10:zero_num_parallel_games=4", 11, 25, 6, 33, 250, 4),
     "go_mz_c4_net": (GO_MZ_C4, "env_game=go:env_board_size=9:nn_type_name=muzero:actor_num_simulation=20:zero_num_parallel_games=4", 21, 7, 10, 8, 9, 0),
-    "othello_gumbel_small": (OTH_AZ, f"env_game=othello:env_board_size=8:actor_num_simulation=16:{GUMBEL}:zero_num_parallel_games=9", 17, 20, 9, 22, 60, 9),
+    "othello_gumbel_small": (OTH_AZ, f"env_game=othello:env_board_size=8:actor_num_simulation=16:{GUMBEL}:zero_num_parallel_games=9", 17, 20, 9, 22, 75, 9),
     "othello_gumbel_c3_net": (OTH_AZ_C3, f"env_game=othello:env_board_size=8:actor_num_simulation=16:{GUMBEL}:zero_num_parallel_games=8", 17, 9, 5, 11, 48, 8),
     "atari_gumbel_small": (ATARI, ATARI_CONF, 9, 7, 3, 9, 20, 6),
+    # BASELINE configs[4]'s search and network on six games: the swap `mid` cycles into a move falls between two Gumbel rounds whose leaves are evaluated ahead
+    "atari_gumbel_c5_net": (ATARI_C5, ATARI_C5_CONF, 51, 2, 21, 2, 4, 1),
     "tictactoe": (TTT, "env_game=tictactoe:actor_num_simulation=16:zero_num_parallel_games=8", 17, 12, 7, 15, 40, 40),
 }
 
@@ -157,8 +164,10 @@ def test_iteration_with_games_in_flight(mz, oracle, tmp_path, name):
     lines, recs = b.compare(min_lines)
     text = "".join(lines) + "".join(recs)
     assert "EV[weight_iter_2.pt]" in text  # the tag follows the last load_model (base_actor.cpp:46)
-    if name in ("go_az_c2_net", "go_mz_c4_net", "othello_gumbel_c3_net", "go_az_small", "go_mz_small"):
+    if name in ("go_az_c2_net", "go_mz_c4_net", "othello_gumbel_c3_net", "go_az_small", "go_mz_small", "atari_gumbel_c5_net"):
         assert b.wk.stats()["sim_launches"] > 0  # the per-game simulation kernel is what ran
+    if name == "atari_gumbel_c5_net":
+        assert b.wk.stats()["pre_launches"] > 0  # ... with rounds of leaves evaluated ahead
 
 
 @pytest.mark.parametrize("name", ["go_az_small", "go_mz_small", "othello_gumbel_small", "atari_gumbel_small"])
