@@ -1,18 +1,11 @@
 // Shared declarations of libmzgpu (product).  HIP/gfx950 only; there is no CPU fallback anywhere.
 #pragma once
-#include "../../include/mzgpu.h"
+#include "common_host.h"
 #include <hip/hip_runtime.h>
-#include <cstdarg>
-#include <cstdio>
 #include <mutex>
-#include <string>
 #include <vector>
 
 namespace mz {
-
-void setError(const char* fmt, ...);
-bool compressToHex(const uint8_t* data, size_t n, std::string* hex); // gzhex.cpp: utils::compressString (ref utils/utils.h:35-91)
-const char* lastError();
 
 #define MZ_HIP(expr)                                                                                          \
     do {                                                                                                      \

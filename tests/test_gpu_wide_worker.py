@@ -132,6 +132,36 @@ def test_shape_without_any_instance_runs_lock_step(mz, oracle):
     _run(mz, oracle, GO.format(n=13, sims=6, games=3), args, [7 * 4 + 2], expect_sim=False)
 
 
+@pytest.mark.parametrize("game,n,c,blocks,sims,games,moves", [("go", 13, 96, 2, 8, 5, 6), ("go", 19, 128, 1, 6, 3, 3), ("go", 9, 80, 2, 10, 6, 8), ("go", 9, 192, 1, 8, 4, 5),
+                                                              ("othello", 8, 96, 2, 10, 6, 12), ("tictactoe", 3, 48, 1, 16, 8, 30)])
+def test_lock_step_shapes_play_on_the_device_rules(mz, oracle, game, n, c, blocks, sims, games, moves):
+    """Shapes with no simulation-kernel instance (19x19 x 128 channels; channel counts that are no 16 * 2^k: 48, 80, 96, 192) run the lock-step cycle — and since
+    round 6 with the leaf environment ON THE DEVICE (go_dev.hip: rules, planes, candidate sort), no host hop inside a move: records equal to the oracle's and to
+    the host-rules mode's, and no host environment time in the stats."""
+    name = {"go": f"go_{n}x{n}", "othello": "othello_8x8", "tictactoe": "tictactoe"}[game]
+    planes, A = (18, n * n + 1) if game == "go" else (4, 65 if game == "othello" else 9)
+    args = (name, planes, n, n, c, n, n, 1, blocks, A, 32, 1, "alphazero")
+    conf = f"env_game={game}:env_board_size={n}:actor_num_simulation={sims}:zero_num_parallel_games={games}"
+    cycles = (sims + 1) * moves + 3
+    kw = dict(vh=args[10], dv=args[11], type_name=args[12])
+    d, od = mz.make_desc(*args[:10], **kw), oracle.make_desc(*args[:10], **kw)
+    w = mz.generate_weights(d, 2)
+    conf += ":program_seed=11:nn_file_name=x.pt"
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    og.cycles(cycles)
+    out = {}
+    for mode in ("", ":mz_device_env=false"):
+        wk = mz.Worker(conf + mode, d, w)
+        wk.command("start")
+        assert wk.run_cycles(cycles) == cycles
+        st = wk.stats()
+        assert st["sim_launches"] == 0 and st["leaf_evals"] == og.leaf_evals()
+        assert (st["ms_env"] == 0) == (mode == ""), (mode, st["ms_env"])
+        out[mode] = (wk.pop_lines(), wk.peek_records(games))
+    assert out[""] == out[":mz_device_env=false"]
+    assert out[""][0] == og.lines() and out[""][1] == og.peek_records(games)
+
+
 # ---- MuZero board games on the one-tile tower (sim_wide_mz.hip sim_kernel_mz_wide) ----
 MZGO = "env_game=go:env_board_size={n}:nn_type_name=muzero:actor_num_simulation={sims}:zero_num_parallel_games={games}"
 
