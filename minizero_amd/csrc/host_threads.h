@@ -1,6 +1,6 @@
 // Host-side threading pieces of the worker (no device code, no HIP): the libstdc++ RNG wrapper, the CPU budget, the spin-wait thread pool behind every
 // parallel host section, and the background compressor of the Atari records' OBS tags.  A header of their own so that the sanitizer harness
-// (tests/csrc/host_stress.cpp: ThreadSanitizer / AddressSanitizer builds, `pytest -m "not gpu"`) compiles exactly the code the worker runs.
+// (tests/csrc/host_check.cpp: ThreadSanitizer / AddressSanitizer builds, `pytest -m "not gpu"`) compiles exactly the code the worker runs.
 #pragma once
 #include "common_host.h"
 #include <pthread.h>
@@ -150,9 +150,11 @@ public:
         // items of an epoch that does not exist yet — through a function object that may be gone (found by round 5's fuzz sweep under eight-fold CPU
         // oversubscription: a segmentation fault in about one of 3 000 cases).  With the state moved first, that compare-exchange fails and the worker leaves.
         state_.store((state_.load(std::memory_order_relaxed) & 0xffffffff00000000ull) | 0x7fffffffull, std::memory_order_release);
-        fn_ = &fn;
-        count_ = count;
-        chunk_ = std::max(1, count / (n_ * 4));
+        // (relaxed atomics, not plain fields: a late worker of the closed epoch may still be READING them in work() — its compare-exchange then fails, so the
+        // values it saw never matter, but a plain read beside these writes is a data race all the same: ThreadSanitizer, tests/test_sanitizers.py, round 6)
+        fn_.store(&fn, std::memory_order_relaxed);
+        count_.store(count, std::memory_order_relaxed);
+        chunk_.store(std::max(1, count / (n_ * 4)), std::memory_order_relaxed);
         processed_.store(0, std::memory_order_relaxed);
         const uint64_t epoch = (state_.load(std::memory_order_relaxed) >> 32) + 1;
         {
@@ -171,10 +173,13 @@ private:
             uint64_t s = state_.load(std::memory_order_acquire);
             if ((s >> 32) != epoch) { return; }
             const int b = static_cast<int>(s & 0xffffffffu);
-            if (b >= count_) { return; }
-            if (!state_.compare_exchange_weak(s, s + static_cast<uint64_t>(chunk_), std::memory_order_acq_rel)) { continue; }
-            const int e = std::min(count_, b + chunk_);
-            for (int i = b; i < e; ++i) { (*fn_)(i); }
+            const int count = count_.load(std::memory_order_relaxed), chunk = chunk_.load(std::memory_order_relaxed);
+            const std::function<void(int)>* fn = fn_.load(std::memory_order_relaxed);
+            if (b >= count) { return; }
+            // success: the state was still (epoch, b), so the epoch had not been closed when the three fields above were read — they are this epoch's
+            if (!state_.compare_exchange_weak(s, s + static_cast<uint64_t>(chunk), std::memory_order_acq_rel)) { continue; }
+            const int e = std::min(count, b + chunk);
+            for (int i = b; i < e; ++i) { (*fn)(i); }
             processed_.fetch_add(e - b, std::memory_order_release);
         }
     }
@@ -202,8 +207,8 @@ private:
     std::vector<std::thread> threads_;
     std::mutex mu_;
     std::condition_variable cv_;
-    const std::function<void(int)>* fn_ = nullptr;
-    int count_ = 0, chunk_ = 1;
+    std::atomic<const std::function<void(int)>*> fn_{nullptr};
+    std::atomic<int> count_{0}, chunk_{1};
     std::atomic<uint64_t> state_{0}; // epoch << 32 | next item
     std::atomic<int> processed_{0}, sleepers_{0};
     std::atomic<bool> quit_{false};
