@@ -73,7 +73,23 @@ def cpu_baseline(conf, seconds):
     return out
 
 
+def kernel_fingerprint():
+    """sha256 over the device sources of libmzgpu (every .hip / .h / .inc under minizero_amd/csrc, names and contents, sorted): what a committed counter summary
+    was taken on.  (`.git` does not travel to the GPU box, so a commit id cannot be read there.)"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "minizero_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
+    if "--kernel-fingerprint" in sys.argv:
+        print(kernel_fingerprint())
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed moves of every game (401 cycles each)")
@@ -232,13 +248,19 @@ def main():
         issued = achieved * (3.0 if bf else 1.0)
         # HBM traffic from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; the x2 on
         # gfx950 per MI355X_MICROARCH.md, re-calibrated on a known-size copy kernel with the same 4-B/lane access, see profiles/README.md)
-        traffic, traffic_src = None, None
-        for name in ("r05_pmc_sim.json", "r04_pmc_sim.json", "r03_pmc_sim.json", "r02_pmc_sim.json", "r01_pmc_sim.json"):
+        # The counters are not collected in this run (a --pmc pass is a rocprofv3 run of its own: tools/refresh_c2_pmc.sh); the summary file records which kernel
+        # SOURCES it was taken on (kernel_fingerprint below), and a file whose fingerprint is not the running build's is reported as stale, not as this build's.
+        traffic, traffic_src, traffic_stale = None, None, None
+        fp_now = kernel_fingerprint()
+        for name in ("r06_pmc_sim.json", "r05_pmc_sim.json", "r04_pmc_sim.json", "r03_pmc_sim.json", "r02_pmc_sim.json", "r01_pmc_sim.json"):
             try:
                 j = json.load(open(os.path.join(ROOT, "profiles", name)))
                 per_cycle = j.get("bytes_per_cycle", j.get("bytes_per_step"))
                 traffic = per_cycle * cpm * args.steps / launches
-                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this bench; bytes per lock-step cycle x cycles per average launch)"
+                traffic_stale = j.get("kernel_fingerprint") != fp_now
+                traffic_src = (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this bench; bytes per lock-step cycle x cycles per average launch)" +
+                               (f" — STALE: taken on kernel sources {j.get('kernel_fingerprint', 'unrecorded')}, this build is {fp_now}" if traffic_stale else
+                                f"; taken on this build's kernel sources ({fp_now})"))
                 break
             except Exception:
                 pass
@@ -270,7 +292,7 @@ def main():
                                    ("sim_kernel<9,9,20,64,2> (per game: PUCT select, Go leaf position/planes/legal mask, stem + 12 x conv3x3 64->64 on "
                                     "v_mfma_f32_16x16x4_f32 with activations in LDS, heads, candidate sort, expand + backup)"),
                          "bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s",
-                         "frac": issued / peak, "f32_equivalent_tflops": achieved, "traffic": None if bf else traffic, "traffic_source": None if bf else traffic_src,
+                         "frac": issued / peak, "f32_equivalent_tflops": achieved, "traffic": None if bf else traffic, "traffic_source": None if bf else traffic_src, "traffic_stale": None if bf else traffic_stale,
                          "launches": launches, "avg_launch_ms": gpu_ms / launches, "flops_per_avg_launch": flops_total / launches,
                          "flops_per_leaf_eval": flops_per_eval, "gpu_ms_per_step": gpu_ms / args.steps,
                          "timing": "HIP events on the worker's stream around every sim_kernel launch of the timed region (a move = three launches of 1 + 16 + 384 cycles queued back to back, so that the host's noise / rotation draws overlap them)",
@@ -288,8 +310,9 @@ def main():
             import run_configs
             out["other_configs"] = {}
             for key in ("c3", "c4", "c5"):
-                # (C5's moves are 3.5 ms each: 30 of them are 0.1 s, and one host hiccup on a loaded box showed as 0.64 M instead of 0.92 M in a round-5 line — its leg is four times as many moves)
-                r = run_configs.run_config(key, moves=args.other_moves * (4 if key == "c5" else 1))
+                # (C5's moves are 3.5 ms each: 30 of them are 0.1 s, and one host hiccup on a loaded box showed as 0.64 M instead of 0.92 M in a round-5 line — its leg is
+                # twenty times as many moves: 600 moves = 2.1 s of timed region since round 6)
+                r = run_configs.run_config(key, moves=args.other_moves * (20 if key == "c5" else 1))
                 out["other_configs"][key] = {"workload": r["config"], "leaf_evals_per_sec": r["leaf_evals_per_sec"], "ms_per_move": r["ms_per_move"],
                                              "games_in_pool": r["games_in_pool"], "moves_timed": r["moves_timed"], "host_threads": r["host_threads"],
                                              "roofline": {k: r["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "launches_by_kernel", "flops_per_leaf_eval", "wall_frac")}}

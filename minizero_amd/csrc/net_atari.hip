@@ -287,20 +287,47 @@ int Net::initialAtari(const float* d_feat, int B, float* d_policy, float* d_logi
     static const int parts_env = getenv("MZ_REPR_PARTS") ? atoi(getenv("MZ_REPR_PARTS")) : 2; // (A/B switch; 1 = the whole batch on the network's stream)
     const int parts = std::max(1, std::min({parts_env, kReprParts, B / 16}));
     if (parts > 1) {
-        if (!at_fork_) {
-            for (hipStream_t& s : at_streams_) { MZ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
-            for (hipEvent_t& e : at_join_) { MZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
-            MZ_HIP(hipEventCreateWithFlags(&at_fork_, hipEventDisableTiming));
+        if (!at_fork_) { // all or nothing: a failure half-way destroys what was made, so the next call starts from scratch instead of leaking the first set
+            hipStream_t ns[kReprParts - 1] = {};
+            hipEvent_t nj[kReprParts - 1] = {}, nf = nullptr;
+            hipError_t e = hipSuccess;
+            for (int k = 0; k < kReprParts - 1 && e == hipSuccess; ++k) { e = hipStreamCreateWithFlags(&ns[k], hipStreamNonBlocking); }
+            for (int k = 0; k < kReprParts - 1 && e == hipSuccess; ++k) { e = hipEventCreateWithFlags(&nj[k], hipEventDisableTiming); }
+            if (e == hipSuccess) { e = hipEventCreateWithFlags(&nf, hipEventDisableTiming); }
+            if (e != hipSuccess) {
+                for (hipStream_t q : ns) { if (q) { (void)hipStreamDestroy(q); } }
+                for (hipEvent_t q : nj) { if (q) { (void)hipEventDestroy(q); } }
+                setError("muzero_atari representation: side streams / events: %s", hipGetErrorString(e));
+                return MZ_ERR_DEVICE;
+            }
+            for (int k = 0; k < kReprParts - 1; ++k) { at_streams_[k] = ns[k]; at_join_[k] = nj[k]; }
+            at_fork_ = nf;
         }
         MZ_HIP(hipEventRecord(at_fork_, stream_)); // the features, and every earlier reader of the buffers
-        for (int k = parts - 1; k >= 0; --k) {
+        // Whatever happens below, the side streams are joined before this function returns: a part that failed half-way must not leave another part's
+        // kernels running on at_buf_ / at_out_ while the caller (or the next call's re-allocation, which only waits for stream_) goes on.
+        int first_error = MZ_OK;
+        bool forked[kReprParts] = {};
+        for (int k = parts - 1; k >= 0 && first_error == MZ_OK; --k) {
             const int first = int(size_t(B) * k / parts), end = int(size_t(B) * (k + 1) / parts);
             hipStream_t s = k == 0 ? stream_ : at_streams_[k - 1];
-            if (k > 0) { MZ_HIP(hipStreamWaitEvent(s, at_fork_, 0)); }
-            if ((rc = chain(first, end - first, s))) { return rc; }
-            if (k > 0) { MZ_HIP(hipEventRecord(at_join_[k - 1], s)); }
+            if (k > 0) {
+                if (hipStreamWaitEvent(s, at_fork_, 0) != hipSuccess) { setError("muzero_atari representation: hipStreamWaitEvent failed"); first_error = MZ_ERR_DEVICE; break; }
+                forked[k] = true;
+            }
+            if ((rc = chain(first, end - first, s))) { first_error = rc; }
         }
-        for (int k = 1; k < parts; ++k) { MZ_HIP(hipStreamWaitEvent(stream_, at_join_[k - 1], 0)); }
+        for (int k = 1; k < parts; ++k) {
+            if (!forked[k]) { continue; }
+            if (first_error == MZ_OK) {
+                if (hipEventRecord(at_join_[k - 1], at_streams_[k - 1]) != hipSuccess || hipStreamWaitEvent(stream_, at_join_[k - 1], 0) != hipSuccess) {
+                    setError("muzero_atari representation: joining a side stream failed");
+                    first_error = MZ_ERR_DEVICE;
+                }
+            }
+            if (first_error != MZ_OK) { (void)hipStreamSynchronize(at_streams_[k - 1]); } // error path: a plain wait (the error message of the first failure stays)
+        }
+        if (first_error != MZ_OK) { return first_error; }
     } else if ((rc = chain(0, B, stream_))) {
         return rc;
     }

@@ -443,13 +443,29 @@ int launchConvBand(const ConvLayer& L, const float* params, const float* in, con
     // (the plan of a layer shape and batch is remembered: the search over band heights is tens of microseconds of host time, a lock-step cycle asks for 13 of them)
     BandPlan bp;
     {
-        static std::mutex mu;
-        static std::map<std::array<int, 6>, BandPlan> plans;
+        // a few remembered plans per host thread in front of the shared table (no lock on the per-cycle path: a trunk asks for two keys, stem and body, thirteen
+        // times a cycle); the shared table is bounded — a caller that varies B without end starts over instead of growing it
         const std::array<int, 6> key{H, W, L.cin_pad, L.cout_pad / 16, B, cus};
-        std::lock_guard<std::mutex> lock(mu);
-        auto it = plans.find(key);
-        if (it == plans.end()) { it = plans.emplace(key, planBand(H, W, L.cin_pad, L.cout_pad / 16, B, cus)).first; }
-        bp = it->second;
+        struct Recent { std::array<int, 6> key; BandPlan plan; bool valid = false; };
+        thread_local Recent recent[4];
+        thread_local int recent_next = 0;
+        bool hit = false;
+        for (const Recent& r : recent) { if (r.valid && r.key == key) { bp = r.plan; hit = true; break; } }
+        if (!hit) {
+            static std::mutex mu;
+            static std::map<std::array<int, 6>, BandPlan> plans;
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                auto it = plans.find(key);
+                if (it == plans.end()) {
+                    if (plans.size() >= 1024) { plans.clear(); }
+                    it = plans.emplace(key, planBand(H, W, L.cin_pad, L.cout_pad / 16, B, cus)).first;
+                }
+                bp = it->second;
+            }
+            recent[recent_next] = Recent{key, bp, true};
+            recent_next = (recent_next + 1) % 4;
+        }
     }
     static const char* const force_th = getenv("MZ_BAND_TH"); // (experiments: a forced band height / tiles per job / waves, where the patch fits; read once)
     static const char* const force_gm = getenv("MZ_BAND_GM");

@@ -151,7 +151,12 @@ constexpr int kGw = 4, kLv = 64 / kGw;                          // lanes per pre
 #ifndef MZ_SPEC_WAYS
 #define MZ_SPEC_WAYS 16 // (a translation unit whose kernels have little LDS to spare defines fewer — a power of two: sim_wide_c.hip, 19x19 Go)
 #endif
+// MZ_SPEC_WAYS is a PER-TRANSLATION-UNIT choice: kSpecWays and everything derived from it (kSpecHelp, kSpecWords, the layouts selectBody walks) have internal
+// linkage (namespace-scope constexpr) and are only used by device code of the same unit — the library is built without relocatable device code, so no kernel or
+// device function is shared between units — and by that unit's OWN host-side LDS sizing.  A host function or a kernel instantiation shared between units must
+// never read them; each unit that sizes LDS from kSpecWords states the value it was built with (MZ_SPEC_WAYS_IS below).
 constexpr int kSpecWays = MZ_SPEC_WAYS;                         // remembered paths (one per recently walked root child)
+#define MZ_SPEC_WAYS_IS(n) static_assert(mz::kSpecWays == (n), "this translation unit sizes its LDS for " #n " remembered paths (pool_body.h MZ_SPEC_WAYS)")
 static_assert((kSpecWays & (kSpecWays - 1)) == 0 && kSpecWays >= 2 && kSpecWays <= 64, "a power of two of at most one wave's lanes");
 // Helper segments (selectSpecHelper): while wave 0 walks levels 1 .. 16 of a remembered path, waves 1 .. 3 evaluate levels 17 .. 32, 33 .. 48 and 49 .. 64 of the path the
 // PREVIOUS walk took, each into its own result block; wave 0 takes a block over when it arrives at the block's entry node with all 16 levels before it accepted.

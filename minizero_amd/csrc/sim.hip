@@ -3,6 +3,8 @@
 
 namespace mz {
 
+MZ_SPEC_WAYS_IS(16); // (the launch code of this unit computes LDS sizes from kSpecWords)
+
 template <int H, int W, int CIN0_PAD, int CDYN_PAD, int CPAD>
 __global__ __launch_bounds__(512) void sim_kernel_mz(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start, int pre_epoch)
 {
@@ -558,14 +560,16 @@ int Net::uploadSimArgs(const SimArgs& a)
 
 bool Net::hasSimKernelWide(int board_n, int env_kind, int num_simulation) const
 {
-    if (desc_.type != 0 || !use_fused_ || repr_.empty()) { return false; }
+    // (precision_: simLaunch takes the wide path for the f32 tower only — one predicate for "is there a kernel" and "will it be launched", so that a shape
+    // that ever has both a bf16x3 tower and a wide instance falls back to the lock-step mode at init instead of failing at its first launch)
+    if (desc_.type != 0 || !use_fused_ || repr_.empty() || precision_ != 0) { return false; }
     HeadParams hp;
     makeHeadParams(&hp);
     GoDevView gv{};
     gv.n = board_n; gv.P = board_n * board_n; gv.W = (gv.P + 63) / 64; gv.Ppad = 64 * gv.W; gv.A = desc_.action_size;
     const int max_depth = num_simulation + 3;
     size_t scratch = std::max(std::max(goLeafSmemBytes(gv, max_depth), azCandSmemBytes(gv.A)), gumbelSmemBytes(gv.A));
-    scratch = std::max(scratch, size_t(2) * (size_t(num_simulation) + 8) * sizeof(float));
+    scratch = std::max(scratch, size_t(2) * (size_t(num_simulation) + 8) * sizeof(float)); // >= the launch's 2 * bound_cap (pool.hip: bound_cap <= n + 3): never says yes to a plan the launch refuses
     return simWidePlan(board_n, env_kind, num_simulation, hp, desc_.num_input_channels, (gv.P + 31) / 32, goLeafSmemBytes(gv, max_depth), scratch, nullptr, nullptr, nullptr);
 }
 
@@ -598,7 +602,7 @@ int Net::simLaunch(Pool& pool, const GoDevView& gv, float* d_policy, float* d_lo
     SimArgs a;
     memset(&a, 0, sizeof(a)); // compared bytewise below: no indeterminate padding
     int c0 = 0;
-    const bool wide = precision_ == 0 && hasSimKernelWide(gv.n, gv.kind, pool.v_.max_depth - 3);
+    const bool wide = hasSimKernelWide(gv.n, gv.kind, pool.v_.max_depth - 3); // (false for the bf16x3 tower)
     if (wide) { if (!makeWideArgs(repr_, true, &a.ta, &c0)) { return MZ_OK; } }
     else if (!makeTowerArgs(repr_, true, true, &a.ta, &c0)) { return MZ_OK; }
     int rc = ensureBatch(gv.games);

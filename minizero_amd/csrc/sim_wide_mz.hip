@@ -10,6 +10,8 @@
 
 namespace mz {
 
+MZ_SPEC_WAYS_IS(16); // (the launch code of this unit computes LDS sizes from kSpecWords)
+
 template <int H, int W, int CIN0Q, int CDYNQ, int C>
 __global__ __launch_bounds__(512) void sim_kernel_mz_wide(const SimArgs* __restrict__ a_, int sim0, int nsims, int host_start, int lf)
 {

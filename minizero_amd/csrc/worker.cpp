@@ -315,7 +315,18 @@ private:
     struct Round { int s0, R; float p_event = 0.0f; bool alt = false; }; // p_event: share of the recent moves in which a simulation of the round missed its leaf / took the second one
     std::vector<unsigned> prestat_prev_; // the counters as of the previous move (summed over the lanes)
     void adaptRounds();
-    bool pairsUsable() { return cfg_.mz_sim_round_pairs && lanes_.size() == 1 && net0().pairsAvailable() && (counted_device_ < 0 || g_workers_on_device[counted_device_].load() == 1); } // two workgroups per leaf (sim.hip sim_pre_pair_kernel_mz)
+    bool pairsUsable() // two workgroups per leaf (sim.hip sim_pre_pair_kernel_mz)
+    {
+        if (!(cfg_.mz_sim_round_pairs && lanes_.size() == 1 && net0().pairsAvailable())) { return false; }
+        const int sharing = counted_device_ < 0 ? 1 : g_workers_on_device[counted_device_].load();
+        if (sharing == 1) { return true; }
+        if (!pairs_off_logged_) { // said once: otherwise nothing explains the slower rounds (an idle or not yet collected worker object on the device is enough)
+            pairs_off_logged_ = true;
+            fprintf(stderr, "[mzgpu] device %d carries %d workers of this process: sim_pre_pair_kernel_mz (two workgroups per leaf) stays off for this worker\n", device_, sharing);
+        }
+        return false;
+    }
+    bool pairs_off_logged_ = false;
     int slab_slots_ = 0;        // hidden-state slots per game
     std::vector<Round> rounds_; // mz_sim_rounds: the rounds of a move whose leaves are evaluated ahead (first simulation, size), from the Gumbel schedule of (n, m)
     void planRounds();

@@ -182,3 +182,46 @@ def test_tictactoe_device_engine_matches_host_engine(mz):
     for g in range(60):
         total += _play_and_compare_game(mz, "tictactoe", "env_game=tictactoe", 3, 4, 9, 7 + g, 9, (g % 3) / 3.0)
     assert total >= 60 * 5
+
+
+def test_device_known_answers(mz):
+    """tests/test_go_known_answers.py on the DEVICE engine (go_dev.hip): positions whose outcome follows from the Tromp-Taylor rule text (capture, suicide,
+    ko / positional superko, area scoring read through the winner under two komi values) and the reference's empty-board quirk — every move made on the device
+    (root_prefix = 0), the legal mask / terminal flag / result read after each."""
+    import test_go_known_answers as K
+    n, PASS, p = K.N, K.PASS, K.p
+
+    def run(moves, komi=0.5):
+        feat, legal, term, ev, pl = mz.godev_playout(n, komi, moves, 0, [0] * (len(moves) + 1))
+        return legal, term, ev, pl  # index s = the position after s moves
+
+    legal, term, ev, pl = run(K.CAPTURE + [PASS])
+    k = len(K.CAPTURE)
+    assert legal[k - 1][p(2, 2)] == 0                      # occupied by white before the capture
+    assert pl[k] == 2 and legal[k][p(2, 2)] == 0           # white: suicide
+    assert legal[k][p(0, 0)] == 1 and legal[k][PASS] == 1
+    assert pl[k + 1] == 1 and legal[k + 1][p(2, 2)] == 1   # black may fill its own eye
+    legal, term, ev, pl = run(K.KO + [p(4, 4), p(4, 0), p(1, 1)])
+    k = len(K.KO)
+    assert pl[k] == 2 and legal[k][p(1, 1)] == 0           # immediate recapture
+    assert legal[k + 2][p(1, 1)] == 1                      # after a threat and its answer
+    assert pl[k + 3] == 1 and legal[k + 3][p(1, 2)] == 0   # and now black may not retake at once
+    legal, term, ev, pl = run([PASS, p(0, 1), PASS, p(1, 0)])
+    assert legal[4][p(0, 0)] == 0                          # multi-stone suicide in the corner
+    legal, term, ev, pl = run([p(0, 2), p(0, 1), p(1, 1), p(1, 0), p(2, 0), PASS, p(0, 0)])
+    assert legal[6][p(0, 0)] == 1 and legal[7][p(0, 1)] == 0 and legal[7][p(1, 0)] == 0  # the capture makes the liberty; both emptied points are suicide for white
+
+    def area_difference_is(moves, diff):
+        for komi, want in ((diff - 0.5, 1.0), (diff + 0.5, -1.0), (float(diff), 0.0)):
+            legal, term, ev, pl = run(moves, komi)
+            assert term[len(moves)] == 1 and not term[:len(moves)].any()
+            assert ev[len(moves)] == want, (moves, komi, ev[len(moves)])
+
+    area_difference_is([PASS, PASS], 25)                   # the reference's empty-board quirk (go.cpp:713)
+    area_difference_is([p(2, 2), PASS, PASS], 25)
+    area_difference_is([p(2, 2), p(0, 0), PASS, PASS], 0)
+    area_difference_is(K.CAPTURE + [PASS, PASS], 4)
+    area_difference_is([p(0, 2), p(0, 4), p(1, 2), PASS, p(2, 2), PASS, p(3, 2), PASS, p(4, 2), PASS, PASS], 14)
+    walls = [m for r in range(5) for m in (p(r, 1), p(r, 3))]
+    area_difference_is(walls + [PASS, PASS], 0)
+    area_difference_is(walls + [p(2, 2), PASS, PASS], 1)

@@ -14,6 +14,7 @@ many cycles they applied each command so that the run can be replayed on the ora
 import os
 import re
 import subprocess
+import sys
 import threading
 import time
 
@@ -53,8 +54,16 @@ def descs(mz, oracle, args):
 
 def write_weights(mz, path, d, w, fmt):
     if fmt == "pt":
-        import pt_writer
-        pt_writer.write_pt(path, d, w)
+        # torch in a process of its own: importing it here would put a second copy of the HIP runtime (torch's bundled one) beside the one libmzgpu runs on
+        np.save(path + ".blob.npy", np.ascontiguousarray(w, np.float32))
+        open(path + ".desc.bin", "wb").write(bytes(d))
+        code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import pt_writer; from minizero_amd.lib import NetDesc; "
+                "d = NetDesc.from_buffer_copy(open(%r, 'rb').read()); pt_writer.write_pt(%r, d, np.load(%r))") % (
+                    os.path.join(ROOT, "tests"), ROOT, path + ".desc.bin", path, path + ".blob.npy")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        os.remove(path + ".blob.npy")
+        os.remove(path + ".desc.bin")
     else:
         from minizero_amd.export_weights import write_mzw
         write_mzw(path[:-3] + ".mzw", d, w)

@@ -164,3 +164,10 @@ def test_capacity_and_argument_errors(mz):
         pool.expand_backup(np.array([9, 0], np.int32), np.zeros((2, 4), np.int32), z, z, np.array([2, 2], np.int32), np.zeros(2, np.float32))
     with pytest.raises(mz.MzError):
         mz.Pool(0, 5, 4, 4)
+
+
+@pytest.mark.parametrize("case", __import__("hand_cases").ALL, ids=lambda c: c.__name__)
+def test_hand_computed_search_cases(mz, case):
+    """tests/hand_cases.py: the expectations come from the reference's formulas worked out by hand (numpy f32 / f64), not from the oracle"""
+    import hand_cases
+    case(lambda conf: hand_cases.PoolAdapter(mz, conf))

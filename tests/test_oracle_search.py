@@ -128,3 +128,10 @@ def test_group_commands_between_cycles(oracle):
     assert reset[0][:len(base[0]) // 4] == base[0][:len(base[0]) // 4] and reset[0] != base[0] and reset[2] == base[2]
     hot = play([17 * 10, ("update_config actor_select_action_softmax_temperature=0.05",), 17 * 20])
     assert hot[0] != base[0] and hot[0][:3] == base[0][:3]
+
+
+@pytest.mark.parametrize("case", __import__("hand_cases").ALL, ids=lambda c: c.__name__)
+def test_hand_computed_search_cases(oracle, case):
+    """tests/hand_cases.py: paper-and-pencil PUCT / init-Q / backup / value-bound cases, here against the oracle's tree (the HIP pool: tests/test_gpu_pool.py)"""
+    import hand_cases
+    case(lambda conf: hand_cases.OracleAdapter(oracle, conf))

@@ -22,16 +22,20 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc1b -- python bench.py $SHORT > $O/bench_pmc1b.json 2> $O/pmc1b.err
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc2 -- python bench.py $SHORT > $O/bench_pmc2.json 2> $O/pmc2.err
 python - <<'PY'
-import csv, glob, json, collections
+import csv, glob, json, collections, subprocess, sys
 O = "gpurun_out/refresh"
+names = {}
+FP = subprocess.check_output([sys.executable, "bench.py", "--kernel-fingerprint"], text=True).strip()  # the kernel sources these counters were taken on (bench.py compares)
 def load(d):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+    global names
     for f in glob.glob(f"{O}/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             # (the simulation kernels of a config: sim_kernel / sim_kernel_mz / sim_kernel_mz_cluster and, with Gumbel rounds, the kernels that evaluate a round's leaves
             # ahead: sim_pre_kernel_mz, sim_pre_pair_kernel_mz, the batched pipeline pre_walk / pre_tower / pre_fc / pre_tail of sim_rounds.hip)
             kn = r["Kernel_Name"]
             k = "sim_kernel" if any(t in kn for t in ("sim_kernel", "sim_pre_kernel", "sim_pre_pair_kernel", "pre_walk_kernel", "pre_tower_kernel", "pre_fc_kernel", "pre_tail_kernel")) else kn.split("(")[0][-40:]
+            names.setdefault(k, set()).add(kn.split("(")[0].replace("void mz::", ""))
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] in ("FETCH_SIZE", "GRBM_GUI_ACTIVE"): n[k] += 1
     return acc, n
@@ -40,7 +44,7 @@ def summarize(tag, a_dir, b_dir, c_dir, cycles, note):
     out = {}
     if "sim_kernel" in a and "sim_kernel" in aw:
         f, w = a["sim_kernel"]["FETCH_SIZE"], aw["sim_kernel"]["WRITE_SIZE"]
-        out.update({"kernel": "sim_kernel", "dispatches": n["sim_kernel"], "lockstep_cycles": cycles, "FETCH_SIZE_KB_total": f, "WRITE_SIZE_KB_total": w,
+        out.update({"kernel": "sim_kernel", "kernel_names": sorted(names.get("sim_kernel", [])), "kernel_fingerprint": FP, "dispatches": n["sim_kernel"], "lockstep_cycles": cycles, "FETCH_SIZE_KB_total": f, "WRITE_SIZE_KB_total": w,
                     "bytes_per_cycle": (2.0 * f + w) * 1024.0 / cycles,
                     "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950: FETCH_SIZE reports half of the bytes, MI355X_MICROARCH.md HBM section; re-calibrated on a copy kernel), " + note})
     if "sim_kernel" in b:
