@@ -114,7 +114,7 @@ protected:
         std::string command;
         while (!quit_.load() && getline(std::cin, command)) {
             const std::string prefix = command.substr(0, command.find(' '));
-            if (!isIgnored(prefix)) { std::cerr << "[command] " << command << std::endl; }
+            if (!isIgnored(prefix)) { logLine("[command] " + command); }
             Command c{command, nullptr};
             if (prefix == "load_model" && !isIgnored(prefix) && command.find(' ') != std::string::npos) { c.weights = readWeights(command.substr(command.find(' ') + 1)); }
             {
@@ -133,6 +133,13 @@ protected:
         mz_weights* w = mz_weights_read(path.c_str());
         if (!w) { std::cerr << mz_last_error() << std::endl; exit(0); }
         return std::shared_ptr<mz_weights>(w, mz_weights_free);
+    }
+
+    // one stderr line, whole: the stdin thread and the device threads all log (chained << on the unbuffered std::cerr interleave inside a line)
+    void logLine(const std::string& line)
+    {
+        std::lock_guard<std::mutex> lock(err_mutex_);
+        std::cerr << line + "\n" << std::flush;
     }
 
     bool isIgnored(const std::string& prefix) const // zero_actor_ignored_command (ref actor_group.cpp:204-212)
@@ -177,9 +184,9 @@ protected:
             if (prefix == "load_model" || prefix == "reset_actors" || prefix == "update_config" || prefix == "start" || prefix == "stop") {
                 mz_worker_stats st;
                 if (mz_worker_get_stats(d.worker, &st) == MZ_OK) {
-                    std::ostringstream oss; // one write: device threads share stderr
-                    oss << "[mzgpu] device " << (&d - devices_.data()) << ": " << command << " after " << st.cycles << " cycles\n";
-                    std::cerr << oss.str() << std::flush;
+                    std::ostringstream oss;
+                    oss << "[mzgpu] device " << (&d - devices_.data()) << ": " << command << " after " << st.cycles << " cycles";
+                    logLine(oss.str());
                 }
             }
             if (prefix == "start") { d.running = true; }
@@ -215,7 +222,7 @@ protected:
     std::string conf_;
     int gpu_id_;
     std::vector<Device> devices_;
-    std::mutex mutex_, out_mutex_;
+    std::mutex mutex_, out_mutex_, err_mutex_;
     struct Command { std::string line; std::shared_ptr<mz_weights> weights; }; // weights: the parsed file of a load_model line
     std::deque<Command> commands_;
     std::shared_ptr<mz_weights> first_weights_;

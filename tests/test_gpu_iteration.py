@@ -352,3 +352,75 @@ def test_iterations_through_the_sp_executable(mz, oracle, tmp_path, name, game, 
     assert all(cursor[g] == len(expected[g]) for g in range(G)), {g: (cursor[g], len(expected[g])) for g in range(G)}
     text = "".join(x.lines)
     assert "EV[weight_iter_0.pt]" in text and "EV[weight_iter_1.pt]" in text and "EV[weight_iter_2.pt]" in text
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# randomised schedules: commands at random cycle counts (inside searches, at move boundaries, back to back), random live configuration changes
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def _seed_range(var, default):
+    v = os.environ.get(var)
+    if not v:
+        return default
+    lo, hi = v.split(":")
+    return list(range(int(lo), int(hi)))
+
+
+FUZZ_BASE = ["go_az_small", "go_mz_small", "othello_gumbel_small", "tictactoe", "atari_gumbel_small", "go_az_c2_net", "othello_gumbel_c3_net"]
+
+
+def _live_keys(rng, gumbel, muzero):
+    """configuration keys the reference reads at every use (config:: globals) and the worker does not turn into device state at creation"""
+    opts = [f"actor_select_action_softmax_temperature={rng.choice([0.25, 0.5, 1.0, 2.0])}",
+            f"actor_resign_threshold={rng.choice([-0.95, -0.8, -0.5, 0.3])}",
+            f"zero_disable_resign_ratio={rng.choice([0.0, 0.1, 0.5, 1.0])}",
+            "actor_select_action_by_count=true:actor_select_action_by_softmax_count=false",
+            "actor_select_action_by_count=false:actor_select_action_by_softmax_count=true"]
+    if gumbel:
+        opts += [f"actor_use_gumbel_noise={rng.choice(['true', 'false'])}"]
+    else:
+        opts += [f"actor_dirichlet_noise_epsilon={rng.choice([0.1, 0.25, 0.5])}", f"actor_dirichlet_noise_alpha={rng.choice([0.03, 0.3, 1.0])}",
+                 f"actor_use_dirichlet_noise={rng.choice(['true', 'false'])}"]
+    if not muzero:
+        opts += [f"actor_use_random_rotation_features={rng.choice(['true', 'false'])}"]
+    k = int(rng.integers(1, 3))
+    return ":".join(rng.choice(opts, size=k, replace=False))
+
+
+@pytest.mark.parametrize("seed", _seed_range("MZ_FUZZ_ITER_SEEDS", list(range(14))))
+def test_random_iteration_schedules(mz, oracle, tmp_path, seed):
+    """A schedule drawn from the seed: which game / network / way in, whether reset_actors applies, and 3-7 segments of `run some cycles` followed by a few
+    protocol lines (stop + start, update_config of live keys, load_model of other weights, reset_actors, keep_alive) — the worker and the oracle get the same lines
+    at the same cycle counts; every finished line and every unfinished record must be equal at the end.  MZ_FUZZ_ITER_SEEDS=lo:hi for longer sweeps."""
+    rng = np.random.default_rng(1000 + seed)
+    name = FUZZ_BASE[seed % len(FUZZ_BASE)] if seed < 2 * len(FUZZ_BASE) else str(rng.choice(FUZZ_BASE))
+    args, conf, cpm, *_ = CASES[name]
+    via = str(rng.choice(["worker", "shared", "blob"]))
+    apply_reset = rng.random() < 0.4
+    b = Both(mz, oracle, tmp_path, conf + (":" + APPLY_RESET if apply_reset else ""), args, via=via, seed=int(rng.integers(1, 1000)), threads=int(rng.choice([1, 2, 4])))
+    gumbel, muzero = "actor_use_gumbel=true" in conf, "nn_type_name=muzero" in conf
+    heavy = name.endswith("_net") or name.startswith("atari")
+    b.send("start")
+    it = 0
+    for _ in range(int(rng.integers(3, 8))):
+        moves = int(rng.integers(1, 6 if heavy else 25))
+        b.run(cpm * moves + (int(rng.integers(0, cpm)) if rng.random() < 0.7 else 0))
+        stopped = rng.random() < 0.6
+        if stopped:
+            b.send("stop")
+            if rng.random() < 0.3:
+                b.run(int(rng.integers(1, 20)), expect=0)
+        for _k in range(int(rng.integers(0, 4))):
+            what = rng.random()
+            if what < 0.35:
+                b.send("update_config " + _live_keys(rng, gumbel, muzero))
+            elif what < 0.7:
+                it += 1
+                b.load_model(it)
+            elif what < 0.9:
+                b.send("reset_actors")
+            else:
+                b.send("keep_alive")
+        if stopped:
+            b.send("start")
+    b.run(cpm * int(rng.integers(1, 4 if heavy else 30)))
+    b.compare(0)

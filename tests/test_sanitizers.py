@@ -137,3 +137,38 @@ def test_parsers_under_asan_ubsan(mz, oracle, binaries, tmp_path):
     assert "fuzz-gz ok" in run(b, "fuzz-gz", 300, 4)
     for game, size in [("tictactoe", 3), ("othello", 8), ("go", 9), ("go", 19), ("atari", 0)]:
         assert "fuzz-env ok" in run(b, "fuzz-env", game, size, 20000 if game != "atari" else 300, 6)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_iteration_schedules_on_the_host_half(oracle, binaries, seed):
+    """tests/test_gpu_iteration.py::test_random_iteration_schedules without a GPU: random protocol lines (stop / start, live update_config keys, load_model of
+    other weights, reset_actors) at random cycle counts through the worker's host half (ASan + UBSan build, T = 4 streams), records equal to the oracle's"""
+    import numpy as np
+    from test_gpu_iteration import _live_keys
+    rng = np.random.default_rng(500 + seed)
+    name = ["tictactoe", "go_noise_resign", "othello_gumbel", "go_muzero", "tictactoe_muzero_gumbel"][seed % 5]
+    args, conf, _, _ = WORKER_CASES[name]
+    cpm = int(conf.split("actor_num_simulation=")[1].split(":")[0]) + 1
+    if rng.random() < 0.4:
+        conf += ":zero_actor_ignored_command=keep_alive"
+    steps, it = [], 0
+    for _ in range(int(rng.integers(3, 7))):
+        steps.append(cpm * int(rng.integers(1, 12)) + (int(rng.integers(0, cpm)) if rng.random() < 0.7 else 0))
+        stopped = rng.random() < 0.6
+        if stopped:
+            steps.append("stop")
+        for _k in range(int(rng.integers(0, 4))):
+            what = rng.random()
+            if what < 0.35:
+                steps.append("update_config " + _live_keys(rng, "actor_use_gumbel=true" in conf, "nn_type_name=muzero" in conf))
+            elif what < 0.7:
+                it += 1
+                steps.append(("load", f"/m/weight_iter_{it}.pt", it))
+            elif what < 0.9:
+                steps.append("reset_actors")
+            else:
+                steps.append("keep_alive")
+        if stopped:
+            steps.append("start")
+    steps.append(cpm * int(rng.integers(1, 15)))
+    worker_vs_oracle(oracle, binaries["asan"], conf, args, 4, steps, seed=int(rng.integers(1, 99)))
