@@ -15,7 +15,8 @@ class MzError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmzgpu.so")
+    # MZ_LIBMZGPU: another build of the same library (tools/gpu_sanitize.sh: the host objects under AddressSanitizer / ThreadSanitizer); never a fallback
+    return os.environ.get("MZ_LIBMZGPU") or os.path.join(_HERE, "libmzgpu.so")
 
 
 class NetDesc(C.Structure):

@@ -1,0 +1,24 @@
+#!/bin/bash
+# The worker's host half under AddressSanitizer / ThreadSanitizer ON THE GPU (the real device behind it: the simulation-kernel paths of runCyclesSim, the Gumbel rounds,
+# the OBS compressor with real Atari records — what the GPU-less harness of tests/test_sanitizers.py cannot reach).  The sanitizer builds of the library
+# (make -C minizero_amd/csrc SAN=address ../libmzgpu_asan.so; SAN=thread ../libmzgpu_tsan.so: host sources instrumented, HIP objects as they are) are loaded by the
+# ctypes mirror through MZ_LIBMZGPU; python itself is not instrumented, so the runtime is preloaded.  Output: gpurun_out/sanitize/{asan,tsan}.log
+#   usage (through gpurun): bash tools/gpu_sanitize.sh [asan|tsan|both]
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/sanitize
+mkdir -p $O
+WHAT=${1:-both}
+TESTS_ASAN="tests/test_gpu_worker.py tests/test_gpu_streams.py tests/test_gpu_baseline_nets.py tests/test_gpu_wide_worker.py tests/test_gpu_loader.py tests/test_gpu_facade.py"
+TESTS_TSAN="tests/test_gpu_streams.py tests/test_gpu_worker.py"
+if [ "$WHAT" = asan ] || [ "$WHAT" = both ]; then
+  ( time env LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:exitcode=66 \
+      MZ_LIBMZGPU=$PWD/minizero_amd/libmzgpu_asan.so timeout 1500 python -m pytest $TESTS_ASAN tests/test_gpu_iteration.py -q -m gpu -k "not executable and not sp_exe" -x 2>&1 | tail -40 ) > $O/asan.log 2>&1
+  tail -5 $O/asan.log
+fi
+if [ "$WHAT" = tsan ] || [ "$WHAT" = both ]; then
+  # (ThreadSanitizer and the ROCm runtime both want large fixed address ranges: if the runtime refuses to start under TSAN the log says so — recorded, not hidden)
+  ( time env LD_PRELOAD=$(gcc -print-file-name=libtsan.so) TSAN_OPTIONS=exitcode=66:halt_on_error=0:report_signal_unsafe=0:ignore_noninstrumented_modules=1 \
+      MZ_LIBMZGPU=$PWD/minizero_amd/libmzgpu_tsan.so timeout 900 python -m pytest $TESTS_TSAN -q -m gpu -k "c1 or small_go or multithreaded or streams or atari_gumbel or commands" 2>&1 | tail -60 ) > $O/tsan.log 2>&1
+  tail -8 $O/tsan.log
+fi
