@@ -424,3 +424,52 @@ def test_random_iteration_schedules(mz, oracle, tmp_path, seed):
             b.send("start")
     b.run(cpm * int(rng.integers(1, 4 if heavy else 30)))
     b.compare(0)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE's own pool sizes and networks, the bench's 16 RNG streams: a weight swap in the middle of a search of every game
+# ------------------------------------------------------------------------------------------------------------------------------------------
+FULL = {
+    # key: (games, cycles before the swap (inside move 1 or 2), cycles after)
+    "c2": (256, 150, 251 + 20),        # 256 games x 401 cycles: the swap after 150 simulations of move 1, then the rest of the move and 20 cycles of move 2
+    "c3": (1024, 17 + 9, 8 + 17 + 3),  # 1024 games, the swap 9 simulations into move 2
+    "c4": (256, 30, 21 + 51 + 4),
+    "c5": (64, 51 + 23, 28 + 51 + 2),  # 64 games: the swap between two Gumbel rounds of move 2
+}
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("key", sorted(FULL))
+def test_full_size_weight_swap_inside_a_search(mz, oracle, tmp_path, key):
+    from minizero_amd.export_weights import write_mzw
+    games, before, after = FULL[key]
+    d, od = mz.DESCS[key](), getattr(oracle, "desc_" + key)()
+    head, tail = mz.CONFIGS[key].split("zero_num_parallel_games=")
+    conf = head + f"zero_num_parallel_games={games}" + (":" + tail.split(":", 1)[1] if ":" in tail else "")
+    files = [str(tmp_path / f"weight_iter_{i}.pt") for i in range(2)]
+    blobs = [mz.generate_weights(d, i) for i in range(2)]
+    for f, w in zip(files, blobs):
+        write_mzw(f[:-3] + ".mzw", d, w)
+    conf += f":program_seed=3:nn_file_name={files[0]}"
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1:oracle_throughput_threads=16", od, blobs[0])
+    wk = mz.Worker(conf + f":mz_rng_streams=16:zero_num_threads={max(2, mz.usable_cpus() - 1)}")
+    wk.command("start")
+    assert wk.run_cycles(before) == before and og.cycles(before) == before
+    for side in (wk, og):
+        side.command("stop")
+    assert wk.run_cycles(7) == 0 and og.cycles(7) == 0
+    wk.command("update_config actor_select_action_softmax_temperature=0.8")
+    og.command("update_config actor_select_action_softmax_temperature=0.8")
+    wk.command("load_model " + files[1])
+    og.command("load_model " + files[1], blobs[1])
+    for side in (wk, og):
+        side.command("reset_actors")  # ignored (the reference's default): the searches go on under the new weights
+        side.command("start")
+    assert wk.run_cycles(after) == after and og.cycles(after) == after
+    st = wk.stats()
+    assert st["leaf_evals"] == og.leaf_evals() == (before + after) * games and st["sim_launches"] > 0
+    assert wk.pop_lines() == og.lines()
+    recs, orecs = wk.peek_records(games), og.peek_records(games)
+    for g, (a, b) in enumerate(zip(recs, orecs)):
+        assert a == b, f"game {g}: records as they stand differ:\n  hip   : {a[:600]}\n  oracle: {b[:600]}"
+    assert all("EV[weight_iter_1.pt]" in r for r in recs)
