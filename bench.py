@@ -315,6 +315,8 @@ def main():
                 r = run_configs.run_config(key, moves=args.other_moves * (20 if key == "c5" else 1))
                 out["other_configs"][key] = {"workload": r["config"], "leaf_evals_per_sec": r["leaf_evals_per_sec"], "ms_per_move": r["ms_per_move"],
                                              "games_in_pool": r["games_in_pool"], "moves_timed": r["moves_timed"], "host_threads": r["host_threads"],
+                                             **({"note": "600 timed moves (2.1 s) cross three sequence boundaries of every game: the OBS tags of 64 x 200 moves (6 MB each) are gzip-compressed on the host "
+                                                         "beside the search; a leg without a boundary (150 moves, what rounds 3-5 timed) is 2-3 % faster on the same box: profiles/r06_gpu_sanitize.txt"} if key == "c5" else {}),
                                              "roofline": {k: r["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "launches_by_kernel", "flops_per_leaf_eval", "wall_frac")}}
         if world == 1 and not args.no_cpu_baseline:
             del worker
