@@ -8,6 +8,9 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/sanitize
 mkdir -p $O
+# (the sanitizer builds stay out of the gpurun snapshot, .gpurunignore: 32 MB; the box has the same toolchain and builds them in a minute)
+[ -f minizero_amd/libmzgpu_asan.so ] || make -s -j8 -C minizero_amd/csrc SAN=address ../libmzgpu_asan.so
+[ -f minizero_amd/libmzgpu_tsan.so ] || make -s -j8 -C minizero_amd/csrc SAN=thread ../libmzgpu_tsan.so
 WHAT=${1:-both}
 TESTS_ASAN="tests/test_gpu_worker.py tests/test_gpu_streams.py tests/test_gpu_baseline_nets.py tests/test_gpu_wide_worker.py tests/test_gpu_loader.py tests/test_gpu_facade.py"
 TESTS_TSAN="tests/test_gpu_worker.py tests/test_gpu_iteration.py" # (not test_gpu_streams.py: its CHECKER, the uninstrumented oracle with T threads of its own, does not survive under the preloaded runtime)
