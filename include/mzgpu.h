@@ -199,6 +199,8 @@ int mz_worker_load_model(mz_worker* w, const char* path, const mz_net_desc* desc
  * run as ONE kernel launch: call with mz_worker_cycles_per_move() (= actor_num_simulation + 1) and poll commands between calls. */
 int mz_worker_run_cycles(mz_worker* w, int n);
 int mz_worker_cycles_per_move(const mz_worker* w);
+/* pipeline lanes the pool is cut into (mz_pipeline_lanes; 0 = chosen by the worker: 1, or 2 for lock-step pools with long cycles) — an execution detail, never visible in a record */
+int mz_worker_lanes(const mz_worker* w);
 /* next pending stdout line ("SelfPlay ... #", ref actor_group.cpp:24-50); returns its length, 0 if none.  buf == NULL: the length of the
  * next line without popping it (Atari records carry their observations as hex and can be tens of megabytes); a buffer that is too small
  * gives MZ_ERR_CAPACITY and leaves the line queued.  mz_worker_peek_record / mz_worker_record answer buf == NULL the same way.

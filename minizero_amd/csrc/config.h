@@ -58,7 +58,7 @@ struct WorkerConfig {
     std::string env_atari_name = "ms_pacman";
     int env_atari_episode_length = 1000; // synthetic Atari-shaped environment: steps per episode
     // not a reference key: number of software-pipelined lanes the games are split into (1 = no pipelining)
-    int mz_pipeline_lanes = 1;
+    int mz_pipeline_lanes = 0; // 0 = chosen by the worker: 1, or 2 for lock-step pools whose cycles are long enough to hide one lane's tree kernels under the other's convolutions (worker.cpp wantsTwoLanes)
     // not a reference key: kernels read/write the pinned host staging directly (no per-cycle memcpy operations)
     // not a reference key: >= 0 pins the worker's host threads to consecutive CPUs (NUMA node of the caller first) from this index
     int mz_cpu_base = -1;

@@ -118,7 +118,19 @@ public:
         return MZ_OK;
     }
     int runCycles(int n);
+    // mz_pipeline_lanes = 0 (automatic): a pool that plays in the lock-step mode with the device rules — a shape without a simulation-kernel instance — and whose
+    // cycle is dominated by long convolution kernels runs faster as TWO lanes on two streams: one lane's single-wave tree kernels (select, leaf, candidates, expand:
+    // ~0.3 ms per cycle with 255 CUs idle) run under the other lane's convolutions.  Measured (profiles/r06_lockstep_lanes.json): 19x19 6b x 128, 256 games, 331 GFLOP
+    // per cycle: 64.1 -> 67.1 k leaf-evals/s; 13x13 6b x 96, 73 GFLOP per cycle: 182 -> 167 k (its convolutions at 128 samples no longer fill the chip) — hence the bound.
+    bool wantsTwoLanes() const
+    {
+        if (cfg_.mz_pipeline_lanes != 0 || lanes_.size() != 1 || shared_net_ || !resident_ || sim_kernel_ || G_ < 64) { return false; }
+        const double P = double(desc_.hidden_channel_height) * desc_.hidden_channel_width, C = desc_.num_hidden_channels;
+        const double conv_flops = 2.0 * 9.0 * P * (double(desc_.num_input_channels) * C + 2.0 * desc_.num_blocks * C * C);
+        return double(G_) * conv_flops >= 2.0e11;
+    }
     int cyclesPerMove() const { return n_ + 1; }
+    int numLanes() const { return static_cast<int>(lanes_.size()); }
     int popLine(char* buf, int cap);
     int waitLines();
     int peekRecord(int game, char* buf, int cap, const char* const* keys = nullptr, const char* const* values = nullptr, int ntags = 0);
@@ -358,7 +370,7 @@ int Worker::init(int device, const char* conf, const mz_net_desc& desc, const fl
     sc.value_rescale = cfg_.actor_mcts_value_rescale;
     sc.flipping_player = flipping_player_;
     sc.atari_init_q = cfg_.atari_init_q;
-    int nl = std::max(1, cfg_.mz_pipeline_lanes);
+    int nl = std::max(1, cfg_.mz_pipeline_lanes); // (0 = automatic: one lane here; mz_worker_create asks wantsTwoLanes() afterwards)
     if (G_ < 2 * nl || shared) { nl = 1; } // a shared network has one stream: one lane
     shared_net_ = shared != nullptr;
     lane_size_ = (G_ + nl - 1) / nl;
@@ -2026,6 +2038,11 @@ mz_worker* mz_worker_create(int device, const char* conf, const mz_net_desc* des
         count = file_weights.size();
     }
     if (w->w.init(device, conf, *desc, weights, count) != MZ_OK) { return nullptr; }
+    if (w->w.wantsTwoLanes()) { // (decided after the first initialisation, which is what knows the kernels the shape gets; records do not depend on the lane count)
+        const std::string conf2 = std::string(conf) + ":mz_pipeline_lanes=2";
+        w.reset(new mz_worker());
+        if (w->w.init(device, conf2.c_str(), *desc, weights, count) != MZ_OK) { return nullptr; }
+    }
     return w.release();
 }
 mz_worker* mz_worker_create_shared(int device, const char* conf, mz_net* net)
@@ -2036,6 +2053,7 @@ mz_worker* mz_worker_create_shared(int device, const char* conf, mz_net* net)
     return w.release();
 }
 int mz_worker_cycles_per_move(const mz_worker* w) { return w ? w->w.cyclesPerMove() : MZ_ERR_ARG; }
+int mz_worker_lanes(const mz_worker* w) { return w ? w->w.numLanes() : MZ_ERR_ARG; }
 void mz_worker_destroy(mz_worker* w) { delete w; }
 int mz_worker_command(mz_worker* w, const char* line)
 {

@@ -134,6 +134,7 @@ def load():
         L.mz_weight_file_reads.restype = C.c_uint64
         L.mz_worker_run_cycles.argtypes = [vp, C.c_int]
         L.mz_worker_cycles_per_move.argtypes = [vp]
+        L.mz_worker_lanes.argtypes = [vp]
         L.mz_net_read_weight_file.argtypes = [C.c_char_p, C.POINTER(NetDesc), fp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mz_worker_pop_line.argtypes = [vp, C.c_char_p, C.c_int]
         L.mz_worker_wait_lines.argtypes = [vp]
@@ -451,6 +452,9 @@ class Worker:
 
     def cycles_per_move(self):
         return _check(self.L, self.L.mz_worker_cycles_per_move(self.h))
+
+    def lanes(self):
+        return _check(self.L, self.L.mz_worker_lanes(self.h))
 
     def pop_lines(self, wait=True):
         """Every finished record.  wait=False: only those that are complete right now (mz_worker_pop_line never blocks: an Atari record whose OBS tag

@@ -162,6 +162,33 @@ def test_lock_step_shapes_play_on_the_device_rules(mz, oracle, game, n, c, block
     assert out[""][0] == og.lines() and out[""][1] == og.peek_records(games)
 
 
+def test_heavy_lock_step_pool_runs_as_two_lanes(mz, oracle):
+    """mz_pipeline_lanes = 0 (default): a lock-step pool whose cycle is long — 19x19 Go, 6 blocks x 128 channels, 160 games: 206 GFLOP of convolutions per cycle —
+    is cut into two lanes on two streams (one lane's single-wave tree kernels under the other's convolutions); lighter pools and every simulation-kernel
+    shape stay on one.  The lane count never shows in a record."""
+    args = ("go_19x19", 18, 19, 19, 128, 19, 19, 1, 6, 362, 32, 1, "alphazero")
+    kw = dict(vh=args[10], dv=args[11], type_name=args[12])
+    d, od = mz.make_desc(*args[:10], **kw), oracle.make_desc(*args[:10], **kw)
+    w = mz.generate_weights(d, 1)
+    conf = "env_game=go:env_board_size=19:actor_num_simulation=2:zero_num_parallel_games=160:program_seed=5:nn_file_name=x.pt"
+    wk = mz.Worker(conf + ":zero_num_threads=4", d, w)
+    assert wk.lanes() == 2
+    light = mz.Worker(conf.replace("zero_num_parallel_games=160", "zero_num_parallel_games=64") + ":zero_num_threads=4", d, w)
+    assert light.lanes() == 1
+    light.close()
+    one = mz.Worker(conf + ":mz_pipeline_lanes=1:zero_num_threads=4", d, w)
+    assert one.lanes() == 1
+    og = oracle.OracleGroup(conf + ":zero_num_threads=1", od, w)
+    cycles = 3 * 2 + 1
+    og.cycles(cycles)
+    for x in (wk, one):
+        x.command("start")
+        assert x.run_cycles(cycles) == cycles
+        assert x.stats()["sim_launches"] == 0 and x.pop_lines() == og.lines() and x.peek_records(160) == og.peek_records(160)
+    sim = mz.Worker("env_game=go:env_board_size=9:actor_num_simulation=4:zero_num_parallel_games=256:program_seed=5:nn_file_name=x.pt", mz.DESCS["c2"](), mz.generate_weights(mz.DESCS["c2"](), 0))
+    assert sim.lanes() == 1
+
+
 # ---- MuZero board games on the one-tile tower (sim_wide_mz.hip sim_kernel_mz_wide) ----
 MZGO = "env_game=go:env_board_size={n}:nn_type_name=muzero:actor_num_simulation={sims}:zero_num_parallel_games={games}"
 
