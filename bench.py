@@ -74,13 +74,13 @@ def cpu_baseline(conf, seconds):
 
 
 def kernel_fingerprint():
-    """sha256 over the device sources of libmzgpu (every .hip / .h / .inc under minizero_amd/csrc, names and contents, sorted): what a committed counter summary
-    was taken on.  (`.git` does not travel to the GPU box, so a commit id cannot be read there.)"""
+    """sha256 over the device sources of libmzgpu (every .hip / .inc and every header under minizero_amd/csrc except the host-only ones, names and contents, sorted):
+    what a committed counter summary was taken on.  (`.git` does not travel to the GPU box, so a commit id cannot be read there.)"""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "minizero_amd", "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h", ".inc")):
+        if name.endswith((".hip", ".h", ".inc")) and name not in ("config.h", "env.h", "host_threads.h", "common_host.h"):
             h.update(name.encode())
             h.update(open(os.path.join(src, name), "rb").read())
     return h.hexdigest()[:16]
