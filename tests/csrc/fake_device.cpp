@@ -67,12 +67,15 @@ hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "fake device"; }
+#ifndef MZ_FAKE_WITH_CAPI // (with capi.cpp linked in — the `-mode sp` executable over the facades — these come from there)
 int mz_device_count(void) { return 1; }
 const char* mz_last_error(void) { return mz::lastError(); }
+#endif
 }
 
 namespace mz {
 
+#ifndef MZ_FAKE_WITH_CAPI
 // ---- what capi.cpp provides in the product ----
 static thread_local char g_err[1024] = "";
 void setError(const char* fmt, ...)
@@ -84,6 +87,18 @@ void setError(const char* fmt, ...)
 }
 const char* lastError() { return g_err; }
 bool readWeightFile(const std::string& path, mz_net_desc*, std::vector<float>*) { setError("fake device: no weight files (%s)", path.c_str()); return false; }
+#else
+// ---- what capi.cpp asks of the device beyond the worker's seam: the stand-alone network / pool entry points are not served ----
+int Net::forwardAZ_any(const float*, int, float*, float*, float*, int) { setError("fake device: mz_net_forward_az is not served"); return MZ_ERR_DEVICE; }
+int Net::initial_any(const float*, int, float*, float*, float*, float*, int) { setError("fake device: mz_net_initial is not served"); return MZ_ERR_DEVICE; }
+int Net::recurrent_any(const float*, const float*, int, float*, float*, float*, float*, float*, int) { setError("fake device: mz_net_recurrent is not served"); return MZ_ERR_DEVICE; }
+int Net::timeForward(int, int, float*, float*, double*) { setError("fake device: no timing"); return MZ_ERR_DEVICE; }
+int Net::timeTowerConv(int, int, float*, double*, double*) { setError("fake device: no timing"); return MZ_ERR_DEVICE; }
+int Pool::select(const int*, int*, int*, int*) { setError("fake device: mz_pool_select is not served"); return MZ_ERR_DEVICE; }
+int Pool::expandBackup(const int*, const int*, const float*, const float*, const int*, const float*, const float*) { setError("fake device: mz_pool_expand_backup is not served"); return MZ_ERR_DEVICE; }
+int Pool::numNodes(int) { setError("fake device: mz_pool_num_nodes is not served"); return MZ_ERR_DEVICE; }
+int Pool::readNodes(int, int, int*, int*, int*, int*, float*, float*, float*, float*, float*, float*, float*) { setError("fake device: mz_pool_read_nodes is not served"); return MZ_ERR_DEVICE; }
+#endif
 float invertValueHost(float v) { return v; } // (muzero_atari is not served)
 int invertValuesOnDevice(int, const float*, int, float*) { setError("fake device"); return MZ_ERR_DEVICE; }
 int sortCandidatesOnDevice(int, const float*, int, int*) { setError("fake device"); return MZ_ERR_DEVICE; }
@@ -98,6 +113,7 @@ struct PoolState {
     std::vector<int> owned;
 };
 std::mutex g_mu;
+std::mutex g_oracle_net_mu; // the oracle's forward runs on ONE process-wide parallel-for (oracle/o_nn.cpp): one caller at a time — several workers (logical devices) take turns
 std::map<const Net*, NetState> g_nets;
 std::map<const Pool*, PoolState> g_pools;
 NetState& stateOf(const Net* n) { std::lock_guard<std::mutex> l(g_mu); return g_nets[n]; }
@@ -152,14 +168,14 @@ int Net::forwardAZ(const float* d_feat, int B, float* d_policy, float* d_logit, 
         }
         feat = planes.data();
     }
-    mzo_net_forward_az(stateOf(this).onet, feat, B, d_policy, d_logit, d_value);
+    { std::lock_guard<std::mutex> l(g_oracle_net_mu); mzo_net_forward_az(stateOf(this).onet, feat, B, d_policy, d_logit, d_value); }
     return MZ_OK;
 }
 int Net::initial(const float* d_feat, int B, float* d_policy, float* d_logit, float* d_value, float* d_hidden, const int* d_dst_idx)
 {
     const size_t hs = size_t(hiddenSize());
     std::vector<float> hidden(size_t(B) * hs);
-    mzo_net_initial(stateOf(this).onet, d_feat, B, d_policy, d_logit, d_value, hidden.data());
+    { std::lock_guard<std::mutex> l(g_oracle_net_mu); mzo_net_initial(stateOf(this).onet, d_feat, B, d_policy, d_logit, d_value, hidden.data()); }
     for (int b = 0; b < B; ++b) { memcpy(d_hidden + size_t(d_dst_idx ? d_dst_idx[b] : b) * hs, hidden.data() + size_t(b) * hs, hs * sizeof(float)); }
     return MZ_OK;
 }
@@ -176,7 +192,7 @@ int Net::recurrent(const float* d_hidden_src, const int* d_src_idx, const float*
             for (int i = 0; i < AC * P; ++i) { act[size_t(b) * AC * P + i] = (AC == 1) ? (i == d_action_ids[b] ? 1.0f : 0.0f) : ((i / P) == d_action_ids[b] ? 1.0f : 0.0f); }
         }
     }
-    mzo_net_recurrent(stateOf(this).onet, hin.data(), act.data(), B, d_policy, d_logit, d_value, d_reward, hout.data());
+    { std::lock_guard<std::mutex> l(g_oracle_net_mu); mzo_net_recurrent(stateOf(this).onet, hin.data(), act.data(), B, d_policy, d_logit, d_value, d_reward, hout.data()); }
     for (int b = 0; b < B; ++b) { memcpy(d_hidden_dst + size_t(d_dst_idx ? d_dst_idx[b] : b) * hs, hout.data() + size_t(b) * hs, hs * sizeof(float)); }
     return MZ_OK;
 }

@@ -234,8 +234,8 @@ def test_load_model_refuses_another_shape(mz, oracle, tmp_path):
 # through the `-mode sp` executable: the devices apply a command between two moves of their games and say after how many cycles
 # ------------------------------------------------------------------------------------------------------------------------------------------
 class Exe:
-    def __init__(self, conf_str, game, env):
-        exe = os.path.join(ROOT, "apps", "mzgpu_sp")
+    def __init__(self, conf_str, game, env, exe=None):
+        exe = exe or os.path.join(ROOT, "apps", "mzgpu_sp")
         assert os.path.exists(exe), "run __graft_entry__.build() first"
         self.p = subprocess.Popen([exe, "-conf_str", conf_str, "-mode", "sp", "-game", game], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                                   stderr=subprocess.PIPE, text=True, env=env)
@@ -281,14 +281,13 @@ EXE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("name,game,args,extra,cpm,G,tail", EXE_CASES, ids=[c[0] for c in EXE_CASES])
-def test_iterations_through_the_sp_executable(mz, oracle, tmp_path, name, game, args, extra, cpm, G, tail):
-    """load_model / reset_actors / start ... stop twice through stdin with G logical devices.  Every device applies a command between two moves of
-    its games (a cycle boundary the reference could have picked too) and logs after how many cycles; the test replays exactly that schedule on one
-    OracleGroup per device and requires every printed record to be the next record of exactly one device — before and after the swaps — and the
-    process to have read each weight file ONCE, whatever G (SURVEY.md 8(e); the reference: once per network, actor_group.cpp:227-232)."""
+def sp_executable_iterations(mz, oracle, tmp_path, game, args, extra, cpm, G, tail, exe=None, worker_extra="", make_env=None):
+    """The body of test_iterations_through_the_sp_executable; `exe` / `worker_extra` / `make_env` let tests/test_sanitizers.py run the same protocol through the
+    executable built over the test-only device stand-in (no GPU, ThreadSanitizer)."""
     env = dict(os.environ)
     env["MZ_DEVICE_MAP"] = ",".join(["0"] * G)
+    if make_env:
+        env.update(make_env)
     d, od = descs(mz, oracle, args)
     files, blobs = [], []
     os.makedirs(os.path.join(str(tmp_path), "model"))
@@ -297,8 +296,8 @@ def test_iterations_through_the_sp_executable(mz, oracle, tmp_path, name, game, 
         files.append(os.path.join(str(tmp_path), "model", f"weight_iter_{it}.pt"))
         write_weights(mz, files[-1], d, blobs[-1], "pt" if it != 1 else "mzw")
     games = 3 * G + 1
-    conf_str = f"nn_file_name={files[0]}:program_seed=5:{extra}:zero_num_parallel_games={games}:zero_num_threads={G}{tail}"
-    x = Exe(conf_str, game, env)
+    conf_str = f"nn_file_name={files[0]}:program_seed=5:{extra}:zero_num_parallel_games={games}:zero_num_threads={G}{tail}{worker_extra}"
+    x = Exe(conf_str, game, env, exe)
     try:
         x.send("start\n")
         x.wait_lines(2 * G)
@@ -314,8 +313,9 @@ def test_iterations_through_the_sp_executable(mz, oracle, tmp_path, name, game, 
         x.wait_err(r"device \d+: stop after", 3 * G)
     finally:
         rc = x.quit()
-    assert rc == 0
     err = "\n".join(x.err)
+    assert rc == 0, err[-3000:]
+    assert "Sanitizer" not in err, err[-6000:]
     assert f"{games} games on {G} GPU(s)" in err
     assert "[mzgpu] weight files read: 3" in err, err[-1500:]  # nn_file_name + two load_model, each ONCE for G devices
     # the schedule every device logged: (command, cycles)
@@ -352,6 +352,15 @@ def test_iterations_through_the_sp_executable(mz, oracle, tmp_path, name, game, 
     assert all(cursor[g] == len(expected[g]) for g in range(G)), {g: (cursor[g], len(expected[g])) for g in range(G)}
     text = "".join(x.lines)
     assert "EV[weight_iter_0.pt]" in text and "EV[weight_iter_1.pt]" in text and "EV[weight_iter_2.pt]" in text
+
+
+@pytest.mark.parametrize("name,game,args,extra,cpm,G,tail", EXE_CASES, ids=[c[0] for c in EXE_CASES])
+def test_iterations_through_the_sp_executable(mz, oracle, tmp_path, name, game, args, extra, cpm, G, tail):
+    """load_model / reset_actors / start ... stop twice through stdin with G logical devices.  Every device applies a command between two moves of
+    its games (a cycle boundary the reference could have picked too) and logs after how many cycles; the test replays exactly that schedule on one
+    OracleGroup per device and requires every printed record to be the next record of exactly one device — before and after the swaps — and the
+    process to have read each weight file ONCE, whatever G (SURVEY.md 8(e); the reference: once per network, actor_group.cpp:227-232)."""
+    sp_executable_iterations(mz, oracle, tmp_path, game, args, extra, cpm, G, tail)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------------

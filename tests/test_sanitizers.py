@@ -172,3 +172,16 @@ def test_random_iteration_schedules_on_the_host_half(oracle, binaries, seed):
             steps.append("start")
     steps.append(cpm * int(rng.integers(1, 15)))
     worker_vs_oracle(oracle, binaries["asan"], conf, args, 4, steps, seed=int(rng.integers(1, 99)))
+
+
+@pytest.mark.parametrize("name,G", [("tictactoe", 2), ("go_reset", 2), ("othello_gumbel_eight_devices", 8)])
+def test_sp_executable_protocol_under_tsan(mz, oracle, binaries, tmp_path, name, G):
+    """apps/mzgpu_sp.cpp itself — include/minizero/actor_group.h: the stdin thread, one host thread per logical device, the stdout / stderr mutexes, one read per
+    weight file (the product's capi.cpp / weights.cpp / ptfile.cpp really read a TorchScript archive and an .mzw) — built over the device stand-in and run under
+    ThreadSanitizer with G logical devices: the same two-iteration protocol as tests/test_gpu_iteration.py::test_iterations_through_the_sp_executable, every device's
+    logged schedule replayed on an oracle of its own, every printed record accounted for, `weight files read: 3`, no sanitizer report."""
+    import test_gpu_iteration as it
+    case = [c for c in it.EXE_CASES if c[0] == name][0]
+    _, game, args, extra, cpm, _, tail = case
+    it.sp_executable_iterations(mz, oracle, tmp_path, game, args, extra, cpm, G, tail, exe=os.path.join(BIN, "mzgpu_sp_tsan"), worker_extra=":mz_device_env=false",
+                                make_env=SAN_ENV)
