@@ -8,7 +8,7 @@
 // What stands behind the seam here is the CHECKER, not a second implementation: the tree is the oracle's MCTS (oracle/o_mcts.cpp through its
 // `mzo_tree_*` entry points), the network the oracle's forward (`mzo_net_*`).  "Device memory" is host memory, a "stream" runs every operation
 // at once.  Only the lock-step mode with the rules on the host is served (hasSimKernel* / hasFusedTower say no; mz_device_env=false is
-// required) for AlphaZero and MuZero board games; the Atari-shaped network, the device rules and every simulation kernel return an error.
+// required) for AlphaZero and MuZero networks (`muzero_atari` with float observations, mz_raw_observations=false); the device rules and every simulation kernel return an error.
 // The product has no such path: libmzgpu.so without a GPU fails with MZ_ERR_DEVICE (tests/test_capi.py).
 #include "../../minizero_amd/csrc/net.h"
 #include "../../minizero_amd/csrc/pool.h"
@@ -99,7 +99,7 @@ int Pool::expandBackup(const int*, const int*, const float*, const float*, const
 int Pool::numNodes(int) { setError("fake device: mz_pool_num_nodes is not served"); return MZ_ERR_DEVICE; }
 int Pool::readNodes(int, int, int*, int*, int*, int*, float*, float*, float*, float*, float*, float*, float*) { setError("fake device: mz_pool_read_nodes is not served"); return MZ_ERR_DEVICE; }
 #endif
-float invertValueHost(float v) { return v; } // (muzero_atari is not served)
+float invertValueHost(float v) { return v; } // (muzero_atari: the oracle's network hands out DECODED values — muzero_network.h:157-174 — where the HIP heads hand out the transformed expectation)
 int invertValuesOnDevice(int, const float*, int, float*) { setError("fake device"); return MZ_ERR_DEVICE; }
 int sortCandidatesOnDevice(int, const float*, int, int*) { setError("fake device"); return MZ_ERR_DEVICE; }
 
@@ -132,8 +132,7 @@ Net::~Net()
 }
 int Net::init(int device, const mz_net_desc& d, const float* raw, size_t n)
 {
-    if (d.type == 2) { return refuse("muzero_atari"); }
-    desc_ = d;
+    desc_ = d; // (muzero_atari too: the oracle's forward returns value / reward already decoded, and invertValueHost above is the identity to match)
     device_ = device;
     MZ_HIP(hipStreamCreateWithFlags(&stream_, 0));
     own_stream_ = true;

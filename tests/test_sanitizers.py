@@ -47,8 +47,8 @@ def worker_vs_oracle(oracle, binary, conf, args, T, steps, seed=3, wseed=0):
     """steps: ints (cycles) and protocol lines; ('load', name, weight_seed) swaps the network on both sides."""
     tn = {"alphazero": 0, "muzero": 1, "muzero_atari": 2}[args[12]]
     games = int(conf.split("zero_num_parallel_games=")[1].split(":")[0])
-    base = f"{conf}:program_seed={seed}:nn_file_name=/m/weight_iter_0.pt"
-    wconf = f"{base}:mz_device_env=false:zero_num_threads={T}:mz_rng_streams={T}"
+    wconf = f"{conf}:program_seed={seed}:nn_file_name=/m/weight_iter_0.pt:mz_device_env=false:zero_num_threads={T}:mz_rng_streams={T}"
+    base = ":".join(kv for kv in conf.split(":") if not kv.startswith("mz_")) + f":program_seed={seed}:nn_file_name=/m/weight_iter_0.pt"  # (worker-only keys stay with the worker)
     chunks = []
     od = oracle.make_desc(*args[:10], vh=args[10], dv=args[11], type_name=args[12])
     og = oracle.OracleGroup(base + ":zero_num_threads=1" + (f":oracle_throughput_threads={T}" if T > 1 else ""), od, oracle.gen_weights(od, wseed))
@@ -81,6 +81,12 @@ WORKER_CASES = {
     "go_muzero": (GO_MZ, "env_game=go:env_board_size=7:nn_type_name=muzero:actor_num_simulation=6:zero_num_parallel_games=16", [7 * 30], 0),
     "tictactoe_muzero_gumbel": (TTT_MZ, f"env_game=tictactoe:nn_type_name=muzero:actor_num_simulation=8:{GUMBEL.replace('sample_size=8', 'sample_size=4')}:zero_num_parallel_games=24",
                                 [9 * 12], 20),
+    # the Atari-shaped game: OBS tags compressed by the background helpers while the worker plays on, intermediate sequences, value rescale, 601-bin heads (decoded by the oracle)
+    "atari_gumbel": (("atari_ms_pacman", 32, 96, 96, 32, 6, 6, 18, 1, 18, 32, 601, "muzero_atari"),
+                     "env_game=atari:nn_type_name=muzero:actor_num_simulation=6:actor_use_dirichlet_noise=false:actor_use_gumbel=true:actor_use_gumbel_noise=true:"
+                     "actor_gumbel_sample_size=4:actor_gumbel_sigma_scale_c=0.1:actor_mcts_value_rescale=true:actor_mcts_reward_discount=0.997:atari_init_q=true:"
+                     "zero_actor_intermediate_sequence_length=5:learner_n_step_return=2:learner_muzero_unrolling_step=1:env_atari_episode_length=16:mz_raw_observations=false:"
+                     "zero_num_parallel_games=8", [7 * 30], 8),
     # the training iteration (tests/test_gpu_iteration.py runs the same protocol on the GPU): stop / update_config / load_model / reset_actors / start, mid-move
     "tictactoe_iteration": (TTT, "env_game=tictactoe:actor_num_simulation=16:zero_num_parallel_games=16:zero_actor_ignored_command=keep_alive",
                             [17 * 5 + 4, "stop", 3, "update_config actor_select_action_softmax_temperature=0.5", ("load", "/m/weight_iter_1.pt", 1), "reset_actors", "start",
